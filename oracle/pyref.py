@@ -1,0 +1,460 @@
+"""CPU oracle (pure-Python big-integer restatement) for the Lurk proving hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is part of the product: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it, and only as
+the checker.  The product path is ``lurk_beta_amd`` -> ``liblurk_hip.so`` (HIP, gfx950).
+
+Why a restatement: the arithmetic of lurk-beta's prover lives in un-vendored git dependencies
+(neptune @ dev, arecibo @ dev, pasta-msm, pasta_curves 0.5.0, halo2curves 0.6.0;
+/root/reference/Cargo.toml:68,120,127-131) and there is no Rust toolchain here, so the reference
+cannot be compiled.  Each function below restates the *published* algorithm of the dependency and
+is pinned against the reference's own golden vectors (see tests/test_oracle_kat.py):
+
+  * Poseidon (neptune): pinned by the BN254 KATs in
+      /root/reference/src/coprocessor/trie/mod.rs:925-1013   (hash8 empty roots)
+      /root/reference/src/lem/store.rs:1464-1475             (hash3 commitment)
+      /root/reference/src/lem/tests/eval_tests.rs:379,442,1940-1959,3868,3904
+    The same field-generic code is then used over Pallas Fq / Vesta Fp: Pasta parity is
+    *transferred*, not directly pinned (no Pasta KAT exists in the reference).
+  * MSM (pasta-msm / arecibo CommitmentEngine::commit): PARITY UNPINNED - the reference holds no
+    golden commitment bytes.  Oracle = textbook group law + naive
+    double-and-add; the C oracle's Pippenger is cross-checked against this.
+  * NTT: PARITY UNPINNED - no NTT exists anywhere in the reference.
+    Oracle = O(n^2) DFT and a recursive radix-2 NTT.
+
+Reference call sites restated here:
+  PoseidonCache::hash3/4/6/8        /root/reference/src/hash.rs:180-204
+  StoreHasher preimage layouts      /root/reference/src/lem/store.rs:29-78
+  Trie empty roots / path / insert  /root/reference/src/coprocessor/trie/mod.rs:434-481,584-633,745-800
+"""
+from __future__ import annotations
+
+import math
+from functools import lru_cache
+
+# --------------------------------------------------------------------------------------------
+# Fields.  (BN254 r is confirmed in-tree at src/parser/syntax.rs:916,932.)
+# --------------------------------------------------------------------------------------------
+PALLAS_P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001  # Pallas base field Fp
+PALLAS_Q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001  # Pallas scalar field Fq
+BN254_R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001   # BN254 scalar field Fr
+
+FIELD_IDS = {"pallas_fp": 0, "pallas_fq": 1, "bn254_fr": 2}
+FIELD_MODULUS = {0: PALLAS_P, 1: PALLAS_Q, 2: BN254_R}
+FIELD_NUM_BITS = {0: 255, 1: 255, 2: 254}  # ff::PrimeField::NUM_BITS
+
+
+def modulus(field_id: int) -> int:
+    return FIELD_MODULUS[field_id]
+
+
+def fe_to_bytes(x: int) -> bytes:
+    """``PrimeField::to_repr()``: 32-byte little-endian canonical (src/field.rs:72-75)."""
+    return int(x).to_bytes(32, "little")
+
+
+def fe_from_bytes(b: bytes) -> int:
+    return int.from_bytes(b, "little")
+
+
+# --------------------------------------------------------------------------------------------
+# SplitMix64 synthetic inputs (seed 0x4C55524B "LURK" + stream id).
+# --------------------------------------------------------------------------------------------
+SEED = 0x4C55524B
+MASK64 = (1 << 64) - 1
+
+
+def splitmix64(state: int) -> tuple[int, int]:
+    state = (state + 0x9E3779B97F4A7C15) & MASK64
+    z = state
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return state, z ^ (z >> 31)
+
+
+def splitmix_at(stream: int, index: int) -> int:
+    """Counter-mode SplitMix64: the ``index``-th output of stream ``stream`` (random access so
+    the GPU generator and the oracle agree without sequential state)."""
+    state = (SEED + (stream << 32) + index * 0x9E3779B97F4A7C15) & MASK64
+    _, out = splitmix64(state)
+    return out
+
+
+def uniform_fe(stream: int, i: int, p: int) -> int:
+    """Uniform field element number ``i`` of ``stream``: 4 x u64 words -> 256-bit LE value, top
+    bits masked to the modulus length, rejection-sampled by bumping a retry counter."""
+    nbits = p.bit_length()
+    retry = 0
+    while True:
+        v = 0
+        for w in range(4):
+            v |= splitmix_at(stream, (i * 4 + w) + (retry << 40)) << (64 * w)
+        v &= (1 << nbits) - 1
+        if v < p:
+            return v
+        retry += 1
+
+
+def witness_like_fe(stream: int, i: int, p: int) -> int:
+    """Distribution "W" of SURVEY.md section 8d: 80 % uniform, 12 % in {0,1}, 8 % < 2^16, and 5 % of
+    positions overwritten by one repeated uniform value (models cached dummy-slot witnesses,
+    /root/reference/src/lem/multiframe.rs:552-577)."""
+    sel = splitmix_at(stream + 100, i) % 100
+    rep = splitmix_at(stream + 101, i) % 100
+    if rep < 5:
+        return uniform_fe(stream + 102, 0, p)
+    if sel < 80:
+        return uniform_fe(stream, i, p)
+    if sel < 92:
+        return splitmix_at(stream + 103, i) & 1
+    return splitmix_at(stream + 103, i) & 0xFFFF
+
+
+# --------------------------------------------------------------------------------------------
+# Poseidon (neptune).  Restates neptune's published parameter generation:
+#   round numbers  - neptune round_numbers.rs (security level M=128, N=256 fixed, +2 full rounds,
+#                    x1.075 partial-round margin)
+#   round constants- neptune round_constants.rs (Grain LFSR, field=1, sbox=1, n=F::NUM_BITS)
+#   MDS            - neptune mds.rs (Cauchy, x_i = i, y_j = t + j)
+#   permutation    - neptune poseidon.rs hash_correct (the "optimized static" schedule used by
+#                    .hash() is algebraically identical; digest must match bit-for-bit)
+# --------------------------------------------------------------------------------------------
+def _round_numbers_are_secure(t: int, rf: int, rp: int) -> bool:
+    n, m = 256.0, 128.0
+    tf, rpf = float(t), float(rp)
+    rf_stat = 6.0 if m <= (n - 3.0) * (tf + 1.0) else 10.0
+    rf_interp = 0.43 * m + math.log2(tf) - rpf
+    rf_grob_1 = 0.21 * n - rpf
+    rf_grob_2 = (0.14 * n - 1.0 - rpf) / (tf - 1.0)
+    rf_max = max(math.ceil(rf_stat), math.ceil(rf_interp), math.ceil(rf_grob_1), math.ceil(rf_grob_2))
+    return rf >= rf_max
+
+
+@lru_cache(maxsize=None)
+def round_numbers(arity: int) -> tuple[int, int]:
+    """(R_F, R_P) for width t = arity + 1, standard strength."""
+    import numpy as np
+
+    t = arity + 1
+    best_rf = best_rp = 0
+    n_sboxes_min = None
+    for rf_test0 in range(2, 1001, 2):
+        for rp_test0 in range(4, 200):
+            if _round_numbers_are_secure(t, rf_test0, rp_test0):
+                rf_test = rf_test0 + 2
+                # neptune computes the margin in f32
+                rp_test = int(np.ceil(np.float32(1.075) * np.float32(rp_test0)))
+                n_sboxes = t * rf_test + rp_test
+                if n_sboxes_min is None or n_sboxes < n_sboxes_min or (
+                    n_sboxes == n_sboxes_min and rf_test < best_rf
+                ):
+                    best_rf, best_rp, n_sboxes_min = rf_test, rp_test, n_sboxes
+    return best_rf, best_rp
+
+
+class _Grain:
+    def __init__(self, init_bits: list[int], field_size: int):
+        assert len(init_bits) == 80
+        self.state = list(init_bits)
+        self.field_size = field_size
+        for _ in range(160):
+            self._new_bit()
+
+    def _new_bit(self) -> int:
+        s = self.state
+        b = s[62] ^ s[51] ^ s[38] ^ s[23] ^ s[13] ^ s[0]
+        s.pop(0)
+        s.append(b)
+        return b
+
+    def next_bit(self) -> int:
+        b = self._new_bit()
+        while not b:
+            self._new_bit()
+            b = self._new_bit()
+        return self._new_bit()
+
+    def next_byte(self, bit_count: int) -> int:
+        acc = 0
+        for i in range(bit_count):
+            acc |= self.next_bit() << (bit_count - 1 - i)
+        return acc
+
+    def next_be_int(self) -> int:
+        rem = self.field_size % 8
+        out = [self.next_byte(rem if rem else 8)]
+        for _ in range(31):
+            out.append(self.next_byte(8))
+        return int.from_bytes(bytes(out), "big")
+
+
+def _append_bits(vec: list[int], n: int, value: int) -> None:
+    for i in reversed(range(n)):
+        vec.append((value >> i) & 1)
+
+
+@lru_cache(maxsize=None)
+def round_constants(field_id: int, arity: int, sbox_param: int = 1) -> tuple[int, ...]:
+    p = modulus(field_id)
+    t = arity + 1
+    rf, rp = round_numbers(arity)
+    bits: list[int] = []
+    _append_bits(bits, 2, 1)            # field = 1 (prime)
+    _append_bits(bits, 4, sbox_param)   # sbox
+    _append_bits(bits, 12, FIELD_NUM_BITS[field_id])
+    _append_bits(bits, 12, t)
+    _append_bits(bits, 10, rf)
+    _append_bits(bits, 10, rp)
+    _append_bits(bits, 30, (1 << 30) - 1)
+    g = _Grain(bits, FIELD_NUM_BITS[field_id])
+    out = []
+    while len(out) < (rf + rp) * t:
+        v = g.next_be_int()
+        if v < p:
+            out.append(v)
+    return tuple(out)
+
+
+@lru_cache(maxsize=None)
+def mds_matrix(field_id: int, arity: int) -> tuple[tuple[int, ...], ...]:
+    p = modulus(field_id)
+    t = arity + 1
+    return tuple(tuple(pow(i + t + j, p - 2, p) for j in range(t)) for i in range(t))
+
+
+def domain_tag(arity: int) -> int:
+    """HashType::MerkleTree: 2^arity - 1."""
+    return (1 << arity) - 1
+
+
+def poseidon_permute(field_id: int, state: list[int]) -> list[int]:
+    p = modulus(field_id)
+    t = len(state)
+    arity = t - 1
+    rf, rp = round_numbers(arity)
+    rc = round_constants(field_id, arity)
+    m = mds_matrix(field_id, arity)
+    half = rf // 2
+    k = 0
+    for r in range(rf + rp):
+        state = [(state[i] + rc[k + i]) % p for i in range(t)]
+        k += t
+        if r < half or r >= half + rp:
+            state = [pow(x, 5, p) for x in state]
+        else:
+            state[0] = pow(state[0], 5, p)
+        state = [sum(state[i] * m[i][j] for i in range(t)) % p for j in range(t)]
+    return state
+
+
+def poseidon_hash(field_id: int, preimage: list[int]) -> int:
+    """``Poseidon::new_with_preimage(preimage, consts).hash()`` (src/hash.rs:181-203)."""
+    arity = len(preimage)
+    assert arity in (3, 4, 6, 8), f"unsupported arity: {arity}"  # src/hash.rs:19-29
+    state = [domain_tag(arity)] + [x % modulus(field_id) for x in preimage]
+    return poseidon_permute(field_id, state)[1]
+
+
+# --------------------------------------------------------------------------------------------
+# Lurk data -> preimages (/root/reference/src/lem/store.rs:29-78,428-505).
+# --------------------------------------------------------------------------------------------
+TAG_NIL, TAG_CONS, TAG_SYM, TAG_FUN, TAG_NUM, TAG_THUNK, TAG_STR, TAG_CHAR, TAG_COMM = range(9)
+TAG_U64, TAG_KEY, TAG_CPROC, TAG_ENV = 9, 10, 11, 12
+
+
+def hash_string(field_id: int, s: str) -> int:
+    """Str cells front to back, terminator (Str, 0) (store.rs:428-441, test :1368-1386)."""
+    h = 0
+    for ch in reversed(s):
+        h = poseidon_hash(field_id, [TAG_CHAR, ord(ch), TAG_STR, h])
+    return h
+
+
+def hash_symbol_path(field_id: int, path: list[str]) -> int:
+    """Symbol .a.b: fold from the root, cell = tuple2[Str name_i, previous], terminator (Sym,0)
+    (store.rs:481-487, test :1389-1412)."""
+    h = 0
+    for name in path:
+        h = poseidon_hash(field_id, [TAG_STR, hash_string(field_id, name), TAG_SYM, h])
+    return h
+
+
+def commit(field_id: int, secret: int, tag: int, payload_hash: int) -> int:
+    """hash3(secret, tag_payload, h_payload) (store.rs:70-73)."""
+    return poseidon_hash(field_id, [secret, tag, payload_hash])
+
+
+# --------------------------------------------------------------------------------------------
+# Trie (arity-8 Poseidon tree).  /root/reference/src/coprocessor/trie/mod.rs
+# --------------------------------------------------------------------------------------------
+def trie_empty_roots(field_id: int, height: int, arity: int = 8) -> list[int]:
+    """init_empty (:464-481): empty_roots[0]=hash8([0;8]), empty_roots[i]=hash8([empty_roots[i-1];8])."""
+    roots = []
+    cur = 0
+    for _ in range(height):
+        cur = poseidon_hash(field_id, [cur] * arity)
+        roots.append(cur)
+    return roots
+
+
+def trie_path(field_id: int, key: int, height: int, arity_bits: int = 3) -> list[int]:
+    """path (:589-608): MSB-first bits, keep the last 3*H bits, 3-bit big-endian digits."""
+    nbits = FIELD_NUM_BITS[field_id]
+    le_bits = [(key >> i) & 1 for i in range(nbits)]
+    # to_le_bits() has NUM_BITS rounded up to a multiple of 64 for the underlying repr; the code
+    # reverses then takes the tail, so only the low 3*H bits matter when 3*H <= nbits.
+    be = list(reversed(le_bits))
+    need = arity_bits * height
+    if need > len(be):
+        be = [0] * (need - len(be)) + be
+    tail = be[len(be) - need:]
+    return [int("".join(map(str, tail[i:i + arity_bits])), 2) for i in range(0, need, arity_bits)]
+
+
+def trie_insert_root(field_id: int, height: int, key: int, value: int) -> int:
+    """Root of an otherwise empty StandardTrie after insert(key -> value) (:745-800)."""
+    empty = [0] + trie_empty_roots(field_id, height)  # empty[h] = root of empty subtree of height h
+    path = trie_path(field_id, key, height)
+    cur = value
+    for level, digit in enumerate(reversed(path)):
+        pre = [empty[level]] * 8
+        pre[digit] = cur
+        cur = poseidon_hash(field_id, pre)
+    return cur
+
+
+def dense_tree_levels(field_id: int, leaves: list[int], arity: int = 8) -> list[list[int]]:
+    """Dense analogue of the trie for BASELINE config 3: level l+1 node i =
+    hash8(level l nodes 8i..8i+7).  Returns [leaves, level1, ..., [root]]."""
+    levels = [list(leaves)]
+    cur = levels[0]
+    while len(cur) > 1:
+        assert len(cur) % arity == 0
+        cur = [poseidon_hash(field_id, cur[i:i + arity]) for i in range(0, len(cur), arity)]
+        levels.append(cur)
+    return levels
+
+
+# --------------------------------------------------------------------------------------------
+# Pasta curves: y^2 = x^3 + 5 over Fp (Pallas, order q) and over Fq (Vesta, order p).
+# Generator (-1, 2) on both (pasta_curves).  Affine identity is encoded (0,0) (repr-c layout,
+# /root/reference/Cargo.toml:42).
+# --------------------------------------------------------------------------------------------
+CURVES = {
+    "pallas": dict(p=PALLAS_P, order=PALLAS_Q, b=5, gen=(PALLAS_P - 1, 2)),
+    "vesta": dict(p=PALLAS_Q, order=PALLAS_P, b=5, gen=(PALLAS_Q - 1, 2)),
+}
+IDENTITY = None
+
+
+def ec_add(curve: str, P, Q):
+    p = CURVES[curve]["p"]
+    if P is None:
+        return Q
+    if Q is None:
+        return P
+    x1, y1 = P
+    x2, y2 = Q
+    if x1 == x2:
+        if (y1 + y2) % p == 0:
+            return None
+        lam = 3 * x1 * x1 * pow(2 * y1, p - 2, p) % p
+    else:
+        lam = (y2 - y1) * pow(x2 - x1, p - 2, p) % p
+    x3 = (lam * lam - x1 - x2) % p
+    return x3, (lam * (x1 - x3) - y1) % p
+
+
+def ec_neg(curve: str, P):
+    if P is None:
+        return None
+    return P[0], (-P[1]) % CURVES[curve]["p"]
+
+
+def ec_mul(curve: str, k: int, P):
+    k %= CURVES[curve]["order"]
+    R = None
+    while k:
+        if k & 1:
+            R = ec_add(curve, R, P)
+        P = ec_add(curve, P, P)
+        k >>= 1
+    return R
+
+
+def ec_on_curve(curve: str, P) -> bool:
+    if P is None:
+        return True
+    p = CURVES[curve]["p"]
+    x, y = P
+    return (y * y - x * x * x - CURVES[curve]["b"]) % p == 0
+
+
+def msm_naive(curve: str, scalars: list[int], points: list) -> object:
+    """Pedersen commit = sum s_i * P_i (arecibo CommitmentEngine::commit ->
+    vartime_multiscalar_mul; caller /root/reference/src/proof/nova.rs:287-293)."""
+    acc = None
+    for s, P in zip(scalars, points):
+        acc = ec_add(curve, acc, ec_mul(curve, s, P))
+    return acc
+
+
+def synth_base_scalar(i: int, order: int) -> int:
+    """Discrete log k_i of synthetic base i (P_i = [k_i]G), stream 0."""
+    return uniform_fe(0, i, order) or 1
+
+
+def synth_bases(curve: str, n: int) -> list:
+    G = CURVES[curve]["gen"]
+    return [ec_mul(curve, synth_base_scalar(i, CURVES[curve]["order"]), G) for i in range(n)]
+
+
+# --------------------------------------------------------------------------------------------
+# NTT over a Pasta field (2-adicity 32, multiplicative generator 5).  PARITY UNPINNED.
+# --------------------------------------------------------------------------------------------
+def root_of_unity(p: int, log_n: int) -> int:
+    assert (p - 1) % (1 << 32) == 0 and log_n <= 32
+    w = pow(5, (p - 1) >> 32, p)  # primitive 2^32-th root
+    return pow(w, 1 << (32 - log_n), p)
+
+
+def dft_naive(p: int, a: list[int], inverse: bool = False) -> list[int]:
+    n = len(a)
+    log_n = n.bit_length() - 1
+    w = root_of_unity(p, log_n)
+    if inverse:
+        w = pow(w, p - 2, p)
+    out = [sum(a[j] * pow(w, (i * j) % n, p) for j in range(n)) % p for i in range(n)]
+    if inverse:
+        ninv = pow(n, p - 2, p)
+        out = [x * ninv % p for x in out]
+    return out
+
+
+def ntt_recursive(p: int, a: list[int], inverse: bool = False) -> list[int]:
+    n = len(a)
+    log_n = n.bit_length() - 1
+    w = root_of_unity(p, log_n)
+    if inverse:
+        w = pow(w, p - 2, p)
+
+    def rec(v, w):
+        m = len(v)
+        if m == 1:
+            return v
+        e = rec(v[0::2], w * w % p)
+        o = rec(v[1::2], w * w % p)
+        out = [0] * m
+        x = 1
+        for i in range(m // 2):
+            tw = x * o[i] % p
+            out[i] = (e[i] + tw) % p
+            out[i + m // 2] = (e[i] - tw) % p
+            x = x * w % p
+        return out
+
+    out = rec(list(a), w)
+    if inverse:
+        ninv = pow(n, p - 2, p)
+        out = [x * ninv % p for x in out]
+    return out
