@@ -1,0 +1,200 @@
+"""ctypes binding of oracle/liblurk_oracle.so (the fast C oracle).  TEST INFRASTRUCTURE ONLY -
+see the header of oracle/oracle.c.  Arrays are numpy uint64, 4 little-endian limbs per element."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from . import pyref
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblurk_oracle.so")
+_lib = None
+
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_SO)
+        _lib.orc_on_curve_affine_mont.restype = ctypes.c_int
+        _lib.orc_num_threads.restype = ctypes.c_int
+    return _lib
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def ints_to_limbs(vals) -> np.ndarray:
+    """list of Python ints -> (n,4) uint64 limbs."""
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        for w in range(4):
+            out[i, w] = (int(v) >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def limbs_to_ints(a: np.ndarray) -> list[int]:
+    a = np.ascontiguousarray(a, dtype=np.uint64).reshape(-1, 4)
+    return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in a]
+
+
+def to_mont(field: int, a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_to_mont(field, _p(a), _p(out), ctypes.c_size_t(a.size // 4))
+    return out
+
+
+def from_mont(field: int, a: np.ndarray) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_from_mont(field, _p(a), _p(out), ctypes.c_size_t(a.size // 4))
+    return out
+
+
+def dot(field: int, a: np.ndarray, b: np.ndarray) -> int:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    lib().orc_dot_canonical(field, _p(a), _p(b), ctypes.c_size_t(a.size // 4), _p(out))
+    return limbs_to_ints(out)[0]
+
+
+def synth_scalars(field: int, stream: int, dist: int, n: int, first: int = 0) -> np.ndarray:
+    out = np.empty((n, 4), dtype=np.uint64)
+    lib().orc_synth_scalars(field, ctypes.c_uint64(stream), dist, ctypes.c_size_t(first), ctypes.c_size_t(n), _p(out))
+    return out
+
+
+def synth_base_scalars(curve: int, n: int, first: int = 0) -> np.ndarray:
+    out = np.empty((n, 4), dtype=np.uint64)
+    lib().orc_synth_base_scalars(curve, ctypes.c_size_t(first), ctypes.c_size_t(n), _p(out))
+    return out
+
+
+def fixed_base_mul(curve: int, k: np.ndarray) -> np.ndarray:
+    """[k_i]G -> affine Montgomery (n, 8)."""
+    k = np.ascontiguousarray(k, dtype=np.uint64)
+    n = k.size // 4
+    out = np.empty((n, 8), dtype=np.uint64)
+    lib().orc_fixed_base_mul(curve, _p(k), ctypes.c_size_t(n), _p(out))
+    return out
+
+
+def synth_bases(curve: int, n: int, first: int = 0) -> np.ndarray:
+    return fixed_base_mul(curve, synth_base_scalars(curve, n, first))
+
+
+_POS_CACHE = {}
+
+
+def poseidon_consts(field: int, arity: int):
+    key = (field, arity)
+    if key not in _POS_CACHE:
+        rf, rp = pyref.round_numbers(arity)
+        rc = ints_to_limbs(pyref.round_constants(field, arity))
+        mds = ints_to_limbs([x for row in pyref.mds_matrix(field, arity) for x in row])
+        _POS_CACHE[key] = (rf, rp, rc, mds)
+    return _POS_CACHE[key]
+
+
+def poseidon_batch(field: int, arity: int, preimages: np.ndarray) -> np.ndarray:
+    """preimages (n, arity, 4) canonical -> digests (n, 4) canonical."""
+    pre = np.ascontiguousarray(preimages, dtype=np.uint64)
+    n = pre.size // (4 * arity)
+    rf, rp, rc, mds = poseidon_consts(field, arity)
+    out = np.empty((n, 4), dtype=np.uint64)
+    lib().orc_poseidon_batch(field, arity, rf, rp, _p(rc), _p(mds), _p(pre), ctypes.c_size_t(n), _p(out))
+    return out
+
+
+def poseidon_tree8(field: int, leaves: np.ndarray, want_levels: bool = False):
+    leaves = np.ascontiguousarray(leaves, dtype=np.uint64)
+    n = leaves.size // 4
+    rf, rp, rc, mds = poseidon_consts(field, 8)
+    root = np.empty(4, dtype=np.uint64)
+    total = 0
+    m = n
+    while m > 1:
+        m //= 8
+        total += m
+    levels = np.empty((total, 4), dtype=np.uint64) if want_levels else None
+    lib().orc_poseidon_tree8(field, rf, rp, _p(rc), _p(mds), _p(leaves), ctypes.c_size_t(n), _p(root),
+                             _p(levels) if want_levels else None)
+    return (root, levels) if want_levels else root
+
+
+def msm_naive(curve: int, bases: np.ndarray, scalars: np.ndarray) -> np.ndarray:
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.empty(12, dtype=np.uint64)
+    lib().orc_msm_naive(curve, _p(bases), _p(scalars), ctypes.c_size_t(scalars.size // 4), _p(out))
+    return out
+
+
+def msm_pippenger(curve: int, bases: np.ndarray, scalars: np.ndarray, nthreads: int = 0) -> np.ndarray:
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.empty(12, dtype=np.uint64)
+    if nthreads <= 0:
+        nthreads = lib().orc_num_threads()
+    lib().orc_msm_pippenger(curve, _p(bases), _p(scalars), ctypes.c_size_t(scalars.size // 4), nthreads, _p(out))
+    return out
+
+
+def jac_to_affine(curve: int, jac: np.ndarray) -> tuple[int, int]:
+    """Jacobian Montgomery (12 limbs) -> canonical affine (x, y) ints; identity -> (0, 0)."""
+    jac = np.ascontiguousarray(jac, dtype=np.uint64)
+    out = np.empty(8, dtype=np.uint64)
+    lib().orc_jac_mont_to_affine_canonical(curve, _p(jac), _p(out))
+    x, y = limbs_to_ints(out)
+    return x, y
+
+
+def affine_to_ints(curve: int, aff_mont: np.ndarray) -> list[tuple[int, int]]:
+    aff_mont = np.ascontiguousarray(aff_mont, dtype=np.uint64)
+    n = aff_mont.size // 8
+    out = np.empty_like(aff_mont)
+    lib().orc_affine_mont_to_canonical(curve, _p(aff_mont), _p(out), ctypes.c_size_t(n))
+    v = limbs_to_ints(out)
+    return [(v[2 * i], v[2 * i + 1]) for i in range(n)]
+
+
+def on_curve(curve: int, aff_mont: np.ndarray) -> bool:
+    aff_mont = np.ascontiguousarray(aff_mont, dtype=np.uint64).reshape(-1, 8)
+    return all(lib().orc_on_curve_affine_mont(curve, _p(np.ascontiguousarray(r))) for r in aff_mont)
+
+
+def gen_mul(curve: int, k: int) -> np.ndarray:
+    out = np.empty(12, dtype=np.uint64)
+    lib().orc_gen_mul(curve, _p(ints_to_limbs([k])), _p(out))
+    return out
+
+
+def jac_add(curve: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    out = np.empty(12, dtype=np.uint64)
+    lib().orc_jac_add(curve, _p(np.ascontiguousarray(a, dtype=np.uint64)), _p(np.ascontiguousarray(b, dtype=np.uint64)), _p(out))
+    return out
+
+
+def ntt(field: int, data: np.ndarray, inverse: bool = False) -> np.ndarray:
+    a = np.array(data, dtype=np.uint64, copy=True).reshape(-1, 4)
+    log_n = int(a.shape[0]).bit_length() - 1
+    assert 1 << log_n == a.shape[0]
+    lib().orc_ntt(field, _p(a), log_n, int(inverse))
+    return a
