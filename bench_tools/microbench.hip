@@ -1,0 +1,178 @@
+// microbench.hip - instruction-rate and field-multiplier probes for gfx950 (tooling, not product).
+// Build: hipcc -O3 -std=c++17 --offload-arch=gfx950 bench_tools/microbench.hip -o bench_tools/microbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <functional>
+#define LURK_MUL_FORCE_INLINE_OFF
+#include "../lurk_beta_amd/csrc/field.cuh"
+using namespace lurk;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
+
+constexpr int ITERS = 4096;
+
+__global__ void k_mad64(uint32_t* out, uint32_t seed) {
+    uint64_t a0 = (uint64_t)(seed + threadIdx.x + 0); uint64_t a1 = (uint64_t)(seed + threadIdx.x + 1); uint64_t a2 = (uint64_t)(seed + threadIdx.x + 2); uint64_t a3 = (uint64_t)(seed + threadIdx.x + 3); uint64_t a4 = (uint64_t)(seed + threadIdx.x + 4); uint64_t a5 = (uint64_t)(seed + threadIdx.x + 5); uint64_t a6 = (uint64_t)(seed + threadIdx.x + 6); uint64_t a7 = (uint64_t)(seed + threadIdx.x + 7);
+    uint32_t x = seed * 3 + threadIdx.x, y = seed * 7 + 1;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_mad_u64_u32 %0, s[20:21], %8, %9, %0\n v_mad_u64_u32 %1, s[20:21], %8, %9, %1\n v_mad_u64_u32 %2, s[20:21], %8, %9, %2\n v_mad_u64_u32 %3, s[20:21], %8, %9, %3\n v_mad_u64_u32 %4, s[20:21], %8, %9, %4\n v_mad_u64_u32 %5, s[20:21], %8, %9, %5\n v_mad_u64_u32 %6, s[20:21], %8, %9, %6\n v_mad_u64_u32 %7, s[20:21], %8, %9, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y) : "s20", "s21");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_mul_lo(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t y = seed * 7 + 1;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n v_mul_lo_u32 %4, %4, %8\n v_mul_lo_u32 %5, %5, %8\n v_mul_lo_u32 %6, %6, %8\n v_mul_lo_u32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_mul_hi(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t y = seed * 7 + 1;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_mul_hi_u32 %0, %0, %8\n v_mul_hi_u32 %1, %1, %8\n v_mul_hi_u32 %2, %2, %8\n v_mul_hi_u32 %3, %3, %8\n v_mul_hi_u32 %4, %4, %8\n v_mul_hi_u32 %5, %5, %8\n v_mul_hi_u32 %6, %6, %8\n v_mul_hi_u32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_mul_u24(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t y = seed * 7 + 1;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_mul_u32_u24_e32 %0, %0, %8\n v_mul_u32_u24_e32 %1, %1, %8\n v_mul_u32_u24_e32 %2, %2, %8\n v_mul_u32_u24_e32 %3, %3, %8\n v_mul_u32_u24_e32 %4, %4, %8\n v_mul_u32_u24_e32 %5, %5, %8\n v_mul_u32_u24_e32 %6, %6, %8\n v_mul_u32_u24_e32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_add_u32(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t y = seed * 7 + 1;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_add_u32_e32 %0, %0, %8\n v_add_u32_e32 %1, %1, %8\n v_add_u32_e32 %2, %2, %8\n v_add_u32_e32 %3, %3, %8\n v_add_u32_e32 %4, %4, %8\n v_add_u32_e32 %5, %5, %8\n v_add_u32_e32 %6, %6, %8\n v_add_u32_e32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_xor(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t y = seed * 7 + 1;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_xor_b32_e32 %0, %0, %8\n v_xor_b32_e32 %1, %1, %8\n v_xor_b32_e32 %2, %2, %8\n v_xor_b32_e32 %3, %3, %8\n v_xor_b32_e32 %4, %4, %8\n v_xor_b32_e32 %5, %5, %8\n v_xor_b32_e32 %6, %6, %8\n v_xor_b32_e32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_fma64(uint32_t* out, uint32_t seed) {
+    double a0 = (double)(seed + threadIdx.x + 0); double a1 = (double)(seed + threadIdx.x + 1); double a2 = (double)(seed + threadIdx.x + 2); double a3 = (double)(seed + threadIdx.x + 3); double a4 = (double)(seed + threadIdx.x + 4); double a5 = (double)(seed + threadIdx.x + 5); double a6 = (double)(seed + threadIdx.x + 6); double a7 = (double)(seed + threadIdx.x + 7);
+    double x = 1.0000001, y = 1e-9;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %1, %1, %8, %9\n v_fma_f64 %2, %2, %8, %9\n v_fma_f64 %3, %3, %8, %9\n v_fma_f64 %4, %4, %8, %9\n v_fma_f64 %5, %5, %8, %9\n v_fma_f64 %6, %6, %8, %9\n v_fma_f64 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
+}
+__global__ void k_lshl_add64(uint32_t* out, uint32_t seed) {
+    uint64_t a0 = (uint64_t)(seed + threadIdx.x + 0); uint64_t a1 = (uint64_t)(seed + threadIdx.x + 1); uint64_t a2 = (uint64_t)(seed + threadIdx.x + 2); uint64_t a3 = (uint64_t)(seed + threadIdx.x + 3); uint64_t a4 = (uint64_t)(seed + threadIdx.x + 4); uint64_t a5 = (uint64_t)(seed + threadIdx.x + 5); uint64_t a6 = (uint64_t)(seed + threadIdx.x + 6); uint64_t a7 = (uint64_t)(seed + threadIdx.x + 7);
+    uint64_t y = seed * 7 + 1;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %8\n v_lshl_add_u64 %1, %1, 0, %8\n v_lshl_add_u64 %2, %2, 0, %8\n v_lshl_add_u64 %3, %3, 0, %8\n v_lshl_add_u64 %4, %4, 0, %8\n v_lshl_add_u64 %5, %5, 0, %8\n v_lshl_add_u64 %6, %6, 0, %8\n v_lshl_add_u64 %7, %7, 0, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_mad_addc(uint32_t* out, uint32_t seed) {
+    uint64_t a0 = seed + threadIdx.x; uint32_t h = 0; uint32_t x = seed * 3 + threadIdx.x, y = seed * 7 + 1;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_mad_u64_u32 %0, s[20:21], %2, %3, %0\n v_mad_u64_u32 %0, s[22:23], %2, %3, %0\n v_mad_u64_u32 %0, s[24:25], %2, %3, %0\n v_mad_u64_u32 %0, s[26:27], %2, %3, %0\n"
+                     "v_addc_co_u32_e64 %1, vcc, 0, %1, s[20:21]\n v_addc_co_u32_e64 %1, vcc, 0, %1, s[22:23]\n v_addc_co_u32_e64 %1, vcc, 0, %1, s[24:25]\n v_addc_co_u32_e64 %1, vcc, 0, %1, s[26:27]\n"
+                     "v_mad_u64_u32 %0, s[20:21], %2, %3, %0\n v_mad_u64_u32 %0, s[22:23], %2, %3, %0\n v_mad_u64_u32 %0, s[24:25], %2, %3, %0\n v_mad_u64_u32 %0, s[26:27], %2, %3, %0\n"
+                     "v_addc_co_u32_e64 %1, vcc, 0, %1, s[20:21]\n v_addc_co_u32_e64 %1, vcc, 0, %1, s[22:23]\n v_addc_co_u32_e64 %1, vcc, 0, %1, s[24:25]\n v_addc_co_u32_e64 %1, vcc, 0, %1, s[26:27]\n"
+                     : "+v"(a0), "+v"(h) : "v"(x), "v"(y) : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a0 ^ h;
+}
+
+template <class P, int IMPL>
+__global__ void k_femul(const Fe<P>* in, Fe<P>* out, int iters) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    Fe<P> x = in[2 * i], y = in[2 * i + 1];
+    for (int k = 0; k < iters; k++) {
+        if (IMPL == 0) x = fe_mul_cios<P>(x, y);
+        else if (IMPL == 1) x = fe_mul_fips<P>(x, y);
+        else x = fe_mul_call<P>(x, y);
+    }
+    out[i] = x;
+}
+template <class P>
+__global__ void k_feadd(const Fe<P>* in, Fe<P>* out, int iters) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    Fe<P> x = in[2 * i], y = in[2 * i + 1];
+    for (int k = 0; k < iters; k++) { x = fe_add<P>(x, y); y = fe_sub<P>(y, x); }
+    out[i] = fe_add<P>(x, y);
+}
+
+static double time_kernel(std::function<void()> f, int reps = 3) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    f();
+    CK(hipDeviceSynchronize());
+    double best = 1e30;
+    for (int r = 0; r < reps; r++) {
+        CK(hipEventRecord(a)); f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        if (ms < best) best = ms;
+    }
+    return best;
+}
+
+int main() {
+    hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
+    printf("device %s, %d CUs, clock %d MHz\n", prop.gcnArchName, prop.multiProcessorCount, prop.clockRate / 1000);
+    const int blocks = prop.multiProcessorCount * 16, threads = 256;
+    uint32_t* d_out; CK(hipMalloc(&d_out, (size_t)blocks * threads * 4));
+    double waves = (double)blocks * threads / 64;
+#define RUN_PROBE(K, PER_ITER, LABEL) { double ms = time_kernel([&] { hipLaunchKernelGGL(K, dim3(blocks), dim3(threads), 0, 0, d_out, 12345u); }); \
+        double winstr = waves * ITERS * PER_ITER; printf("%-22s %8.3f ms  %8.2f G wave-instr/s  %7.2f T lane-ops/s  (%.2f cyc/wave-instr/SIMD @2.4GHz)\n", LABEL, ms, winstr / ms / 1e6, winstr * 64 / ms / 1e9, \
+        2.4e9 * (ms / 1e3) * prop.multiProcessorCount * 4 / winstr); }
+    RUN_PROBE(k_mad64, 8, "v_mad_u64_u32");
+    RUN_PROBE(k_mul_lo, 8, "v_mul_lo_u32");
+    RUN_PROBE(k_mul_hi, 8, "v_mul_hi_u32");
+    RUN_PROBE(k_mul_u24, 8, "v_mul_u32_u24");
+    RUN_PROBE(k_add_u32, 8, "v_add_u32");
+    RUN_PROBE(k_xor, 8, "v_xor_b32");
+    RUN_PROBE(k_fma64, 8, "v_fma_f64");
+    RUN_PROBE(k_lshl_add64, 8, "v_lshl_add_u64");
+    RUN_PROBE(k_mad_addc, 16, "mad+addc (dep chain)");
+
+    // field multiplier variants
+    size_t n = (size_t)blocks * threads;
+    std::vector<uint32_t> h(n * 16);
+    uint64_t s = 88172645463325252ull;
+    for (auto& w : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; w = (uint32_t)s; }
+    for (size_t i = 0; i < n * 2; i++) h[i * 8 + 7] &= 0x1fffffff;  // < every modulus
+    void *d_in, *d_o0, *d_o1, *d_o2;
+    CK(hipMalloc(&d_in, n * 64)); CK(hipMalloc(&d_o0, n * 32)); CK(hipMalloc(&d_o1, n * 32)); CK(hipMalloc(&d_o2, n * 32));
+    CK(hipMemcpy(d_in, h.data(), n * 64, hipMemcpyHostToDevice));
+    const int MI = 512;
+#define RUN_MUL(P, IMPL, OUT, LABEL) { double ms = time_kernel([&] { hipLaunchKernelGGL((k_femul<P, IMPL>), dim3(blocks), dim3(threads), 0, 0, (const Fe<P>*)d_in, (Fe<P>*)OUT, MI); }); \
+        printf("%-28s %8.3f ms  %8.2f G field-mul/s\n", LABEL, ms, (double)n * MI / ms / 1e6); }
+    RUN_MUL(PallasFp, 0, d_o0, "fe_mul Pallas cios(compiler)");
+    RUN_MUL(PallasFp, 1, d_o1, "fe_mul Pallas fips(asm)");
+    RUN_MUL(PallasFp, 2, d_o2, "fe_mul Pallas fips noinline");
+    {
+        std::vector<uint32_t> r0(n * 8), r1(n * 8), r2(n * 8);
+        CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r2.data(), d_o2, n * 32, hipMemcpyDeviceToHost));
+        size_t bad1 = 0, bad2 = 0;
+        for (size_t i = 0; i < n * 8; i++) { bad1 += r0[i] != r1[i]; bad2 += r0[i] != r2[i]; }
+        printf("  Pallas: fips vs cios mismatching words: %zu, noinline vs cios: %zu (of %zu)\n", bad1, bad2, n * 8);
+    }
+    RUN_MUL(Bn254Fr, 0, d_o0, "fe_mul BN254 cios(compiler)");
+    RUN_MUL(Bn254Fr, 1, d_o1, "fe_mul BN254 fips(asm)");
+    {
+        std::vector<uint32_t> r0(n * 8), r1(n * 8);
+        CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost));
+        size_t bad1 = 0;
+        for (size_t i = 0; i < n * 8; i++) bad1 += r0[i] != r1[i];
+        printf("  BN254: fips vs cios mismatching words: %zu (of %zu)\n", bad1, n * 8);
+    }
+    { double ms = time_kernel([&] { hipLaunchKernelGGL((k_feadd<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o0, MI); });
+      printf("%-28s %8.3f ms  %8.2f G field-add-or-sub/s\n", "fe_add+fe_sub Pallas", ms, (double)n * MI * 2 / ms / 1e6); }
+    return 0;
+}

@@ -1,0 +1,143 @@
+/*
+ * lurk_hip.h - C ABI of liblurk_hip.so: the MI355X (gfx950) proving hot path for Lurk.
+ *
+ * This is the drop-in boundary.  lurk-beta has no backend plugin registry; the seam is one level
+ * below its Rust generics, where arecibo calls the `pasta-msm` C symbols and where lurk-beta's
+ * PoseidonCache calls neptune.  Every entry point below names the
+ * reference interface it replaces.  Conventions kept from that seam:
+ *   - plain pointers and sizes only; the caller owns every buffer, borrowed for the call;
+ *   - field elements are 32 bytes, 4 x u64 little-endian limbs;
+ *   - curve points use the pasta_curves `repr-c` layouts (/root/reference/Cargo.toml:42):
+ *       affine  {x, y}      64 B, Montgomery form, identity = (0, 0)
+ *       jacobian{x, y, z}   96 B, Montgomery form, identity has z = 0
+ *   - scalars handed to the MSM are Montgomery form when is_mont != 0 (how pasta_curves stores
+ *     them in memory), canonical integers otherwise;
+ *   - Poseidon / NTT take and return canonical bytes (`PrimeField::to_repr()`,
+ *     /root/reference/src/field.rs:72-75);
+ *   - every function returns 0 on success, non-zero on failure; lurk_hip_last_error() then holds
+ *     the message for the calling thread (pasta-msm returns {code, message}; the Rust side panics
+ *     on non-zero).  There is NO CPU fallback: without a usable gfx950 device every compute entry
+ *     point fails with LURK_HIP_ERR_NO_DEVICE.
+ *   - entry points are thread-safe (arecibo commits from rayon worker threads).
+ *   - *_dev variants take device pointers and a hipStream_t (as void*; NULL = default stream) and
+ *     do not synchronise: inputs stay resident in HBM across calls.
+ */
+#ifndef LURK_HIP_H
+#define LURK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* field ids (LurkField instances, /root/reference/src/field.rs:265-279) */
+#define LURK_FIELD_PALLAS_FP 0 /* pasta_curves::Fp  = pallas::Base  = vesta::Scalar */
+#define LURK_FIELD_PALLAS_FQ 1 /* pasta_curves::Fq  = pallas::Scalar = vesta::Base  */
+#define LURK_FIELD_BN254_FR 2  /* halo2curves::bn256::Fr (the field of every KAT in the reference) */
+
+/* curve ids (CurveCycleEquipped engines, /root/reference/src/proof/nova.rs:40-71) */
+#define LURK_CURVE_PALLAS 0
+#define LURK_CURVE_VESTA 1
+
+#define LURK_HIP_OK 0
+#define LURK_HIP_ERR_NO_DEVICE 1
+#define LURK_HIP_ERR_INVALID_ARG 2
+#define LURK_HIP_ERR_HIP 3
+#define LURK_HIP_ERR_OOM 4
+
+/* ---- runtime ---------------------------------------------------------------------------- */
+int lurk_hip_device_count(void);
+const char* lurk_hip_last_error(void);
+const char* lurk_hip_version(void);
+/* bind the calling thread to a device (one process per GPU; the multi-GPU layer calls this) */
+int lurk_hip_set_device(int device);
+/* per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) */
+int lurk_hip_profile_enable(int on);
+int lurk_hip_profile_reset(void);
+/* total milliseconds and launch count recorded for kernels whose name starts with `prefix` */
+int lurk_hip_profile_get(const char* prefix, double* total_ms, uint64_t* launches);
+
+/* ---- Pedersen MSM ------------------------------------------------------------------------
+ * Replaces pasta-msm's
+ *   void mult_pippenger_pallas(pallas_point* out, const pallas_affine* points, size_t npoints,
+ *                              const pallas_scalar* scalars, bool is_mont);        (and _vesta)
+ * reached from arecibo CommitmentEngine::commit -> DlogGroup::vartime_multiscalar_mul, whose
+ * lurk-beta callers are RecursiveSNARK::new / prove_step (/root/reference/src/proof/nova.rs:287-293,
+ * /root/reference/src/proof/supernova.rs:231-244) and PublicParams::setup (nova.rs:205). */
+int lurk_hip_msm_pallas(void* out_jacobian96, const void* bases_affine64, size_t npoints,
+                        const void* scalars32, int is_mont);
+int lurk_hip_msm_vesta(void* out_jacobian96, const void* bases_affine64, size_t npoints,
+                       const void* scalars32, int is_mont);
+
+/* Resident-bases context: the commitment key `ck` is constant for the whole proof
+ * (/root/reference/src/proof/nova.rs:196-216), so it is uploaded once and kept in HBM.
+ * Mirrors the msm-context API of the argumentcomputer pasta-msm fork (init(points) -> ctx,
+ * with(ctx, scalars) -> point).  flags: bit0 = build the per-window precomputed table
+ * (2^(c*k) * P_i for every window k; costs windows x 64 B x npoints of HBM). */
+typedef struct lurk_hip_msm_ctx lurk_hip_msm_ctx;
+#define LURK_MSM_FLAG_PRECOMPUTE 1
+int lurk_hip_msm_ctx_create(lurk_hip_msm_ctx** ctx, int curve, const void* bases_affine64,
+                            size_t npoints, int flags);
+/* same, bases already in device memory (borrowed for the lifetime of the ctx unless precomputed) */
+int lurk_hip_msm_ctx_create_dev(lurk_hip_msm_ctx** ctx, int curve, const void* d_bases_affine64,
+                                size_t npoints, int flags, void* stream);
+/* commit to the first nscalars bases: out = sum_i scalars[i] * bases[i]  (nscalars <= npoints,
+ * as CommitmentEngine::commit uses ck[..v.len()]) */
+int lurk_hip_msm_ctx_run(lurk_hip_msm_ctx* ctx, void* out_jacobian96, const void* scalars32,
+                         size_t nscalars, int is_mont);
+/* device scalars in, 96-byte result written to *host* memory out_jacobian96 after the stream
+ * has been synchronised by this call (the result is needed by the host-side transcript) */
+int lurk_hip_msm_ctx_run_dev(lurk_hip_msm_ctx* ctx, void* out_jacobian96, const void* d_scalars32,
+                             size_t nscalars, int is_mont, void* stream);
+/* asynchronous form: enqueue only; result (96 B, Jacobian Montgomery) lands in d_out_jacobian96 */
+int lurk_hip_msm_ctx_enqueue_dev(lurk_hip_msm_ctx* ctx, void* d_out_jacobian96,
+                                 const void* d_scalars32, size_t nscalars, int is_mont, void* stream);
+int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx);
+
+/* Group helpers used by the multi-GPU gather (sum of per-rank partial commitments) and by tests:
+ * out = sum of `count` Jacobian points (host memory, 96 B each). */
+int lurk_hip_point_sum(int curve, void* out_jacobian96, const void* points_jacobian96, size_t count);
+/* Jacobian (Montgomery) -> canonical affine bytes (x, y), 64 B; identity -> all zero */
+int lurk_hip_point_to_affine_canonical(int curve, void* out_xy64, const void* point_jacobian96);
+
+/* ---- Poseidon ----------------------------------------------------------------------------
+ * Replaces neptune's Poseidon::new_with_preimage(preimage, constants).hash() as called by
+ * PoseidonCache::hash3/hash4/hash6/hash8 (/root/reference/src/hash.rs:180-204); constants are
+ * PoseidonConstants::new() (standard strength, Merkle-tree domain tag; hash.rs:59-84).
+ * preimages: n x arity x 32 B canonical; digests: n x 32 B canonical.  arity in {3,4,6,8}
+ * (anything else fails, as HashArity::from panics, hash.rs:19-29). */
+int lurk_hip_poseidon_batch(int field_id, int arity, const void* preimages, size_t n, void* digests);
+int lurk_hip_poseidon_batch_dev(int field_id, int arity, const void* d_preimages, size_t n,
+                                void* d_digests, void* stream);
+/* Dense arity-8 tree (the dense analogue of coprocessor::trie::Trie,
+ * /root/reference/src/coprocessor/trie/mod.rs:434-481): node = hash8(children in index order).
+ * n_leaves must be a power of 8, >= 8.  levels_or_null (if given) receives every internal level,
+ * level 1 first, root last: (n_leaves/8 + n_leaves/64 + ... + 1) x 32 B. */
+int lurk_hip_poseidon_tree8(int field_id, const void* leaves, size_t n_leaves, void* root32,
+                            void* levels_or_null);
+/* device form: d_levels must hold (n_leaves-1)/7 elements (all internal levels, root last) */
+int lurk_hip_poseidon_tree8_dev(int field_id, const void* d_leaves, size_t n_leaves, void* d_levels,
+                                void* stream);
+/* the constants the library generated (canonical): rc has (rf+rp)*(arity+1) elements, mds
+ * (arity+1)^2; pass NULL to query sizes only */
+int lurk_hip_poseidon_constants(int field_id, int arity, int* rf, int* rp, void* rc, void* mds);
+
+/* ---- NTT ---------------------------------------------------------------------------------
+ * No reference counterpart: radix-2 NTT over a Pasta field, natural order in
+ * and out, omega = 5^((p-1)/2^32)^(2^(32-log_n)); inverse includes the 1/n scaling. */
+int lurk_hip_ntt(int field_id, void* inout, unsigned log_n, int inverse);
+int lurk_hip_ntt_dev(int field_id, void* d_inout, unsigned log_n, int inverse, void* stream);
+
+/* ---- synthetic inputs (bench / tests) -------------------------------------
+ * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */
+int lurk_hip_synth_scalars_dev(int field_id, uint64_t stream_id, int dist, size_t first, size_t n,
+                               void* d_out32, int out_mont, void* stream);
+/* bases P_i = [k_i]G, k_i = uniform(stream 0, first+i) (0 -> 1); affine Montgomery, 64 B each */
+int lurk_hip_synth_bases_dev(int curve, size_t first, size_t n, void* d_out_affine64, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LURK_HIP_H */

@@ -1,0 +1,17 @@
+"""lurk_beta_amd - MI355X-native proving hot path for Lurk (Pedersen MSM over the Pasta curves,
+neptune-compatible Poseidon batch/tree, radix-2 NTT) as hand-written gfx950 HIP kernels behind the
+C ABI of include/lurk_hip.h.  This package is the thin host-side mirror of the reference's
+interfaces for that path (PoseidonCache, Trie roots, CommitmentEngine::commit); all arithmetic runs
+in liblurk_hip.so on the GPU - there is no CPU fallback."""
+from . import _lib
+from ._lib import LurkHipError
+
+FIELD_PALLAS_FP, FIELD_PALLAS_FQ, FIELD_BN254_FR = 0, 1, 2
+CURVE_PALLAS, CURVE_VESTA = 0, 1
+
+from .poseidon import PoseidonCache, HashArity, poseidon_batch, poseidon_tree8, poseidon_constants  # noqa: E402
+
+__all__ = [
+    "LurkHipError", "PoseidonCache", "HashArity", "poseidon_batch", "poseidon_tree8", "poseidon_constants",
+    "FIELD_PALLAS_FP", "FIELD_PALLAS_FQ", "FIELD_BN254_FR", "CURVE_PALLAS", "CURVE_VESTA",
+]

@@ -1,0 +1,88 @@
+"""ctypes loader for liblurk_hip.so (the C-ABI drop-in boundary, include/lurk_hip.h).
+
+There is no fallback: if the HIP library has not been built (``python -c 'import
+__graft_entry__ as g; g.build()'`` or ``make -C lurk_beta_amd/csrc``) loading raises, and every
+compute entry point raises ``LurkHipError`` when no gfx950 device is usable."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblurk_hip.so")
+_lib = None
+
+c_void_p, c_size_t, c_int, c_uint, c_u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64
+
+
+class LurkHipError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(message or f"lurk_hip error {code}")
+        self.code = code
+
+
+# every symbol include/lurk_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "lurk_hip_device_count": (c_int, []),
+    "lurk_hip_last_error": (ctypes.c_char_p, []),
+    "lurk_hip_version": (ctypes.c_char_p, []),
+    "lurk_hip_set_device": (c_int, [c_int]),
+    "lurk_hip_profile_enable": (c_int, [c_int]),
+    "lurk_hip_profile_reset": (c_int, []),
+    "lurk_hip_profile_get": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_u64)]),
+    "lurk_hip_msm_pallas": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
+    "lurk_hip_msm_vesta": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
+    "lurk_hip_msm_ctx_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int]),
+    "lurk_hip_msm_ctx_create_dev": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_msm_ctx_run": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "lurk_hip_msm_ctx_run_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_msm_ctx_enqueue_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_msm_ctx_destroy": (c_int, [c_void_p]),
+    "lurk_hip_point_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
+    "lurk_hip_point_to_affine_canonical": (c_int, [c_int, c_void_p, c_void_p]),
+    "lurk_hip_poseidon_batch": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "lurk_hip_poseidon_batch_dev": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_poseidon_tree8": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_poseidon_tree8_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_poseidon_constants": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p]),
+    "lurk_hip_ntt": (c_int, [c_int, c_void_p, c_uint, c_int]),
+    "lurk_hip_ntt_dev": (c_int, [c_int, c_void_p, c_uint, c_int, c_void_p]),
+    "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
+    "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
+}
+
+
+def load():
+    """Load liblurk_hip.so and bind every declared symbol.  Raises if the library is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is not built: the HIP extension is the product path and there is no CPU "
+                "fallback.  Build it with `make -C lurk_beta_amd/csrc` (hipcc, gfx950)."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            if os.environ.get("LURK_HIP_PARTIAL") and not hasattr(lib, name):
+                continue  # development only: a partially built library
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise LurkHipError(rc, load().lurk_hip_last_error().decode())
+
+
+def ptr(x) -> c_void_p:
+    """Pointer of a numpy array (host) or a torch tensor (host or device) or a raw int."""
+    if x is None:
+        return c_void_p(0)
+    if isinstance(x, int):
+        return c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return c_void_p(x.data_ptr())
+    return c_void_p(x.ctypes.data)

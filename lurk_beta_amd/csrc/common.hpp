@@ -1,0 +1,133 @@
+// common.hpp - host runtime glue shared by the .hip translation units of liblurk_hip.so:
+// error reporting behind the C ABI, device selection, RAII device memory, per-kernel HIP-event
+// timing on the launch stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/lurk_hip.h"
+
+namespace lurk {
+
+// thread-local last error (lurk_hip_last_error)
+void set_error(int code, const std::string& msg);
+int last_error_code();
+
+struct HipFailure {
+    int code;
+    std::string msg;
+};
+
+#define LURK_HIP_CHECK(expr)                                                                              \
+    do {                                                                                                  \
+        hipError_t _e = (expr);                                                                           \
+        if (_e != hipSuccess) {                                                                           \
+            throw ::lurk::HipFailure{_e == hipErrorOutOfMemory ? LURK_HIP_ERR_OOM : LURK_HIP_ERR_HIP,     \
+                                     std::string(#expr) + ": " + hipGetErrorString(_e)};                 \
+        }                                                                                                 \
+    } while (0)
+
+#define LURK_REQUIRE(cond, msg)                                                       \
+    do {                                                                              \
+        if (!(cond)) throw ::lurk::HipFailure{LURK_HIP_ERR_INVALID_ARG, std::string(msg)}; \
+    } while (0)
+
+// Fails loudly (no CPU fallback) unless a gfx950 device is usable.
+void require_device();
+
+// Wraps the body of a C-ABI entry point: converts exceptions to error codes.
+template <class F>
+int guarded(F&& f) {
+    try {
+        require_device();
+        f();
+        set_error(0, "");
+        return 0;
+    } catch (const HipFailure& e) {
+        set_error(e.code, e.msg);
+        return e.code;
+    } catch (const std::exception& e) {
+        set_error(LURK_HIP_ERR_HIP, e.what());
+        return LURK_HIP_ERR_HIP;
+    }
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t n) { alloc(n); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { release(); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; }
+        return *this;
+    }
+    ~DevBuf() { release(); }
+    void alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        LURK_HIP_CHECK(hipMalloc(&p, n));
+        bytes = n;
+    }
+    void ensure(size_t n) {
+        if (n > bytes) alloc(n);
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// ---- per-kernel timing -------------------------------------------------------------------
+// When enabled, launches go through Profiler::Scope which records a HIP event pair on the launch
+// stream around the kernel; totals are resolved lazily (events are synchronised on query).
+class Profiler {
+  public:
+    static Profiler& get();
+    void enable(bool on) { enabled_ = on; }
+    bool enabled() const { return enabled_; }
+    void reset();
+    void begin(const char* name, hipStream_t s);
+    void end(hipStream_t s);
+    void query(const char* prefix, double* total_ms, uint64_t* launches);
+
+  private:
+    struct Rec { std::string name; hipEvent_t a, b; };
+    std::mutex mu_;
+    bool enabled_ = false;
+    std::vector<Rec> recs_;
+    std::vector<hipEvent_t> pool_;
+    hipEvent_t open_a_ = nullptr;
+    std::string open_name_;
+    std::map<std::string, std::pair<double, uint64_t>> done_;
+    hipEvent_t get_event();
+};
+
+struct ProfScope {
+    hipStream_t s;
+    bool on;
+    ProfScope(const char* name, hipStream_t st) : s(st), on(Profiler::get().enabled()) {
+        if (on) Profiler::get().begin(name, s);
+    }
+    ~ProfScope() {
+        if (on) Profiler::get().end(s);
+    }
+};
+
+inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+int num_cus();  // multiprocessor count of the current device
+
+}  // namespace lurk

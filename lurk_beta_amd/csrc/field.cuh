@@ -1,0 +1,385 @@
+// field.cuh - 255-bit prime-field arithmetic for gfx950 (and for the host code of the library).
+//
+// Representation: 8 x 32-bit little-endian limbs in Montgomery form with R = 2^256.  This is
+// byte-identical to the 4 x u64 `[u64;4]` Montgomery representation pasta_curves / halo2curves
+// use, so commitment keys and witness vectors cross the C ABI without
+// conversion (what arecibo hands to pasta-msm, /root/reference/src/proof/nova.rs:287-293).
+//
+// The same header compiles for the device (hipcc, gfx950) and for the host side of the library;
+// tests/host_harness also builds it with g++ to check it against the oracle without a GPU.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define LURK_HD __host__ __device__ __forceinline__
+#else
+#define LURK_HD inline
+#endif
+
+namespace lurk {
+
+// ------------------------------------------------------------------------------------------
+// Field parameter packs.  All constants are constexpr so that the fully unrolled Montgomery
+// reduction folds the zero / one limbs of the Pasta moduli (p = 2^254 + 126-bit tail:
+// limbs 4..6 are 0, limb 0 is 1, -p^-1 mod 2^32 = -1) into fewer v_mad_u64_u32.
+// ------------------------------------------------------------------------------------------
+struct PallasFp {  // base field of Pallas = scalar field of Vesta
+    static constexpr int ID = 0;
+    static constexpr int NBITS = 255;
+    static constexpr uint32_t INV = 0xffffffffu;
+    LURK_HD static constexpr uint32_t mod(int i) {
+        constexpr uint32_t m[8] = {0x00000001u, 0x992d30edu, 0x094cf91bu, 0x224698fcu, 0x00000000u, 0x00000000u, 0x00000000u, 0x40000000u};
+        return m[i];
+    }
+    LURK_HD static constexpr uint32_t r(int i) {
+        constexpr uint32_t m[8] = {0xfffffffdu, 0x34786d38u, 0xe41914adu, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
+        return m[i];
+    }
+    LURK_HD static constexpr uint32_t r2(int i) {
+        constexpr uint32_t m[8] = {0x0000000fu, 0x8c78ecb3u, 0x8b0de0e7u, 0xd7d30dbdu, 0xc3c95d18u, 0x7797a99bu, 0x7b9cb714u, 0x096d41afu};
+        return m[i];
+    }
+    // 5^((p-1)/2^32): primitive 2^32-th root of unity, Montgomery form
+    LURK_HD static constexpr uint32_t w32(int i) {
+        constexpr uint32_t m[8] = {0xbad6dbf0u, 0xa28db849u, 0xd3b539dfu, 0x9083cd03u, 0x9dc8448eu, 0xfba6b9cau, 0x7b89c6dau, 0x3ec92874u};
+        return m[i];
+    }
+};
+
+struct PallasFq {  // scalar field of Pallas = base field of Vesta; LurkField for the Pallas cycle
+    static constexpr int ID = 1;
+    static constexpr int NBITS = 255;
+    static constexpr uint32_t INV = 0xffffffffu;
+    LURK_HD static constexpr uint32_t mod(int i) {
+        constexpr uint32_t m[8] = {0x00000001u, 0x8c46eb21u, 0x0994a8ddu, 0x224698fcu, 0x00000000u, 0x00000000u, 0x00000000u, 0x40000000u};
+        return m[i];
+    }
+    LURK_HD static constexpr uint32_t r(int i) {
+        constexpr uint32_t m[8] = {0xfffffffdu, 0x5b2b3e9cu, 0xe3420567u, 0x992c350bu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
+        return m[i];
+    }
+    LURK_HD static constexpr uint32_t r2(int i) {
+        constexpr uint32_t m[8] = {0x0000000fu, 0xfc9678ffu, 0x891a16e3u, 0x67bb433du, 0x04ccf590u, 0x7fae2310u, 0x7ccfdaa9u, 0x096d41afu};
+        return m[i];
+    }
+    LURK_HD static constexpr uint32_t w32(int i) {
+        constexpr uint32_t m[8] = {0x8c9942deu, 0x21807742u, 0x21b60494u, 0xcc495789u, 0xb2efbee2u, 0xac2e5d27u, 0x7f2db056u, 0x0b79fa89u};
+        return m[i];
+    }
+};
+
+struct Bn254Fr {  // BN254 scalar field: the field every golden vector of the reference is over
+    static constexpr int ID = 2;
+    static constexpr int NBITS = 254;
+    static constexpr uint32_t INV = 0xefffffffu;
+    LURK_HD static constexpr uint32_t mod(int i) {
+        constexpr uint32_t m[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
+        return m[i];
+    }
+    LURK_HD static constexpr uint32_t r(int i) {
+        constexpr uint32_t m[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u, 0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
+        return m[i];
+    }
+    LURK_HD static constexpr uint32_t r2(int i) {
+        constexpr uint32_t m[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+        return m[i];
+    }
+    LURK_HD static constexpr uint32_t w32(int i) { return 0; }  // NTT is not offered over BN254
+};
+
+// ------------------------------------------------------------------------------------------
+template <class P>
+struct alignas(16) Fe {
+    uint32_t l[8];
+};
+
+template <class P>
+LURK_HD Fe<P> fe_zero() {
+    Fe<P> z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z.l[i] = 0;
+    return z;
+}
+template <class P>
+LURK_HD Fe<P> fe_one() {  // Montgomery 1
+    Fe<P> z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z.l[i] = P::r(i);
+    return z;
+}
+template <class P>
+LURK_HD Fe<P> fe_r2() {
+    Fe<P> z;
+#pragma unroll
+    for (int i = 0; i < 8; i++) z.l[i] = P::r2(i);
+    return z;
+}
+template <class P>
+LURK_HD bool fe_is_zero(const Fe<P>& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.l[i];
+    return o == 0;
+}
+template <class P>
+LURK_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o |= a.l[i] ^ b.l[i];
+    return o == 0;
+}
+
+// r = a - MOD if a >= MOD (a < 2*MOD)
+template <class P>
+LURK_HD void fe_cond_sub(uint32_t* t) {
+    uint32_t d[8];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = (uint64_t)t[i] - P::mod(i) - borrow;
+        d[i] = (uint32_t)x;
+        borrow = (uint32_t)(x >> 63);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = borrow ? t[i] : d[i];
+}
+
+template <class P>
+LURK_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {  // moduli are < 2^255: no carry out of limb 7
+        uint64_t x = (uint64_t)a.l[i] + b.l[i] + c;
+        r.l[i] = (uint32_t)x;
+        c = (uint32_t)(x >> 32);
+    }
+    fe_cond_sub<P>(r.l);
+    return r;
+}
+template <class P>
+LURK_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
+    Fe<P> r;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = (uint64_t)a.l[i] - b.l[i] - borrow;
+        r.l[i] = (uint32_t)x;
+        borrow = (uint32_t)(x >> 63);
+    }
+    uint32_t mask = 0u - borrow, c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = (uint64_t)r.l[i] + (P::mod(i) & mask) + c;
+        r.l[i] = (uint32_t)x;
+        c = (uint32_t)(x >> 32);
+    }
+    return r;
+}
+template <class P>
+LURK_HD Fe<P> fe_neg(const Fe<P>& a) {
+    return fe_sub<P>(fe_zero<P>(), a);
+}
+template <class P>
+LURK_HD Fe<P> fe_dbl(const Fe<P>& a) {
+    return fe_add<P>(a, a);
+}
+
+// ---- Montgomery product, portable form (host code of the library; device variant 0) --------
+// CIOS, 32-bit limbs, 64-bit accumulate.  Valid "no extra carry word" form because every modulus
+// here has its top limb < 2^31 - 1.
+template <class P>
+LURK_HD Fe<P> fe_mul_cios(const Fe<P>& a, const Fe<P>& b) {
+    uint32_t t[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t bi = b.l[i];
+        uint64_t acc = (uint64_t)a.l[0] * bi + t[0];
+        uint32_t m = (uint32_t)acc * P::INV;
+        uint64_t red = (uint64_t)m * P::mod(0) + (uint32_t)acc;
+        uint32_t c1 = (uint32_t)(acc >> 32), c2 = (uint32_t)(red >> 32);
+#pragma unroll
+        for (int j = 1; j < 8; j++) {
+            acc = (uint64_t)a.l[j] * bi + t[j] + c1;
+            c1 = (uint32_t)(acc >> 32);
+            red = (uint64_t)m * P::mod(j) + (uint32_t)acc + c2;
+            c2 = (uint32_t)(red >> 32);
+            t[j - 1] = (uint32_t)red;
+        }
+        t[7] = c1 + c2;
+    }
+    fe_cond_sub<P>(t);
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    return r;
+}
+
+// ---- multiply-accumulate primitives for the column-wise (product scanning) device form ------
+// acc64 += a*b with the carry-out captured as a lane mask in an SGPR pair; the carries of one
+// column are folded into the third accumulator word afterwards (fold_carry).  gfx950 needs two
+// wait states between a VALU writing an SGPR/VCC and a VALU reading it as carry-in, and hipcc does
+// not pad hazards whose producer or consumer is inside an asm statement: deferring the v_addc to
+// the end of the column provides the distance, column_fence() covers the short columns.
+// Host: portable C++ with the same semantics (what tests/host_harness checks vs the oracle).
+LURK_HD void mad_c(uint64_t& acc, uint64_t& carry, uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "v"(b));
+#else
+    uint64_t p = (uint64_t)a * b;
+    acc += p;
+    carry = (acc < p) ? 1u : 0u;
+#endif
+}
+// same with b a wave-uniform constant (modulus limb) held in an SGPR
+LURK_HD void mad_ck(uint64_t& acc, uint64_t& carry, uint32_t a, uint32_t k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %0" : "+v"(acc), "=s"(carry) : "v"(a), "s"(k));
+#else
+    mad_c(acc, carry, a, k);
+#endif
+}
+LURK_HD void column_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_nop 1");
+#endif
+}
+LURK_HD void fold_carry(uint32_t& hi, uint64_t carry) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(hi) : "s"(carry) : "vcc");
+#else
+    hi += (uint32_t)carry;
+#endif
+}
+
+// Montgomery product a*b/R mod p.  Finely-integrated product scanning (column-wise) over 32-bit
+// limbs: 64 v_mad_u64_u32 for a*b plus one per non-trivial modulus limb for the reduction (32 for
+// the Pasta moduli, whose limbs 4..6 are 0 and limb 0 is 1; 64 for BN254).
+template <class P>
+LURK_HD Fe<P> fe_mul_fips(const Fe<P>& a, const Fe<P>& b) {
+    uint32_t m[8], t[8];
+    uint64_t lo = 0;
+    uint32_t hi = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        uint64_t cm[16];
+        int n = 0;
+        const int i0 = k < 8 ? 0 : k - 7, i1 = k < 8 ? k : 7;
+#pragma unroll
+        for (int i = i0; i <= i1; i++) mad_c(lo, cm[n++], a.l[i], b.l[k - i]);
+#pragma unroll
+        for (int i = i0; i <= (k < 8 ? k - 1 : 7); i++)
+            if (P::mod(k - i) != 0) mad_ck(lo, cm[n++], m[i], P::mod(k - i));
+        bool carry_in_one = false;
+        uint32_t c0 = 0;
+        if (k < 8) {
+            c0 = (uint32_t)lo;
+            m[k] = c0 * P::INV;
+            if (P::mod(0) == 1 && P::INV == 0xffffffffu) {
+                carry_in_one = true;  // m[k]*1 only clears the low word and carries iff it was non-zero
+            } else {
+                mad_ck(lo, cm[n++], m[k], P::mod(0));
+            }
+        }
+        column_fence();
+#pragma unroll
+        for (int i = 0; i < n; i++) fold_carry(hi, cm[i]);
+        if (k >= 8) t[k - 8] = (uint32_t)lo;  // after column 15 the overflow word is 0: result < 2p
+        lo = (lo >> 32) | ((uint64_t)hi << 32);
+        if (carry_in_one) lo += (c0 != 0 ? 1u : 0u);
+        hi = 0;
+    }
+    fe_cond_sub<P>(t);
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    return r;
+}
+
+// Device code calls the multiplier as a real function (arguments and result in VGPRs, no scratch):
+// a 255-bit product is ~300 instructions, and kernels such as Poseidon (81 products per dense
+// layer) or the XYZZ point addition would otherwise unroll into code far beyond the 64 KiB
+// instruction cache.  LURK_MUL_IMPL=0 selects the portable CIOS form (compiler-scheduled).
+#ifndef LURK_MUL_IMPL
+#define LURK_MUL_IMPL 1
+#endif
+template <class P>
+LURK_HD Fe<P> fe_mul_inline(const Fe<P>& a, const Fe<P>& b) {
+#if LURK_MUL_IMPL == 0
+    return fe_mul_cios<P>(a, b);
+#else
+    return fe_mul_fips<P>(a, b);
+#endif
+}
+#if defined(__HIPCC__)
+template <class P>
+__device__ __attribute__((noinline)) Fe<P> fe_mul_call(Fe<P> a, Fe<P> b) {
+    return fe_mul_inline<P>(a, b);
+}
+#endif
+template <class P>
+LURK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LURK_MUL_FORCE_INLINE)
+    return fe_mul_call<P>(a, b);
+#else
+    return fe_mul_inline<P>(a, b);
+#endif
+}
+template <class P>
+LURK_HD Fe<P> fe_sqr(const Fe<P>& a) {
+    return fe_mul<P>(a, a);
+}
+
+template <class P>
+LURK_HD Fe<P> fe_to_mont(const Fe<P>& a) {
+    return fe_mul<P>(a, fe_r2<P>());
+}
+template <class P>
+LURK_HD Fe<P> fe_from_mont(const Fe<P>& a) {
+    Fe<P> one = fe_zero<P>();
+    one.l[0] = 1;
+    return fe_mul<P>(a, one);
+}
+template <class P>
+LURK_HD Fe<P> fe_from_u64(uint64_t v) {  // canonical small integer -> Montgomery
+    Fe<P> x = fe_zero<P>();
+    x.l[0] = (uint32_t)v;
+    x.l[1] = (uint32_t)(v >> 32);
+    return fe_to_mont<P>(x);
+}
+
+// a^e, e given as 8 x 32-bit limbs (plain integer)
+template <class P>
+LURK_HD Fe<P> fe_pow(const Fe<P>& a, const uint32_t* e) {
+    Fe<P> acc = fe_one<P>();
+    for (int i = 255; i >= 0; i--) {
+        acc = fe_sqr<P>(acc);
+        if ((e[i >> 5] >> (i & 31)) & 1) acc = fe_mul<P>(acc, a);
+    }
+    return acc;
+}
+template <class P>
+LURK_HD Fe<P> fe_inv(const Fe<P>& a) {  // a^(p-2); 0 -> 0
+    uint32_t e[8];
+    uint32_t borrow = 2;
+    for (int i = 0; i < 8; i++) {
+        uint64_t x = (uint64_t)P::mod(i) - borrow;
+        e[i] = (uint32_t)x;
+        borrow = (uint32_t)(x >> 63);
+    }
+    return fe_pow<P>(a, e);
+}
+
+// canonical integer comparison helper: is the canonical value >= MOD ?
+template <class P>
+LURK_HD bool fe_canonical_ge_mod(const uint32_t* v) {
+    for (int i = 7; i >= 0; i--) {
+        if (v[i] > P::mod(i)) return true;
+        if (v[i] < P::mod(i)) return false;
+    }
+    return true;
+}
+
+}  // namespace lurk

@@ -1,0 +1,227 @@
+// poseidon.hip - Poseidon batch hasher and dense arity-8 tree builder for gfx950.
+//
+// Kernel shape (north_star): one Poseidon state per lane (t x 8 VGPRs), the whole constant image
+// (round constants, MDS, pre-sparse and sparse matrices; <= 40 KiB for t = 9) staged once per
+// workgroup in LDS and read back as wave-uniform broadcasts (every lane of a wave is in the same
+// round, so every ds_read hits one address: conflict-free).  No MFMA: the work is 255-bit modular
+// multiplication on the integer VALU (v_mad_u64_u32), ~2.1k field multiplications per hash8.
+//
+// Replaces: PoseidonCache::hash3/4/6/8 -> neptune Poseidon::hash (/root/reference/src/hash.rs:180-204)
+// and the hash8 tree of coprocessor::trie (/root/reference/src/coprocessor/trie/mod.rs:434-481).
+#include <memory>
+
+#include "common.hpp"
+#include "poseidon.cuh"
+#include "poseidon_params.hpp"
+
+namespace lurk {
+
+constexpr int POSEIDON_BLOCK = 256;
+enum : int { PF_IN_MONT = 1, PF_OUT_MONT = 2 };
+
+template <class P, int T>
+__global__ __launch_bounds__(POSEIDON_BLOCK) void poseidon_batch_kernel(const uint4* __restrict__ pre, uint4* __restrict__ out,
+                                                                          size_t n, const uint4* __restrict__ img, int img_vec4,
+                                                                          int rf, int rp, int flags) {
+    extern __shared__ uint4 lds[];
+    for (int i = threadIdx.x; i < img_vec4; i += POSEIDON_BLOCK) lds[i] = img[i];
+    __syncthreads();
+    const Fe<P>* C = reinterpret_cast<const Fe<P>*>(lds);
+    constexpr int A = T - 1;
+    for (size_t h = (size_t)blockIdx.x * POSEIDON_BLOCK + threadIdx.x; h < n; h += (size_t)gridDim.x * POSEIDON_BLOCK) {
+        Fe<P> s[T];
+        s[0] = C[0];
+        const uint4* src = pre + h * (A * 2);
+#pragma unroll
+        for (int i = 0; i < A; i++) {
+            uint4 lo = src[2 * i], hi = src[2 * i + 1];
+            Fe<P> x;
+            x.l[0] = lo.x; x.l[1] = lo.y; x.l[2] = lo.z; x.l[3] = lo.w;
+            x.l[4] = hi.x; x.l[5] = hi.y; x.l[6] = hi.z; x.l[7] = hi.w;
+            s[i + 1] = (flags & PF_IN_MONT) ? x : fe_to_mont<P>(x);
+        }
+        poseidon_permute<P, T>(s, C, rf, rp);
+        Fe<P> d = (flags & PF_OUT_MONT) ? s[1] : fe_from_mont<P>(s[1]);
+        out[2 * h] = make_uint4(d.l[0], d.l[1], d.l[2], d.l[3]);
+        out[2 * h + 1] = make_uint4(d.l[4], d.l[5], d.l[6], d.l[7]);
+    }
+}
+
+// ---- per-(field, arity) constants, generated on the host once and kept in HBM ---------------
+struct PoseidonConsts {
+    int rf = 0, rp = 0, t = 0;
+    std::vector<uint32_t> rc_canon, mds_canon;  // for lurk_hip_poseidon_constants
+    std::vector<uint32_t> image;
+    std::map<int, DevBuf> dev;  // device id -> image
+};
+static std::mutex g_pc_mu;
+static std::map<std::pair<int, int>, std::unique_ptr<PoseidonConsts>> g_pc;
+
+template <class P>
+static std::unique_ptr<PoseidonConsts> build_consts(int arity) {
+    PoseidonParams<P> pp = make_poseidon_params<P>(arity);
+    auto pc = std::make_unique<PoseidonConsts>();
+    pc->rf = pp.rf;
+    pc->rp = pp.rp;
+    pc->t = pp.t;
+    pc->image = poseidon_device_image<P>(pp);
+    for (auto& x : pp.rc) {
+        Fe<P> c = fe_from_mont<P>(x);
+        for (int i = 0; i < 8; i++) pc->rc_canon.push_back(c.l[i]);
+    }
+    for (auto& x : pp.mds) {
+        Fe<P> c = fe_from_mont<P>(x);
+        for (int i = 0; i < 8; i++) pc->mds_canon.push_back(c.l[i]);
+    }
+    return pc;
+}
+
+static PoseidonConsts& get_consts(int field_id, int arity) {
+    LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+    LURK_REQUIRE(arity == 3 || arity == 4 || arity == 6 || arity == 8, "unsupported arity (must be 3, 4, 6 or 8)");
+    std::lock_guard<std::mutex> lk(g_pc_mu);
+    auto key = std::make_pair(field_id, arity);
+    auto it = g_pc.find(key);
+    if (it == g_pc.end()) {
+        std::unique_ptr<PoseidonConsts> pc;
+        if (field_id == 0) pc = build_consts<PallasFp>(arity);
+        else if (field_id == 1) pc = build_consts<PallasFq>(arity);
+        else pc = build_consts<Bn254Fr>(arity);
+        it = g_pc.emplace(key, std::move(pc)).first;
+    }
+    return *it->second;
+}
+
+static const uint4* device_image(PoseidonConsts& pc, hipStream_t s) {
+    int dev = 0;
+    LURK_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_pc_mu);
+    auto it = pc.dev.find(dev);
+    if (it == pc.dev.end()) {
+        DevBuf b(pc.image.size() * 4);
+        LURK_HIP_CHECK(hipMemcpy(b.p, pc.image.data(), pc.image.size() * 4, hipMemcpyHostToDevice));
+        it = pc.dev.emplace(dev, std::move(b)).first;
+    }
+    return it->second.as<uint4>();
+}
+
+template <class P, int T>
+static void launch_batch(const void* d_pre, void* d_out, size_t n, PoseidonConsts& pc, int flags, hipStream_t s) {
+    if (n == 0) return;
+    const uint4* img = device_image(pc, s);
+    int img_vec4 = (int)(pc.image.size() / 4);
+    size_t lds_bytes = (size_t)img_vec4 * 16;
+    static bool attr_set = false;
+    auto kern = poseidon_batch_kernel<P, T>;
+    LURK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    (void)attr_set;
+    unsigned blocks = div_up(n, POSEIDON_BLOCK);
+    unsigned cap = (unsigned)num_cus() * 2;  // 2 workgroups (8 waves) per CU, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    ProfScope ps("poseidon_batch", s);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(POSEIDON_BLOCK), lds_bytes, s, (const uint4*)d_pre, (uint4*)d_out, n, img, img_vec4,
+                       pc.rf, pc.rp, flags);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+
+template <class P>
+static void launch_batch_f(int arity, const void* d_pre, void* d_out, size_t n, PoseidonConsts& pc, int flags, hipStream_t s) {
+    switch (arity) {
+        case 3: launch_batch<P, 4>(d_pre, d_out, n, pc, flags, s); break;
+        case 4: launch_batch<P, 5>(d_pre, d_out, n, pc, flags, s); break;
+        case 6: launch_batch<P, 7>(d_pre, d_out, n, pc, flags, s); break;
+        case 8: launch_batch<P, 9>(d_pre, d_out, n, pc, flags, s); break;
+    }
+}
+
+void poseidon_batch_device(int field_id, int arity, const void* d_pre, void* d_out, size_t n, int flags, hipStream_t s) {
+    PoseidonConsts& pc = get_consts(field_id, arity);
+    if (field_id == 0) launch_batch_f<PallasFp>(arity, d_pre, d_out, n, pc, flags, s);
+    else if (field_id == 1) launch_batch_f<PallasFq>(arity, d_pre, d_out, n, pc, flags, s);
+    else launch_batch_f<Bn254Fr>(arity, d_pre, d_out, n, pc, flags, s);
+}
+
+static bool is_pow8(size_t n) {
+    if (n < 8) return false;
+    while (n % 8 == 0) n /= 8;
+    return n == 1;
+}
+
+// Level-synchronous tree: every level is one batch launch on the same stream; levels stay in HBM
+// (inner levels are kept in Montgomery form between launches and converted in place at the end
+// only if the caller asked for them... simpler and exact: each level is written canonical).
+void poseidon_tree8_device(int field_id, const void* d_leaves, size_t n_leaves, void* d_levels, hipStream_t s) {
+    LURK_REQUIRE(is_pow8(n_leaves), "n_leaves must be a power of 8 (>= 8)");
+    const char* in = (const char*)d_leaves;
+    char* out = (char*)d_levels;
+    size_t cur = n_leaves;
+    while (cur > 1) {
+        size_t next = cur / 8;
+        poseidon_batch_device(field_id, 8, in, out, next, 0, s);
+        in = out;
+        out += next * 32;
+        cur = next;
+    }
+}
+
+}  // namespace lurk
+
+using namespace lurk;
+
+extern "C" {
+
+int lurk_hip_poseidon_constants(int field_id, int arity, int* rf, int* rp, void* rc, void* mds) {
+    // pure host computation: usable without a device (tests compare it with the oracle on CPU)
+    try {
+        PoseidonConsts& pc = get_consts(field_id, arity);
+        if (rf) *rf = pc.rf;
+        if (rp) *rp = pc.rp;
+        if (rc) memcpy(rc, pc.rc_canon.data(), pc.rc_canon.size() * 4);
+        if (mds) memcpy(mds, pc.mds_canon.data(), pc.mds_canon.size() * 4);
+        set_error(0, "");
+        return 0;
+    } catch (const HipFailure& e) {
+        set_error(e.code, e.msg);
+        return e.code;
+    }
+}
+
+int lurk_hip_poseidon_batch_dev(int field_id, int arity, const void* d_preimages, size_t n, void* d_digests, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(n == 0 || (d_preimages && d_digests), "null buffer");
+        poseidon_batch_device(field_id, arity, d_preimages, d_digests, n, 0, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_poseidon_batch(int field_id, int arity, const void* preimages, size_t n, void* digests) {
+    return guarded([&] {
+        get_consts(field_id, arity);  // validates arguments first
+        if (n == 0) return;
+        LURK_REQUIRE(preimages && digests, "null buffer");
+        DevBuf in(n * arity * 32), out(n * 32);
+        LURK_HIP_CHECK(hipMemcpy(in.p, preimages, n * arity * 32, hipMemcpyHostToDevice));
+        poseidon_batch_device(field_id, arity, in.p, out.p, n, 0, nullptr);
+        LURK_HIP_CHECK(hipMemcpy(digests, out.p, n * 32, hipMemcpyDeviceToHost));
+    });
+}
+
+int lurk_hip_poseidon_tree8_dev(int field_id, const void* d_leaves, size_t n_leaves, void* d_levels, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(d_leaves && d_levels, "null buffer");
+        poseidon_tree8_device(field_id, d_leaves, n_leaves, d_levels, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_poseidon_tree8(int field_id, const void* leaves, size_t n_leaves, void* root32, void* levels_or_null) {
+    return guarded([&] {
+        LURK_REQUIRE(leaves && root32, "null buffer");
+        LURK_REQUIRE(is_pow8(n_leaves), "n_leaves must be a power of 8 (>= 8)");
+        size_t internal = (n_leaves - 1) / 7;
+        DevBuf in(n_leaves * 32), lv(internal * 32);
+        LURK_HIP_CHECK(hipMemcpy(in.p, leaves, n_leaves * 32, hipMemcpyHostToDevice));
+        poseidon_tree8_device(field_id, in.p, n_leaves, lv.p, nullptr);
+        LURK_HIP_CHECK(hipMemcpy(root32, (char*)lv.p + (internal - 1) * 32, 32, hipMemcpyDeviceToHost));
+        if (levels_or_null) LURK_HIP_CHECK(hipMemcpy(levels_or_null, lv.p, internal * 32, hipMemcpyDeviceToHost));
+    });
+}
+}

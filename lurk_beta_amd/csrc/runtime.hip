@@ -1,0 +1,150 @@
+// runtime.hip - error state, device checks, profiler, misc C-ABI entry points.
+#include "common.hpp"
+
+namespace lurk {
+
+static thread_local int tl_code = 0;
+static thread_local std::string tl_msg;
+
+void set_error(int code, const std::string& msg) {
+    tl_code = code;
+    tl_msg = msg;
+}
+int last_error_code() { return tl_code; }
+
+static int g_device_state = -1;  // -1 unknown, 0 none, 1 ok
+static std::string g_device_msg;
+static std::mutex g_device_mu;
+static int g_num_cus = 0;
+
+void require_device() {
+    std::lock_guard<std::mutex> lk(g_device_mu);
+    if (g_device_state < 0) {
+        int n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n == 0) {
+            g_device_state = 0;
+            g_device_msg = std::string("no HIP device available (") + (e != hipSuccess ? hipGetErrorString(e) : "device count 0") +
+                           "); liblurk_hip has no CPU fallback";
+        } else {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            hipDeviceProp_t prop;
+            e = hipGetDeviceProperties(&prop, dev);
+            if (e != hipSuccess) {
+                g_device_state = 0;
+                g_device_msg = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+            } else if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+                g_device_state = 0;
+                g_device_msg = std::string("device is ") + prop.gcnArchName + ", liblurk_hip is built for gfx950 only";
+            } else {
+                g_device_state = 1;
+                g_num_cus = prop.multiProcessorCount;
+            }
+        }
+    }
+    if (g_device_state == 0) throw HipFailure{LURK_HIP_ERR_NO_DEVICE, g_device_msg};
+}
+
+int num_cus() { return g_num_cus > 0 ? g_num_cus : 256; }
+
+Profiler& Profiler::get() {
+    static Profiler p;
+    return p;
+}
+hipEvent_t Profiler::get_event() {
+    if (!pool_.empty()) {
+        hipEvent_t e = pool_.back();
+        pool_.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    LURK_HIP_CHECK(hipEventCreate(&e));
+    return e;
+}
+void Profiler::begin(const char* name, hipStream_t s) {
+    std::lock_guard<std::mutex> lk(mu_);
+    open_a_ = get_event();
+    open_name_ = name;
+    LURK_HIP_CHECK(hipEventRecord(open_a_, s));
+}
+void Profiler::end(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(mu_);
+    hipEvent_t b = get_event();
+    LURK_HIP_CHECK(hipEventRecord(b, s));
+    recs_.push_back({open_name_, open_a_, b});
+    open_a_ = nullptr;
+}
+void Profiler::reset() {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto& r : recs_) {
+        (void)hipEventSynchronize(r.b);
+        pool_.push_back(r.a);
+        pool_.push_back(r.b);
+    }
+    recs_.clear();
+    done_.clear();
+}
+void Profiler::query(const char* prefix, double* total_ms, uint64_t* launches) {
+    std::lock_guard<std::mutex> lk(mu_);
+    for (auto& r : recs_) {
+        LURK_HIP_CHECK(hipEventSynchronize(r.b));
+        float ms = 0;
+        LURK_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        auto& d = done_[r.name];
+        d.first += ms;
+        d.second += 1;
+        pool_.push_back(r.a);
+        pool_.push_back(r.b);
+    }
+    recs_.clear();
+    double tot = 0;
+    uint64_t cnt = 0;
+    size_t pl = strlen(prefix);
+    for (auto& kv : done_)
+        if (kv.first.compare(0, pl, prefix) == 0) {
+            tot += kv.second.first;
+            cnt += kv.second.second;
+        }
+    *total_ms = tot;
+    *launches = cnt;
+}
+
+}  // namespace lurk
+
+using namespace lurk;
+
+extern "C" {
+
+int lurk_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+const char* lurk_hip_last_error(void) {
+    static thread_local std::string copy;
+    if (lurk::last_error_code() == 0) return "";
+    copy = std::string("lurk_hip error ") + std::to_string(lurk::last_error_code()) + ": " + lurk::tl_msg;
+    return copy.c_str();
+}
+const char* lurk_hip_version(void) { return "lurk-hip 0.1 (gfx950)"; }
+
+int lurk_hip_set_device(int device) {
+    return guarded([&] {
+        LURK_HIP_CHECK(hipSetDevice(device));
+    });
+}
+int lurk_hip_profile_enable(int on) {
+    Profiler::get().enable(on != 0);
+    return 0;
+}
+int lurk_hip_profile_reset(void) {
+    return guarded([&] { Profiler::get().reset(); });
+}
+int lurk_hip_profile_get(const char* prefix, double* total_ms, uint64_t* launches) {
+    return guarded([&] {
+        LURK_REQUIRE(prefix && total_ms && launches, "null argument");
+        Profiler::get().query(prefix, total_ms, launches);
+    });
+}
+}

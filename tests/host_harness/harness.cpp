@@ -1,0 +1,82 @@
+// Host-side harness: compiles the library's host/device headers (field.cuh, curve.cuh, ...) with
+// plain g++ so their arithmetic can be checked against the oracle without a GPU.  TEST ONLY: the
+// product never runs these on the CPU; the kernels in lurk_beta_amd/csrc/*.hip are the product.
+#include <stddef.h>
+#include "../../lurk_beta_amd/csrc/field.cuh"
+using namespace lurk;
+
+template <class P>
+static void mul_n(const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n, int op) {
+    for (size_t i = 0; i < n; i++) {
+        Fe<P> x, y, r;
+        for (int k = 0; k < 8; k++) { x.l[k] = a[8 * i + k]; y.l[k] = b[8 * i + k]; }
+        switch (op) {
+            case 0: r = fe_mul<P>(x, y); break;
+            case 1: r = fe_add<P>(x, y); break;
+            case 2: r = fe_sub<P>(x, y); break;
+            case 3: r = fe_sqr<P>(x); break;
+            case 4: r = fe_inv<P>(x); break;
+            case 5: r = fe_to_mont<P>(x); break;
+            case 6: r = fe_from_mont<P>(x); break;
+            case 7: r = fe_neg<P>(x); break;
+            default: r = fe_zero<P>();
+        }
+        for (int k = 0; k < 8; k++) o[8 * i + k] = r.l[k];
+    }
+}
+extern "C" void hh_fe_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
+    if (field == 0) mul_n<PallasFp>(a, b, o, n, op);
+    else if (field == 1) mul_n<PallasFq>(a, b, o, n, op);
+    else mul_n<Bn254Fr>(a, b, o, n, op);
+}
+
+// ---------------------------------------------------------------------------------------------
+#include "../../lurk_beta_amd/csrc/poseidon.cuh"
+#include "../../lurk_beta_amd/csrc/poseidon_params.hpp"
+
+template <class P, int T>
+static void poseidon_n(int mode, const uint32_t* pre, size_t n, uint32_t* out) {
+    PoseidonParams<P> pp = make_poseidon_params<P>(T - 1);
+    std::vector<uint32_t> img = poseidon_device_image<P>(pp);
+    for (size_t h = 0; h < n; h++) {
+        Fe<P> s[T];
+        s[0] = pp.domain_tag;
+        for (int i = 1; i < T; i++) {
+            Fe<P> x;
+            for (int k = 0; k < 8; k++) x.l[k] = pre[(h * (T - 1) + (i - 1)) * 8 + k];
+            s[i] = fe_to_mont<P>(x);
+        }
+        if (mode == 0) poseidon_permute<P, T>(s, (const Fe<P>*)img.data(), pp.rf, pp.rp);
+        else poseidon_permute_plain<P, T>(s, pp.rc.data(), pp.mds.data(), pp.rf, pp.rp);
+        Fe<P> d = fe_from_mont<P>(s[1]);
+        for (int k = 0; k < 8; k++) out[h * 8 + k] = d.l[k];
+    }
+}
+template <class P>
+static void poseidon_f(int arity, int mode, const uint32_t* pre, size_t n, uint32_t* out) {
+    switch (arity) {
+        case 3: poseidon_n<P, 4>(mode, pre, n, out); break;
+        case 4: poseidon_n<P, 5>(mode, pre, n, out); break;
+        case 6: poseidon_n<P, 7>(mode, pre, n, out); break;
+        case 8: poseidon_n<P, 9>(mode, pre, n, out); break;
+    }
+}
+extern "C" void hh_poseidon(int field, int arity, int mode, const uint32_t* pre, size_t n, uint32_t* out) {
+    if (field == 0) poseidon_f<PallasFp>(arity, mode, pre, n, out);
+    else if (field == 1) poseidon_f<PallasFq>(arity, mode, pre, n, out);
+    else poseidon_f<Bn254Fr>(arity, mode, pre, n, out);
+}
+// canonical round constants + mds + (rf, rp) for comparison with the oracle's generator
+template <class P>
+static int params_f(int arity, int* rf, int* rp, uint32_t* rc, uint32_t* mds) {
+    PoseidonParams<P> pp = make_poseidon_params<P>(arity);
+    *rf = pp.rf; *rp = pp.rp;
+    for (size_t i = 0; i < pp.rc.size(); i++) { Fe<P> c = fe_from_mont<P>(pp.rc[i]); for (int k = 0; k < 8; k++) rc[i * 8 + k] = c.l[k]; }
+    for (size_t i = 0; i < pp.mds.size(); i++) { Fe<P> c = fe_from_mont<P>(pp.mds[i]); for (int k = 0; k < 8; k++) mds[i * 8 + k] = c.l[k]; }
+    return (int)pp.rc.size();
+}
+extern "C" int hh_poseidon_params(int field, int arity, int* rf, int* rp, uint32_t* rc, uint32_t* mds) {
+    if (field == 0) return params_f<PallasFp>(arity, rf, rp, rc, mds);
+    if (field == 1) return params_f<PallasFq>(arity, rf, rp, rc, mds);
+    return params_f<Bn254Fr>(arity, rf, rp, rc, mds);
+}

@@ -1,0 +1,58 @@
+"""CPU-only: the library's host/device arithmetic headers (compiled with g++ by tests/host_harness)
+and its host-side Poseidon parameter generation, against the oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import coracle as C
+from oracle import pyref as R
+from tests import host_harness as H
+
+vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)  # noqa: E731
+
+
+def _op(f, o, a, b):
+    A, B = C.ints_to_limbs(a), C.ints_to_limbs(b)
+    O = np.zeros_like(A)
+    H.lib().hh_fe_op(f, o, vp(A), vp(B), vp(O), ctypes.c_size_t(len(a)))
+    return C.limbs_to_ints(O)
+
+
+@pytest.mark.parametrize("f", [0, 1, 2])
+def test_field_ops(f):
+    p = R.modulus(f)
+    Rm = 1 << 256
+    Ri = pow(Rm, -1, p)
+    a = [R.uniform_fe(9, i, p) for i in range(300)] + [0, 1, p - 1, p - 1, 0]
+    b = [R.uniform_fe(10, i, p) for i in range(300)] + [0, p - 1, p - 1, 1, 5]
+    assert _op(f, 0, a, b) == [x * y * Ri % p for x, y in zip(a, b)]
+    assert _op(f, 1, a, b) == [(x + y) % p for x, y in zip(a, b)]
+    assert _op(f, 2, a, b) == [(x - y) % p for x, y in zip(a, b)]
+    assert _op(f, 3, a, b) == [x * x * Ri % p for x in a]
+    assert _op(f, 5, a, b) == [x * Rm % p for x in a]
+    assert _op(f, 6, a, b) == [x * Ri % p for x in a]
+    assert _op(f, 7, a, b) == [(-x) % p for x in a]
+    aa = a[:10] + [0]
+    assert _op(f, 4, aa, aa) == [(pow(x * Ri % p, -1, p) * Rm % p if x else 0) for x in aa]
+
+
+@pytest.mark.parametrize("f", [0, 1, 2])
+@pytest.mark.parametrize("arity", [3, 4, 6, 8])
+def test_poseidon_params_and_sparse_schedule(f, arity):
+    L = H.lib()
+    rf, rp = ctypes.c_int(), ctypes.c_int()
+    rc = np.zeros((700, 4), dtype=np.uint64)
+    mds = np.zeros((81, 4), dtype=np.uint64)
+    n = L.hh_poseidon_params(f, arity, ctypes.byref(rf), ctypes.byref(rp), vp(rc), vp(mds))
+    assert (rf.value, rp.value) == R.round_numbers(arity)
+    assert C.limbs_to_ints(rc[:n]) == list(R.round_constants(f, arity))
+    assert C.limbs_to_ints(mds[: (arity + 1) ** 2]) == [x for r in R.mds_matrix(f, arity) for x in r]
+    p = R.modulus(f)
+    pre = [[R.uniform_fe(2, i * arity + j, p) for j in range(arity)] for i in range(4)] + [[0] * arity, [p - 1] * arity]
+    PRE = C.ints_to_limbs([x for r in pre for x in r])
+    want = C.limbs_to_ints(C.poseidon_batch(f, arity, PRE))
+    for mode in (0, 1):  # 0 = sparse schedule (what the kernel runs), 1 = plain schedule
+        out = np.zeros((len(pre), 4), dtype=np.uint64)
+        L.hh_poseidon(f, arity, mode, vp(PRE), ctypes.c_size_t(len(pre)), vp(out))
+        assert C.limbs_to_ints(out) == want, (f, arity, mode)
