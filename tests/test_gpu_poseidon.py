@@ -66,7 +66,7 @@ def test_tree8_matches_oracle(hip, f, height):
     assert np.array_equal(root, oroot)
     assert np.array_equal(levels, olevels)
     with pytest.raises(LurkHipError):
-        poseidon_tree8(f, leaves[:12])
+        poseidon_tree8(f, np.zeros((12, 4), dtype=np.uint64))  # not a power of 8
 
 
 def test_tree8_empty_roots_are_the_trie_kats(hip):
