@@ -91,9 +91,6 @@ int lurk_hip_msm_ctx_run(lurk_hip_msm_ctx* ctx, void* out_jacobian96, const void
  * has been synchronised by this call (the result is needed by the host-side transcript) */
 int lurk_hip_msm_ctx_run_dev(lurk_hip_msm_ctx* ctx, void* out_jacobian96, const void* d_scalars32,
                              size_t nscalars, int is_mont, void* stream);
-/* asynchronous form: enqueue only; result (96 B, Jacobian Montgomery) lands in d_out_jacobian96 */
-int lurk_hip_msm_ctx_enqueue_dev(lurk_hip_msm_ctx* ctx, void* d_out_jacobian96,
-                                 const void* d_scalars32, size_t nscalars, int is_mont, void* stream);
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx);
 
 /* Group helpers used by the multi-GPU gather (sum of per-rank partial commitments) and by tests:

@@ -1,0 +1,94 @@
+"""Host-side mirror of the Pedersen commitment path over the HIP library.
+
+Mirrors arecibo's ``CommitmentKey`` / ``CommitmentEngine::commit(ck, v)`` =
+``vartime_multiscalar_mul(v, &ck[..v.len()])`` as lurk-beta reaches it through
+``RecursiveSNARK::new`` / ``prove_step`` (/root/reference/src/proof/nova.rs:287-293,
+/root/reference/src/proof/supernova.rs:231-244).  The commitment key is uploaded once and stays
+resident in HBM (``lurk_hip_msm_ctx_*``); ``commit`` streams only the scalars."""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+CURVE_SCALAR_FIELD = {0: 1, 1: 0}  # Pallas scalars live in Fq, Vesta scalars in Fp
+CURVE_BASE_FIELD = {0: 0, 1: 1}
+
+
+def msm(curve: int, bases: np.ndarray, scalars: np.ndarray, is_mont: bool = False) -> np.ndarray:
+    """One-shot ``mult_pippenger_{pallas,vesta}``: host buffers in, 96-byte Jacobian out (12 u64)."""
+    lib = _lib.load()
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    n = scalars.size // 4
+    assert bases.size // 8 == n, "bases and scalars differ in length"
+    out = np.zeros(12, dtype=np.uint64)
+    fn = lib.lurk_hip_msm_pallas if curve == 0 else lib.lurk_hip_msm_vesta
+    _lib.check(fn(_lib.ptr(out), _lib.ptr(bases), n, _lib.ptr(scalars), int(is_mont)))
+    return out
+
+
+def point_to_affine(curve: int, jac: np.ndarray) -> tuple[int, int]:
+    """Jacobian (Montgomery) -> canonical affine (x, y) ints; identity -> (0, 0)."""
+    lib = _lib.load()
+    jac = np.ascontiguousarray(jac, dtype=np.uint64)
+    out = np.zeros(8, dtype=np.uint64)
+    _lib.check(lib.lurk_hip_point_to_affine_canonical(curve, _lib.ptr(out), _lib.ptr(jac)))
+    v = [int(out[4 * k]) | int(out[4 * k + 1]) << 64 | int(out[4 * k + 2]) << 128 | int(out[4 * k + 3]) << 192 for k in range(2)]
+    return v[0], v[1]
+
+
+def point_sum(curve: int, points: np.ndarray) -> np.ndarray:
+    """Sum of Jacobian points (count x 12 u64) -> Jacobian.  Used to fold per-rank partial commitments."""
+    lib = _lib.load()
+    points = np.ascontiguousarray(points, dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
+    _lib.check(lib.lurk_hip_point_sum(curve, _lib.ptr(out), _lib.ptr(points), points.size // 12))
+    return out
+
+
+class CommitmentKey:
+    """Resident commitment key (``ck``): n affine bases kept in HBM for the lifetime of the object."""
+
+    def __init__(self, curve: int, bases, n: int | None = None, precompute: bool = False, device: bool = False, stream=None):
+        lib = _lib.load()
+        self.curve = curve
+        self._ctx = ctypes.c_void_p()
+        flags = 1 if precompute else 0
+        if device:
+            assert n is not None
+            self.n = n
+            self._keepalive = bases  # borrowed device memory must outlive the ctx
+            _lib.check(lib.lurk_hip_msm_ctx_create_dev(ctypes.byref(self._ctx), curve, _lib.ptr(bases), n, flags, _lib.ptr(stream)))
+        else:
+            bases = np.ascontiguousarray(bases, dtype=np.uint64)
+            self.n = bases.size // 8
+            _lib.check(lib.lurk_hip_msm_ctx_create(ctypes.byref(self._ctx), curve, _lib.ptr(bases), self.n, flags))
+
+    def commit(self, scalars: np.ndarray, is_mont: bool = False) -> np.ndarray:
+        """``CE::commit(ck, v)``: host scalars (len <= n) -> Jacobian commitment."""
+        lib = _lib.load()
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.lurk_hip_msm_ctx_run(self._ctx, _lib.ptr(out), _lib.ptr(scalars), scalars.size // 4, int(is_mont)))
+        return out
+
+    def commit_device(self, d_scalars, n: int, is_mont: bool = False, stream=None) -> np.ndarray:
+        """Scalars already resident in HBM (a torch tensor or a raw device pointer)."""
+        lib = _lib.load()
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.lurk_hip_msm_ctx_run_dev(self._ctx, _lib.ptr(out), _lib.ptr(d_scalars), n, int(is_mont), _lib.ptr(stream)))
+        return out
+
+    def close(self):
+        if self._ctx:
+            _lib.load().lurk_hip_msm_ctx_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -80,3 +80,35 @@ extern "C" int hh_poseidon_params(int field, int arity, int* rf, int* rp, uint32
     if (field == 1) return params_f<PallasFq>(arity, rf, rp, rc, mds);
     return params_f<Bn254Fr>(arity, rf, rp, rc, mds);
 }
+
+// ---------------------------------------------------------------------------------------------
+#include "../../lurk_beta_amd/csrc/curve.cuh"
+
+// mode 0: acc = sum (+/-) P_i with xyzz_madd; mode 1: pairwise xyzz_add of xyzz_from_affine;
+// mode 2: sum k_i * P_i with xyzz_mul_small (k_i = signs[i] as small integer).  Output: affine Montgomery.
+template <class P>
+static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, size_t n, uint32_t* out) {
+    Xyzz<P> acc = xyzz_identity<P>();
+    for (size_t i = 0; i < n; i++) {
+        Affine<P> a;
+        for (int k = 0; k < 8; k++) { a.x.l[k] = bases[i * 16 + k]; a.y.l[k] = bases[i * 16 + 8 + k]; }
+        if (mode == 0) xyzz_madd<P>(acc, a, signs[i] != 0);
+        else if (mode == 1) {
+            Xyzz<P> q = xyzz_from_affine<P>(a);
+            if (signs[i]) q.y = fe_neg<P>(q.y);
+            xyzz_add<P>(acc, q);
+        } else {
+            Xyzz<P> q = xyzz_mul_small<P>(xyzz_from_affine<P>(a), signs[i]);
+            xyzz_add<P>(acc, q);
+        }
+    }
+    Affine<P> r = xyzz_to_affine<P>(acc);
+    // round-trip through the Jacobian helpers as well
+    Jacobian<P> j = jacobian_from_affine<P>(r);
+    r = xyzz_to_affine<P>(xyzz_from_jacobian<P>(j));
+    for (int k = 0; k < 8; k++) { out[k] = r.x.l[k]; out[8 + k] = r.y.l[k]; }
+}
+extern "C" void hh_curve_sum(int curve, int mode, const uint32_t* bases, const uint32_t* signs, size_t n, uint32_t* out) {
+    if (curve == 0) curve_sum<PallasFp>(mode, bases, signs, n, out);
+    else curve_sum<PallasFq>(mode, bases, signs, n, out);
+}

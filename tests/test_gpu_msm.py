@@ -1,0 +1,160 @@
+"""Parity of the HIP Pedersen MSM (through the C ABI) against the oracle.  Needs an MI355X.
+
+The reference holds no golden commitment (MSM parity is unpinned), so the
+anchors are: naive double-and-add (oracle/pyref.py, oracle/oracle.c), the oracle's Pippenger, and -
+at BASELINE.json's full sizes - the discrete-log checksum  sum s_i [k_i]G == [sum s_i k_i] G."""
+import numpy as np
+import pytest
+
+from oracle import coracle as C
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+CURVES = [("pallas", 0), ("vesta", 1)]
+
+
+def _sf(c):  # scalar field id of curve c
+    return 1 if c == 0 else 0
+
+
+def test_synth_generators_match_oracle(hip):
+    import torch
+
+    from lurk_beta_amd import synth
+
+    for f in (0, 1, 2):
+        for dist in (0, 1):
+            got = synth.scalars(f, 5, dist, 3000, first=17).cpu().numpy().view(np.uint64)
+            assert np.array_equal(got, C.synth_scalars(f, 5, dist, 3000, first=17)), (f, dist)
+        gm = synth.scalars(f, 5, 0, 100, mont=True).cpu().numpy().view(np.uint64)
+        assert np.array_equal(gm, C.to_mont(f, C.synth_scalars(f, 5, 0, 100)))
+    for c in (0, 1):
+        got = synth.bases(c, 700, first=3).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, C.synth_bases(c, 700, first=3)), c
+        assert C.on_curve(c, got[:50])
+
+
+@pytest.mark.parametrize("cn,c", CURVES)
+@pytest.mark.parametrize("n", [1, 2, 7, 100, 1000])
+def test_small_msm_matches_naive(hip, cn, c, n):
+    from lurk_beta_amd import msm, point_to_affine
+
+    B = C.synth_bases(c, n)
+    S = C.synth_scalars(_sf(c), 1, 0, n)
+    want = C.jac_to_affine(c, C.msm_naive(c, B, S))
+    assert point_to_affine(c, msm(c, B, S, is_mont=False)) == want
+    assert point_to_affine(c, msm(c, B, C.to_mont(_sf(c), S), is_mont=True)) == want
+
+
+def test_pyref_cross_check(hip):
+    """Tiny case against the pure-Python group law (independent of the C oracle)."""
+    from lurk_beta_amd import msm, point_to_affine
+
+    pts = R.synth_bases("pallas", 5)
+    s = [R.uniform_fe(1, i, R.PALLAS_Q) for i in range(5)]
+    B = C.synth_bases(0, 5)
+    assert point_to_affine(0, msm(0, B, C.ints_to_limbs(s))) == R.msm_naive("pallas", s, pts)
+
+
+@pytest.mark.parametrize("cn,c", CURVES)
+def test_edge_cases(hip, cn, c):
+    from lurk_beta_amd import msm, point_to_affine
+
+    q = R.CURVES[cn]["order"]
+    n = 64
+    B = C.synth_bases(c, n)
+    B[1] = 0                      # identity base (0,0)
+    B[3] = B[2]                   # repeated base -> doubling inside a bucket when scalars agree
+    B[5] = B[4]
+    s = [R.uniform_fe(9, i, q) for i in range(n)]
+    s[2] = s[3] = 12345           # same bucket, same point: exercises the doubling branch
+    s[4], s[5] = 777, q - 777     # P and -P in the same bucket: identity mid-chain
+    s[6] = 0
+    s[7] = 1
+    s[8] = q - 1
+    s[9] = 0x8000                 # digit exactly 2^15 (largest positive bucket)
+    s[10] = 0x8001                # first value that recodes to a negative digit with carry
+    s[11] = (1 << 254) | 0xFFFF   # carries rippling from the bottom, top window in use
+    s[12] = int("ffff" * 15, 16) % q
+    S = C.ints_to_limbs(s)
+    want = C.jac_to_affine(c, C.msm_naive(c, B, S))
+    assert point_to_affine(c, msm(c, B, S)) == want
+    # all-zero scalars -> identity, encoded z = 0 / affine (0,0)
+    out = msm(c, B, np.zeros((n, 4), dtype=np.uint64))
+    assert point_to_affine(c, out) == (0, 0) and not out[8:].any()
+    # empty input
+    assert point_to_affine(c, msm(c, np.zeros((0, 8), dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64))) == (0, 0)
+    # every scalar identical: one hot bucket per window (the workgroup tree path)
+    n2 = 5000
+    B2 = C.synth_bases(c, n2)
+    S2 = np.tile(C.ints_to_limbs([s[0]]), (n2, 1))
+    assert point_to_affine(c, msm(c, B2, S2)) == C.jac_to_affine(c, C.msm_pippenger(c, B2, S2))
+    # every base identical and every scalar 1: n * P through the doubling path
+    B3 = np.tile(B[:1], (300, 1))
+    S3 = C.ints_to_limbs([1] * 300)
+    assert point_to_affine(c, msm(c, B3, S3)) == C.jac_to_affine(c, C.msm_naive(c, B3, S3))
+
+
+@pytest.mark.parametrize("dist", [0, 1])
+@pytest.mark.parametrize("log_n", [14, 16])
+def test_medium_msm_matches_oracle_pippenger(hip, dist, log_n):
+    from lurk_beta_amd import msm, point_to_affine
+
+    n = 1 << log_n
+    B = C.synth_bases(0, n)
+    S = C.synth_scalars(1, 1, dist, n)
+    assert point_to_affine(0, msm(0, B, S)) == C.jac_to_affine(0, C.msm_pippenger(0, B, S))
+
+
+def test_commitment_key_prefix_and_precompute(hip):
+    """CE::commit(ck, v) uses ck[..v.len()]; the precomputed-table context must agree bit for bit."""
+    from lurk_beta_amd import CommitmentKey, point_to_affine
+
+    n = 4096
+    B = C.synth_bases(0, n)
+    ck = CommitmentKey(0, B)
+    ckp = CommitmentKey(0, B, precompute=True)
+    for m, dist in ((n, 0), (n, 1), (1000, 0), (1, 0), (0, 0)):
+        S = C.synth_scalars(1, 3, dist, m)
+        want = C.jac_to_affine(0, C.msm_pippenger(0, B[:m], S)) if m else (0, 0)
+        assert point_to_affine(0, ck.commit(S)) == want, (m, dist)
+        assert point_to_affine(0, ckp.commit(S)) == want, ("precompute", m, dist)
+        assert point_to_affine(0, ck.commit(C.to_mont(1, S), is_mont=True)) == want
+    from lurk_beta_amd import LurkHipError
+
+    with pytest.raises(LurkHipError):
+        ck.commit(C.synth_scalars(1, 3, 0, n + 1))
+    ck.close()
+    ckp.close()
+
+
+def test_point_sum(hip):
+    from lurk_beta_amd import msm, point_sum, point_to_affine
+
+    n = 512
+    B = C.synth_bases(0, n)
+    S = C.synth_scalars(1, 4, 0, n)
+    parts = np.stack([msm(0, B[i::4], S[i::4]) for i in range(4)])
+    assert point_to_affine(0, point_sum(0, parts)) == C.jac_to_affine(0, C.msm_pippenger(0, B, S))
+
+
+@pytest.mark.parametrize("log_n,dist,precompute", [(20, 0, False), (20, 1, False), (20, 1, True), (22, 0, False)])
+def test_full_size_dlog_checksum(hip, log_n, dist, precompute):
+    """BASELINE.json sizes (2^20, 2^22): inputs generated in HBM, result checked bit-exactly by the
+    size-independent identity  sum_i s_i [k_i]G = [sum_i s_i k_i mod q] G."""
+    import torch
+
+    from lurk_beta_amd import CommitmentKey, point_to_affine, synth
+
+    n = 1 << log_n
+    d_bases = synth.bases(0, n)
+    d_scalars = synth.scalars(1, 1, dist, n, mont=True)
+    torch.cuda.synchronize()
+    ck = CommitmentKey(0, d_bases, n=n, device=True, precompute=precompute)
+    got = point_to_affine(0, ck.commit_device(d_scalars, n, is_mont=True))
+    k = C.synth_base_scalars(0, n)
+    s = C.synth_scalars(1, 1, dist, n)
+    want = C.jac_to_affine(0, C.gen_mul(0, C.dot(1, k, s)))
+    assert got == want
+    ck.close()

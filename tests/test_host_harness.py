@@ -56,3 +56,34 @@ def test_poseidon_params_and_sparse_schedule(f, arity):
         out = np.zeros((len(pre), 4), dtype=np.uint64)
         L.hh_poseidon(f, arity, mode, vp(PRE), ctypes.c_size_t(len(pre)), vp(out))
         assert C.limbs_to_ints(out) == want, (f, arity, mode)
+
+
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+def test_xyzz_group_law_with_exceptional_cases(cn, c):
+    L = H.lib()
+    B = C.synth_bases(c, 12)
+    B[3] = B[2]          # same point twice in a row -> doubling branch of madd/add
+    B[5] = 0             # identity base
+    B[7] = B[6]          # with opposite signs below -> P + (-P) = identity mid-chain
+    pts = [None if pt == (0, 0) else pt for pt in C.affine_to_ints(c, B)]
+    signs = np.array([0, 1, 0, 0, 1, 0, 0, 1, 0, 1, 1, 0], dtype=np.uint32)
+    want = None
+    for pt, s in zip(pts, signs):
+        want = R.ec_add(cn, want, R.ec_neg(cn, pt) if s else pt)
+    for mode in (0, 1):
+        out = np.zeros(8, dtype=np.uint64)
+        L.hh_curve_sum(c, mode, vp(B), vp(signs), ctypes.c_size_t(12), vp(out))
+        assert C.affine_to_ints(c, out)[0] == want, mode
+    # chain that ends on the identity
+    B2 = np.concatenate([B[:1], B[:1]])
+    out = np.zeros(8, dtype=np.uint64)
+    L.hh_curve_sum(c, 0, vp(B2), vp(np.array([0, 1], dtype=np.uint32)), ctypes.c_size_t(2), vp(out))
+    assert C.affine_to_ints(c, out)[0] == (0, 0)
+    # small-scalar multiples
+    ks = np.array([0, 1, 2, 3, 17, 255, 32768, 65535, 1, 0, 5, 6], dtype=np.uint32)
+    want = None
+    for pt, k in zip(pts, ks):
+        want = R.ec_add(cn, want, R.ec_mul(cn, int(k), pt) if pt else None)
+    out = np.zeros(8, dtype=np.uint64)
+    L.hh_curve_sum(c, 2, vp(B), vp(ks), ctypes.c_size_t(12), vp(out))
+    assert C.affine_to_ints(c, out)[0] == want
