@@ -60,6 +60,14 @@ def load():
                 f"{LIB_PATH} is not built: the HIP extension is the product path and there is no CPU "
                 "fallback.  Build it with `make -C lurk_beta_amd/csrc` (hipcc, gfx950)."
             )
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+        # /opt/rocm's).  Importing torch first makes the dynamic loader bind liblurk_hip.so to that
+        # copy; loading ours first would put two ROCr instances in the process and the second one
+        # cannot open the device.  Without torch the library binds to /opt/rocm's runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             if os.environ.get("LURK_HIP_PARTIAL") and not hasattr(lib, name):
