@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py - Pedersen MSM throughput of the HIP hot path (BASELINE.json metric: "MSM Mscalar-mul/s").
+
+A "step" is one commitment  C = sum_i s_i * ck_i  over Pallas: scalars and the commitment key are
+already resident in HBM when the timed region starts (the PCIe-inclusive rate is noted in
+DESIGN.md, never here).  N = 1: n = 2^log_n points on one GPU (default 2^22, the size the metric
+is quoted at; `--log-n 20` is BASELINE.json configs[1]).  N > 1: one process per GPU, every rank
+owns its own 2^log_n-point shard of an (N * 2^log_n)-point commitment (weak scaling); each step
+ends with the path's real exchange: an RCCL all_gather of the 96-byte partial commitments and the
+group sum on every rank.
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (msm_accumulate): algorithmic
+bytes (96 B/point: 32 B scalar + 64 B base) over its mean launch duration measured with HIP events on
+the launch stream inside the timed region.  `cpu_baseline` times the CPU oracle (a port, not the
+reference: the reference cannot be built here) on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=22)
+    ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
+    ap.add_argument("--precompute", type=int, default=0, help="1 = context with the per-window precomputed table")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-log-n", type=int, default=20)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import lurk_beta_amd as L
+    from lurk_beta_amd import _lib, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    lib = _lib.load()
+    _lib.check(lib.lurk_hip_set_device(local_rank))
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    n = 1 << args.log_n
+    dist_id = 0 if args.dist == "uniform" else 1
+    first = rank * n  # rank r owns points [r*n, (r+1)*n) of the global commitment
+    d_bases = synth.bases(L.CURVE_PALLAS, n, first=first)
+    d_scalars = synth.scalars(L.FIELD_PALLAS_FQ, 1, dist_id, n, first=first, mont=True)
+    torch.cuda.synchronize()
+    ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n, device=True, precompute=bool(args.precompute))
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        part = ck.commit_device(d_scalars, n, is_mont=True, stream=stream)  # 96-byte Jacobian, host
+        if world == 1:
+            return part
+        mine = torch.from_numpy(part.view(np.int64)).cuda()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        pts = torch.stack(gathered).cpu().numpy().view(np.uint64)
+        return L.point_sum(L.CURVE_PALLAS, pts)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        result = step()
+    lib.lurk_hip_profile_enable(1)
+    lib.lurk_hip_profile_reset()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    lib.lurk_hip_profile_enable(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    def prof(prefix):
+        tot, cnt = ctypes.c_double(), ctypes.c_uint64()
+        _lib.check(lib.lurk_hip_profile_get(prefix.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
+        return tot.value, cnt.value
+
+    kernels = {k: prof(k) for k in ("msm_digits", "msm_sort", "msm_accumulate", "msm_finalize", "msm_reduce")}
+
+    if rank == 0:
+        total_points = n * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = total_points / (elapsed / args.steps) / 1e6
+        acc_ms, acc_cnt = kernels["msm_accumulate"]
+        acc_avg_ms = acc_ms / max(acc_cnt, 1)
+        alg_bytes = 96.0 * n  # per launch: one rank's shard
+        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_msm_accumulate.json")
+        if os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as f:
+                    pmc = json.load(f)
+                if pmc.get("log_n") == args.log_n:
+                    traffic = pmc.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MSM Mscalar-mul/s (Pallas Pedersen commitment, bases+scalars resident in HBM)",
+            "value": round(value, 3),
+            "unit": "Mscalar-mul/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8 (255-bit Montgomery, integer VALU)",
+            "data": "synthetic",
+            "config": {
+                "workload": f"2^{args.log_n}-point Pallas Pedersen MSM per GPU ({args.dist} scalars), "
+                            f"{'precomputed-table' if args.precompute else 'plain'} resident commitment key",
+                "points_per_gpu": n,
+                "total_points": total_points,
+                "window_bits": 16,
+                "parallelism": f"shard{world}+all_gather(96B)" if world > 1 else "single",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "msm_accumulate_kernel",
+                "achieved": round(achieved, 3),
+                "peak": 8000.0,
+                "unit": "GB/s",
+                "frac": round(achieved / 8000.0, 6),
+                "traffic": traffic,
+                "avg_launch_ms": round(acc_avg_ms, 4),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md for the mad-rate roofline",
+            },
+            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernels.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, result if world == 1 and args.cpu_sample_log_n == args.log_n else None)
+        print(json.dumps(out), flush=True)
+    ck.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, gpu_result):
+    """CPU oracle Pippenger (per-thread chunks, c ~ ln n: the cpu_best_msm shape) on a bounded
+    sample: the first 2^cpu_sample_log_n points of the same synthetic workload."""
+    import numpy as np
+
+    from oracle import coracle as C
+
+    m = 1 << min(args.cpu_sample_log_n, args.log_n)
+    dist_id = 0 if args.dist == "uniform" else 1
+    B = C.synth_bases(0, m)
+    S = C.synth_scalars(1, 1, dist_id, m)
+    cores = C.lib().orc_num_threads()
+    C.msm_pippenger(0, B[:4096], S[:4096])  # warm up the thread pool
+    t0 = time.perf_counter()
+    r = C.msm_pippenger(0, B, S)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(m / dt / 1e6, 4),
+        "unit": "Mscalar-mul/s",
+        "cores": cores,
+        "host_cores": os.cpu_count(),
+        "kind": "port",
+        "sample": f"first 2^{min(args.cpu_sample_log_n, args.log_n)} points of the same workload, one MSM, {dt:.2f} s "
+                  "(CPU restatement oracle/oracle.c, OpenMP; NOT the reference's pasta-msm)",
+    }
+
+
+if __name__ == "__main__":
+    main()
