@@ -1,0 +1,62 @@
+"""Multi-GPU layer for the commitment path: one process per GPU, points sharded across ranks.
+
+A Pedersen commitment is linear in its (scalar, base) pairs, so a key of n points is cut into
+`world` contiguous slices; each rank keeps its slice of the key resident in its own HBM and commits to
+its slice of the witness.  The only exchange is the gather of the 96-byte partial commitments
+(RCCL all_gather over xGMI when the group backend is "nccl"; "gloo" on CPU for tests) followed by
+the group sum on every rank - never a reduction of bucket arrays (RCCL cannot
+reduce elliptic-curve points, and bucket arrays are ~100 MB per GPU).
+
+Folding steps themselves do not shard: each prove_step mutates the running instance
+(/root/reference/src/proof/nova.rs:282-295); what shards is the work inside one commitment."""
+from __future__ import annotations
+
+import numpy as np
+
+from .msm import CommitmentKey, point_sum
+
+
+def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous slice [lo, hi) of rank `rank`; the first n_total % world ranks get one extra point."""
+    base, extra = divmod(n_total, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_partials(partial: np.ndarray, group=None) -> np.ndarray:
+    """all_gather of one 96-byte Jacobian point per rank -> (world, 12) uint64 on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64).copy())
+    if backend == "nccl":
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return torch.stack(out).cpu().numpy().view(np.uint64)
+
+
+def allreduce_commitment(curve: int, partial: np.ndarray, group=None) -> np.ndarray:
+    """Group-sum of the per-rank partial commitments; every rank gets the full commitment."""
+    return point_sum(curve, gather_partials(partial, group))
+
+
+class ShardedCommitmentKey:
+    """Rank-local slice of a commitment key.  `bases` is this rank's slice (host array, or a device
+    tensor with device=True); commit() takes this rank's slice of the scalar vector."""
+
+    def __init__(self, curve: int, bases, n_local: int | None = None, group=None, **kw):
+        self.curve = curve
+        self.group = group
+        self.ck = CommitmentKey(curve, bases, n=n_local, **kw)
+
+    def commit(self, scalars, is_mont: bool = False) -> np.ndarray:
+        return allreduce_commitment(self.curve, self.ck.commit(scalars, is_mont), self.group)
+
+    def commit_device(self, d_scalars, n: int, is_mont: bool = False, stream=None) -> np.ndarray:
+        return allreduce_commitment(self.curve, self.ck.commit_device(d_scalars, n, is_mont, stream), self.group)
+
+    def close(self):
+        self.ck.close()
