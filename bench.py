@@ -104,7 +104,7 @@ def main():
         _lib.check(lib.lurk_hip_profile_get(prefix.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
         return tot.value, cnt.value
 
-    kernels = {k: prof(k) for k in ("msm_digits", "msm_sort", "msm_accumulate", "msm_finalize", "msm_reduce")}
+    kernels = {k: prof(k) for k in ("msm_digits", "msm_sort", "msm_tasks", "msm_accumulate", "msm_finalize", "msm_reduce")}
 
     if rank == 0:
         total_points = n * world

@@ -62,31 +62,43 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist_kernel(const uint32_t
     for (int b = threadIdx.x; b < MSM_B; b += MSM_SORT_BLOCK) dst[b] = lds_hist[b];
 }
 
-// block g (key space): per-bucket counts, bucket starts, task starts, per-block scatter offsets
-__global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t* __restrict__ block_hist, int blocks_per_space, uint32_t* __restrict__ cnt,
-                                                          uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ task_start,
-                                                          uint32_t* __restrict__ space_tasks, size_t space_stride) {
+// thread per (window w, bin b): exclusive running count down the K chunk rows of window w.
+// block_hist[w*K + k][b] becomes the offset of chunk k inside (window w, bucket b); cntw[w][b] the total.
+__global__ __launch_bounds__(256) void msm_colscan_kernel(uint32_t* __restrict__ block_hist, uint32_t* __restrict__ cntw) {
+    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;  // w * B + b
+    if (id >= (size_t)MSM_W * MSM_B) return;
+    size_t w = id / MSM_B, b = id % MSM_B;
+    uint32_t* col = block_hist + (w * MSM_K) * MSM_B + b;
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < MSM_K; k++) {
+        uint32_t v = col[(size_t)k * MSM_B];
+        col[(size_t)k * MSM_B] = run;
+        run += v;
+    }
+    cntw[id] = run;
+}
+
+// block g (key space), 1024 threads x 32 bins: bucket sizes, bucket starts (absolute positions in
+// `sorted`), task starts, and base_off[w][b] = where window w's entries of bucket b begin.
+// G == MSM_W: space g is window g.  G == 1: the single space merges all windows (precomputed table).
+__global__ __launch_bounds__(1024) void msm_binscan_kernel(const uint32_t* __restrict__ cntw, int G, uint32_t* __restrict__ cnt,
+                                                             uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ task_start,
+                                                             uint32_t* __restrict__ space_tasks, uint32_t* __restrict__ base_off,
+                                                             size_t space_stride) {
     __shared__ uint32_t sh_a[1024], sh_b[1024];
     const int g = blockIdx.x, t = threadIdx.x;
     constexpr int PER = MSM_B / 1024;  // 32 bins per thread
+    const int nwin = G == 1 ? MSM_W : 1, w0 = G == 1 ? 0 : g;
     uint32_t c[PER];
-#pragma unroll
-    for (int j = 0; j < PER; j++) c[j] = 0;
-    uint32_t* hist = block_hist + (size_t)g * blocks_per_space * MSM_B + (size_t)t * PER;
-    for (int blk = 0; blk < blocks_per_space; blk++) {
-        uint32_t* row = hist + (size_t)blk * MSM_B;
-#pragma unroll
-        for (int j = 0; j < PER; j++) {
-            uint32_t v = row[j];
-            row[j] = c[j];  // exclusive running count inside the bucket
-            c[j] += v;
-        }
-    }
     uint32_t tot = 0, ttot = 0;
 #pragma unroll
     for (int j = 0; j < PER; j++) {
-        tot += c[j];
-        ttot += (c[j] + MSM_S - 1) / MSM_S;
+        uint32_t v = 0;
+        for (int w = 0; w < nwin; w++) v += cntw[(size_t)(w0 + w) * MSM_B + (size_t)t * PER + j];
+        c[j] = v;
+        tot += v;
+        ttot += (v + MSM_S - 1) / MSM_S;
     }
     sh_a[t] = tot;
     sh_b[t] = ttot;
@@ -98,27 +110,24 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(uint32_t* __restrict__ b
         sh_b[t] += b;
         __syncthreads();
     }
-    uint32_t run = sh_a[t] - tot, trun = sh_b[t] - ttot;
-    const uint32_t base = (uint32_t)((size_t)g * space_stride);
-    uint32_t rel[PER];
+    uint32_t run = (uint32_t)((size_t)g * space_stride) + sh_a[t] - tot, trun = sh_b[t] - ttot;
 #pragma unroll
     for (int j = 0; j < PER; j++) {
-        size_t gb = (size_t)g * MSM_B + (size_t)t * PER + j;
+        size_t bin = (size_t)t * PER + j, gb = (size_t)g * MSM_B + bin;
         cnt[gb] = c[j];
-        bucket_start[gb] = base + run;
-        task_start[(size_t)g * (MSM_B + 1) + (size_t)t * PER + j] = trun;
-        rel[j] = base + run;
+        bucket_start[gb] = run;
+        task_start[(size_t)g * (MSM_B + 1) + bin] = trun;
+        uint32_t wrun = run;
+        for (int w = 0; w < nwin; w++) {
+            base_off[(size_t)(w0 + w) * MSM_B + bin] = wrun;
+            wrun += cntw[(size_t)(w0 + w) * MSM_B + bin];
+        }
         run += c[j];
         trun += (c[j] + MSM_S - 1) / MSM_S;
     }
     if (t == 1023) {
         task_start[(size_t)g * (MSM_B + 1) + MSM_B] = trun;
         space_tasks[g] = trun;
-    }
-    for (int blk = 0; blk < blocks_per_space; blk++) {
-        uint32_t* row = hist + (size_t)blk * MSM_B;
-#pragma unroll
-        for (int j = 0; j < PER; j++) row[j] += rel[j];
     }
 }
 
@@ -136,12 +145,14 @@ __global__ void msm_task_base_kernel(const uint32_t* __restrict__ space_tasks, u
 
 // block (k, w): scatter entries of window w / chunk k to their sorted positions
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter_kernel(const uint32_t* __restrict__ digits,
-                                                                       const uint32_t* __restrict__ block_off, uint32_t* __restrict__ sorted,
+                                                                       const uint32_t* __restrict__ block_off,
+                                                                       const uint32_t* __restrict__ base_off, uint32_t* __restrict__ sorted,
                                                                        size_t n, size_t chunk, size_t table_stride_per_window) {
     extern __shared__ uint32_t lds_off[];
     const int k = blockIdx.x, w = blockIdx.y;
     const uint32_t* off = block_off + (size_t)(w * MSM_K + k) * MSM_B;
-    for (int b = threadIdx.x; b < MSM_B; b += MSM_SORT_BLOCK) lds_off[b] = off[b];
+    const uint32_t* boff = base_off + (size_t)w * MSM_B;
+    for (int b = threadIdx.x; b < MSM_B; b += MSM_SORT_BLOCK) lds_off[b] = off[b] + boff[b];
     __syncthreads();
     size_t lo = (size_t)k * chunk, hi = lo + chunk < n ? lo + chunk : n;
     const uint32_t* src = digits + (size_t)w * n;
@@ -157,14 +168,11 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter_kernel(const uint3
 }
 
 // ---- 3. accumulate -------------------------------------------------------------------------
-template <class P>
-__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
-                                                                         const uint32_t* __restrict__ cnt,
-                                                                         const uint32_t* __restrict__ bucket_start,
-                                                                         const uint32_t* __restrict__ task_start,
-                                                                         const uint32_t* __restrict__ space_task_base, int G,
-                                                                         Xyzz<P>* __restrict__ partials) {
-    uint32_t t = blockIdx.x * MSM_ACC_BLOCK + threadIdx.x;
+// task table: task t -> [first, last) of the sorted list (<= MSM_S entries of one bucket)
+__global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bucket_start,
+                                                          const uint32_t* __restrict__ task_start,
+                                                          const uint32_t* __restrict__ space_task_base, int G, uint2* __restrict__ task_info) {
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= space_task_base[G]) return;
     int g = 0;
     while (g + 1 < G && space_task_base[g + 1] <= t) g++;
@@ -175,8 +183,65 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uin
     size_t gb = (size_t)g * MSM_B + b;
     uint32_t first = bucket_start[gb] + part * MSM_S;
     uint32_t end = bucket_start[gb] + cnt[gb];
-    uint32_t last = first + MSM_S < end ? first + MSM_S : end;
-    partials[t] = msm_task_accumulate<P>(sorted, first, last, table);
+    task_info[t] = make_uint2(first, first + MSM_S < end ? first + MSM_S : end);
+}
+
+// Longest-task-first order: tasks are counting-sorted by length (1..MSM_S) in descending order, so
+// the 64 lanes of a wave run tasks of equal length (no lane waits for the longest task of its wave;
+// bucket sizes are ragged - Poisson around n/2^15 per window - and skewed for witness-like scalars)
+// and the short tasks fill the tail of the launch.
+__global__ __launch_bounds__(256) void msm_len_hist_kernel(const uint2* __restrict__ task_info, const uint32_t* __restrict__ space_task_base,
+                                                             int G, uint32_t* __restrict__ len_hist) {
+    __shared__ uint32_t sh[MSM_S + 1];
+    if (threadIdx.x <= MSM_S) sh[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < space_task_base[G]) {
+        uint2 ti = task_info[t];
+        atomicAdd(&sh[ti.y - ti.x], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= MSM_S && sh[threadIdx.x]) atomicAdd(&len_hist[threadIdx.x], sh[threadIdx.x]);
+}
+// len_hist -> start offset of each length class, longest first (single small block)
+__global__ void msm_len_scan_kernel(uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t run = 0;
+        for (int l = MSM_S; l >= 0; l--) {
+            len_cursor[l] = run;
+            run += len_hist[l];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void msm_len_scatter_kernel(const uint2* __restrict__ task_info, const uint32_t* __restrict__ space_task_base,
+                                                                int G, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+    __shared__ uint32_t sh_cnt[MSM_S + 1], sh_base[MSM_S + 1];
+    if (threadIdx.x <= MSM_S) sh_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    bool valid = t < space_task_base[G];
+    uint32_t len = 0, rank = 0;
+    if (valid) {
+        uint2 ti = task_info[t];
+        len = ti.y - ti.x;
+        rank = atomicAdd(&sh_cnt[len], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x <= MSM_S && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = atomicAdd(&len_cursor[threadIdx.x], sh_cnt[threadIdx.x]);
+    __syncthreads();
+    if (valid) order[sh_base[len] + rank] = t;
+}
+
+template <class P>
+__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
+                                                                         const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
+                                                                         const uint32_t* __restrict__ space_task_base, int G,
+                                                                         Xyzz<P>* __restrict__ partials) {
+    uint32_t i = blockIdx.x * MSM_ACC_BLOCK + threadIdx.x;
+    if (i >= space_task_base[G]) return;
+    uint32_t t = order[i];
+    uint2 ti = task_info[t];
+    partials[t] = msm_task_accumulate<P>(sorted, ti.x, ti.y, table);
 }
 
 // ---- 4. finalize ---------------------------------------------------------------------------
@@ -238,49 +303,55 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __re
 }
 
 // ---- 5. bucket reduction -------------------------------------------------------------------
+// sum_b b*B_b with the bucket b stored at index idx = b-1:  sum (idx+1) X_idx = S + sum_k 2^k P_k,
+// S = sum X, P_k = sum of the X whose idx has bit k set.  The (S, P_0..P_{k-1}) vectors of two
+// adjacent segments of 2^k items merge with k+1 independent additions (the new plane k is the upper
+// half's S), so the whole reduction is 15 levels of depth ONE addition each: these tail kernels are
+// latency bound (~13 us per dependent XYZZ addition) and a running-sum formulation needs >100 of them.
+// level k: in[g][seg][0..k] (segments of 2^k items) -> out[g][seg/2][0..k+1]
 template <class P>
-__global__ __launch_bounds__(256) void msm_reduce0_kernel(const Xyzz<P>* __restrict__ buckets, int G, Xyzz<P>* __restrict__ S1,
-                                                            Xyzz<P>* __restrict__ T1) {
-    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;  // (g, j)
-    if (id >= (size_t)G * MSM_NSEG1) return;
-    Xyzz<P> S, T;
-    msm_running_sum<P>(buckets + id * MSM_L0, MSM_L0, S, T);
-    S1[id] = S;
-    T1[id] = T;
+__global__ __launch_bounds__(256) void msm_planes_kernel(const Xyzz<P>* __restrict__ in, Xyzz<P>* __restrict__ out, int k, int G) {
+    const size_t nseg_out = (size_t)MSM_B >> (k + 1);
+    const size_t comps_out = (size_t)k + 2, comps_in = (size_t)k + 1;
+    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)G * nseg_out * comps_out) return;
+    size_t c = id % comps_out, seg = (id / comps_out) % nseg_out, g = id / (comps_out * nseg_out);
+    const Xyzz<P>* lo = in + ((g * (nseg_out * 2) + 2 * seg) * comps_in);
+    const Xyzz<P>* hi = lo + comps_in;
+    Xyzz<P> r;
+    if (c <= (size_t)k) {
+        r = lo[c];
+        xyzz_add<P>(r, hi[c]);
+    } else {
+        r = hi[0];
+    }
+    out[id] = r;
 }
+// block g, 16 lanes: W = S + sum_k 2^k P_k by a tree-shaped Horner (15 doublings + 5 additions deep)
 template <class P>
-__global__ __launch_bounds__(128) void msm_reduce1_kernel(const Xyzz<P>* __restrict__ S1, const Xyzz<P>* __restrict__ T1, int G,
-                                                            Xyzz<P>* __restrict__ S2, Xyzz<P>* __restrict__ T2, Xyzz<P>* __restrict__ U2) {
-    size_t id = (size_t)blockIdx.x * 128 + threadIdx.x;  // (g, k)
-    if (id >= (size_t)G * MSM_NSEG2) return;
-    Xyzz<P> S, T;
-    msm_running_sum<P>(S1 + id * MSM_L1, MSM_L1, S, T);
-    S2[id] = S;
-    T2[id] = T;
-    Xyzz<P> u = xyzz_identity<P>();
-    for (int r = 0; r < MSM_L1; r++) xyzz_add<P>(u, T1[id * MSM_L1 + r]);
-    U2[id] = u;
-}
-// block g: tree-reduce the 128 level-2 segments into the key-space total
-template <class P>
-__global__ __launch_bounds__(MSM_NSEG2) void msm_reduce_final_kernel(const Xyzz<P>* __restrict__ S2, const Xyzz<P>* __restrict__ T2,
-                                                                       const Xyzz<P>* __restrict__ U2, Xyzz<P>* __restrict__ ws) {
-    __shared__ uint4 lds_raw[MSM_NSEG2 * sizeof(Xyzz<P>) / 16];
+__global__ __launch_bounds__(64) void msm_horner_kernel(const Xyzz<P>* __restrict__ planes, Xyzz<P>* __restrict__ ws) {
+    __shared__ uint4 lds_raw[16 * sizeof(Xyzz<P>) / 16];
     Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
-    const int g = blockIdx.x, k = threadIdx.x;
-    size_t id = (size_t)g * MSM_NSEG2 + k;
-    Xyzz<P> a = U2[id];
-    block_tree_sum<P, MSM_NSEG2>(a, sh);
+    const int g = blockIdx.x, t = threadIdx.x;
+    const Xyzz<P>* v = planes + (size_t)g * (MSM_C);  // [S, P_0 .. P_14]
+    if (t < 16) sh[t] = t < MSM_C - 1 ? v[1 + t] : xyzz_identity<P>();
     __syncthreads();
-    Xyzz<P> b = T2[id];
-    block_tree_sum<P, MSM_NSEG2>(b, sh);
-    __syncthreads();
-    Xyzz<P> s = S2[id];
-    Xyzz<P> c = xyzz_mul_small<P>(s, (uint32_t)k);
-    block_tree_sum<P, MSM_NSEG2>(c, sh);
-    __syncthreads();
-    block_tree_sum<P, MSM_NSEG2>(s, sh);
-    if (k == 0) ws[g] = msm_space_total<P>(a, b, c, s);
+    for (int lvl = 0; lvl < 4; lvl++) {  // q_j = q_2j + 2^(2^lvl) * q_2j+1
+        Xyzz<P> r;
+        bool active = t < (8 >> lvl);
+        if (active) {
+            r = xyzz_dbl_n<P>(sh[2 * t + 1], 1 << lvl);
+            xyzz_add<P>(r, sh[2 * t]);
+        }
+        __syncthreads();
+        if (active) sh[t] = r;
+        __syncthreads();
+    }
+    if (t == 0) {
+        Xyzz<P> r = sh[0];
+        xyzz_add<P>(r, v[0]);
+        ws[g] = r;
+    }
 }
 
 // ---- precomputed table: T[w*n + i] = 2^(16 w) * P_i ------------------------------------------
@@ -315,8 +386,8 @@ struct MsmCtx : MsmCtxBase {
     size_t table_stride = 0;         // = npoints when precomputed (window w at w*npoints), else 0
     std::mutex mu;
     // workspace
-    DevBuf digits, sorted, block_hist, cnt, bucket_start, task_start, space_tasks, space_task_base, partials, buckets, big_list, big_count,
-        S1, T1, S2, T2, U2, ws;
+    DevBuf digits, sorted, block_hist, cntw, base_off, cnt, bucket_start, task_start, space_tasks, space_task_base, task_info, task_order, len_hist, partials,
+        buckets, big_list, big_count, planes_a, planes_b, ws;
     Xyzz<P>* ws_host = nullptr;
     size_t ws_n = 0;
 
@@ -363,14 +434,16 @@ struct MsmCtx : MsmCtxBase {
         space_tasks.ensure(64 * 4);
         space_task_base.ensure(64 * 4);
         partials.ensure(ntask_max * sizeof(Xyzz<P>));
+        task_info.ensure(ntask_max * sizeof(uint2));
+        task_order.ensure(ntask_max * 4);
+        len_hist.ensure(2 * (MSM_S + 1) * 4);
         buckets.ensure((size_t)g * MSM_B * sizeof(Xyzz<P>));
         big_list.ensure((size_t)g * MSM_B * 4);
         big_count.ensure(16);
-        S1.ensure((size_t)g * MSM_NSEG1 * sizeof(Xyzz<P>));
-        T1.ensure((size_t)g * MSM_NSEG1 * sizeof(Xyzz<P>));
-        S2.ensure((size_t)g * MSM_NSEG2 * sizeof(Xyzz<P>));
-        T2.ensure((size_t)g * MSM_NSEG2 * sizeof(Xyzz<P>));
-        U2.ensure((size_t)g * MSM_NSEG2 * sizeof(Xyzz<P>));
+        cntw.ensure((size_t)MSM_W * MSM_B * 4);
+        base_off.ensure((size_t)MSM_W * MSM_B * 4);
+        planes_a.ensure((size_t)g * MSM_B * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
+        planes_b.ensure((size_t)g * MSM_B * sizeof(Xyzz<P>));
         ws.ensure((size_t)MSM_W * sizeof(Xyzz<P>));
         if (!ws_host) LURK_HIP_CHECK(hipHostMalloc((void**)&ws_host, MSM_W * sizeof(Xyzz<P>)));
         ws_n = n;
@@ -403,25 +476,38 @@ struct MsmCtx : MsmCtxBase {
             ProfScope ps("msm_sort", s);
             hipLaunchKernelGGL(msm_hist_kernel, dim3(MSM_K, MSM_W), dim3(MSM_SORT_BLOCK), lds, s, digits.as<uint32_t>(),
                                block_hist.as<uint32_t>(), n, chunk);
-            // generic: space g = window g owns blocks [g*K, (g+1)*K) and sorted[g*n, (g+1)*n)
-            // precomputed: one space owning all W*K blocks and sorted[0, W*n)
-            hipLaunchKernelGGL(msm_scan_kernel, dim3(g), dim3(1024), 0, s, block_hist.as<uint32_t>(), precomputed ? MSM_W * MSM_K : MSM_K,
-                               cnt.as<uint32_t>(), bucket_start.as<uint32_t>(), task_start.as<uint32_t>(), space_tasks.as<uint32_t>(),
+            // generic: space g = window g owns sorted[g*n, (g+1)*n); precomputed: one space owning sorted[0, W*n)
+            hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up((size_t)MSM_W * MSM_B, 256)), dim3(256), 0, s, block_hist.as<uint32_t>(),
+                               cntw.as<uint32_t>());
+            hipLaunchKernelGGL(msm_binscan_kernel, dim3(g), dim3(1024), 0, s, cntw.as<uint32_t>(), g, cnt.as<uint32_t>(),
+                               bucket_start.as<uint32_t>(), task_start.as<uint32_t>(), space_tasks.as<uint32_t>(), base_off.as<uint32_t>(),
                                precomputed ? (size_t)0 : n);
             hipLaunchKernelGGL(msm_task_base_kernel, dim3(1), dim3(64), 0, s, space_tasks.as<uint32_t>(), space_task_base.as<uint32_t>(), g);
             hipLaunchKernelGGL(msm_scatter_kernel, dim3(MSM_K, MSM_W), dim3(MSM_SORT_BLOCK), lds, s, digits.as<uint32_t>(),
-                               block_hist.as<uint32_t>(), sorted.as<uint32_t>(), n, chunk, table_stride);
+                               block_hist.as<uint32_t>(), base_off.as<uint32_t>(), sorted.as<uint32_t>(), n, chunk, table_stride);
         }
         const size_t ntask_max = (size_t)g * MSM_B + (size_t)MSM_W * n / MSM_S + MSM_W + 1;
         {
+            ProfScope ps("msm_tasks", s);
+            LURK_HIP_CHECK(hipMemsetAsync(big_count.p, 0, 4, s));
+            LURK_HIP_CHECK(hipMemsetAsync(len_hist.p, 0, 2 * (MSM_S + 1) * 4, s));
+            uint32_t* lh = len_hist.as<uint32_t>();
+            hipLaunchKernelGGL(msm_tasks_kernel, dim3(div_up(ntask_max, 256)), dim3(256), 0, s, cnt.as<uint32_t>(), bucket_start.as<uint32_t>(),
+                               task_start.as<uint32_t>(), space_task_base.as<uint32_t>(), g, task_info.as<uint2>());
+            hipLaunchKernelGGL(msm_len_hist_kernel, dim3(div_up(ntask_max, 256)), dim3(256), 0, s, task_info.as<uint2>(),
+                               space_task_base.as<uint32_t>(), g, lh);
+            hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, s, lh, lh + MSM_S + 1);
+            hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(div_up(ntask_max, 256)), dim3(256), 0, s, task_info.as<uint2>(),
+                               space_task_base.as<uint32_t>(), g, lh + MSM_S + 1, task_order.as<uint32_t>());
+        }
+        {
             ProfScope ps("msm_accumulate", s);
             hipLaunchKernelGGL((msm_accumulate_kernel<P>), dim3(div_up(ntask_max, MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s,
-                               sorted.as<uint32_t>(), table, cnt.as<uint32_t>(), bucket_start.as<uint32_t>(), task_start.as<uint32_t>(),
-                               space_task_base.as<uint32_t>(), g, partials.as<Xyzz<P>>());
+                               sorted.as<uint32_t>(), table, task_info.as<uint2>(), task_order.as<uint32_t>(), space_task_base.as<uint32_t>(), g,
+                               partials.as<Xyzz<P>>());
         }
         {
             ProfScope ps("msm_finalize", s);
-            LURK_HIP_CHECK(hipMemsetAsync(big_count.p, 0, 4, s));
             hipLaunchKernelGGL((msm_finalize_kernel<P>), dim3(div_up((size_t)g * MSM_B, 256)), dim3(256), 0, s, partials.as<Xyzz<P>>(),
                                cnt.as<uint32_t>(), task_start.as<uint32_t>(), space_task_base.as<uint32_t>(), g, buckets.as<Xyzz<P>>(),
                                big_list.as<uint32_t>(), big_count.as<uint32_t>());
@@ -431,12 +517,14 @@ struct MsmCtx : MsmCtxBase {
         }
         {
             ProfScope ps("msm_reduce", s);
-            hipLaunchKernelGGL((msm_reduce0_kernel<P>), dim3(div_up((size_t)g * MSM_NSEG1, 256)), dim3(256), 0, s, buckets.as<Xyzz<P>>(), g,
-                               S1.as<Xyzz<P>>(), T1.as<Xyzz<P>>());
-            hipLaunchKernelGGL((msm_reduce1_kernel<P>), dim3(div_up((size_t)g * MSM_NSEG2, 128)), dim3(128), 0, s, S1.as<Xyzz<P>>(),
-                               T1.as<Xyzz<P>>(), g, S2.as<Xyzz<P>>(), T2.as<Xyzz<P>>(), U2.as<Xyzz<P>>());
-            hipLaunchKernelGGL((msm_reduce_final_kernel<P>), dim3(g), dim3(MSM_NSEG2), 0, s, S2.as<Xyzz<P>>(), T2.as<Xyzz<P>>(),
-                               U2.as<Xyzz<P>>(), ws.as<Xyzz<P>>());
+            const Xyzz<P>* in = buckets.as<Xyzz<P>>();
+            Xyzz<P>* bufs[2] = {planes_a.as<Xyzz<P>>(), planes_b.as<Xyzz<P>>()};
+            for (int k = 0; k < MSM_C - 1; k++) {
+                size_t threads = (size_t)g * ((size_t)MSM_B >> (k + 1)) * (k + 2);
+                hipLaunchKernelGGL((msm_planes_kernel<P>), dim3(div_up(threads, 256)), dim3(256), 0, s, in, bufs[k & 1], k, g);
+                in = bufs[k & 1];
+            }
+            hipLaunchKernelGGL((msm_horner_kernel<P>), dim3(g), dim3(64), 0, s, in, ws.as<Xyzz<P>>());
         }
         LURK_HIP_CHECK(hipGetLastError());
         LURK_HIP_CHECK(hipMemcpyAsync(ws_host, ws.p, (size_t)g * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));

@@ -9,7 +9,8 @@
 //   3. accumulate  buckets are cut into tasks of <= S sorted entries; one lane per task runs
 //                  XYZZ mixed additions over gathered bases                    (msm_task_accumulate)
 //   4. finalize    per bucket: sum of its task partials (hot buckets by a workgroup tree)
-//   5. reduce      sum_b b*B_b by two levels of segmented running sums + one tree  (msm_reduce_*)
+//   5. reduce      sum_b b*B_b = S + sum_k 2^k P_k: bit-plane merge tree (15 levels of depth one
+//                  addition) + tree-shaped Horner                              (msm.hip)
 //   6. combine     sum_w 2^(16w) * W_w : 240 sequential doublings -> done on the host over 16
 //                  points (a latency-bound tail; with the precomputed table G = 1 and it vanishes)
 // "Key space" = set of buckets entries are sorted into: one per window in the generic mode
@@ -23,9 +24,6 @@ namespace lurk {
 constexpr int MSM_C = 16;                      // window bits
 constexpr int MSM_W = 16;                      // windows (16*16 = 256 >= 255 + carry)
 constexpr int MSM_B = 1 << (MSM_C - 1);        // buckets per key space (|digit| in 1..2^15)
-constexpr int MSM_L0 = 16, MSM_L1 = 16;        // reduction segment lengths
-constexpr int MSM_NSEG1 = MSM_B / MSM_L0;      // 2048
-constexpr int MSM_NSEG2 = MSM_NSEG1 / MSM_L1;  // 128
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 
 // Signed-digit recoding of a canonical 255-bit scalar (8 x u32 LE): out[w] = |d_w| | sign<<31.
@@ -68,36 +66,10 @@ LURK_HD Xyzz<P> msm_task_accumulate(const uint32_t* sorted, uint32_t first, uint
     return acc;
 }
 
-// Segmented running sum over `len` consecutive items x[0..len): returns S = sum x[r] and
-// T = sum r * x[r]  (0-based weights).
-template <class P>
-LURK_HD void msm_running_sum(const Xyzz<P>* x, int len, Xyzz<P>& S, Xyzz<P>& T) {
-    Xyzz<P> run = xyzz_identity<P>(), sum = xyzz_identity<P>();
-    for (int r = len - 1; r >= 1; r--) {
-        xyzz_add<P>(run, x[r]);
-        xyzz_add<P>(sum, run);
-    }
-    xyzz_add<P>(run, x[0]);
-    S = run;
-    T = sum;
-}
-
 template <class P>
 LURK_HD Xyzz<P> xyzz_dbl_n(Xyzz<P> p, int n) {
     for (int i = 0; i < n; i++) p = xyzz_dbl<P>(p);
     return p;
-}
-
-// Key-space total from the four tree-reduced quantities (see msm.hip reduce_final):
-//   sum_b b*B_b = A + L0*(Bs + L1*Cs) + Stot      (bucket b is stored at index b-1)
-template <class P>
-LURK_HD Xyzz<P> msm_space_total(const Xyzz<P>& A, const Xyzz<P>& Bs, const Xyzz<P>& Cs, const Xyzz<P>& Stot) {
-    Xyzz<P> t = xyzz_dbl_n<P>(Cs, 4);  // * L1 = 16
-    xyzz_add<P>(t, Bs);
-    t = xyzz_dbl_n<P>(t, 4);  // * L0 = 16
-    xyzz_add<P>(t, A);
-    xyzz_add<P>(t, Stot);
-    return t;
 }
 
 // Host tail: sum_g 2^(16 g) * ws[g], Horner from the top window.
