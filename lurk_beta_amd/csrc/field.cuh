@@ -129,17 +129,42 @@ LURK_HD bool fe_eq(const Fe<P>& a, const Fe<P>& b) {
     return o == 0;
 }
 
+// Carry chains.  On the device they are written with clang's add/sub-with-carry builtins: hipcc
+// lowers them to v_add_co/v_addc_co chains, pads the gfx950 carry hazard (two wait states between a
+// VALU carry write and its VALU read) and interleaves independent chains; the portable 64-bit form
+// below compiles to v_lshl_add_u64 plus zero-extension moves and is ~4x slower on gfx950.
+LURK_HD uint32_t addc32(uint32_t a, uint32_t b, uint32_t& carry) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned c;
+    uint32_t r = __builtin_addc(a, b, carry, &c);
+    carry = c;
+    return r;
+#else
+    uint64_t x = (uint64_t)a + b + carry;
+    carry = (uint32_t)(x >> 32);
+    return (uint32_t)x;
+#endif
+}
+LURK_HD uint32_t subb32(uint32_t a, uint32_t b, uint32_t& borrow) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned c;
+    uint32_t r = __builtin_subc(a, b, borrow, &c);
+    borrow = c;
+    return r;
+#else
+    uint64_t x = (uint64_t)a - b - borrow;
+    borrow = (uint32_t)(x >> 63);
+    return (uint32_t)x;
+#endif
+}
+
 // r = a - MOD if a >= MOD (a < 2*MOD)
 template <class P>
 LURK_HD void fe_cond_sub(uint32_t* t) {
     uint32_t d[8];
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)t[i] - P::mod(i) - borrow;
-        d[i] = (uint32_t)x;
-        borrow = (uint32_t)(x >> 63);
-    }
+    for (int i = 0; i < 8; i++) d[i] = subb32(t[i], P::mod(i), borrow);
 #pragma unroll
     for (int i = 0; i < 8; i++) t[i] = borrow ? t[i] : d[i];
 }
@@ -149,11 +174,7 @@ LURK_HD Fe<P> fe_add(const Fe<P>& a, const Fe<P>& b) {
     Fe<P> r;
     uint32_t c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {  // moduli are < 2^255: no carry out of limb 7
-        uint64_t x = (uint64_t)a.l[i] + b.l[i] + c;
-        r.l[i] = (uint32_t)x;
-        c = (uint32_t)(x >> 32);
-    }
+    for (int i = 0; i < 8; i++) r.l[i] = addc32(a.l[i], b.l[i], c);  // moduli are < 2^255: no carry out of limb 7
     fe_cond_sub<P>(r.l);
     return r;
 }
@@ -162,18 +183,10 @@ LURK_HD Fe<P> fe_sub(const Fe<P>& a, const Fe<P>& b) {
     Fe<P> r;
     uint32_t borrow = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)a.l[i] - b.l[i] - borrow;
-        r.l[i] = (uint32_t)x;
-        borrow = (uint32_t)(x >> 63);
-    }
+    for (int i = 0; i < 8; i++) r.l[i] = subb32(a.l[i], b.l[i], borrow);
     uint32_t mask = 0u - borrow, c = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t x = (uint64_t)r.l[i] + (P::mod(i) & mask) + c;
-        r.l[i] = (uint32_t)x;
-        c = (uint32_t)(x >> 32);
-    }
+    for (int i = 0; i < 8; i++) r.l[i] = addc32(r.l[i], P::mod(i) & mask, c);
     return r;
 }
 template <class P>
