@@ -89,6 +89,27 @@ __global__ void k_mad_addc(uint32_t* out, uint32_t seed) {
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)a0 ^ h;
 }
 
+
+#define PROBE8(NAME, TEXT, CLOB)                                                                              \
+    __global__ void NAME(uint32_t* out, uint32_t seed) {                                                      \
+        uint32_t a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        for (int it = 0; it < ITERS; it++) {                                                                  \
+            asm volatile(TEXT : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : : CLOB); \
+        }                                                                                                     \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                   \
+    }
+#define R8(I) I(0) I(1) I(2) I(3) I(4) I(5) I(6) I(7)
+#define I_ADDC64(n) "v_addc_co_u32_e64 %" #n ", vcc, 0, %" #n ", s[20:21]\n"
+#define I_ADDC32(n) "v_addc_co_u32_e32 %" #n ", vcc, 0, %" #n ", vcc\n"
+#define I_ADDS(n) "v_add_u32_e32 %" #n ", s20, %" #n "\n"
+#define I_CNDM(n) "v_cndmask_b32_e64 %" #n ", %" #n ", 1, s[20:21]\n"
+#define I_ADD3(n) "v_add3_u32 %" #n ", %" #n ", %" #n ", 1\n"
+PROBE8(k_addc_e64, R8(I_ADDC64), "vcc")
+PROBE8(k_addc_e32, R8(I_ADDC32), "vcc")
+PROBE8(k_add_sgpr, R8(I_ADDS), "vcc")
+PROBE8(k_cndmask_s, R8(I_CNDM), "vcc")
+PROBE8(k_add3, R8(I_ADD3), "vcc")
+
 template <class P, int IMPL>
 __global__ void k_femul(const Fe<P>* in, Fe<P>* out, int iters) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -96,7 +117,8 @@ __global__ void k_femul(const Fe<P>* in, Fe<P>* out, int iters) {
     for (int k = 0; k < iters; k++) {
         if (IMPL == 0) x = fe_mul_cios<P>(x, y);
         else if (IMPL == 1) x = fe_mul_fips<P>(x, y);
-        else x = fe_mul_call<P>(x, y);
+        else if (IMPL == 2) x = fe_mul_call<P>(x, y);
+        else x = fe_mul_asm<P>(x, y);
     }
     out[i] = x;
 }
@@ -140,6 +162,11 @@ int main() {
     RUN_PROBE(k_fma64, 8, "v_fma_f64");
     RUN_PROBE(k_lshl_add64, 8, "v_lshl_add_u64");
     RUN_PROBE(k_mad_addc, 16, "mad+addc (dep chain)");
+    RUN_PROBE(k_addc_e64, 8, "v_addc_co e64 sgpr-carry");
+    RUN_PROBE(k_addc_e32, 8, "v_addc_co e32 vcc (dep)");
+    RUN_PROBE(k_add_sgpr, 8, "v_add_u32 sgpr operand");
+    RUN_PROBE(k_cndmask_s, 8, "v_cndmask e64 sgpr mask");
+    RUN_PROBE(k_add3, 8, "v_add3_u32 (VOP3)");
 
     // field multiplier variants
     size_t n = (size_t)blocks * threads;
@@ -155,7 +182,8 @@ int main() {
         printf("%-28s %8.3f ms  %8.2f G field-mul/s\n", LABEL, ms, (double)n * MI / ms / 1e6); }
     RUN_MUL(PallasFp, 0, d_o0, "fe_mul Pallas cios(compiler)");
     RUN_MUL(PallasFp, 1, d_o1, "fe_mul Pallas fips(asm)");
-    RUN_MUL(PallasFp, 2, d_o2, "fe_mul Pallas fips noinline");
+    RUN_MUL(PallasFp, 2, d_o2, "fe_mul Pallas default noinline");
+    RUN_MUL(PallasFp, 3, d_o1, "fe_mul Pallas asm-block");
     {
         std::vector<uint32_t> r0(n * 8), r1(n * 8), r2(n * 8);
         CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r2.data(), d_o2, n * 32, hipMemcpyDeviceToHost));
@@ -165,6 +193,7 @@ int main() {
     }
     RUN_MUL(Bn254Fr, 0, d_o0, "fe_mul BN254 cios(compiler)");
     RUN_MUL(Bn254Fr, 1, d_o1, "fe_mul BN254 fips(asm)");
+    RUN_MUL(Bn254Fr, 3, d_o1, "fe_mul BN254 asm-block");
     {
         std::vector<uint32_t> r0(n * 8), r1(n * 8);
         CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost));

@@ -315,13 +315,20 @@ LURK_HD Fe<P> fe_mul_fips(const Fe<P>& a, const Fe<P>& b) {
 // a 255-bit product is ~300 instructions, and kernels such as Poseidon (81 products per dense
 // layer) or the XYZZ point addition would otherwise unroll into code far beyond the 64 KiB
 // instruction cache.  LURK_MUL_IMPL=0 selects the portable CIOS form (compiler-scheduled).
+// LURK_MUL_IMPL=2 (device default): the generated single-asm-block form (field_mul_asm.cuh);
+// 1: the statement-per-mad form above; 0: portable CIOS.
 #ifndef LURK_MUL_IMPL
-#define LURK_MUL_IMPL 1
+#define LURK_MUL_IMPL 2
 #endif
+}  // namespace lurk
+#include "field_mul_asm.cuh"
+namespace lurk {
 template <class P>
 LURK_HD Fe<P> fe_mul_inline(const Fe<P>& a, const Fe<P>& b) {
 #if LURK_MUL_IMPL == 0
     return fe_mul_cios<P>(a, b);
+#elif LURK_MUL_IMPL == 2 && defined(__HIP_DEVICE_COMPILE__)
+    return fe_mul_asm<P>(a, b);
 #else
     return fe_mul_fips<P>(a, b);
 #endif
