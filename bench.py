@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=22)
     ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--precompute", type=int, default=0, help="1 = context with the per-window precomputed table")
+    ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt"], default="msm",
+                    help="msm = the headline metric; poseidon_tree / ntt = the other hot-path kernels (BASELINE configs[2], N1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20)
     args = ap.parse_args()
@@ -58,6 +60,9 @@ def main():
     _lib.check(lib.lurk_hip_set_device(local_rank))
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    if args.workload != "msm":
+        return other_workloads(args, lib, world, rank)
 
     n = 1 << args.log_n
     dist_id = 0 if args.dist == "uniform" else 1
@@ -166,6 +171,84 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def other_workloads(args, lib, world, rank):
+    """Poseidon arity-8 tree (BASELINE configs[2]: 2^24 Pallas-Fq leaves) and the radix-2 NTT, same timing
+    contract: inputs resident in HBM, K timed steps.  Replicas only for N > 1 (no exchange step is modelled;
+    SURVEY.md section 8e describes the 8-root gather for a sharded tree)."""
+    import numpy as np
+    import torch
+
+    import lurk_beta_amd as L
+    from lurk_beta_amd import _lib, synth
+
+    stream = torch.cuda.current_stream().cuda_stream
+    F = L.FIELD_PALLAS_FQ
+    if args.workload == "poseidon_tree":
+        log_n = args.log_n if args.log_n % 3 == 0 else 24
+        n = 1 << log_n
+        d_leaves = synth.scalars(F, 2, 0, n)
+        d_levels = torch.empty(((n - 1) // 7, 4), dtype=torch.int64, device="cuda")
+
+        def step():
+            _lib.check(lib.lurk_hip_poseidon_tree8_dev(F, _lib.ptr(d_leaves), n, _lib.ptr(d_levels), _lib.ptr(stream)))
+
+        unit, per_step_units, kname = "Mleaves/s", n, "poseidon_batch"
+        alg_bytes = 32.0 * n + 64.0 * ((n - 1) // 7)  # leaves read once; every internal node written once and read once
+        workload = f"Poseidon arity-8 tree over 2^{log_n} Pallas-Fq leaves ({(n - 1) // 7} hash8)"
+    else:
+        log_n = args.log_n
+        n = 1 << log_n
+        d_data = synth.scalars(F, 3, 0, n)
+
+        def step():
+            _lib.check(lib.lurk_hip_ntt_dev(F, _lib.ptr(d_data), log_n, 0, _lib.ptr(stream)))
+
+        unit, per_step_units, kname = "Melements/s", n, "ntt"
+        passes = -(-log_n // 10) + 1  # bit-reversal pass + ceil(log_n / 10) fused-stage passes
+        alg_bytes = 64.0 * passes * n
+        workload = f"radix-2 NTT, 2^{log_n} Pallas-Fq elements (parity unpinned: no reference counterpart)"
+    torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    lib.lurk_hip_profile_enable(1)
+    lib.lurk_hip_profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    lib.lurk_hip_profile_enable(0)
+    tot, cnt = ctypes.c_double(), ctypes.c_uint64()
+    _lib.check(lib.lurk_hip_profile_get(kname.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
+    if rank == 0:
+        kernel_ms_per_step = tot.value / args.steps
+        achieved = alg_bytes / (kernel_ms_per_step * 1e-3) / 1e9 if kernel_ms_per_step > 0 else 0.0
+        out = {
+            "metric": f"{args.workload} throughput", "value": round(per_step_units * world / (elapsed / args.steps) / 1e6, 3), "unit": unit,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit Montgomery, integer VALU)",
+            "data": "synthetic", "config": {"workload": workload, "parallelism": "single" if world == 1 else f"replicas{world}"},
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel_ms_per_step": round(kernel_ms_per_step, 4),
+                         "algorithmic_bytes_per_step": alg_bytes},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import coracle as C
+
+            m = min(n, 1 << 18)
+            sample = C.synth_scalars(1, 2 if args.workload == "poseidon_tree" else 3, 0, m)
+            t1 = time.perf_counter()
+            if args.workload == "poseidon_tree":
+                C.poseidon_tree8(1, sample)
+            else:
+                C.ntt(1, sample)
+            dt = time.perf_counter() - t1
+            out["cpu_baseline"] = {"value": round(m / dt / 1e6, 4), "unit": unit, "cores": C.lib().orc_num_threads(), "kind": "port",
+                                   "sample": f"first 2^18 {'leaves' if args.workload == 'poseidon_tree' else 'elements'} of the same workload, {dt:.2f} s (oracle/oracle.c, OpenMP)"}
+        print(json.dumps(out), flush=True)
 
 
 def cpu_baseline(args, gpu_result):

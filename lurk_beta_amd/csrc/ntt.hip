@@ -9,6 +9,9 @@
 // workgroup loads a tile of 2^LDS_LOG elements whose indices differ only in the bits the fused
 // stages touch, runs those butterflies out of LDS (twiddles from a resident table), and writes the
 // tile back, so an n = 2^24 transform makes ceil(24/LDS_LOG) passes over HBM instead of 24.
+#include <memory>
+#include <tuple>
+
 #include "common.hpp"
 #include "field.cuh"
 
@@ -90,32 +93,62 @@ static Fe<F> host_omega(unsigned log_n, bool inverse) {
     return w;
 }
 
+// Twiddle tables and the bit-reversal scratch buffer are cached per (device, field, log_n, direction):
+// generating n/2 powers costs more field multiplications than the transform itself.
+struct NttPlan {
+    DevBuf tw, tmp;
+    std::mutex mu;
+};
+static std::mutex g_plan_mu;
+static std::map<std::tuple<int, int, unsigned, bool>, std::unique_ptr<NttPlan>> g_plans;
+
+template <class F>
+static NttPlan& ntt_plan(unsigned log_n, bool inverse, hipStream_t s) {
+    int dev = 0;
+    LURK_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto key = std::make_tuple(dev, (int)F::ID, log_n, inverse);
+    auto it = g_plans.find(key);
+    if (it == g_plans.end()) {
+        const size_t n = (size_t)1 << log_n;
+        auto plan = std::make_unique<NttPlan>();
+        plan->tw.alloc((n / 2 ? n / 2 : 1) * 32);
+        plan->tmp.alloc(n * 32);
+        if (n > 1) {
+            Fe<F> omega = host_omega<F>(log_n, inverse);
+            hipLaunchKernelGGL((ntt_twiddle_kernel<F>), dim3(div_up(n / 2, 256)), dim3(256), 0, s, omega, n / 2, plan->tw.template as<Fe<F>>());
+            LURK_HIP_CHECK(hipGetLastError());
+            LURK_HIP_CHECK(hipStreamSynchronize(s));
+        }
+        it = g_plans.emplace(key, std::move(plan)).first;
+    }
+    return *it->second;
+}
+
 template <class F>
 static void ntt_device(void* d_data, unsigned log_n, bool inverse, hipStream_t s) {
     LURK_REQUIRE(log_n <= 28, "log_n too large");
     const size_t n = (size_t)1 << log_n;
-    DevBuf tmp(n * 32), tw((n / 2 ? n / 2 : 1) * 32);
-    Fe<F> omega = host_omega<F>(log_n, inverse);
+    NttPlan& plan = ntt_plan<F>(log_n, inverse, s);
+    std::lock_guard<std::mutex> lk(plan.mu);  // one transform at a time per plan (shared scratch)
+    Fe<F>* tmp = plan.tmp.template as<Fe<F>>();
+    const Fe<F>* tw = plan.tw.template as<Fe<F>>();
     ProfScope ps("ntt", s);
-    if (n > 1)
-        hipLaunchKernelGGL((ntt_twiddle_kernel<F>), dim3(div_up(n / 2, 256)), dim3(256), 0, s, omega, n / 2, tw.as<Fe<F>>());
-    hipLaunchKernelGGL((ntt_bitrev_kernel<F>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Fe<F>*)d_data, tmp.as<Fe<F>>(), log_n);
+    hipLaunchKernelGGL((ntt_bitrev_kernel<F>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Fe<F>*)d_data, tmp, log_n);
     Fe<F> scale = fe_one<F>();
     if (inverse) scale = fe_inv<F>(fe_from_u64<F>((uint64_t)n));
     unsigned s0 = 0;
-    if (log_n == 0) {
-        hipLaunchKernelGGL((ntt_stages_kernel<F>), dim3(1), dim3(NTT_BLOCK), 32, s, tmp.as<Fe<F>>(), tw.as<Fe<F>>(), log_n, 0u, 0u, scale, 0, 1);
-    }
+    if (log_n == 0) hipLaunchKernelGGL((ntt_stages_kernel<F>), dim3(1), dim3(NTT_BLOCK), 32, s, tmp, tw, log_n, 0u, 0u, scale, 0, 1);
     while (s0 < log_n) {
         unsigned ns = log_n - s0 < (unsigned)NTT_LDS_LOG ? log_n - s0 : NTT_LDS_LOG;
         bool last = s0 + ns == log_n;
-        hipLaunchKernelGGL((ntt_stages_kernel<F>), dim3((unsigned)(n >> ns)), dim3(NTT_BLOCK), ((size_t)32 << ns), s, tmp.as<Fe<F>>(),
-                           tw.as<Fe<F>>(), log_n, s0, ns, scale, (last && inverse) ? 1 : 0, last ? 1 : 0);
+        hipLaunchKernelGGL((ntt_stages_kernel<F>), dim3((unsigned)(n >> ns)), dim3(NTT_BLOCK), ((size_t)32 << ns), s, tmp, tw, log_n, s0, ns,
+                           scale, (last && inverse) ? 1 : 0, last ? 1 : 0);
         s0 += ns;
     }
     LURK_HIP_CHECK(hipGetLastError());
-    LURK_HIP_CHECK(hipMemcpyAsync(d_data, tmp.p, n * 32, hipMemcpyDeviceToDevice, s));
-    LURK_HIP_CHECK(hipStreamSynchronize(s));  // tmp / tw are freed on return
+    LURK_HIP_CHECK(hipMemcpyAsync(d_data, tmp, n * 32, hipMemcpyDeviceToDevice, s));
+    LURK_HIP_CHECK(hipStreamSynchronize(s));  // the plan's scratch is released to the next caller
 }
 
 }  // namespace lurk
