@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=22)
     ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--precompute", type=int, default=0, help="1 = context with the per-window precomputed table")
+    ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
     ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt"], default="msm",
                     help="msm = the headline metric; poseidon_tree / ntt = the other hot-path kernels (BASELINE configs[2], N1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -70,7 +71,7 @@ def main():
     d_bases = synth.bases(L.CURVE_PALLAS, n, first=first)
     d_scalars = synth.scalars(L.FIELD_PALLAS_FQ, 1, dist_id, n, first=first, mont=True)
     torch.cuda.synchronize()
-    ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n, device=True, precompute=bool(args.precompute))
+    ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
@@ -147,7 +148,7 @@ def main():
                             f"{'precomputed-table' if args.precompute else 'plain'} resident commitment key",
                 "points_per_gpu": n,
                 "total_points": total_points,
-                "window_bits": 16,
+                "window_bits": args.window_bits or (16 if not args.precompute else (20 if args.log_n >= 21 else 18)),
                 "parallelism": f"shard{world}+all_gather(96B)" if world > 1 else "single",
             },
             "roofline": {

@@ -75,9 +75,12 @@ int lurk_hip_msm_vesta(void* out_jacobian96, const void* bases_affine64, size_t 
  * (/root/reference/src/proof/nova.rs:196-216), so it is uploaded once and kept in HBM.
  * Mirrors the msm-context API of the argumentcomputer pasta-msm fork (init(points) -> ctx,
  * with(ctx, scalars) -> point).  flags: bit0 = build the per-window precomputed table
- * (2^(c*k) * P_i for every window k; costs windows x 64 B x npoints of HBM). */
+ * (2^(c*k) * P_i for every window k; costs windows x 64 B x npoints of HBM; every window then shares
+ * one bucket set, so the window grows to c = 18 or 20 bits: 15 n / 13 n mixed additions instead of
+ * 16 n); bits 8..15 = window-bit override for the table mode (16..20, 0 = automatic). */
 typedef struct lurk_hip_msm_ctx lurk_hip_msm_ctx;
 #define LURK_MSM_FLAG_PRECOMPUTE 1
+#define LURK_MSM_FLAG_WINDOW_BITS(c) (((c) & 0xff) << 8)
 int lurk_hip_msm_ctx_create(lurk_hip_msm_ctx** ctx, int curve, const void* bases_affine64,
                             size_t npoints, int flags);
 /* same, bases already in device memory (borrowed for the lifetime of the ctx unless precomputed) */

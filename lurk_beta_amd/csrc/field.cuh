@@ -311,6 +311,64 @@ LURK_HD Fe<P> fe_mul_fips(const Fe<P>& a, const Fe<P>& b) {
     return r;
 }
 
+// Host-side product (the library's host code: parameter generation, the <= 20-point MSM tail):
+// 4 x 64-bit limbs, CIOS with unsigned __int128 - the same bytes as the 8 x 32-bit device form.
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__SIZEOF_INT128__)
+template <class P>
+inline Fe<P> fe_mul_host64(const Fe<P>& a, const Fe<P>& b) {
+    typedef unsigned __int128 u128;
+    uint64_t x[4], y[4], m[4], t[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 4; i++) {
+        x[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
+        y[i] = (uint64_t)b.l[2 * i] | ((uint64_t)b.l[2 * i + 1] << 32);
+        m[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
+    }
+    // -m^-1 mod 2^64 from the 32-bit constant by one Newton step
+    uint64_t inv32 = P::INV;                      // -m^-1 mod 2^32
+    uint64_t ninv = (uint64_t)0 - inv32;          // m^-1 mod 2^32 (as 64-bit, low half exact)
+    ninv *= 2 - m[0] * ninv;                      // exact mod 2^64
+    const uint64_t inv = (uint64_t)0 - ninv;
+    for (int i = 0; i < 4; i++) {
+        u128 c = 0;
+        for (int j = 0; j < 4; j++) {
+            c += (u128)x[j] * y[i] + t[j];
+            t[j] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[4] = (uint64_t)c;
+        t[5] = (uint64_t)(c >> 64);
+        uint64_t q = t[0] * inv;
+        c = ((u128)q * m[0] + t[0]) >> 64;
+        for (int j = 1; j < 4; j++) {
+            c += (u128)q * m[j] + t[j];
+            t[j - 1] = (uint64_t)c;
+            c >>= 64;
+        }
+        c += t[4];
+        t[3] = (uint64_t)c;
+        t[4] = t[5] + (uint64_t)(c >> 64);
+    }
+    // conditional subtraction
+    uint64_t d[4];
+    u128 br = 0;
+    for (int i = 0; i < 4; i++) {
+        u128 v = (u128)t[i] - m[i] - br;
+        d[i] = (uint64_t)v;
+        br = (v >> 64) & 1;
+    }
+    bool ge = t[4] != 0 || br == 0;
+    Fe<P> r;
+    for (int i = 0; i < 4; i++) {
+        uint64_t v = ge ? d[i] : t[i];
+        r.l[2 * i] = (uint32_t)v;
+        r.l[2 * i + 1] = (uint32_t)(v >> 32);
+    }
+    return r;
+}
+#define LURK_HAVE_HOST64 1
+#endif
+
 // Device code calls the multiplier as a real function (arguments and result in VGPRs, no scratch):
 // a 255-bit product is ~300 instructions, and kernels such as Poseidon (81 products per dense
 // layer) or the XYZZ point addition would otherwise unroll into code far beyond the 64 KiB
@@ -329,6 +387,8 @@ LURK_HD Fe<P> fe_mul_inline(const Fe<P>& a, const Fe<P>& b) {
     return fe_mul_cios<P>(a, b);
 #elif LURK_MUL_IMPL == 2 && defined(__HIP_DEVICE_COMPILE__)
     return fe_mul_asm<P>(a, b);
+#elif !defined(__HIP_DEVICE_COMPILE__) && defined(LURK_HAVE_HOST64) && !defined(LURK_HOST_PORTABLE_MUL)
+    return fe_mul_host64<P>(a, b);
 #else
     return fe_mul_fips<P>(a, b);
 #endif

@@ -5,14 +5,15 @@
 // /root/reference/src/proof/supernova.rs:231-244).  See msm_core.cuh for the pipeline; this file
 // holds the kernels, the resident-bases context and the C ABI.
 //
-// Memory plan (n scalars, W = 16 windows, G key spaces, B = 2^15 buckets each):
+// Memory plan (n scalars, c-bit windows, W windows, NB = G * 2^(c-1) keys <= 2^19):
 //   bases / table   64 B x n (x W with the precomputed table)   resident for the ctx lifetime
-//   digits, sorted  4 B x W x n each                             streamed once per call
-//   block_hist      4 B x (W*K) x B = 32 MiB                     LDS-privatised counting sort
-//   partials        128 B x (G*B + W*n/S)                        XYZZ task sums
-//   buckets         128 B x G*B
-// Algorithmic HBM bytes per call: 96 B per point (32 B scalar + 64 B base) - the kernel is bound by
-// the integer VALU (v_mad_u64_u32), not by HBM.
+//   digits          4 B x W x n                                  streamed once per call
+//   inter           8 B x W x n  (low key bits, entry)           between the two sort passes
+//   sorted          4 B x W x n  (table index | sign)
+//   partials        128 B x (NB + W*n/S)                         XYZZ task sums
+//   buckets, planes 128 B x NB (x3)
+// Algorithmic HBM bytes per call: 96 B per point (32 B scalar + 64 B base) - the dominant kernel is
+// bound by the integer VALU (v_mad_u64_u32 + carry folds), not by HBM.
 #include <memory>
 
 #include "common.hpp"
@@ -20,185 +21,276 @@
 
 namespace lurk {
 
-constexpr int MSM_K = 16;          // chunks per window in the counting sort (W*K = 256 blocks = 1 per CU)
+constexpr int MSM_P = 1024;        // coarse partitions of the key space (pass 1 of the sort): write heads per CU
+constexpr int MSM_NB1 = 256;       // workgroups of pass 1 (one per CU)
 constexpr int MSM_SORT_BLOCK = 1024;
 constexpr int MSM_S = 64;          // sorted entries per accumulation task
 constexpr int MSM_SMALL = 16;      // buckets with <= this many task partials are summed by one lane
 constexpr int MSM_ACC_BLOCK = 256;
 
+struct MsmShape {
+    int c, W, G;           // window bits, windows, key spaces
+    uint32_t B, NB;        // buckets per space, total keys
+    int LB;                // low key bits sorted in pass 2 (NB >> LB == MSM_P)
+    int NG;                // scan groups of MSM_GRP keys
+    size_t n, stride;      // scalars in this call; table stride per window (0 in plain mode)
+};
+
 // ---- 1. digits ---------------------------------------------------------------------------
 template <class SF>  // scalar field
-__global__ __launch_bounds__(256) void msm_digits_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ digits, size_t n,
+__global__ __launch_bounds__(256) void msm_digits_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ digits, MsmShape sh,
                                                            int is_mont) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= sh.n) return;
     uint4 lo = scalars[2 * i], hi = scalars[2 * i + 1];
     Fe<SF> s;
     s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
     s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
     if (is_mont) s = fe_from_mont<SF>(s);
-    uint32_t d[MSM_W];
-    msm_scalar_digits(s.l, d);
-#pragma unroll
-    for (int w = 0; w < MSM_W; w++) digits[(size_t)w * n + i] = d[w];
+    uint32_t carry = 0;
+    for (int w = 0; w < sh.W; w++) digits[(size_t)w * sh.n + i] = msm_digit_step(s.l, w, sh.c, carry);
 }
 
-// ---- 2. counting sort ----------------------------------------------------------------------
-// block (k, w): LDS histogram of window w over chunk k
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ block_hist,
-                                                                    size_t n, size_t chunk) {
-    extern __shared__ uint32_t lds_hist[];
-    const int k = blockIdx.x, w = blockIdx.y;
-    for (int b = threadIdx.x; b < MSM_B; b += MSM_SORT_BLOCK) lds_hist[b] = 0;
-    __syncthreads();
-    size_t lo = (size_t)k * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    const uint32_t* src = digits + (size_t)w * n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_BLOCK) {
-        uint32_t b = src[i] & ~MSM_SIGN;
-        if (b) atomicAdd(&lds_hist[b - 1], 1u);
-    }
-    __syncthreads();
-    uint32_t* dst = block_hist + (size_t)(w * MSM_K + k) * MSM_B;
-    for (int b = threadIdx.x; b < MSM_B; b += MSM_SORT_BLOCK) dst[b] = lds_hist[b];
+// entry e = w * n + i  ->  key = space * B + |d| - 1 (space = w in plain mode, 0 with the table)
+__device__ __forceinline__ uint32_t msm_key(const MsmShape& sh, uint32_t w, uint32_t mag) {
+    return (sh.G == 1 ? 0u : w * sh.B) + mag - 1u;
 }
 
-// thread per (window w, bin b): exclusive running count down the K chunk rows of window w.
-// block_hist[w*K + k][b] becomes the offset of chunk k inside (window w, bucket b); cntw[w][b] the total.
-__global__ __launch_bounds__(256) void msm_colscan_kernel(uint32_t* __restrict__ block_hist, uint32_t* __restrict__ cntw) {
-    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;  // w * B + b
-    if (id >= (size_t)MSM_W * MSM_B) return;
-    size_t w = id / MSM_B, b = id % MSM_B;
-    uint32_t* col = block_hist + (w * MSM_K) * MSM_B + b;
-    uint32_t run = 0;
-#pragma unroll
-    for (int k = 0; k < MSM_K; k++) {
-        uint32_t v = col[(size_t)k * MSM_B];
-        col[(size_t)k * MSM_B] = run;
-        run += v;
+// ---- 2a. sort pass 1: coarse partition by the high key bits -------------------------------------
+// block blk owns entries [blk*chunk, (blk+1)*chunk) of the digit array
+__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ block_hist,
+                                                                     MsmShape sh, size_t chunk) {
+    __shared__ uint32_t h[MSM_P];
+    if (threadIdx.x < MSM_P) h[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t total = (size_t)sh.W * sh.n;
+    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
+    for (size_t e = lo + threadIdx.x; e < hi; e += MSM_SORT_BLOCK) {
+        uint32_t mag = digits[e] & ~MSM_SIGN;
+        if (mag) atomicAdd(&h[msm_key(sh, (uint32_t)(e / sh.n), mag) >> sh.LB], 1u);
     }
-    cntw[id] = run;
+    __syncthreads();
+    if (threadIdx.x < MSM_P) block_hist[(size_t)blockIdx.x * MSM_P + threadIdx.x] = h[threadIdx.x];
 }
 
-// block g (key space), 1024 threads x 32 bins: bucket sizes, bucket starts (absolute positions in
-// `sorted`), task starts, and base_off[w][b] = where window w's entries of bucket b begin.
-// G == MSM_W: space g is window g.  G == 1: the single space merges all windows (precomputed table).
-__global__ __launch_bounds__(1024) void msm_binscan_kernel(const uint32_t* __restrict__ cntw, int G, uint32_t* __restrict__ cnt,
-                                                             uint32_t* __restrict__ bucket_start, uint32_t* __restrict__ task_start,
-                                                             uint32_t* __restrict__ space_tasks, uint32_t* __restrict__ base_off,
-                                                             size_t space_stride) {
-    __shared__ uint32_t sh_a[1024], sh_b[1024];
-    const int g = blockIdx.x, t = threadIdx.x;
-    constexpr int PER = MSM_B / 1024;  // 32 bins per thread
-    const int nwin = G == 1 ? MSM_W : 1, w0 = G == 1 ? 0 : g;
-    uint32_t c[PER];
-    uint32_t tot = 0, ttot = 0;
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        uint32_t v = 0;
-        for (int w = 0; w < nwin; w++) v += cntw[(size_t)(w0 + w) * MSM_B + (size_t)t * PER + j];
-        c[j] = v;
-        tot += v;
-        ttot += (v + MSM_S - 1) / MSM_S;
-    }
-    sh_a[t] = tot;
-    sh_b[t] = ttot;
+// block p: exclusive scan of partition p's counts over the MSM_NB1 pass-1 blocks
+__global__ __launch_bounds__(MSM_NB1) void msm_scan1_kernel(uint32_t* __restrict__ block_hist, uint32_t* __restrict__ part_cnt) {
+    __shared__ uint32_t sh[MSM_NB1];
+    const int p = blockIdx.x, t = threadIdx.x;
+    uint32_t v = block_hist[(size_t)t * MSM_P + p];
+    sh[t] = v;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {  // Hillis-Steele inclusive scan
-        uint32_t a = t >= off ? sh_a[t - off] : 0, b = t >= off ? sh_b[t - off] : 0;
+    for (int off = 1; off < MSM_NB1; off <<= 1) {
+        uint32_t a = t >= off ? sh[t - off] : 0;
         __syncthreads();
-        sh_a[t] += a;
-        sh_b[t] += b;
+        sh[t] += a;
         __syncthreads();
     }
-    uint32_t run = (uint32_t)((size_t)g * space_stride) + sh_a[t] - tot, trun = sh_b[t] - ttot;
-#pragma unroll
-    for (int j = 0; j < PER; j++) {
-        size_t bin = (size_t)t * PER + j, gb = (size_t)g * MSM_B + bin;
-        cnt[gb] = c[j];
-        bucket_start[gb] = run;
-        task_start[(size_t)g * (MSM_B + 1) + bin] = trun;
-        uint32_t wrun = run;
-        for (int w = 0; w < nwin; w++) {
-            base_off[(size_t)(w0 + w) * MSM_B + bin] = wrun;
-            wrun += cntw[(size_t)(w0 + w) * MSM_B + bin];
+    block_hist[(size_t)t * MSM_P + p] = sh[t] - v;
+    if (t == MSM_NB1 - 1) part_cnt[p] = sh[t];
+}
+// single block: part_start[0..P] = exclusive scan of part_cnt
+__global__ __launch_bounds__(MSM_P) void msm_part_start_kernel(const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ part_start) {
+    __shared__ uint32_t sh[MSM_P];
+    const int t = threadIdx.x;
+    uint32_t v = part_cnt[t];
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < MSM_P; off <<= 1) {
+        uint32_t a = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += a;
+        __syncthreads();
+    }
+    part_start[t] = sh[t] - v;
+    if (t == MSM_P - 1) part_start[MSM_P] = sh[t];
+}
+
+__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint32_t* __restrict__ digits,
+                                                                        const uint32_t* __restrict__ block_off,
+                                                                        const uint32_t* __restrict__ part_start, uint2* __restrict__ inter,
+                                                                        MsmShape sh, size_t chunk) {
+    __shared__ uint32_t off[MSM_P];
+    if (threadIdx.x < MSM_P) off[threadIdx.x] = part_start[threadIdx.x] + block_off[(size_t)blockIdx.x * MSM_P + threadIdx.x];
+    __syncthreads();
+    const size_t total = (size_t)sh.W * sh.n;
+    const uint32_t low_mask = (1u << sh.LB) - 1u;
+    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
+    for (size_t e = lo + threadIdx.x; e < hi; e += MSM_SORT_BLOCK) {
+        uint32_t d = digits[e];
+        uint32_t mag = d & ~MSM_SIGN;
+        if (mag) {
+            uint32_t w = (uint32_t)(e / sh.n);
+            uint32_t i = (uint32_t)(e - (size_t)w * sh.n);
+            uint32_t key = msm_key(sh, w, mag);
+            uint32_t pos = atomicAdd(&off[key >> sh.LB], 1u);
+            inter[pos] = make_uint2(key & low_mask, ((uint32_t)((size_t)w * sh.stride) + i) | (d & MSM_SIGN));
         }
+    }
+}
+
+// ---- 2b. sort pass 2: block p sorts partition p by the low key bits ---------------------------------
+// Emits the final sorted entry list, the bucket sizes and the bucket starts of its 2^LB keys.
+__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part2_kernel(const uint2* __restrict__ inter, const uint32_t* __restrict__ part_start,
+                                                                     uint32_t* __restrict__ sorted, uint32_t* __restrict__ cnt,
+                                                                     uint32_t* __restrict__ bucket_start, MsmShape sh) {
+    extern __shared__ uint32_t lds[];  // [2^LB] counters, then [MSM_SORT_BLOCK] scan scratch
+    const int p = blockIdx.x, t = threadIdx.x;
+    const uint32_t nbins = 1u << sh.LB;
+    uint32_t* h = lds;
+    uint32_t* scr = lds + nbins;
+    for (uint32_t b = t; b < nbins; b += MSM_SORT_BLOCK) h[b] = 0;
+    __syncthreads();
+    const uint32_t lo = part_start[p], hi = part_start[p + 1];
+    constexpr int U = 8;  // independent loads in flight per lane: the sweeps are latency bound otherwise
+    for (uint32_t base = lo; base < hi; base += MSM_SORT_BLOCK * U) {
+        uint32_t k[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint32_t e = base + u * MSM_SORT_BLOCK + t;
+            k[u] = e < hi ? inter[e].x : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (k[u] != 0xffffffffu) atomicAdd(&h[k[u]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the bins: each thread owns a contiguous run of bins
+    const uint32_t per = (nbins + MSM_SORT_BLOCK - 1) / MSM_SORT_BLOCK;
+    uint32_t sum = 0;
+    for (uint32_t j = 0; j < per; j++) {
+        uint32_t b = t * per + j;
+        if (b < nbins) sum += h[b];
+    }
+    scr[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < MSM_SORT_BLOCK; off <<= 1) {
+        uint32_t a = t >= off ? scr[t - off] : 0;
+        __syncthreads();
+        scr[t] += a;
+        __syncthreads();
+    }
+    uint32_t run = lo + scr[t] - sum;
+    for (uint32_t j = 0; j < per; j++) {
+        uint32_t b = t * per + j;
+        if (b < nbins) {
+            uint32_t c = h[b];
+            size_t key = ((size_t)p << sh.LB) + b;
+            cnt[key] = c;
+            bucket_start[key] = run;
+            h[b] = run;  // becomes the scatter cursor
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (uint32_t base = lo; base < hi; base += MSM_SORT_BLOCK * U) {
+        uint2 v[U];
+        uint32_t pos[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            uint32_t e = base + u * MSM_SORT_BLOCK + t;
+            v[u] = e < hi ? inter[e] : make_uint2(0xffffffffu, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (v[u].x != 0xffffffffu) pos[u] = atomicAdd(&h[v[u].x], 1u);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (v[u].x != 0xffffffffu) sorted[pos[u]] = v[u].y;
+    }
+}
+
+// ---- 3. task planning ------------------------------------------------------------------------
+// block g (group of MSM_GRP keys), 1024 threads x 32 keys: task starts inside the group + group total
+__global__ __launch_bounds__(1024) void msm_taskscan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ task_start,
+                                                              uint32_t* __restrict__ group_tasks) {
+    __shared__ uint32_t sh[1024];
+    const int g = blockIdx.x, t = threadIdx.x;
+    constexpr int PER = MSM_GRP / 1024;
+    const uint4* src = reinterpret_cast<const uint4*>(cnt + (size_t)g * MSM_GRP + (size_t)t * PER);
+    uint32_t c[PER];
+    uint32_t tot = 0;
+#pragma unroll
+    for (int j = 0; j < PER / 4; j++) {
+        uint4 v = src[j];
+        c[4 * j] = (v.x + MSM_S - 1) / MSM_S;
+        c[4 * j + 1] = (v.y + MSM_S - 1) / MSM_S;
+        c[4 * j + 2] = (v.z + MSM_S - 1) / MSM_S;
+        c[4 * j + 3] = (v.w + MSM_S - 1) / MSM_S;
+        tot += c[4 * j] + c[4 * j + 1] + c[4 * j + 2] + c[4 * j + 3];
+    }
+    sh[t] = tot;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t a = t >= off ? sh[t - off] : 0;
+        __syncthreads();
+        sh[t] += a;
+        __syncthreads();
+    }
+    uint32_t run = sh[t] - tot;
+    uint32_t* dst = task_start + (size_t)g * (MSM_GRP + 1) + (size_t)t * PER;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        dst[j] = run;
         run += c[j];
-        trun += (c[j] + MSM_S - 1) / MSM_S;
     }
     if (t == 1023) {
-        task_start[(size_t)g * (MSM_B + 1) + MSM_B] = trun;
-        space_tasks[g] = trun;
+        task_start[(size_t)g * (MSM_GRP + 1) + MSM_GRP] = run;
+        group_tasks[g] = run;
     }
 }
-
-// exclusive scan of the per-space task totals (G <= 16) -> space_task_base[0..G]
-__global__ void msm_task_base_kernel(const uint32_t* __restrict__ space_tasks, uint32_t* __restrict__ space_task_base, int G) {
+// exclusive scan of the per-group task totals (NG <= 16) -> group_task_base[0..NG]
+__global__ void msm_task_base_kernel(const uint32_t* __restrict__ group_tasks, uint32_t* __restrict__ group_task_base, int NG) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint32_t run = 0;
-        for (int g = 0; g < G; g++) {
-            space_task_base[g] = run;
-            run += space_tasks[g];
+        for (int g = 0; g < NG; g++) {
+            group_task_base[g] = run;
+            run += group_tasks[g];
         }
-        space_task_base[G] = run;
+        group_task_base[NG] = run;
     }
 }
-
-// block (k, w): scatter entries of window w / chunk k to their sorted positions
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter_kernel(const uint32_t* __restrict__ digits,
-                                                                       const uint32_t* __restrict__ block_off,
-                                                                       const uint32_t* __restrict__ base_off, uint32_t* __restrict__ sorted,
-                                                                       size_t n, size_t chunk, size_t table_stride_per_window) {
-    extern __shared__ uint32_t lds_off[];
-    const int k = blockIdx.x, w = blockIdx.y;
-    const uint32_t* off = block_off + (size_t)(w * MSM_K + k) * MSM_B;
-    const uint32_t* boff = base_off + (size_t)w * MSM_B;
-    for (int b = threadIdx.x; b < MSM_B; b += MSM_SORT_BLOCK) lds_off[b] = off[b] + boff[b];
-    __syncthreads();
-    size_t lo = (size_t)k * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    const uint32_t* src = digits + (size_t)w * n;
-    const uint32_t tbase = (uint32_t)((size_t)w * table_stride_per_window);
-    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_BLOCK) {
-        uint32_t d = src[i];
-        uint32_t b = d & ~MSM_SIGN;
-        if (b) {
-            uint32_t pos = atomicAdd(&lds_off[b - 1], 1u);
-            sorted[pos] = (tbase + (uint32_t)i) | (d & MSM_SIGN);
-        }
-    }
-}
-
-// ---- 3. accumulate -------------------------------------------------------------------------
 // task table: task t -> [first, last) of the sorted list (<= MSM_S entries of one bucket)
 __global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bucket_start,
                                                           const uint32_t* __restrict__ task_start,
-                                                          const uint32_t* __restrict__ space_task_base, int G, uint2* __restrict__ task_info) {
+                                                          const uint32_t* __restrict__ group_task_base, int NG, uint2* __restrict__ task_info) {
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= space_task_base[G]) return;
+    if (t >= group_task_base[NG]) return;
     int g = 0;
-    while (g + 1 < G && space_task_base[g + 1] <= t) g++;
-    uint32_t tl = t - space_task_base[g];
-    const uint32_t* ts = task_start + (size_t)g * (MSM_B + 1);
-    uint32_t b = msm_upper_slot(ts, MSM_B, tl);
+    while (g + 1 < NG && group_task_base[g + 1] <= t) g++;
+    uint32_t tl = t - group_task_base[g];
+    const uint32_t* ts = task_start + (size_t)g * (MSM_GRP + 1);
+    uint32_t b = msm_upper_slot(ts, MSM_GRP, tl);
     uint32_t part = tl - ts[b];
-    size_t gb = (size_t)g * MSM_B + b;
-    uint32_t first = bucket_start[gb] + part * MSM_S;
-    uint32_t end = bucket_start[gb] + cnt[gb];
+    size_t key = (size_t)g * MSM_GRP + b;
+    uint32_t first = bucket_start[key] + part * MSM_S;
+    uint32_t end = bucket_start[key] + cnt[key];
     task_info[t] = make_uint2(first, first + MSM_S < end ? first + MSM_S : end);
 }
 
 // Longest-task-first order: tasks are counting-sorted by length (1..MSM_S) in descending order, so
 // the 64 lanes of a wave run tasks of equal length (no lane waits for the longest task of its wave;
-// bucket sizes are ragged - Poisson around n/2^15 per window - and skewed for witness-like scalars)
-// and the short tasks fill the tail of the launch.
-__global__ __launch_bounds__(256) void msm_len_hist_kernel(const uint2* __restrict__ task_info, const uint32_t* __restrict__ space_task_base,
-                                                             int G, uint32_t* __restrict__ len_hist) {
+// bucket sizes are ragged - Poisson around their mean - and skewed for witness-like scalars) and the
+// short tasks fill the tail of the launch.  Full tasks (length MSM_S, the bulk at large n) are
+// counted per wave with one ballot instead of one LDS atomic each.
+__global__ __launch_bounds__(1024) void msm_len_hist_kernel(const uint2* __restrict__ task_info, const uint32_t* __restrict__ group_task_base,
+                                                              int NG, uint32_t* __restrict__ len_hist) {
     __shared__ uint32_t sh[MSM_S + 1];
     if (threadIdx.x <= MSM_S) sh[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < space_task_base[G]) {
-        uint2 ti = task_info[t];
-        atomicAdd(&sh[ti.y - ti.x], 1u);
+    const uint32_t ntasks = group_task_base[NG];
+    for (uint32_t base = blockIdx.x * 8192u; base < ntasks; base += gridDim.x * 8192u) {
+        for (uint32_t k = 0; k < 8; k++) {
+            uint32_t t = base + k * 1024u + threadIdx.x;
+            uint32_t len = 0;
+            if (t < ntasks) {
+                uint2 ti = task_info[t];
+                len = ti.y - ti.x;
+            }
+            unsigned long long full = __ballot(len == MSM_S);
+            if (full && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)full) - 1)) atomicAdd(&sh[MSM_S], (uint32_t)__popcll(full));
+            if (len != 0 && len != MSM_S) atomicAdd(&sh[len], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x <= MSM_S && sh[threadIdx.x]) atomicAdd(&len_hist[threadIdx.x], sh[threadIdx.x]);
@@ -213,56 +305,70 @@ __global__ void msm_len_scan_kernel(uint32_t* __restrict__ len_hist, uint32_t* _
         }
     }
 }
-__global__ __launch_bounds__(256) void msm_len_scatter_kernel(const uint2* __restrict__ task_info, const uint32_t* __restrict__ space_task_base,
-                                                                int G, uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+__global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __restrict__ task_info,
+                                                                 const uint32_t* __restrict__ group_task_base, int NG,
+                                                                 uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
     __shared__ uint32_t sh_cnt[MSM_S + 1], sh_base[MSM_S + 1];
-    if (threadIdx.x <= MSM_S) sh_cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    bool valid = t < space_task_base[G];
-    uint32_t len = 0, rank = 0;
-    if (valid) {
-        uint2 ti = task_info[t];
-        len = ti.y - ti.x;
-        rank = atomicAdd(&sh_cnt[len], 1u);
+    const uint32_t ntasks = group_task_base[NG];
+    for (uint32_t base = blockIdx.x * 1024u; base < ntasks; base += gridDim.x * 1024u) {
+        if (threadIdx.x <= MSM_S) sh_cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint32_t t = base + threadIdx.x;
+        uint32_t len = 0, rank = 0;
+        if (t < ntasks) {
+            uint2 ti = task_info[t];
+            len = ti.y - ti.x;
+        }
+        unsigned long long full = __ballot(len == MSM_S);
+        if (len == MSM_S) {
+            int lane = threadIdx.x & 63, leader = __ffsll((long long)full) - 1;
+            uint32_t wbase = 0;
+            if (lane == leader) wbase = atomicAdd(&sh_cnt[MSM_S], (uint32_t)__popcll(full));
+            wbase = __shfl(wbase, leader);
+            rank = wbase + (uint32_t)__popcll(full & ((1ull << lane) - 1ull));
+        } else if (len != 0) {
+            rank = atomicAdd(&sh_cnt[len], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x <= MSM_S && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = atomicAdd(&len_cursor[threadIdx.x], sh_cnt[threadIdx.x]);
+        __syncthreads();
+        if (len != 0) order[sh_base[len] + rank] = t;
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x <= MSM_S && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = atomicAdd(&len_cursor[threadIdx.x], sh_cnt[threadIdx.x]);
-    __syncthreads();
-    if (valid) order[sh_base[len] + rank] = t;
 }
 
+// ---- 4. accumulate -------------------------------------------------------------------------
 template <class P>
 __global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
                                                                          const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
-                                                                         const uint32_t* __restrict__ space_task_base, int G,
+                                                                         const uint32_t* __restrict__ group_task_base, int NG,
                                                                          Xyzz<P>* __restrict__ partials) {
     uint32_t i = blockIdx.x * MSM_ACC_BLOCK + threadIdx.x;
-    if (i >= space_task_base[G]) return;
+    if (i >= group_task_base[NG]) return;
     uint32_t t = order[i];
     uint2 ti = task_info[t];
     partials[t] = msm_task_accumulate<P>(sorted, ti.x, ti.y, table);
 }
 
-// ---- 4. finalize ---------------------------------------------------------------------------
+// ---- 5. finalize ---------------------------------------------------------------------------
 template <class P>
 __global__ __launch_bounds__(256) void msm_finalize_kernel(const Xyzz<P>* __restrict__ partials, const uint32_t* __restrict__ cnt,
                                                              const uint32_t* __restrict__ task_start,
-                                                             const uint32_t* __restrict__ space_task_base, int G, Xyzz<P>* __restrict__ buckets,
-                                                             uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
-    size_t gb = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (gb >= (size_t)G * MSM_B) return;
-    int g = (int)(gb / MSM_B);
-    uint32_t b = (uint32_t)(gb % MSM_B);
-    uint32_t nt = (cnt[gb] + MSM_S - 1) / MSM_S;
-    uint32_t first = space_task_base[g] + task_start[(size_t)g * (MSM_B + 1) + b];
+                                                             const uint32_t* __restrict__ group_task_base, uint32_t NB,
+                                                             Xyzz<P>* __restrict__ buckets, uint32_t* __restrict__ big_list,
+                                                             uint32_t* __restrict__ big_count) {
+    size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (key >= NB) return;
+    uint32_t g = (uint32_t)(key / MSM_GRP), b = (uint32_t)(key % MSM_GRP);
+    uint32_t nt = (cnt[key] + MSM_S - 1) / MSM_S;
+    uint32_t first = group_task_base[g] + task_start[(size_t)g * (MSM_GRP + 1) + b];
     if (nt > MSM_SMALL) {
-        big_list[atomicAdd(big_count, 1u)] = (uint32_t)gb;
+        big_list[atomicAdd(big_count, 1u)] = (uint32_t)key;
         return;
     }
     Xyzz<P> acc = xyzz_identity<P>();
     for (uint32_t i = 0; i < nt; i++) xyzz_add<P>(acc, partials[first + i]);
-    buckets[gb] = acc;
+    buckets[key] = acc;
 }
 
 template <class P, int BLOCK>
@@ -283,35 +389,34 @@ __device__ void block_tree_sum(Xyzz<P>& acc, Xyzz<P>* sh) {
 template <class P>
 __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __restrict__ partials, const uint32_t* __restrict__ cnt,
                                                                const uint32_t* __restrict__ task_start,
-                                                               const uint32_t* __restrict__ space_task_base, Xyzz<P>* __restrict__ buckets,
+                                                               const uint32_t* __restrict__ group_task_base, Xyzz<P>* __restrict__ buckets,
                                                                const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count) {
     extern __shared__ uint4 lds_raw[];
     Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
     const uint32_t nbig = *big_count;
     for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {
-        uint32_t gb = big_list[i];
-        int g = gb / MSM_B;
-        uint32_t b = gb % MSM_B;
-        uint32_t nt = (cnt[gb] + MSM_S - 1) / MSM_S;
-        uint32_t first = space_task_base[g] + task_start[(size_t)g * (MSM_B + 1) + b];
+        uint32_t key = big_list[i];
+        uint32_t g = key / MSM_GRP, b = key % MSM_GRP;
+        uint32_t nt = (cnt[key] + MSM_S - 1) / MSM_S;
+        uint32_t first = group_task_base[g] + task_start[(size_t)g * (MSM_GRP + 1) + b];
         Xyzz<P> acc = xyzz_identity<P>();
         for (uint32_t j = threadIdx.x; j < nt; j += 256) xyzz_add<P>(acc, partials[first + j]);
         block_tree_sum<P, 256>(acc, sh);
-        if (threadIdx.x == 0) buckets[gb] = acc;
+        if (threadIdx.x == 0) buckets[key] = acc;
         __syncthreads();
     }
 }
 
-// ---- 5. bucket reduction -------------------------------------------------------------------
+// ---- 6. bucket reduction -------------------------------------------------------------------
 // sum_b b*B_b with the bucket b stored at index idx = b-1:  sum (idx+1) X_idx = S + sum_k 2^k P_k,
 // S = sum X, P_k = sum of the X whose idx has bit k set.  The (S, P_0..P_{k-1}) vectors of two
 // adjacent segments of 2^k items merge with k+1 independent additions (the new plane k is the upper
-// half's S), so the whole reduction is 15 levels of depth ONE addition each: these tail kernels are
-// latency bound (~13 us per dependent XYZZ addition) and a running-sum formulation needs >100 of them.
+// half's S), so the whole reduction is c-1 levels of depth ONE addition each: these tail kernels are
+// latency bound (~10 us per dependent XYZZ addition) and a running-sum formulation needs >100 of them.
 // level k: in[g][seg][0..k] (segments of 2^k items) -> out[g][seg/2][0..k+1]
 template <class P>
-__global__ __launch_bounds__(256) void msm_planes_kernel(const Xyzz<P>* __restrict__ in, Xyzz<P>* __restrict__ out, int k, int G) {
-    const size_t nseg_out = (size_t)MSM_B >> (k + 1);
+__global__ __launch_bounds__(256) void msm_planes_kernel(const Xyzz<P>* __restrict__ in, Xyzz<P>* __restrict__ out, int k, int G, uint32_t B) {
+    const size_t nseg_out = (size_t)B >> (k + 1);
     const size_t comps_out = (size_t)k + 2, comps_in = (size_t)k + 1;
     size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= (size_t)G * nseg_out * comps_out) return;
@@ -327,14 +432,15 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const Xyzz<P>* __restri
     }
     out[id] = r;
 }
-// block g, 16 lanes: W = S + sum_k 2^k P_k by a tree-shaped Horner (15 doublings + 5 additions deep)
+// plain mode (c = 16): block g, 16 lanes: W_g = S + sum_k 2^k P_k by a tree-shaped Horner
+// (15 doublings + 5 additions deep)
 template <class P>
-__global__ __launch_bounds__(64) void msm_horner_kernel(const Xyzz<P>* __restrict__ planes, Xyzz<P>* __restrict__ ws) {
+__global__ __launch_bounds__(64) void msm_horner16_kernel(const Xyzz<P>* __restrict__ planes, Xyzz<P>* __restrict__ ws) {
     __shared__ uint4 lds_raw[16 * sizeof(Xyzz<P>) / 16];
     Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
     const int g = blockIdx.x, t = threadIdx.x;
-    const Xyzz<P>* v = planes + (size_t)g * (MSM_C);  // [S, P_0 .. P_14]
-    if (t < 16) sh[t] = t < MSM_C - 1 ? v[1 + t] : xyzz_identity<P>();
+    const Xyzz<P>* v = planes + (size_t)g * 16;  // [S, P_0 .. P_14]
+    if (t < 16) sh[t] = t < 15 ? v[1 + t] : xyzz_identity<P>();
     __syncthreads();
     for (int lvl = 0; lvl < 4; lvl++) {  // q_j = q_2j + 2^(2^lvl) * q_2j+1
         Xyzz<P> r;
@@ -354,19 +460,20 @@ __global__ __launch_bounds__(64) void msm_horner_kernel(const Xyzz<P>* __restric
     }
 }
 
-// ---- precomputed table: T[w*n + i] = 2^(16 w) * P_i ------------------------------------------
+// ---- precomputed table: T[w*n + i] = 2^(c w) * P_i ----------------------------------------------
 template <class P>
-__global__ __launch_bounds__(256) void msm_precompute_kernel(const Affine<P>* __restrict__ bases, size_t n, Affine<P>* __restrict__ table) {
+__global__ __launch_bounds__(256) void msm_precompute_kernel(const Affine<P>* __restrict__ bases, size_t n, Affine<P>* __restrict__ table, int c,
+                                                               int W) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     Affine<P> a = bases[i];
     table[i] = a;
     Xyzz<P> p = xyzz_from_affine<P>(a);
-    for (int w = 1; w < MSM_W; w++) {
-        p = xyzz_dbl_n<P>(p, MSM_C);
+    for (int w = 1; w < W; w++) {
+        p = xyzz_dbl_n<P>(p, c);
         Affine<P> q = xyzz_to_affine<P>(p);
         table[(size_t)w * n + i] = q;
-        p = xyzz_from_affine<P>(q);  // keep ZZ = 1: cheaper doublings, smaller drift
+        p = xyzz_from_affine<P>(q);  // keep ZZ = 1
     }
 }
 
@@ -375,6 +482,7 @@ struct MsmCtxBase {
     int curve = 0;
     size_t npoints = 0;
     bool precomputed = false;
+    int c = MSM_C_PLAIN;
     virtual ~MsmCtxBase() {}
     virtual void run(const void* d_scalars, size_t n, int is_mont, hipStream_t s, void* out_jac96_host) = 0;
 };
@@ -383,34 +491,52 @@ template <class P, class SF>
 struct MsmCtx : MsmCtxBase {
     DevBuf own_bases;                // bases (or the whole table when precomputed)
     const Affine<P>* table = nullptr;
-    size_t table_stride = 0;         // = npoints when precomputed (window w at w*npoints), else 0
     std::mutex mu;
-    // workspace
-    DevBuf digits, sorted, block_hist, cntw, base_off, cnt, bucket_start, task_start, space_tasks, space_task_base, task_info, task_order, len_hist, partials,
-        buckets, big_list, big_count, planes_a, planes_b, ws;
-    Xyzz<P>* ws_host = nullptr;
+    DevBuf digits, inter, sorted, block_hist, part_cnt, part_start, cnt, bucket_start, task_start, group_tasks, group_task_base, task_info,
+        task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, ws;
+    Xyzz<P>* host_pts = nullptr;  // pinned: window sums or bit planes for the host tail
     size_t ws_n = 0;
 
     ~MsmCtx() override {
-        if (ws_host) (void)hipHostFree(ws_host);
+        if (host_pts) (void)hipHostFree(host_pts);
     }
-    int G() const { return precomputed ? 1 : MSM_W; }
 
-    void set_bases_device(const void* d_bases, size_t n, bool copy, bool precompute, hipStream_t s) {
+    MsmShape shape(size_t n) const {
+        MsmShape sh;
+        sh.c = c;
+        sh.W = msm_num_windows(c);
+        sh.G = precomputed ? 1 : sh.W;
+        sh.B = 1u << (c - 1);
+        sh.NB = (uint32_t)sh.G * sh.B;
+        sh.LB = 0;
+        while ((sh.NB >> sh.LB) > (uint32_t)MSM_P) sh.LB++;
+        sh.NG = (int)(sh.NB / MSM_GRP);
+        sh.n = n;
+        sh.stride = precomputed ? npoints : 0;
+        return sh;
+    }
+
+    void set_bases_device(const void* d_bases, size_t n, bool copy, bool precompute, int c_override, hipStream_t s) {
         npoints = n;
         precomputed = precompute;
-        LURK_REQUIRE(n < ((size_t)1 << 31) / (precompute ? MSM_W : 1), "too many points for 31-bit table indices");
+        // plain: 16-bit windows (W = 16 key spaces of 2^15 buckets).  With the table every window shares
+        // one key space, so the window can grow: 2^19 buckets pay off from ~2^21 points, 2^17 below.
+        c = precompute ? (n >= ((size_t)1 << 21) ? 20 : 18) : MSM_C_PLAIN;
+        if (c_override) c = c_override;
+        LURK_REQUIRE(c >= 16 && c <= 20, "window bits must be in 16..20");
+        LURK_REQUIRE(precompute || c == MSM_C_PLAIN, "the plain mode uses 16-bit windows");
+        const int W = msm_num_windows(c);
+        LURK_REQUIRE(n < ((size_t)1 << 31) / (precompute ? W : 1), "too many points for 31-bit table indices");
         if (precompute) {
-            own_bases.alloc((size_t)MSM_W * n * sizeof(Affine<P>));
+            own_bases.alloc((size_t)W * n * sizeof(Affine<P>));
             if (n) {
                 ProfScope ps("msm_precompute", s);
                 hipLaunchKernelGGL((msm_precompute_kernel<P>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Affine<P>*)d_bases, n,
-                                   own_bases.as<Affine<P>>());
+                                   own_bases.as<Affine<P>>(), c, W);
                 LURK_HIP_CHECK(hipGetLastError());
             }
             LURK_HIP_CHECK(hipStreamSynchronize(s));
             table = own_bases.as<Affine<P>>();
-            table_stride = n;
         } else if (copy) {
             own_bases.alloc(n * sizeof(Affine<P>));
             LURK_HIP_CHECK(hipMemcpyAsync(own_bases.p, d_bases, n * sizeof(Affine<P>), hipMemcpyDeviceToDevice, s));
@@ -421,32 +547,34 @@ struct MsmCtx : MsmCtxBase {
         }
     }
 
-    void ensure_workspace(size_t n) {
-        if (n <= ws_n && ws_n != 0) return;
-        const int g = G();
-        size_t ntask_max = (size_t)g * MSM_B + (size_t)MSM_W * n / MSM_S + MSM_W + 1;
-        digits.ensure((size_t)MSM_W * n * 4);
-        sorted.ensure((size_t)MSM_W * n * 4);
-        block_hist.ensure((size_t)MSM_W * MSM_K * MSM_B * 4);
-        cnt.ensure((size_t)g * MSM_B * 4);
-        bucket_start.ensure((size_t)g * MSM_B * 4);
-        task_start.ensure((size_t)g * (MSM_B + 1) * 4);
-        space_tasks.ensure(64 * 4);
-        space_task_base.ensure(64 * 4);
-        partials.ensure(ntask_max * sizeof(Xyzz<P>));
-        task_info.ensure(ntask_max * sizeof(uint2));
-        task_order.ensure(ntask_max * 4);
+    size_t ntask_max(const MsmShape& sh) const { return (size_t)sh.NB + (size_t)sh.W * sh.n / MSM_S + 1; }
+
+    void ensure_workspace(const MsmShape& sh) {
+        if (sh.n <= ws_n && ws_n != 0) return;
+        const size_t entries = (size_t)sh.W * sh.n, nt = ntask_max(sh);
+        digits.ensure(entries * 4);
+        inter.ensure(entries * 8);
+        sorted.ensure(entries * 4);
+        block_hist.ensure((size_t)MSM_NB1 * MSM_P * 4);
+        part_cnt.ensure(MSM_P * 4);
+        part_start.ensure((MSM_P + 1) * 4);
+        cnt.ensure((size_t)sh.NB * 4);
+        bucket_start.ensure((size_t)sh.NB * 4);
+        task_start.ensure((size_t)sh.NG * (MSM_GRP + 1) * 4);
+        group_tasks.ensure(64 * 4);
+        group_task_base.ensure(64 * 4);
+        task_info.ensure(nt * sizeof(uint2));
+        task_order.ensure(nt * 4);
         len_hist.ensure(2 * (MSM_S + 1) * 4);
-        buckets.ensure((size_t)g * MSM_B * sizeof(Xyzz<P>));
-        big_list.ensure((size_t)g * MSM_B * 4);
+        partials.ensure(nt * sizeof(Xyzz<P>));
+        buckets.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
+        big_list.ensure((size_t)sh.NB * 4);
         big_count.ensure(16);
-        cntw.ensure((size_t)MSM_W * MSM_B * 4);
-        base_off.ensure((size_t)MSM_W * MSM_B * 4);
-        planes_a.ensure((size_t)g * MSM_B * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
-        planes_b.ensure((size_t)g * MSM_B * sizeof(Xyzz<P>));
-        ws.ensure((size_t)MSM_W * sizeof(Xyzz<P>));
-        if (!ws_host) LURK_HIP_CHECK(hipHostMalloc((void**)&ws_host, MSM_W * sizeof(Xyzz<P>)));
-        ws_n = n;
+        planes_a.ensure((size_t)sh.NB * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
+        planes_b.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
+        ws.ensure(32 * sizeof(Xyzz<P>));
+        if (!host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&host_pts, 32 * sizeof(Xyzz<P>)));
+        ws_n = sh.n;
     }
 
     void run(const void* d_scalars, size_t n, int is_mont, hipStream_t s, void* out_jac96_host) override {
@@ -457,80 +585,82 @@ struct MsmCtx : MsmCtxBase {
             *out = jacobian_from_affine<P>(Affine<P>{fe_zero<P>(), fe_zero<P>()});
             return;
         }
-        ensure_workspace(n);
-        const int g = G();
-        const size_t chunk = (n + MSM_K - 1) / MSM_K;
-        const size_t lds = (size_t)MSM_B * 4;
+        const MsmShape sh = shape(n);
+        ensure_workspace(sh);
+        const size_t entries = (size_t)sh.W * n;
+        const size_t chunk = (entries + MSM_NB1 - 1) / MSM_NB1;
+        const size_t nt = ntask_max(sh);
         {
             ProfScope ps("msm_digits", s);
-            hipLaunchKernelGGL((msm_digits_kernel<SF>), dim3(div_up(n, 256)), dim3(256), 0, s, (const uint4*)d_scalars, digits.as<uint32_t>(), n,
+            hipLaunchKernelGGL((msm_digits_kernel<SF>), dim3(div_up(n, 256)), dim3(256), 0, s, (const uint4*)d_scalars, digits.as<uint32_t>(), sh,
                                is_mont);
         }
         {
-            static bool attr = false;
-            if (!attr) {
-                LURK_HIP_CHECK(hipFuncSetAttribute((const void*)msm_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                LURK_HIP_CHECK(hipFuncSetAttribute((const void*)msm_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr = true;
-            }
             ProfScope ps("msm_sort", s);
-            hipLaunchKernelGGL(msm_hist_kernel, dim3(MSM_K, MSM_W), dim3(MSM_SORT_BLOCK), lds, s, digits.as<uint32_t>(),
-                               block_hist.as<uint32_t>(), n, chunk);
-            // generic: space g = window g owns sorted[g*n, (g+1)*n); precomputed: one space owning sorted[0, W*n)
-            hipLaunchKernelGGL(msm_colscan_kernel, dim3(div_up((size_t)MSM_W * MSM_B, 256)), dim3(256), 0, s, block_hist.as<uint32_t>(),
-                               cntw.as<uint32_t>());
-            hipLaunchKernelGGL(msm_binscan_kernel, dim3(g), dim3(1024), 0, s, cntw.as<uint32_t>(), g, cnt.as<uint32_t>(),
-                               bucket_start.as<uint32_t>(), task_start.as<uint32_t>(), space_tasks.as<uint32_t>(), base_off.as<uint32_t>(),
-                               precomputed ? (size_t)0 : n);
-            hipLaunchKernelGGL(msm_task_base_kernel, dim3(1), dim3(64), 0, s, space_tasks.as<uint32_t>(), space_task_base.as<uint32_t>(), g);
-            hipLaunchKernelGGL(msm_scatter_kernel, dim3(MSM_K, MSM_W), dim3(MSM_SORT_BLOCK), lds, s, digits.as<uint32_t>(),
-                               block_hist.as<uint32_t>(), base_off.as<uint32_t>(), sorted.as<uint32_t>(), n, chunk, table_stride);
+            hipLaunchKernelGGL(msm_hist1_kernel, dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, digits.as<uint32_t>(), block_hist.as<uint32_t>(), sh,
+                               chunk);
+            hipLaunchKernelGGL(msm_scan1_kernel, dim3(MSM_P), dim3(MSM_NB1), 0, s, block_hist.as<uint32_t>(), part_cnt.as<uint32_t>());
+            hipLaunchKernelGGL(msm_part_start_kernel, dim3(1), dim3(MSM_P), 0, s, part_cnt.as<uint32_t>(), part_start.as<uint32_t>());
+            hipLaunchKernelGGL(msm_scatter1_kernel, dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, digits.as<uint32_t>(), block_hist.as<uint32_t>(),
+                               part_start.as<uint32_t>(), inter.as<uint2>(), sh, chunk);
+            hipLaunchKernelGGL(msm_part2_kernel, dim3(MSM_P), dim3(MSM_SORT_BLOCK), (((size_t)1 << sh.LB) + MSM_SORT_BLOCK) * 4, s,
+                               inter.as<uint2>(), part_start.as<uint32_t>(), sorted.as<uint32_t>(), cnt.as<uint32_t>(),
+                               bucket_start.as<uint32_t>(), sh);
         }
-        const size_t ntask_max = (size_t)g * MSM_B + (size_t)MSM_W * n / MSM_S + MSM_W + 1;
         {
             ProfScope ps("msm_tasks", s);
             LURK_HIP_CHECK(hipMemsetAsync(big_count.p, 0, 4, s));
             LURK_HIP_CHECK(hipMemsetAsync(len_hist.p, 0, 2 * (MSM_S + 1) * 4, s));
             uint32_t* lh = len_hist.as<uint32_t>();
-            hipLaunchKernelGGL(msm_tasks_kernel, dim3(div_up(ntask_max, 256)), dim3(256), 0, s, cnt.as<uint32_t>(), bucket_start.as<uint32_t>(),
-                               task_start.as<uint32_t>(), space_task_base.as<uint32_t>(), g, task_info.as<uint2>());
-            hipLaunchKernelGGL(msm_len_hist_kernel, dim3(div_up(ntask_max, 256)), dim3(256), 0, s, task_info.as<uint2>(),
-                               space_task_base.as<uint32_t>(), g, lh);
+            hipLaunchKernelGGL(msm_taskscan_kernel, dim3(sh.NG), dim3(1024), 0, s, cnt.as<uint32_t>(), task_start.as<uint32_t>(),
+                               group_tasks.as<uint32_t>());
+            hipLaunchKernelGGL(msm_task_base_kernel, dim3(1), dim3(64), 0, s, group_tasks.as<uint32_t>(), group_task_base.as<uint32_t>(), sh.NG);
+            hipLaunchKernelGGL(msm_tasks_kernel, dim3(div_up(nt, 256)), dim3(256), 0, s, cnt.as<uint32_t>(), bucket_start.as<uint32_t>(),
+                               task_start.as<uint32_t>(), group_task_base.as<uint32_t>(), sh.NG, task_info.as<uint2>());
+            hipLaunchKernelGGL(msm_len_hist_kernel, dim3(256), dim3(1024), 0, s, task_info.as<uint2>(), group_task_base.as<uint32_t>(), sh.NG, lh);
             hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, s, lh, lh + MSM_S + 1);
-            hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(div_up(ntask_max, 256)), dim3(256), 0, s, task_info.as<uint2>(),
-                               space_task_base.as<uint32_t>(), g, lh + MSM_S + 1, task_order.as<uint32_t>());
+            hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, task_info.as<uint2>(), group_task_base.as<uint32_t>(), sh.NG,
+                               lh + MSM_S + 1, task_order.as<uint32_t>());
         }
         {
             ProfScope ps("msm_accumulate", s);
-            hipLaunchKernelGGL((msm_accumulate_kernel<P>), dim3(div_up(ntask_max, MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s,
-                               sorted.as<uint32_t>(), table, task_info.as<uint2>(), task_order.as<uint32_t>(), space_task_base.as<uint32_t>(), g,
+            hipLaunchKernelGGL((msm_accumulate_kernel<P>), dim3(div_up(nt, MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, sorted.as<uint32_t>(),
+                               table, task_info.as<uint2>(), task_order.as<uint32_t>(), group_task_base.as<uint32_t>(), sh.NG,
                                partials.as<Xyzz<P>>());
         }
         {
             ProfScope ps("msm_finalize", s);
-            hipLaunchKernelGGL((msm_finalize_kernel<P>), dim3(div_up((size_t)g * MSM_B, 256)), dim3(256), 0, s, partials.as<Xyzz<P>>(),
-                               cnt.as<uint32_t>(), task_start.as<uint32_t>(), space_task_base.as<uint32_t>(), g, buckets.as<Xyzz<P>>(),
+            hipLaunchKernelGGL((msm_finalize_kernel<P>), dim3(div_up((size_t)sh.NB, 256)), dim3(256), 0, s, partials.as<Xyzz<P>>(),
+                               cnt.as<uint32_t>(), task_start.as<uint32_t>(), group_task_base.as<uint32_t>(), sh.NB, buckets.as<Xyzz<P>>(),
                                big_list.as<uint32_t>(), big_count.as<uint32_t>());
             hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(512), dim3(256), 256 * sizeof(Xyzz<P>), s, partials.as<Xyzz<P>>(),
-                               cnt.as<uint32_t>(), task_start.as<uint32_t>(), space_task_base.as<uint32_t>(), buckets.as<Xyzz<P>>(),
+                               cnt.as<uint32_t>(), task_start.as<uint32_t>(), group_task_base.as<uint32_t>(), buckets.as<Xyzz<P>>(),
                                big_list.as<uint32_t>(), big_count.as<uint32_t>());
         }
+        const Xyzz<P>* planes = nullptr;
         {
             ProfScope ps("msm_reduce", s);
             const Xyzz<P>* in = buckets.as<Xyzz<P>>();
             Xyzz<P>* bufs[2] = {planes_a.as<Xyzz<P>>(), planes_b.as<Xyzz<P>>()};
-            for (int k = 0; k < MSM_C - 1; k++) {
-                size_t threads = (size_t)g * ((size_t)MSM_B >> (k + 1)) * (k + 2);
-                hipLaunchKernelGGL((msm_planes_kernel<P>), dim3(div_up(threads, 256)), dim3(256), 0, s, in, bufs[k & 1], k, g);
+            for (int k = 0; k < sh.c - 1; k++) {
+                size_t threads = (size_t)sh.G * ((size_t)sh.B >> (k + 1)) * (k + 2);
+                hipLaunchKernelGGL((msm_planes_kernel<P>), dim3(div_up(threads, 256)), dim3(256), 0, s, in, bufs[k & 1], k, sh.G, sh.B);
                 in = bufs[k & 1];
             }
-            hipLaunchKernelGGL((msm_horner_kernel<P>), dim3(g), dim3(64), 0, s, in, ws.as<Xyzz<P>>());
+            planes = in;  // [G][c] points: S, P_0 .. P_{c-2}
+            if (sh.G > 1) hipLaunchKernelGGL((msm_horner16_kernel<P>), dim3(sh.G), dim3(64), 0, s, planes, ws.as<Xyzz<P>>());
         }
         LURK_HIP_CHECK(hipGetLastError());
-        LURK_HIP_CHECK(hipMemcpyAsync(ws_host, ws.p, (size_t)g * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
-        LURK_HIP_CHECK(hipStreamSynchronize(s));
-        // host tail over <= 16 points: sum_w 2^(16w) * W_w (240 sequential doublings)
-        Xyzz<P> total = msm_combine_windows<P>(ws_host, g);
+        Xyzz<P> total;
+        if (sh.G > 1) {
+            LURK_HIP_CHECK(hipMemcpyAsync(host_pts, ws.p, (size_t)sh.G * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
+            LURK_HIP_CHECK(hipStreamSynchronize(s));
+            total = msm_combine_windows<P>(host_pts, sh.G, sh.c);  // sum_w 2^(c w) W_w on <= 16 points
+        } else {
+            LURK_HIP_CHECK(hipMemcpyAsync(host_pts, planes, (size_t)sh.c * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
+            LURK_HIP_CHECK(hipStreamSynchronize(s));
+            total = msm_planes_horner<P>(host_pts, sh.c);  // one key space: c points, c-1 doublings
+        }
         *out = jacobian_from_affine<P>(xyzz_to_affine<P>(total));
     }
 };
@@ -541,9 +671,11 @@ static MsmCtxBase* new_ctx(int curve) {
     c->curve = curve;
     return c;
 }
-static void ctx_set_bases(MsmCtxBase* c, const void* d_bases, size_t n, bool copy, bool pre, hipStream_t s) {
-    if (c->curve == LURK_CURVE_PALLAS) static_cast<MsmCtx<PallasFp, PallasFq>*>(c)->set_bases_device(d_bases, n, copy, pre, s);
-    else static_cast<MsmCtx<PallasFq, PallasFp>*>(c)->set_bases_device(d_bases, n, copy, pre, s);
+static void ctx_set_bases(MsmCtxBase* c, const void* d_bases, size_t n, bool copy, int flags, hipStream_t s) {
+    bool pre = (flags & LURK_MSM_FLAG_PRECOMPUTE) != 0;
+    int c_override = (flags >> 8) & 0xff;
+    if (c->curve == LURK_CURVE_PALLAS) static_cast<MsmCtx<PallasFp, PallasFq>*>(c)->set_bases_device(d_bases, n, copy, pre, c_override, s);
+    else static_cast<MsmCtx<PallasFq, PallasFp>*>(c)->set_bases_device(d_bases, n, copy, pre, c_override, s);
 }
 
 template <class P>
@@ -571,7 +703,7 @@ static int msm_oneshot(int curve, void* out, const void* bases, size_t n, const 
             LURK_HIP_CHECK(hipMemcpy(db.p, bases, n * 64, hipMemcpyHostToDevice));
             LURK_HIP_CHECK(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
         }
-        ctx_set_bases(c.get(), db.p, n, false, false, nullptr);
+        ctx_set_bases(c.get(), db.p, n, false, 0, nullptr);
         c->run(ds.p, n, is_mont, nullptr, out);
     });
 }
@@ -598,10 +730,9 @@ int lurk_hip_msm_ctx_create(lurk_hip_msm_ctx** ctx, int curve, const void* bases
         LURK_REQUIRE(ctx, "null ctx pointer");
         LURK_REQUIRE(n == 0 || bases, "null bases");
         std::unique_ptr<MsmCtxBase> c(new_ctx(curve));
-        bool pre = (flags & LURK_MSM_FLAG_PRECOMPUTE) != 0;
         DevBuf tmp(n * 64);
         if (n) LURK_HIP_CHECK(hipMemcpy(tmp.p, bases, n * 64, hipMemcpyHostToDevice));
-        ctx_set_bases(c.get(), tmp.p, n, /*copy=*/true, pre, nullptr);
+        ctx_set_bases(c.get(), tmp.p, n, /*copy=*/true, flags, nullptr);
         *ctx = new lurk_hip_msm_ctx{std::move(c)};
     });
 }
@@ -610,8 +741,7 @@ int lurk_hip_msm_ctx_create_dev(lurk_hip_msm_ctx** ctx, int curve, const void* d
         LURK_REQUIRE(ctx, "null ctx pointer");
         LURK_REQUIRE(n == 0 || d_bases, "null bases");
         std::unique_ptr<MsmCtxBase> c(new_ctx(curve));
-        bool pre = (flags & LURK_MSM_FLAG_PRECOMPUTE) != 0;
-        ctx_set_bases(c.get(), d_bases, n, /*copy=*/false, pre, (hipStream_t)stream);
+        ctx_set_bases(c.get(), d_bases, n, /*copy=*/false, flags, (hipStream_t)stream);
         *ctx = new lurk_hip_msm_ctx{std::move(c)};
     });
 }

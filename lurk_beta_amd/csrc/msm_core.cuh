@@ -2,45 +2,54 @@
 // in msm.hip call these with their thread/block indices, tests/host_harness replays the same
 // pipeline serially on the CPU).
 //
-// Pipeline (c = 16-bit signed windows, W = 16 windows, B = 2^15 buckets per key space):
-//   1. digits      scalar -> 16 signed digits d_w in [-2^15, 2^15]           (msm_scalar_digits)
-//   2. sort        counting sort of (point, sign) entries by bucket, per key space; LDS-privatised
-//                  histograms, no global atomics                                (msm.hip)
-//   3. accumulate  buckets are cut into tasks of <= S sorted entries; one lane per task runs
-//                  XYZZ mixed additions over gathered bases                    (msm_task_accumulate)
+// Pipeline (c-bit signed windows, W = ceil(256/c) windows, B = 2^(c-1) buckets per key space):
+//   1. digits      scalar -> W signed digits d_w in [-2^(c-1), 2^(c-1)]        (msm_scalar_digits)
+//   2. sort        two-pass partitioned counting sort of (point, sign) entries by key
+//                  (key = space*B + |d|-1): 256 coarse partitions, then the low key bits inside
+//                  each partition; LDS counters only, every global write lands in a region small
+//                  enough for the L2 to merge lines                             (msm.hip)
+//   3. accumulate  buckets are cut into tasks of <= S sorted entries, ordered longest first; one
+//                  lane per task runs XYZZ mixed additions over gathered bases  (msm_task_accumulate)
 //   4. finalize    per bucket: sum of its task partials (hot buckets by a workgroup tree)
-//   5. reduce      sum_b b*B_b = S + sum_k 2^k P_k: bit-plane merge tree (15 levels of depth one
-//                  addition) + tree-shaped Horner                              (msm.hip)
-//   6. combine     sum_w 2^(16w) * W_w : 240 sequential doublings -> done on the host over 16
-//                  points (a latency-bound tail; with the precomputed table G = 1 and it vanishes)
-// "Key space" = set of buckets entries are sorted into: one per window in the generic mode
-// (G = 16); a single shared one (G = 1) when the context holds the precomputed table
-// T[w*n + i] = 2^(16w) * P_i, because then every window's entry refers to its own table row.
+//   5. reduce      sum_b b*B_b = S + sum_k 2^k P_k: bit-plane merge tree (c-1 levels of depth one
+//                  addition) + Horner                                           (msm.hip)
+//   6. combine     sum_w 2^(c*w) * W_w on the host over <= 16 points (sequential doublings: a
+//                  latency-bound tail that one host core runs ~20x faster than one GPU lane)
+// "Key space" = set of buckets entries are sorted into: one per window in the plain mode (G = W,
+// c = 16); a single shared one (G = 1, c = 18 or 20) when the context holds the precomputed table
+// T[w*n + i] = 2^(c*w) * P_i, because then every window's entry refers to its own table row and
+// the wider window costs no extra bucket sets (13 n mixed additions instead of 16 n at c = 20).
 #pragma once
 #include "curve.cuh"
 
 namespace lurk {
 
-constexpr int MSM_C = 16;                      // window bits
-constexpr int MSM_W = 16;                      // windows (16*16 = 256 >= 255 + carry)
-constexpr int MSM_B = 1 << (MSM_C - 1);        // buckets per key space (|digit| in 1..2^15)
+constexpr int MSM_C_PLAIN = 16;                // window bits of the plain mode
+constexpr int MSM_MAX_W = 16;                  // windows: ceil(256 / c), c >= 16
+constexpr int MSM_GRP = 1 << 15;               // keys per scan group
 constexpr uint32_t MSM_SIGN = 0x80000000u;
 
-// Signed-digit recoding of a canonical 255-bit scalar (8 x u32 LE): out[w] = |d_w| | sign<<31.
-LURK_HD void msm_scalar_digits(const uint32_t* s, uint32_t* out) {
-    uint32_t carry = 0;
-#pragma unroll
-    for (int w = 0; w < MSM_W; w++) {
-        uint32_t raw = ((s[w >> 1] >> ((w & 1) * 16)) & 0xffffu) + carry;
-        if (raw > (uint32_t)MSM_B) {
-            out[w] = (0x10000u - raw) | MSM_SIGN;
-            carry = 1;
-        } else {
-            out[w] = raw;
-            carry = 0;
-        }
+LURK_HD int msm_num_windows(int c) { return (256 + c - 1) / c; }
+
+// Signed-digit recoding of a canonical 255-bit scalar (8 x u32 LE) with c-bit windows, one window
+// per call (w ascending, carry threaded through): returns |d_w| | sign<<31 with |d_w| <= 2^(c-1).
+// Scalars are < 2^255 and W*c >= 256, so the top window never carries out.
+LURK_HD uint32_t msm_digit_step(const uint32_t* s, int w, int c, uint32_t& carry) {
+    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1u;
+    const int bit = w * c, limb = bit >> 5, sh = bit & 31;
+    uint32_t raw = 0;
+    if (limb < 8) {
+        uint64_t v = s[limb];
+        if (limb + 1 < 8) v |= (uint64_t)s[limb + 1] << 32;
+        raw = (uint32_t)(v >> sh) & mask;
     }
-    // scalars are < 2^255: the top window never carries out
+    raw += carry;
+    if (raw > half) {
+        carry = 1;
+        return ((1u << c) - raw) | MSM_SIGN;
+    }
+    carry = 0;
+    return raw;
 }
 
 // largest g with start[g] <= t, over start[0..n] (start[n] is the sentinel = total)
@@ -72,14 +81,25 @@ LURK_HD Xyzz<P> xyzz_dbl_n(Xyzz<P> p, int n) {
     return p;
 }
 
-// Host tail: sum_g 2^(16 g) * ws[g], Horner from the top window.
+// Host tail: sum_g 2^(c g) * ws[g], Horner from the top window.
 template <class P>
-LURK_HD Xyzz<P> msm_combine_windows(const Xyzz<P>* ws, int g) {
+LURK_HD Xyzz<P> msm_combine_windows(const Xyzz<P>* ws, int g, int c) {
     Xyzz<P> acc = xyzz_identity<P>();
     for (int w = g - 1; w >= 0; w--) {
-        acc = xyzz_dbl_n<P>(acc, MSM_C);
+        acc = xyzz_dbl_n<P>(acc, c);
         xyzz_add<P>(acc, ws[w]);
     }
+    return acc;
+}
+// Host Horner over the bit planes of one key space: v = [S, P_0 .. P_{c-2}] -> S + sum_k 2^k P_k
+template <class P>
+LURK_HD Xyzz<P> msm_planes_horner(const Xyzz<P>* v, int c) {
+    Xyzz<P> acc = xyzz_identity<P>();
+    for (int k = c - 2; k >= 0; k--) {
+        acc = xyzz_dbl<P>(acc);
+        xyzz_add<P>(acc, v[1 + k]);
+    }
+    xyzz_add<P>(acc, v[0]);
     return acc;
 }
 

@@ -52,11 +52,12 @@ def point_sum(curve: int, points: np.ndarray) -> np.ndarray:
 class CommitmentKey:
     """Resident commitment key (``ck``): n affine bases kept in HBM for the lifetime of the object."""
 
-    def __init__(self, curve: int, bases, n: int | None = None, precompute: bool = False, device: bool = False, stream=None):
+    def __init__(self, curve: int, bases, n: int | None = None, precompute: bool = False, device: bool = False, stream=None,
+                 window_bits: int = 0):
         lib = _lib.load()
         self.curve = curve
         self._ctx = ctypes.c_void_p()
-        flags = 1 if precompute else 0
+        flags = (1 if precompute else 0) | ((window_bits & 0xFF) << 8)
         if device:
             assert n is not None
             self.n = n

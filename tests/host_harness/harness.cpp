@@ -19,6 +19,8 @@ static void mul_n(const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n, i
             case 5: r = fe_to_mont<P>(x); break;
             case 6: r = fe_from_mont<P>(x); break;
             case 7: r = fe_neg<P>(x); break;
+            case 8: r = fe_mul_fips<P>(x, y); break;   // device column-wise schedule, portable primitives
+            case 9: r = fe_mul_cios<P>(x, y); break;
             default: r = fe_zero<P>();
         }
         for (int k = 0; k < 8; k++) o[8 * i + k] = r.l[k];

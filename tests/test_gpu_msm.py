@@ -115,12 +115,24 @@ def test_commitment_key_prefix_and_precompute(hip):
     B = C.synth_bases(0, n)
     ck = CommitmentKey(0, B)
     ckp = CommitmentKey(0, B, precompute=True)
+    ckw = {c: CommitmentKey(0, B, precompute=True, window_bits=c) for c in (16, 17, 19, 20)}
     for m, dist in ((n, 0), (n, 1), (1000, 0), (1, 0), (0, 0)):
         S = C.synth_scalars(1, 3, dist, m)
         want = C.jac_to_affine(0, C.msm_pippenger(0, B[:m], S)) if m else (0, 0)
         assert point_to_affine(0, ck.commit(S)) == want, (m, dist)
         assert point_to_affine(0, ckp.commit(S)) == want, ("precompute", m, dist)
+        for c, k in ckw.items():
+            assert point_to_affine(0, k.commit(S)) == want, ("precompute", c, m, dist)
         assert point_to_affine(0, ck.commit(C.to_mont(1, S), is_mont=True)) == want
+    # scalars that stress the signed-digit recoding at every window width
+    q = R.PALLAS_Q
+    edge = [0, 1, q - 1, (1 << 254) | 0xFFFFF, int("f" * 63, 16) % q, 1 << 19, (1 << 19) + 1, (1 << 17) + 1, 0x80000, 0x7FFFF]
+    S = C.ints_to_limbs(edge)
+    want = C.jac_to_affine(0, C.msm_naive(0, B[: len(edge)], S))
+    for k in [ck, ckp] + list(ckw.values()):
+        assert point_to_affine(0, k.commit(S)) == want
+    for k in ckw.values():
+        k.close()
     from lurk_beta_amd import LurkHipError
 
     with pytest.raises(LurkHipError):
@@ -139,7 +151,7 @@ def test_point_sum(hip):
     assert point_to_affine(0, point_sum(0, parts)) == C.jac_to_affine(0, C.msm_pippenger(0, B, S))
 
 
-@pytest.mark.parametrize("log_n,dist,precompute", [(20, 0, False), (20, 1, False), (20, 1, True), (22, 0, False)])
+@pytest.mark.parametrize("log_n,dist,precompute", [(20, 0, False), (20, 1, False), (20, 1, True), (22, 0, False), (22, 1, True)])
 def test_full_size_dlog_checksum(hip, log_n, dist, precompute):
     """BASELINE.json sizes (2^20, 2^22): inputs generated in HBM, result checked bit-exactly by the
     size-independent identity  sum_i s_i [k_i]G = [sum_i s_i k_i mod q] G."""

@@ -27,6 +27,8 @@ def test_field_ops(f):
     a = [R.uniform_fe(9, i, p) for i in range(300)] + [0, 1, p - 1, p - 1, 0]
     b = [R.uniform_fe(10, i, p) for i in range(300)] + [0, p - 1, p - 1, 1, 5]
     assert _op(f, 0, a, b) == [x * y * Ri % p for x, y in zip(a, b)]
+    assert _op(f, 8, a, b) == [x * y * Ri % p for x, y in zip(a, b)]  # fe_mul_fips (device schedule)
+    assert _op(f, 9, a, b) == [x * y * Ri % p for x, y in zip(a, b)]  # fe_mul_cios
     assert _op(f, 1, a, b) == [(x + y) % p for x, y in zip(a, b)]
     assert _op(f, 2, a, b) == [(x - y) % p for x, y in zip(a, b)]
     assert _op(f, 3, a, b) == [x * x * Ri % p for x in a]
