@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=22)
     ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--precompute", type=int, default=0, help="1 = context with the per-window precomputed table")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="commitments in flight (1 = synchronous; 2..3 = async slots: the tail of one overlaps the accumulation of the next)")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
     ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt"], default="msm",
                     help="msm = the headline metric; poseidon_tree / ntt = the other hot-path kernels (BASELINE configs[2], N1)")
@@ -74,8 +76,9 @@ def main():
     ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     stream = torch.cuda.current_stream().cuda_stream
 
-    def step():
-        part = ck.commit_device(d_scalars, n, is_mont=True, stream=stream)  # 96-byte Jacobian, host
+    depth = max(1, min(3, args.pipeline))
+
+    def finish(part):
         if world == 1:
             return part
         mine = torch.from_numpy(part.view(np.int64)).cuda()
@@ -84,19 +87,33 @@ def main():
         pts = torch.stack(gathered).cpu().numpy().view(np.uint64)
         return L.point_sum(L.CURVE_PALLAS, pts)
 
+    def run_steps(k):
+        """k complete commitments; with depth > 1 up to `depth` of them are in flight at once."""
+        res = None
+        if depth == 1:
+            for _ in range(k):
+                res = finish(ck.commit_device(d_scalars, n, is_mont=True, stream=stream))  # 96-byte Jacobian, host
+            return res
+        for i in range(k):
+            slot = i % depth
+            if i >= depth:
+                res = finish(ck.wait(slot))
+            ck.submit_device(slot, d_scalars, n, is_mont=True, stream=stream)
+        for i in range(max(0, k - depth), k):
+            res = finish(ck.wait(i % depth))
+        return res
+
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        result = step()
+    result = run_steps(args.warmup)
     lib.lurk_hip_profile_enable(1)
     lib.lurk_hip_profile_reset()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
+    result = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     lib.lurk_hip_profile_enable(0)
@@ -110,7 +127,7 @@ def main():
         _lib.check(lib.lurk_hip_profile_get(prefix.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
         return tot.value, cnt.value
 
-    kernels = {k: prof(k) for k in ("msm_digits", "msm_sort", "msm_tasks", "msm_accumulate", "msm_finalize", "msm_reduce")}
+    kernels = {k: prof(k) for k in ("msm_sort", "msm_tasks", "msm_accumulate", "msm_finalize", "msm_reduce")}
 
     if rank == 0:
         total_points = n * world
@@ -148,8 +165,9 @@ def main():
                             f"{'precomputed-table' if args.precompute else 'plain'} resident commitment key",
                 "points_per_gpu": n,
                 "total_points": total_points,
-                "window_bits": args.window_bits or (16 if not args.precompute else (20 if args.log_n >= 21 else 18)),
+                "window_bits": args.window_bits or (20 if args.precompute else 16),
                 "parallelism": f"shard{world}+all_gather(96B)" if world > 1 else "single",
+                "commitments_in_flight": depth,
             },
             "roofline": {
                 "bound": "hbm",

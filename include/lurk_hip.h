@@ -94,6 +94,15 @@ int lurk_hip_msm_ctx_run(lurk_hip_msm_ctx* ctx, void* out_jacobian96, const void
  * has been synchronised by this call (the result is needed by the host-side transcript) */
 int lurk_hip_msm_ctx_run_dev(lurk_hip_msm_ctx* ctx, void* out_jacobian96, const void* d_scalars32,
                              size_t nscalars, int is_mont, void* stream);
+/* Asynchronous form: up to LURK_MSM_SLOTS commitments in flight per context, each with its own
+ * workspace and stream - e.g. commit(W) and commit(T) of one folding step, or the commitments of
+ * consecutive steps - so that the latency-bound tail of one overlaps the throughput-bound bucket
+ * accumulation of the next.  submit enqueues (ordered after `stream`, the stream that produced the
+ * scalars) and returns; wait blocks for that slot and writes the 96-byte result to host memory. */
+#define LURK_MSM_SLOTS 3
+int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars32,
+                                size_t nscalars, int is_mont, void* stream);
+int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out_jacobian96);
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx);
 
 /* Group helpers used by the multi-GPU gather (sum of per-rank partial commitments) and by tests:

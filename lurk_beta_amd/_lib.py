@@ -36,6 +36,8 @@ SIGNATURES = {
     "lurk_hip_msm_ctx_create_dev": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lurk_hip_msm_ctx_run": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "lurk_hip_msm_ctx_run_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_msm_ctx_submit_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_msm_ctx_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lurk_hip_msm_ctx_destroy": (c_int, [c_void_p]),
     "lurk_hip_point_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     "lurk_hip_point_to_affine_canonical": (c_int, [c_int, c_void_p, c_void_p]),

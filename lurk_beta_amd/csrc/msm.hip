@@ -7,7 +7,7 @@
 //
 // Memory plan (n scalars, c-bit windows, W windows, NB = G * 2^(c-1) keys <= 2^19):
 //   bases / table   64 B x n (x W with the precomputed table)   resident for the ctx lifetime
-//   digits          4 B x W x n                                  streamed once per call
+//   scalars         32 B x n, read by both sweeps of sort pass 1  caller's
 //   inter           8 B x W x n  (low key bits, entry)           between the two sort passes
 //   sorted          4 B x W x n  (table index | sign)
 //   partials        128 B x (NB + W*n/S)                         XYZZ task sums
@@ -37,37 +37,38 @@ struct MsmShape {
 };
 
 // ---- 1. digits ---------------------------------------------------------------------------
+// Both sweeps of sort pass 1 read the scalars themselves (32 B each) and recode them on the fly:
+// cheaper than materialising W digits per scalar (4 W bytes written once and read twice).
 template <class SF>  // scalar field
-__global__ __launch_bounds__(256) void msm_digits_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ digits, MsmShape sh,
-                                                           int is_mont) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= sh.n) return;
+__device__ __forceinline__ Fe<SF> msm_load_scalar(const uint4* __restrict__ scalars, size_t i, int is_mont) {
     uint4 lo = scalars[2 * i], hi = scalars[2 * i + 1];
     Fe<SF> s;
     s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
     s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
-    if (is_mont) s = fe_from_mont<SF>(s);
-    uint32_t carry = 0;
-    for (int w = 0; w < sh.W; w++) digits[(size_t)w * sh.n + i] = msm_digit_step(s.l, w, sh.c, carry);
+    return is_mont ? fe_from_mont<SF>(s) : s;
 }
 
-// entry e = w * n + i  ->  key = space * B + |d| - 1 (space = w in plain mode, 0 with the table)
+// entry (w, i) -> key = space * B + |d| - 1 (space = w in plain mode, 0 with the table)
 __device__ __forceinline__ uint32_t msm_key(const MsmShape& sh, uint32_t w, uint32_t mag) {
     return (sh.G == 1 ? 0u : w * sh.B) + mag - 1u;
 }
 
 // ---- 2a. sort pass 1: coarse partition by the high key bits -------------------------------------
-// block blk owns entries [blk*chunk, (blk+1)*chunk) of the digit array
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint32_t* __restrict__ digits, uint32_t* __restrict__ block_hist,
-                                                                     MsmShape sh, size_t chunk) {
+// block blk owns scalars [blk*chunk, (blk+1)*chunk)
+template <class SF>
+__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ block_hist,
+                                                                     MsmShape sh, size_t chunk, int is_mont) {
     __shared__ uint32_t h[MSM_P];
     if (threadIdx.x < MSM_P) h[threadIdx.x] = 0;
     __syncthreads();
-    const size_t total = (size_t)sh.W * sh.n;
-    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
-    for (size_t e = lo + threadIdx.x; e < hi; e += MSM_SORT_BLOCK) {
-        uint32_t mag = digits[e] & ~MSM_SIGN;
-        if (mag) atomicAdd(&h[msm_key(sh, (uint32_t)(e / sh.n), mag) >> sh.LB], 1u);
+    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_BLOCK) {
+        Fe<SF> s = msm_load_scalar<SF>(scalars, i, is_mont);
+        uint32_t carry = 0;
+        for (int w = 0; w < sh.W; w++) {
+            uint32_t mag = msm_digit_step(s.l, w, sh.c, carry) & ~MSM_SIGN;
+            if (mag) atomicAdd(&h[msm_key(sh, (uint32_t)w, mag) >> sh.LB], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < MSM_P) block_hist[(size_t)blockIdx.x * MSM_P + threadIdx.x] = h[threadIdx.x];
@@ -106,25 +107,27 @@ __global__ __launch_bounds__(MSM_P) void msm_part_start_kernel(const uint32_t* _
     if (t == MSM_P - 1) part_start[MSM_P] = sh[t];
 }
 
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint32_t* __restrict__ digits,
+template <class SF>
+__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint4* __restrict__ scalars,
                                                                         const uint32_t* __restrict__ block_off,
                                                                         const uint32_t* __restrict__ part_start, uint2* __restrict__ inter,
-                                                                        MsmShape sh, size_t chunk) {
+                                                                        MsmShape sh, size_t chunk, int is_mont) {
     __shared__ uint32_t off[MSM_P];
     if (threadIdx.x < MSM_P) off[threadIdx.x] = part_start[threadIdx.x] + block_off[(size_t)blockIdx.x * MSM_P + threadIdx.x];
     __syncthreads();
-    const size_t total = (size_t)sh.W * sh.n;
     const uint32_t low_mask = (1u << sh.LB) - 1u;
-    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < total ? lo + chunk : total;
-    for (size_t e = lo + threadIdx.x; e < hi; e += MSM_SORT_BLOCK) {
-        uint32_t d = digits[e];
-        uint32_t mag = d & ~MSM_SIGN;
-        if (mag) {
-            uint32_t w = (uint32_t)(e / sh.n);
-            uint32_t i = (uint32_t)(e - (size_t)w * sh.n);
-            uint32_t key = msm_key(sh, w, mag);
-            uint32_t pos = atomicAdd(&off[key >> sh.LB], 1u);
-            inter[pos] = make_uint2(key & low_mask, ((uint32_t)((size_t)w * sh.stride) + i) | (d & MSM_SIGN));
+    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
+    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_BLOCK) {
+        Fe<SF> s = msm_load_scalar<SF>(scalars, i, is_mont);
+        uint32_t carry = 0;
+        for (int w = 0; w < sh.W; w++) {
+            uint32_t d = msm_digit_step(s.l, w, sh.c, carry);
+            uint32_t mag = d & ~MSM_SIGN;
+            if (mag) {
+                uint32_t key = msm_key(sh, (uint32_t)w, mag);
+                uint32_t pos = atomicAdd(&off[key >> sh.LB], 1u);
+                inter[pos] = make_uint2(key & low_mask, ((uint32_t)((size_t)w * sh.stride) + (uint32_t)i) | (d & MSM_SIGN));
+            }
         }
     }
 }
@@ -338,17 +341,12 @@ __global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __re
 }
 
 // ---- 4. accumulate -------------------------------------------------------------------------
+// The kernel lives in msm_acc.hip: that translation unit is compiled with the multiplier inlined
+// (no argument marshalling around the ten products of a mixed addition); everything else in this
+// file calls the multiplier as a function to keep the latency-bound tail kernels small.
 template <class P>
-__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
-                                                                         const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
-                                                                         const uint32_t* __restrict__ group_task_base, int NG,
-                                                                         Xyzz<P>* __restrict__ partials) {
-    uint32_t i = blockIdx.x * MSM_ACC_BLOCK + threadIdx.x;
-    if (i >= group_task_base[NG]) return;
-    uint32_t t = order[i];
-    uint2 ti = task_info[t];
-    partials[t] = msm_task_accumulate<P>(sorted, ti.x, ti.y, table);
-}
+void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
+                           const uint32_t* group_task_base, int NG, Xyzz<P>* partials, size_t nt, hipStream_t s);
 
 // ---- 5. finalize ---------------------------------------------------------------------------
 template <class P>
@@ -478,28 +476,43 @@ __global__ __launch_bounds__(256) void msm_precompute_kernel(const Affine<P>* __
 }
 
 // ---- context -------------------------------------------------------------------------------
+constexpr int MSM_SLOTS = 3;  // commitments in flight per context (independent workspaces + streams)
+
 struct MsmCtxBase {
     int curve = 0;
     size_t npoints = 0;
     bool precomputed = false;
     int c = MSM_C_PLAIN;
     virtual ~MsmCtxBase() {}
+    // synchronous: enqueue on `s` with slot 0's workspace, wait, host tail
     virtual void run(const void* d_scalars, size_t n, int is_mont, hipStream_t s, void* out_jac96_host) = 0;
+    // asynchronous: enqueue on the slot's own stream (after `after`, the stream that produced the scalars)
+    virtual void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after) = 0;
+    virtual void wait(int slot, void* out_jac96_host) = 0;
 };
 
 template <class P, class SF>
 struct MsmCtx : MsmCtxBase {
     DevBuf own_bases;                // bases (or the whole table when precomputed)
     const Affine<P>* table = nullptr;
-    std::mutex mu;
-    DevBuf digits, inter, sorted, block_hist, part_cnt, part_start, cnt, bucket_start, task_start, group_tasks, group_task_base, task_info,
-        task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, ws;
-    Xyzz<P>* host_pts = nullptr;  // pinned: window sums or bit planes for the host tail
-    size_t ws_n = 0;
 
-    ~MsmCtx() override {
-        if (host_pts) (void)hipHostFree(host_pts);
-    }
+    struct Work {
+        std::mutex mu;
+        DevBuf inter, sorted, block_hist, part_cnt, part_start, cnt, bucket_start, task_start, group_tasks, group_task_base, task_info,
+            task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, ws;
+        Xyzz<P>* host_pts = nullptr;  // pinned: window sums or bit planes for the host tail
+        size_t ws_n = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t ready = nullptr;
+        bool pending = false;
+        size_t pending_n = 0;
+        ~Work() {
+            if (host_pts) (void)hipHostFree(host_pts);
+            if (stream) (void)hipStreamDestroy(stream);
+            if (ready) (void)hipEventDestroy(ready);
+        }
+    };
+    Work work[MSM_SLOTS];
 
     MsmShape shape(size_t n) const {
         MsmShape sh;
@@ -520,8 +533,8 @@ struct MsmCtx : MsmCtxBase {
         npoints = n;
         precomputed = precompute;
         // plain: 16-bit windows (W = 16 key spaces of 2^15 buckets).  With the table every window shares
-        // one key space, so the window can grow: 2^19 buckets pay off from ~2^21 points, 2^17 below.
-        c = precompute ? (n >= ((size_t)1 << 21) ? 20 : 18) : MSM_C_PLAIN;
+        // one key space, so the window grows to 20 bits (13 windows whose top one still holds 15 bits).
+        c = precompute ? 20 : MSM_C_PLAIN;
         if (c_override) c = c_override;
         LURK_REQUIRE(c >= 16 && c <= 20, "window bits must be in 16..20");
         LURK_REQUIRE(precompute || c == MSM_C_PLAIN, "the plain mode uses 16-bit windows");
@@ -549,119 +562,165 @@ struct MsmCtx : MsmCtxBase {
 
     size_t ntask_max(const MsmShape& sh) const { return (size_t)sh.NB + (size_t)sh.W * sh.n / MSM_S + 1; }
 
-    void ensure_workspace(const MsmShape& sh) {
-        if (sh.n <= ws_n && ws_n != 0) return;
+    void ensure_workspace(Work& wk, const MsmShape& sh) {
+        if (sh.n <= wk.ws_n && wk.ws_n != 0) return;
         const size_t entries = (size_t)sh.W * sh.n, nt = ntask_max(sh);
-        digits.ensure(entries * 4);
-        inter.ensure(entries * 8);
-        sorted.ensure(entries * 4);
-        block_hist.ensure((size_t)MSM_NB1 * MSM_P * 4);
-        part_cnt.ensure(MSM_P * 4);
-        part_start.ensure((MSM_P + 1) * 4);
-        cnt.ensure((size_t)sh.NB * 4);
-        bucket_start.ensure((size_t)sh.NB * 4);
-        task_start.ensure((size_t)sh.NG * (MSM_GRP + 1) * 4);
-        group_tasks.ensure(64 * 4);
-        group_task_base.ensure(64 * 4);
-        task_info.ensure(nt * sizeof(uint2));
-        task_order.ensure(nt * 4);
-        len_hist.ensure(2 * (MSM_S + 1) * 4);
-        partials.ensure(nt * sizeof(Xyzz<P>));
-        buckets.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
-        big_list.ensure((size_t)sh.NB * 4);
-        big_count.ensure(16);
-        planes_a.ensure((size_t)sh.NB * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
-        planes_b.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
-        ws.ensure(32 * sizeof(Xyzz<P>));
-        if (!host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&host_pts, 32 * sizeof(Xyzz<P>)));
-        ws_n = sh.n;
+        wk.inter.ensure(entries * 8);
+        wk.sorted.ensure(entries * 4);
+        wk.block_hist.ensure((size_t)MSM_NB1 * MSM_P * 4);
+        wk.part_cnt.ensure(MSM_P * 4);
+        wk.part_start.ensure((MSM_P + 1) * 4);
+        wk.cnt.ensure((size_t)sh.NB * 4);
+        wk.bucket_start.ensure((size_t)sh.NB * 4);
+        wk.task_start.ensure((size_t)sh.NG * (MSM_GRP + 1) * 4);
+        wk.group_tasks.ensure(64 * 4);
+        wk.group_task_base.ensure(64 * 4);
+        wk.task_info.ensure(nt * sizeof(uint2));
+        wk.task_order.ensure(nt * 4);
+        wk.len_hist.ensure(2 * (MSM_S + 1) * 4);
+        wk.partials.ensure(nt * sizeof(Xyzz<P>));
+        wk.buckets.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
+        wk.big_list.ensure((size_t)sh.NB * 4);
+        wk.big_count.ensure(16);
+        wk.planes_a.ensure((size_t)sh.NB * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
+        wk.planes_b.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
+        wk.ws.ensure(32 * sizeof(Xyzz<P>));
+        if (!wk.host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&wk.host_pts, 32 * sizeof(Xyzz<P>)));
+        wk.ws_n = sh.n;
+    }
+
+    // every kernel of one commitment + the D2H of its <= 20 result points, on stream s
+    void enqueue(Work& wk, const void* d_scalars, size_t n, int is_mont, hipStream_t s) {
+        const MsmShape sh = shape(n);
+        ensure_workspace(wk, sh);
+        const size_t chunk = (n + MSM_NB1 - 1) / MSM_NB1;
+        const size_t nt = ntask_max(sh);
+        {
+            ProfScope ps("msm_sort", s);
+            hipLaunchKernelGGL((msm_hist1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, (const uint4*)d_scalars,
+                               wk.block_hist.template as<uint32_t>(), sh, chunk, is_mont);
+            hipLaunchKernelGGL(msm_scan1_kernel, dim3(MSM_P), dim3(MSM_NB1), 0, s, wk.block_hist.template as<uint32_t>(),
+                               wk.part_cnt.template as<uint32_t>());
+            hipLaunchKernelGGL(msm_part_start_kernel, dim3(1), dim3(MSM_P), 0, s, wk.part_cnt.template as<uint32_t>(),
+                               wk.part_start.template as<uint32_t>());
+            hipLaunchKernelGGL((msm_scatter1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, (const uint4*)d_scalars,
+                               wk.block_hist.template as<uint32_t>(), wk.part_start.template as<uint32_t>(), wk.inter.template as<uint2>(), sh,
+                               chunk, is_mont);
+            hipLaunchKernelGGL(msm_part2_kernel, dim3(MSM_P), dim3(MSM_SORT_BLOCK), (((size_t)1 << sh.LB) + MSM_SORT_BLOCK) * 4, s,
+                               wk.inter.template as<uint2>(), wk.part_start.template as<uint32_t>(), wk.sorted.template as<uint32_t>(),
+                               wk.cnt.template as<uint32_t>(), wk.bucket_start.template as<uint32_t>(), sh);
+        }
+        {
+            ProfScope ps("msm_tasks", s);
+            LURK_HIP_CHECK(hipMemsetAsync(wk.big_count.p, 0, 4, s));
+            LURK_HIP_CHECK(hipMemsetAsync(wk.len_hist.p, 0, 2 * (MSM_S + 1) * 4, s));
+            uint32_t* lh = wk.len_hist.template as<uint32_t>();
+            hipLaunchKernelGGL(msm_taskscan_kernel, dim3(sh.NG), dim3(1024), 0, s, wk.cnt.template as<uint32_t>(),
+                               wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>());
+            hipLaunchKernelGGL(msm_task_base_kernel, dim3(1), dim3(64), 0, s, wk.group_tasks.template as<uint32_t>(),
+                               wk.group_task_base.template as<uint32_t>(), sh.NG);
+            hipLaunchKernelGGL(msm_tasks_kernel, dim3(div_up(nt, 256)), dim3(256), 0, s, wk.cnt.template as<uint32_t>(),
+                               wk.bucket_start.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, wk.task_info.template as<uint2>());
+            hipLaunchKernelGGL(msm_len_hist_kernel, dim3(256), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh);
+            hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, s, lh, lh + MSM_S + 1);
+            hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh + MSM_S + 1, wk.task_order.template as<uint32_t>());
+        }
+        {
+            ProfScope ps("msm_accumulate", s);
+            msm_launch_accumulate<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
+                                     wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
+                                     wk.partials.template as<Xyzz<P>>(), nt, s);
+        }
+        {
+            ProfScope ps("msm_finalize", s);
+            hipLaunchKernelGGL((msm_finalize_kernel<P>), dim3(div_up((size_t)sh.NB, 256)), dim3(256), 0, s, wk.partials.template as<Xyzz<P>>(),
+                               wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
+                               wk.group_task_base.template as<uint32_t>(), sh.NB, wk.buckets.template as<Xyzz<P>>(),
+                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>());
+            hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(512), dim3(256), 256 * sizeof(Xyzz<P>), s, wk.partials.template as<Xyzz<P>>(),
+                               wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
+                               wk.group_task_base.template as<uint32_t>(), wk.buckets.template as<Xyzz<P>>(),
+                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>());
+        }
+        {
+            ProfScope ps("msm_reduce", s);
+            const Xyzz<P>* in = wk.buckets.template as<Xyzz<P>>();
+            Xyzz<P>* bufs[2] = {wk.planes_a.template as<Xyzz<P>>(), wk.planes_b.template as<Xyzz<P>>()};
+            for (int k = 0; k < sh.c - 1; k++) {
+                size_t threads = (size_t)sh.G * ((size_t)sh.B >> (k + 1)) * (k + 2);
+                hipLaunchKernelGGL((msm_planes_kernel<P>), dim3(div_up(threads, 256)), dim3(256), 0, s, in, bufs[k & 1], k, sh.G, sh.B);
+                in = bufs[k & 1];
+            }
+            // `in` = [G][c] points: S, P_0 .. P_{c-2}
+            if (sh.G > 1) {
+                hipLaunchKernelGGL((msm_horner16_kernel<P>), dim3(sh.G), dim3(64), 0, s, in, wk.ws.template as<Xyzz<P>>());
+                LURK_HIP_CHECK(hipMemcpyAsync(wk.host_pts, wk.ws.p, (size_t)sh.G * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
+            } else {
+                LURK_HIP_CHECK(hipMemcpyAsync(wk.host_pts, in, (size_t)sh.c * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
+            }
+        }
+        LURK_HIP_CHECK(hipGetLastError());
+    }
+
+    // host tail over the <= 20 points the device left in pinned memory (stream already synchronised)
+    void host_tail(Work& wk, size_t n, Jacobian<P>* out) {
+        const MsmShape sh = shape(n);
+        Xyzz<P> total = sh.G > 1 ? msm_combine_windows<P>(wk.host_pts, sh.G, sh.c)  // sum_w 2^(c w) W_w
+                                 : msm_planes_horner<P>(wk.host_pts, sh.c);         // one key space: c-1 doublings
+        *out = jacobian_from_affine<P>(xyzz_to_affine<P>(total));
     }
 
     void run(const void* d_scalars, size_t n, int is_mont, hipStream_t s, void* out_jac96_host) override {
-        std::lock_guard<std::mutex> lk(mu);
         LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
         Jacobian<P>* out = (Jacobian<P>*)out_jac96_host;
         if (n == 0) {
             *out = jacobian_from_affine<P>(Affine<P>{fe_zero<P>(), fe_zero<P>()});
             return;
         }
-        const MsmShape sh = shape(n);
-        ensure_workspace(sh);
-        const size_t entries = (size_t)sh.W * n;
-        const size_t chunk = (entries + MSM_NB1 - 1) / MSM_NB1;
-        const size_t nt = ntask_max(sh);
-        {
-            ProfScope ps("msm_digits", s);
-            hipLaunchKernelGGL((msm_digits_kernel<SF>), dim3(div_up(n, 256)), dim3(256), 0, s, (const uint4*)d_scalars, digits.as<uint32_t>(), sh,
-                               is_mont);
+        Work& wk = work[0];
+        std::lock_guard<std::mutex> lk(wk.mu);
+        LURK_REQUIRE(!wk.pending, "slot 0 has a submitted commitment that was not waited for");
+        enqueue(wk, d_scalars, n, is_mont, s);
+        LURK_HIP_CHECK(hipStreamSynchronize(s));
+        host_tail(wk, n, out);
+    }
+
+    void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after) override {
+        LURK_REQUIRE(slot >= 0 && slot < MSM_SLOTS, "slot out of range");
+        LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
+        Work& wk = work[slot];
+        std::lock_guard<std::mutex> lk(wk.mu);
+        LURK_REQUIRE(!wk.pending, "slot is busy: wait for it first");
+        if (!wk.stream) {
+            LURK_HIP_CHECK(hipStreamCreateWithFlags(&wk.stream, hipStreamNonBlocking));
+            LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.ready, hipEventDisableTiming));
         }
-        {
-            ProfScope ps("msm_sort", s);
-            hipLaunchKernelGGL(msm_hist1_kernel, dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, digits.as<uint32_t>(), block_hist.as<uint32_t>(), sh,
-                               chunk);
-            hipLaunchKernelGGL(msm_scan1_kernel, dim3(MSM_P), dim3(MSM_NB1), 0, s, block_hist.as<uint32_t>(), part_cnt.as<uint32_t>());
-            hipLaunchKernelGGL(msm_part_start_kernel, dim3(1), dim3(MSM_P), 0, s, part_cnt.as<uint32_t>(), part_start.as<uint32_t>());
-            hipLaunchKernelGGL(msm_scatter1_kernel, dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, digits.as<uint32_t>(), block_hist.as<uint32_t>(),
-                               part_start.as<uint32_t>(), inter.as<uint2>(), sh, chunk);
-            hipLaunchKernelGGL(msm_part2_kernel, dim3(MSM_P), dim3(MSM_SORT_BLOCK), (((size_t)1 << sh.LB) + MSM_SORT_BLOCK) * 4, s,
-                               inter.as<uint2>(), part_start.as<uint32_t>(), sorted.as<uint32_t>(), cnt.as<uint32_t>(),
-                               bucket_start.as<uint32_t>(), sh);
+        if (n) {
+            // the scalars were produced on the caller's stream: order the slot stream after it
+            LURK_HIP_CHECK(hipEventRecord(wk.ready, after));
+            LURK_HIP_CHECK(hipStreamWaitEvent(wk.stream, wk.ready, 0));
+            enqueue(wk, d_scalars, n, is_mont, wk.stream);
         }
-        {
-            ProfScope ps("msm_tasks", s);
-            LURK_HIP_CHECK(hipMemsetAsync(big_count.p, 0, 4, s));
-            LURK_HIP_CHECK(hipMemsetAsync(len_hist.p, 0, 2 * (MSM_S + 1) * 4, s));
-            uint32_t* lh = len_hist.as<uint32_t>();
-            hipLaunchKernelGGL(msm_taskscan_kernel, dim3(sh.NG), dim3(1024), 0, s, cnt.as<uint32_t>(), task_start.as<uint32_t>(),
-                               group_tasks.as<uint32_t>());
-            hipLaunchKernelGGL(msm_task_base_kernel, dim3(1), dim3(64), 0, s, group_tasks.as<uint32_t>(), group_task_base.as<uint32_t>(), sh.NG);
-            hipLaunchKernelGGL(msm_tasks_kernel, dim3(div_up(nt, 256)), dim3(256), 0, s, cnt.as<uint32_t>(), bucket_start.as<uint32_t>(),
-                               task_start.as<uint32_t>(), group_task_base.as<uint32_t>(), sh.NG, task_info.as<uint2>());
-            hipLaunchKernelGGL(msm_len_hist_kernel, dim3(256), dim3(1024), 0, s, task_info.as<uint2>(), group_task_base.as<uint32_t>(), sh.NG, lh);
-            hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, s, lh, lh + MSM_S + 1);
-            hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, task_info.as<uint2>(), group_task_base.as<uint32_t>(), sh.NG,
-                               lh + MSM_S + 1, task_order.as<uint32_t>());
+        wk.pending = true;
+        wk.pending_n = n;
+    }
+
+    void wait(int slot, void* out_jac96_host) override {
+        LURK_REQUIRE(slot >= 0 && slot < MSM_SLOTS, "slot out of range");
+        Work& wk = work[slot];
+        std::lock_guard<std::mutex> lk(wk.mu);
+        LURK_REQUIRE(wk.pending, "nothing was submitted on this slot");
+        Jacobian<P>* out = (Jacobian<P>*)out_jac96_host;
+        wk.pending = false;
+        if (wk.pending_n == 0) {
+            *out = jacobian_from_affine<P>(Affine<P>{fe_zero<P>(), fe_zero<P>()});
+            return;
         }
-        {
-            ProfScope ps("msm_accumulate", s);
-            hipLaunchKernelGGL((msm_accumulate_kernel<P>), dim3(div_up(nt, MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, sorted.as<uint32_t>(),
-                               table, task_info.as<uint2>(), task_order.as<uint32_t>(), group_task_base.as<uint32_t>(), sh.NG,
-                               partials.as<Xyzz<P>>());
-        }
-        {
-            ProfScope ps("msm_finalize", s);
-            hipLaunchKernelGGL((msm_finalize_kernel<P>), dim3(div_up((size_t)sh.NB, 256)), dim3(256), 0, s, partials.as<Xyzz<P>>(),
-                               cnt.as<uint32_t>(), task_start.as<uint32_t>(), group_task_base.as<uint32_t>(), sh.NB, buckets.as<Xyzz<P>>(),
-                               big_list.as<uint32_t>(), big_count.as<uint32_t>());
-            hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(512), dim3(256), 256 * sizeof(Xyzz<P>), s, partials.as<Xyzz<P>>(),
-                               cnt.as<uint32_t>(), task_start.as<uint32_t>(), group_task_base.as<uint32_t>(), buckets.as<Xyzz<P>>(),
-                               big_list.as<uint32_t>(), big_count.as<uint32_t>());
-        }
-        const Xyzz<P>* planes = nullptr;
-        {
-            ProfScope ps("msm_reduce", s);
-            const Xyzz<P>* in = buckets.as<Xyzz<P>>();
-            Xyzz<P>* bufs[2] = {planes_a.as<Xyzz<P>>(), planes_b.as<Xyzz<P>>()};
-            for (int k = 0; k < sh.c - 1; k++) {
-                size_t threads = (size_t)sh.G * ((size_t)sh.B >> (k + 1)) * (k + 2);
-                hipLaunchKernelGGL((msm_planes_kernel<P>), dim3(div_up(threads, 256)), dim3(256), 0, s, in, bufs[k & 1], k, sh.G, sh.B);
-                in = bufs[k & 1];
-            }
-            planes = in;  // [G][c] points: S, P_0 .. P_{c-2}
-            if (sh.G > 1) hipLaunchKernelGGL((msm_horner16_kernel<P>), dim3(sh.G), dim3(64), 0, s, planes, ws.as<Xyzz<P>>());
-        }
-        LURK_HIP_CHECK(hipGetLastError());
-        Xyzz<P> total;
-        if (sh.G > 1) {
-            LURK_HIP_CHECK(hipMemcpyAsync(host_pts, ws.p, (size_t)sh.G * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
-            LURK_HIP_CHECK(hipStreamSynchronize(s));
-            total = msm_combine_windows<P>(host_pts, sh.G, sh.c);  // sum_w 2^(c w) W_w on <= 16 points
-        } else {
-            LURK_HIP_CHECK(hipMemcpyAsync(host_pts, planes, (size_t)sh.c * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
-            LURK_HIP_CHECK(hipStreamSynchronize(s));
-            total = msm_planes_horner<P>(host_pts, sh.c);  // one key space: c points, c-1 doublings
-        }
-        *out = jacobian_from_affine<P>(xyzz_to_affine<P>(total));
+        LURK_HIP_CHECK(hipStreamSynchronize(wk.stream));
+        host_tail(wk, wk.pending_n, out);
     }
 };
 
@@ -759,6 +818,19 @@ int lurk_hip_msm_ctx_run_dev(lurk_hip_msm_ctx* ctx, void* out, const void* d_sca
         LURK_REQUIRE(ctx && out, "null argument");
         LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
         ctx->impl->run(d_scalars, n, is_mont, (hipStream_t)stream, out);
+    });
+}
+int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars, size_t n, int is_mont, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx, "null ctx");
+        LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
+        ctx->impl->submit(slot, d_scalars, n, is_mont, (hipStream_t)stream);
+    });
+}
+int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && out, "null argument");
+        ctx->impl->wait(slot, out);
     });
 }
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx) {

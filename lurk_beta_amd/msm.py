@@ -83,6 +83,20 @@ class CommitmentKey:
         _lib.check(lib.lurk_hip_msm_ctx_run_dev(self._ctx, _lib.ptr(out), _lib.ptr(d_scalars), n, int(is_mont), _lib.ptr(stream)))
         return out
 
+    def submit_device(self, slot: int, d_scalars, n: int, is_mont: bool = False, stream=None) -> None:
+        """Asynchronous commit on `slot` (0..2); pair with ``wait(slot)``."""
+        lib = _lib.load()
+        self._keep = getattr(self, "_keep", {})
+        self._keep[slot] = d_scalars  # the scalars must stay alive until wait()
+        _lib.check(lib.lurk_hip_msm_ctx_submit_dev(self._ctx, slot, _lib.ptr(d_scalars), n, int(is_mont), _lib.ptr(stream)))
+
+    def wait(self, slot: int) -> np.ndarray:
+        lib = _lib.load()
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.lurk_hip_msm_ctx_wait(self._ctx, slot, _lib.ptr(out)))
+        getattr(self, "_keep", {}).pop(slot, None)
+        return out
+
     def close(self):
         if self._ctx:
             _lib.load().lurk_hip_msm_ctx_destroy(self._ctx)

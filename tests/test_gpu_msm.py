@@ -141,6 +141,38 @@ def test_commitment_key_prefix_and_precompute(hip):
     ckp.close()
 
 
+def test_async_slots(hip):
+    """submit/wait: three commitments in flight on one context give the same bytes as the synchronous call."""
+    import torch
+
+    from lurk_beta_amd import CommitmentKey, LurkHipError, point_to_affine, synth
+
+    n = 1 << 14
+    d_bases = synth.bases(0, n)
+    scal = [synth.scalars(1, 10 + j, j % 2, n, mont=True) for j in range(5)]
+    torch.cuda.synchronize()
+    for pre in (False, True):
+        ck = CommitmentKey(0, d_bases, n=n, device=True, precompute=pre)
+        want = [ck.commit_device(sc, n, is_mont=True) for sc in scal]
+        got = [None] * 5
+        for j in range(5):
+            slot = j % 3
+            if j >= 3:
+                got[j - 3] = ck.wait(slot)
+            ck.submit_device(slot, scal[j], n, is_mont=True, stream=torch.cuda.current_stream().cuda_stream)
+        for j in range(2, 5):
+            got[j] = ck.wait(j % 3)
+        for a, b in zip(got, want):
+            assert point_to_affine(0, a) == point_to_affine(0, b)
+        with pytest.raises(LurkHipError):
+            ck.wait(0)  # nothing pending
+        ck.submit_device(1, scal[0], n, is_mont=True)
+        with pytest.raises(LurkHipError):
+            ck.submit_device(1, scal[1], n, is_mont=True)  # slot busy
+        ck.wait(1)
+        ck.close()
+
+
 def test_point_sum(hip):
     from lurk_beta_amd import msm, point_sum, point_to_affine
 
