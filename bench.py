@@ -3,7 +3,10 @@
 
 A "step" is one commitment  C = sum_i s_i * ck_i  over Pallas: scalars and the commitment key are
 already resident in HBM when the timed region starts (the PCIe-inclusive rate is noted in
-DESIGN.md, never here).  N = 1: n = 2^log_n points on one GPU (default 2^22, the size the metric
+DESIGN.md, never here).  By default two commitments are in flight (`--pipeline 2`, the commit(W) /
+commit(T) pair of a folding step): every step is still one complete MSM and all K results are
+produced inside the timed region; `--pipeline 1` is the fully synchronous form.  The resident key
+carries the precomputed per-window table by default (`--precompute 0` = plain 64 B/point key).  N = 1: n = 2^log_n points on one GPU (default 2^22, the size the metric
 is quoted at; `--log-n 20` is BASELINE.json configs[1]).  N > 1: one process per GPU, every rank
 owns its own 2^log_n-point shard of an (N * 2^log_n)-point commitment (weak scaling); each step
 ends with the path's real exchange: an RCCL all_gather of the 96-byte partial commitments and the
@@ -34,8 +37,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=22)
     ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
-    ap.add_argument("--precompute", type=int, default=0, help="1 = context with the per-window precomputed table")
-    ap.add_argument("--pipeline", type=int, default=1,
+    ap.add_argument("--precompute", type=int, default=1,
+                    help="1 = resident key with the per-window precomputed table (13 x 64 B per point, 20-bit windows); 0 = plain key")
+    ap.add_argument("--pipeline", type=int, default=2,
                     help="commitments in flight (1 = synchronous; 2..3 = async slots: the tail of one overlaps the accumulation of the next)")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
     ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt"], default="msm",
@@ -73,7 +77,10 @@ def main():
     d_bases = synth.bases(L.CURVE_PALLAS, n, first=first)
     d_scalars = synth.scalars(L.FIELD_PALLAS_FQ, 1, dist_id, n, first=first, mont=True)
     torch.cuda.synchronize()
+    t_setup = time.perf_counter()
     ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
+    torch.cuda.synchronize()
+    setup_ms = (time.perf_counter() - t_setup) * 1e3
     stream = torch.cuda.current_stream().cuda_stream
 
     depth = max(1, min(3, args.pipeline))
@@ -116,6 +123,14 @@ def main():
     result = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
+    # per-kernel durations (HIP events on the launch stream) come from synchronous commitments so that
+    # overlapping launches of the other slots do not stretch them
+    lib.lurk_hip_profile_reset()
+    t1 = time.perf_counter()
+    nsync = 3
+    for _ in range(nsync):
+        ck.commit_device(d_scalars, n, is_mont=True, stream=stream)
+    sync_ms = (time.perf_counter() - t1) / nsync * 1e3
     lib.lurk_hip_profile_enable(0)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -179,9 +194,12 @@ def main():
                 "traffic": traffic,
                 "avg_launch_ms": round(acc_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "integer-VALU bound (v_mad_u64_u32), not HBM bound: see DESIGN.md for the mad-rate roofline",
+                "mixed_additions_per_launch": (13 if args.precompute and not args.window_bits else msm_windows(args)) * n,
+                "note": "integer-VALU bound (v_mad_u64_u32 + carry folds), not HBM bound: see DESIGN.md for the VALU roofline",
             },
-            "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in kernels.items()},
+            "kernel_ms_per_commit_sync": {k: round(v[0] / max(v[1], 1) * (v[1] / nsync), 4) for k, v in kernels.items()},
+            "sync_ms_per_commit": round(sync_ms, 4),
+            "setup_ms_once": round(setup_ms, 1),
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, result if world == 1 and args.cpu_sample_log_n == args.log_n else None)
@@ -190,6 +208,11 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def msm_windows(args):
+    c = args.window_bits or (20 if args.precompute else 16)
+    return -(-256 // c)
 
 
 def other_workloads(args, lib, world, rank):
