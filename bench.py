@@ -42,8 +42,10 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2,
                     help="commitments in flight (1 = synchronous; 2..3 = async slots: the tail of one overlaps the accumulation of the next)")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
-    ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt"], default="msm",
-                    help="msm = the headline metric; poseidon_tree / ntt = the other hot-path kernels (BASELINE configs[2], N1)")
+    ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt", "fold_step"], default="msm",
+                    help="msm = the headline metric; poseidon_tree / ntt = the other hot-path kernels (BASELINE configs[2], N1); "
+                         "fold_step = synthetic stand-in for one Nova folding step of benches/fibonacci.rs (configs[0]/[3])")
+    ap.add_argument("--rc", type=int, default=100, help="fold_step: reduction count (frames per step), 100 or 900")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20)
     args = ap.parse_args()
@@ -68,6 +70,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
+    if args.workload == "fold_step":
+        return fold_step_workload(args, lib, world, rank)
     if args.workload != "msm":
         return other_workloads(args, lib, world, rank)
 
@@ -208,6 +212,80 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def fold_step_workload(args, lib, world, rank):
+    """Synthetic stand-in for the device work of ONE Nova folding step of benches/fibonacci.rs on the
+    Pallas cycle (the bench itself needs cargo + arecibo and cannot run here):
+      commit(W): n_vars  ~ 9 119 * rc points, witness-like scalars   (src/lem/eval.rs:1966)
+      commit(T): n_cons  ~ 11 141 * rc points, uniform scalars       (src/lem/eval.rs:1967)
+      slot-witness Poseidon batch: 21 hashes per frame (14 hash4 + 6 hash8 + 1 hash3, eval.rs:1960-1964)
+    Reported as "equivalent Lurk iterations/s" = rc / t(step).  It leaves out what stays on the CPU in the
+    reference (sparse mat-vec, transcript, circuit synthesis): an upper bound on the end-to-end rate, flagged
+    synthetic."""
+    import numpy as np
+    import torch
+
+    import lurk_beta_amd as L
+    from lurk_beta_amd import _lib, synth
+
+    rc = args.rc
+    n_w, n_t = 9119 * rc, 11141 * rc
+    n_key = max(n_w, n_t)
+    stream = torch.cuda.current_stream().cuda_stream
+    d_bases = synth.bases(L.CURVE_PALLAS, n_key)
+    d_w = synth.scalars(L.FIELD_PALLAS_FQ, 1, 1, n_w, mont=True)
+    d_t = synth.scalars(L.FIELD_PALLAS_FQ, 2, 0, n_t, mont=True)
+    pre4 = synth.scalars(L.FIELD_PALLAS_FQ, 3, 1, 14 * rc * 4)
+    pre8 = synth.scalars(L.FIELD_PALLAS_FQ, 4, 1, 6 * rc * 8)
+    pre3 = synth.scalars(L.FIELD_PALLAS_FQ, 5, 1, 1 * rc * 3)
+    out = torch.empty((21 * rc, 4), dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
+    F = L.FIELD_PALLAS_FQ
+
+    def step():
+        ck.submit_device(0, d_w, n_w, is_mont=True, stream=stream)
+        ck.submit_device(1, d_t, n_t, is_mont=True, stream=stream)
+        _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 4, _lib.ptr(pre4), 14 * rc, _lib.ptr(out), _lib.ptr(stream)))
+        _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 8, _lib.ptr(pre8), 6 * rc, _lib.ptr(out[14 * rc:]), _lib.ptr(stream)))
+        _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 3, _lib.ptr(pre3), rc, _lib.ptr(out[20 * rc:]), _lib.ptr(stream)))
+        cw, ct = ck.wait(0), ck.wait(1)
+        torch.cuda.synchronize()
+        return cw, ct
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        res = {
+            "metric": "equivalent Lurk iterations/s (synthetic stand-in for one Nova folding step, Pallas)",
+            "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
+            "config": {"workload": f"fold-step stand-in rc={rc}: MSM(W) {n_w} pts witness-like + MSM(T) {n_t} pts uniform + {21 * rc} Poseidon slot hashes",
+                       "note": "device work only (commitments + slot hashes); sparse mat-vec / transcript / synthesis not modelled"},
+        }
+        if not args.no_cpu_baseline:
+            from oracle import coracle as C
+
+            m = min(n_t, 1 << 20)
+            B = C.synth_bases(0, m)
+            t1 = time.perf_counter()
+            C.msm_pippenger(0, B[: min(n_w, m)], C.synth_scalars(1, 1, 1, min(n_w, m)))
+            C.msm_pippenger(0, B, C.synth_scalars(1, 2, 0, m))
+            dt = time.perf_counter() - t1
+            scale = (n_w + n_t) / (min(n_w, m) + m)
+            res["cpu_baseline"] = {"value": round(rc / (dt * scale), 2), "unit": "iterations/s", "cores": C.lib().orc_num_threads(), "kind": "port",
+                                   "sample": f"both MSMs truncated to <= 2^20 points ({dt:.2f} s), scaled linearly to the full step; oracle/oracle.c OpenMP Pippenger"}
+        print(json.dumps(res), flush=True)
+    ck.close()
 
 
 def msm_windows(args):

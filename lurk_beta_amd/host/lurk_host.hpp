@@ -1,0 +1,171 @@
+// lurk_host.hpp - C++ host-side mirror of the reference's interfaces for the hot path, written
+// against the C ABI only (include/lurk_hip.h): what a Rust maintainer binds through FFI
+//  expressed in the language available in this image.
+//
+//   lurk::host::PoseidonCache   <- PoseidonCache<F>::hash3/4/6/8, compute_hash  (/root/reference/src/hash.rs:86-204)
+//   lurk::host::Trie            <- coprocessor::trie::Trie<F, 8, HEIGHT>        (/root/reference/src/coprocessor/trie/mod.rs:328-800)
+//   lurk::host::CommitmentKey   <- arecibo CommitmentKey + CE::commit(ck, v)     (callers /root/reference/src/proof/nova.rs:287-293)
+//
+// Field elements are 32-byte canonical little-endian values (Fe); points use the repr-c layouts.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/lurk_hip.h"
+
+namespace lurk {
+namespace host {
+
+struct Fe {
+    std::array<uint64_t, 4> l{};
+    Fe() = default;
+    explicit Fe(uint64_t v) { l[0] = v; }
+    bool operator<(const Fe& o) const { return l < o.l; }
+    bool operator==(const Fe& o) const { return l == o.l; }
+    bool is_zero() const { return !(l[0] | l[1] | l[2] | l[3]); }
+    bool bit(int i) const { return (l[i >> 6] >> (i & 63)) & 1; }
+};
+
+inline void check(int rc) {
+    if (rc != 0) throw std::runtime_error(lurk_hip_last_error());  // the Rust side panics on a non-zero code
+}
+
+class PoseidonCache {
+  public:
+    explicit PoseidonCache(int field_id) : field_(field_id) {}
+    Fe hash3(const std::array<Fe, 3>& p) { return compute(p.data(), 3); }
+    Fe hash4(const std::array<Fe, 4>& p) { return compute(p.data(), 4); }
+    Fe hash6(const std::array<Fe, 6>& p) { return compute(p.data(), 6); }
+    Fe hash8(const std::array<Fe, 8>& p) { return compute(p.data(), 8); }
+    // hash.rs:97-113: dispatch on the arity, anything but 3,4,6,8 is unreachable!/panic
+    Fe compute_hash(const std::vector<Fe>& p) {
+        if (p.size() != 3 && p.size() != 4 && p.size() != 6 && p.size() != 8) throw std::invalid_argument("unsupported arity");
+        return compute(p.data(), (int)p.size());
+    }
+    // batched entry (store hydration hashes one DAG level per call)
+    std::vector<Fe> hash_many(int arity, const std::vector<Fe>& flat_preimages) {
+        size_t n = flat_preimages.size() / arity;
+        std::vector<Fe> out(n);
+        check(lurk_hip_poseidon_batch(field_, arity, flat_preimages.data(), n, out.data()));
+        return out;
+    }
+
+  private:
+    Fe compute(const Fe* p, int arity) {
+        std::vector<Fe> key(p, p + arity);
+        auto it = memo_.find(key);
+        if (it != memo_.end()) return it->second;
+        Fe d;
+        check(lurk_hip_poseidon_batch(field_, arity, p, 1, &d));
+        memo_.emplace(std::move(key), d);
+        return d;
+    }
+    int field_;
+    std::map<std::vector<Fe>, Fe> memo_;
+};
+
+// Sparse arity-8 Poseidon trie (StandardTrie = height 85).
+class Trie {
+  public:
+    Trie(int field_id, int height, PoseidonCache& cache) : field_(field_id), height_(height), cache_(cache) {
+        Fe cur;  // empty element = 0 (trie/mod.rs:430-433)
+        for (int i = 0; i < height; i++) {  // init_empty (:464-481)
+            std::array<Fe, 8> pre;
+            pre.fill(cur);
+            cur = reg(pre);
+            empty_roots_.push_back(cur);
+        }
+        root_ = height ? empty_roots_.back() : Fe();
+    }
+    Fe root() const { return root_; }
+    Fe empty_root_for_height(int h) const { return h == 0 ? Fe() : empty_roots_[h - 1]; }
+    // path (:589-608): MSB-first bits, keep the last 3*H bits, 3-bit big-endian digits
+    std::vector<int> path(const Fe& key) const {
+        int nbits = field_ == LURK_FIELD_BN254_FR ? 254 : 255, need = 3 * height_;
+        std::vector<int> be;
+        for (int i = need - 1; i >= 0; i--) be.push_back(i < nbits ? key.bit(i) : 0);
+        std::vector<int> out;
+        for (int i = 0; i < need; i += 3) out.push_back(be[i] << 2 | be[i + 1] << 1 | be[i + 2]);
+        return out;
+    }
+    bool lookup(const Fe& key, Fe* value) const {  // (:635-652)
+        auto p = path(key);
+        auto pres = along(p);
+        *value = pres.back()[p.back()];
+        return !value->is_zero();
+    }
+    bool insert(const Fe& key, const Fe& value) {  // (:745-800)
+        auto p = path(key);
+        auto pres = along(p);
+        bool existed = !pres.back()[p.back()].is_zero();
+        Fe cur = value;
+        for (int lvl = height_ - 1; lvl >= 0; lvl--) {
+            std::array<Fe, 8> pre = pres[lvl];
+            pre[p[lvl]] = cur;
+            cur = reg(pre);
+        }
+        root_ = cur;
+        return existed;
+    }
+
+  private:
+    Fe reg(const std::array<Fe, 8>& pre) {
+        Fe h = cache_.hash8(pre);
+        children_[h] = pre;
+        return h;
+    }
+    std::vector<std::array<Fe, 8>> along(const std::vector<int>& p) const {
+        std::vector<std::array<Fe, 8>> out;
+        Fe node = root_;
+        for (int lvl = 0; lvl < height_; lvl++) {
+            auto it = children_.find(node);
+            std::array<Fe, 8> pre;
+            if (it != children_.end()) pre = it->second;
+            else pre.fill(empty_root_for_height(height_ - lvl - 1));
+            out.push_back(pre);
+            node = pre[p[lvl]];
+        }
+        return out;
+    }
+    int field_, height_;
+    PoseidonCache& cache_;
+    std::map<Fe, std::array<Fe, 8>> children_;
+    std::vector<Fe> empty_roots_;
+    Fe root_;
+};
+
+struct Affine { Fe x, y; };       // Montgomery limbs, identity = (0,0)
+struct Jacobian { Fe x, y, z; };  // Montgomery limbs, identity: z = 0
+
+// Resident commitment key; commit(v) = sum v_i * ck_i over ck[..v.len()].
+class CommitmentKey {
+  public:
+    CommitmentKey(int curve, const std::vector<Affine>& ck, bool precompute) : curve_(curve) {
+        check(lurk_hip_msm_ctx_create(&ctx_, curve, ck.data(), ck.size(), precompute ? LURK_MSM_FLAG_PRECOMPUTE : 0));
+    }
+    ~CommitmentKey() { lurk_hip_msm_ctx_destroy(ctx_); }
+    CommitmentKey(const CommitmentKey&) = delete;
+    Jacobian commit(const std::vector<Fe>& scalars, bool is_mont) const {
+        Jacobian out;
+        check(lurk_hip_msm_ctx_run(ctx_, &out, scalars.data(), scalars.size(), is_mont ? 1 : 0));
+        return out;
+    }
+    // canonical affine (x, y) of a commitment: what bit-exactness is defined on
+    std::array<Fe, 2> to_affine(const Jacobian& p) const {
+        std::array<Fe, 2> xy;
+        check(lurk_hip_point_to_affine_canonical(curve_, xy.data(), &p));
+        return xy;
+    }
+
+  private:
+    int curve_;
+    lurk_hip_msm_ctx* ctx_ = nullptr;
+};
+
+}  // namespace host
+}  // namespace lurk

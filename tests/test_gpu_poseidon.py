@@ -76,3 +76,70 @@ def test_tree8_empty_roots_are_the_trie_kats(hip):
     for h, name in ((1, "hash8_zeros"), (2, "empty_root_2"), (3, "empty_root_3"), (4, "empty_root_4")):
         root = poseidon_tree8(kat.BN, np.zeros((8 ** h, 4), dtype=np.uint64))
         assert C.limbs_to_ints(root)[0] == kat.golden_int(name)
+
+
+def test_trie_mirror_reproduces_reference_kats(hip):
+    """coprocessor::trie::Trie through the GPU hasher: empty roots, path, insert, lookup
+    (trie/mod.rs:925-1017, eval_tests.rs:3868,3904)."""
+    from lurk_beta_amd.trie import Trie
+
+    t3 = Trie(kat.BN, height=3)
+    assert [t3.empty_root_for_height(h) for h in (0, 1, 2, 3)] == [0, kat.golden_int("hash8_zeros"), kat.golden_int("empty_root_2"),
+                                                                    kat.golden_int("empty_root_3")]
+    assert t3.leaves() == 512 and t3.path(500) == kat.GOLDEN["trie_path_500_h3"]
+    t = Trie(kat.BN)  # StandardTrie: arity 8, height 85
+    assert t.root == kat.golden_int("empty_root_85")
+    assert t.lookup(123) is None
+    assert t.insert(123, 456) is False
+    assert t.root == kat.golden_int("trie_insert_123_456")
+    assert t.lookup(123) == 456 and t.lookup(124) is None
+    assert t.insert(123, 789) is True and t.lookup(123) == 789
+    # the same operations over Pallas Fq agree with the oracle's recursion
+    tp = Trie(1, height=5)
+    tp.insert(77, 1234)
+    assert tp.root == R.trie_insert_root(1, 5, 77, 1234)
+
+
+def test_store_hydration_level_batches(hip):
+    """StoreHasher layouts hashed level by level on the GPU == node-by-node recursion in the oracle
+    (store.rs:29-78; KAT: (commit (lambda (x) x)), eval_tests.rs:379)."""
+    from lurk_beta_amd import PoseidonCache
+    from lurk_beta_amd.store_hasher import hydrate
+
+    def string_nodes(nodes, s):  # Str cells, terminator (Str, 0)
+        nodes.append(("atom", R.TAG_STR, 0))
+        cur = len(nodes) - 1
+        for ch in reversed(s):
+            nodes.append(("atom", R.TAG_CHAR, ord(ch)))
+            nodes.append(("tuple2", R.TAG_STR, len(nodes) - 1, cur))
+            cur = len(nodes) - 1
+        return cur
+
+    def symbol_nodes(nodes, path, tag=R.TAG_SYM):
+        nodes.append(("atom", R.TAG_SYM, 0))
+        cur = len(nodes) - 1
+        for k, name in enumerate(path):
+            sn = string_nodes(nodes, name)
+            nodes.append(("tuple2", tag if k == len(path) - 1 else R.TAG_SYM, sn, cur))
+            cur = len(nodes) - 1
+        return cur
+
+    nodes = []
+    x = symbol_nodes(nodes, ["lurk", "user", "x"])
+    nil = symbol_nodes(nodes, ["lurk", "nil"], tag=R.TAG_NIL)
+    nodes.append(("tuple2", R.TAG_CONS, x, nil))          # (x)
+    args = len(nodes) - 1
+    nodes.append(("atom", R.TAG_ENV, 0))                  # empty env
+    env = len(nodes) - 1
+    nodes.append(("atom", R.TAG_NIL, 0))                  # dummy
+    dummy = len(nodes) - 1
+    nodes.append(("tuple4", R.TAG_FUN, args, x, env, dummy))
+    fun = len(nodes) - 1
+    nodes.append(("comm", 0, fun))
+    digests = hydrate(PoseidonCache(kat.BN), nodes)
+    assert digests[-1] == kat.golden_int("commit_lambda_x_x")
+    assert digests[nil] == R.hash_symbol_path(kat.BN, ["lurk", "nil"])
+    # compact (env binding) layout
+    nodes2 = [("atom", R.TAG_SYM, 11), ("atom", R.TAG_NUM, 22), ("atom", R.TAG_ENV, 0), ("compact", R.TAG_ENV, 0, 1, 2)]
+    d2 = hydrate(PoseidonCache(1), nodes2)
+    assert d2[3] == R.poseidon_hash(1, [11, R.TAG_NUM, 22, 0])
