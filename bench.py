@@ -326,7 +326,11 @@ def other_workloads(args, lib, world, rank):
             _lib.check(lib.lurk_hip_ntt_dev(F, _lib.ptr(d_data), log_n, 0, _lib.ptr(stream)))
 
         unit, per_step_units, kname = "Melements/s", n, "ntt"
-        passes = -(-log_n // 10) + 1  # bit-reversal pass + ceil(log_n / 10) fused-stage passes
+        left, passes = max(0, log_n - 11), 2  # bit-reversal pass + the 11-stage pass ...
+        while left > 0:                        # ... + later passes of <= 9 stages (mirrors ntt.hip)
+            ns = left if left <= 9 else min(8, (left + 1) // 2)
+            left -= ns
+            passes += 1
         alg_bytes = 64.0 * passes * n
         workload = f"radix-2 NTT, 2^{log_n} Pallas-Fq elements (parity unpinned: no reference counterpart)"
     torch.cuda.synchronize()

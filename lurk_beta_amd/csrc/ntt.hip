@@ -5,10 +5,15 @@
 // omega_n = (5^((p-1)/2^32))^(2^(32-log_n)); natural order in, natural order out; the inverse
 // transform uses omega^-1 and scales by 1/n.
 //
-// Shape: decimation-in-time after a bit-reversal gather.  Stages are fused LDS_LOG at a time: a
-// workgroup loads a tile of 2^LDS_LOG elements whose indices differ only in the bits the fused
-// stages touch, runs those butterflies out of LDS (twiddles from a resident table), and writes the
-// tile back, so an n = 2^24 transform makes ceil(24/LDS_LOG) passes over HBM instead of 24.
+// Shape: decimation-in-time after a bit-reversal permutation, in passes that each fuse several
+// radix-2 stages out of an LDS tile:
+//   * the permutation is a 32x32 LDS transpose (both the reads and the writes are 1 KiB rows);
+//   * pass 1 (stages 1..11) works on 2048 contiguous elements;
+//   * a later pass covering stages s0+1..s0+ns takes, per workgroup, C = 2048 / 2^ns neighbouring
+//     sub-transforms so that every global row is C x 32 B contiguous, "twists" each element once by
+//     omega_N^(t * rev(l)) (N = 2^(s0+ns), t = position inside the already transformed 2^s0 block),
+//     after which every stage only needs the 2^(ns-1) local twiddles, kept in LDS;
+//   * the last pass writes straight into the caller's buffer (scaled / converted as needed).
 #include <memory>
 #include <tuple>
 
@@ -17,8 +22,6 @@
 
 namespace lurk {
 
-constexpr int NTT_LDS_LOG = 10;  // 1024 elements x 32 B = 32 KiB per workgroup
-constexpr int NTT_BLOCK = 256;
 
 template <class F>
 __device__ Fe<F> ntt_pow(Fe<F> base, uint64_t e) {
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void ntt_twiddle_kernel(Fe<F> omega, size_t ha
     if (i < half) tw[i] = ntt_pow<F>(omega, i);
 }
 
-// dst[bitrev(i)] = to_mont(src[i])  (out of place)
+// dst[bitrev(i)] = to_mont(src[i])  (out of place), small sizes
 template <class F>
 __global__ __launch_bounds__(256) void ntt_bitrev_kernel(const Fe<F>* __restrict__ src, Fe<F>* __restrict__ dst, unsigned log_n) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -46,41 +49,78 @@ __global__ __launch_bounds__(256) void ntt_bitrev_kernel(const Fe<F>* __restrict
     size_t r = log_n ? (__brevll((unsigned long long)i) >> (64 - log_n)) : 0;
     dst[r] = fe_to_mont<F>(src[i]);
 }
-
-// Fused stages [s0, s0+ns): stage s (1-based span m = 2^s) pairs indices differing in bit s-1.
-// Tile = all indices sharing the bits outside [s0, s0+ns): local index bits map to global bits
-// s0 .. s0+ns-1; the remaining global bits come from the tile id (low part below s0, high above).
+// same for log_n >= 10 as a tiled transpose: index bits [hi:5][mid][lo:5] -> [rev lo][rev mid][rev hi];
+// block = one value of mid; reads rows of 32 consecutive lo, writes rows of 32 consecutive rev(hi)
 template <class F>
-__global__ __launch_bounds__(NTT_BLOCK) void ntt_stages_kernel(Fe<F>* __restrict__ a, const Fe<F>* __restrict__ tw, unsigned log_n, unsigned s0,
-                                                                 unsigned ns, Fe<F> scale, int do_scale, int out_canonical) {
+__global__ __launch_bounds__(256) void ntt_bitrev_tiled_kernel(const Fe<F>* __restrict__ src, Fe<F>* __restrict__ dst, unsigned log_n) {
+    __shared__ uint4 lds_raw[32 * 33 * 2];
+    Fe<F>* sh = reinterpret_cast<Fe<F>*>(lds_raw);
+    const unsigned mbits = log_n - 10;
+    const size_t mid = blockIdx.x;
+    const size_t rmid = mbits ? (__brevll((unsigned long long)mid) >> (64 - mbits)) : 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned e = r * 256 + threadIdx.x, hi = e >> 5, lo = e & 31;
+        sh[lo * 33 + hi] = fe_to_mont<F>(src[((size_t)hi << (log_n - 5)) | (mid << 5) | lo]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned e = r * 256 + threadIdx.x, a = e >> 5, b = e & 31;  // a = rev5(lo), b = rev5(hi)
+        unsigned lo = __brev(a) >> 27, hi = __brev(b) >> 27;
+        dst[((size_t)a << (log_n - 5)) | (rmid << 5) | b] = sh[lo * 33 + hi];
+    }
+}
+
+constexpr int NTT_TILE_LOG = 11;      // 2048 elements (64 KiB) per workgroup
+constexpr int NTT_PASS_BLOCK = 512;
+
+// One pass: stages s0+1 .. s0+ns.  cbits = log2(C), ns + cbits <= NTT_TILE_LOG.  Tile layout in LDS:
+// [l][c] (l = index inside the sub-transform, c = which of the C neighbouring sub-transforms).
+template <class F>
+__global__ __launch_bounds__(NTT_PASS_BLOCK) void ntt_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out,
+                                                                    const Fe<F>* __restrict__ tw, unsigned log_n, unsigned s0, unsigned ns,
+                                                                    unsigned cbits, Fe<F> scale, int do_scale, int out_canonical) {
     extern __shared__ uint4 lds_raw[];
     Fe<F>* sh = reinterpret_cast<Fe<F>*>(lds_raw);
-    const size_t tile = blockIdx.x;
-    const size_t low_mask = ((size_t)1 << s0) - 1;
-    const size_t tile_low = tile & low_mask, tile_high = tile >> s0;
-    const unsigned tile_n = 1u << ns;
-    auto gidx = [&](unsigned l) -> size_t { return (tile_high << (s0 + ns)) | ((size_t)l << s0) | tile_low; };
-    for (unsigned l = threadIdx.x; l < tile_n; l += NTT_BLOCK) sh[l] = a[gidx(l)];
+    Fe<F>* lt = sh + ((size_t)1 << (ns + cbits));  // local twiddles: omega_{2^ns}^j, j < 2^(ns-1)
+    const unsigned C = 1u << cbits, tile_n = 1u << (ns + cbits);
+    const size_t half_n = (size_t)1 << (log_n - 1);
+    // block id -> (H, tbase): the 2^s0 low positions are cut into groups of C
+    const size_t groups = ((size_t)1 << s0) >> cbits;  // >= 1
+    const size_t H = blockIdx.x / groups, tbase = (blockIdx.x % groups) << cbits;
+    for (unsigned j = threadIdx.x; j < (1u << ns) / 2; j += NTT_PASS_BLOCK) lt[j] = tw[(size_t)j << (log_n - ns)];
+    for (unsigned e = threadIdx.x; e < tile_n; e += NTT_PASS_BLOCK) {
+        unsigned c = e & (C - 1), l = e >> cbits;
+        size_t t = tbase + c;
+        Fe<F> v = in[(H << (s0 + ns)) | ((size_t)l << s0) | t];
+        if (s0) {  // twist by omega_N^(t * rev_ns(l)), N = 2^(s0+ns): index into the omega^i table with the sign fold
+            size_t idx = (t * (size_t)(__brev(l) >> (32 - ns))) << (log_n - s0 - ns);
+            Fe<F> w = tw[idx & (half_n - 1)];
+            if (idx & half_n) w = fe_neg<F>(w);
+            v = fe_mul<F>(v, w);
+        }
+        sh[e] = v;  // e == l * C + c
+    }
     __syncthreads();
     for (unsigned st = 0; st < ns; st++) {
-        const unsigned s = s0 + st + 1;  // global stage, span 2^s
-        for (unsigned bf = threadIdx.x; bf < tile_n / 2; bf += NTT_BLOCK) {
-            unsigned lo_bits = bf & ((1u << st) - 1);
-            unsigned l0 = ((bf >> st) << (st + 1)) | lo_bits, l1 = l0 | (1u << st);
-            // position inside the span of stage s: global index modulo 2^(s-1)
-            size_t j = (((size_t)lo_bits) << s0) | tile_low;
-            Fe<F> w = tw[j << (log_n - s)];
-            Fe<F> u = sh[l0], t = fe_mul<F>(sh[l1], w);
-            sh[l0] = fe_add<F>(u, t);
-            sh[l1] = fe_sub<F>(u, t);
+        for (unsigned bf = threadIdx.x; bf < tile_n / 2; bf += NTT_PASS_BLOCK) {
+            unsigned c = bf & (C - 1), pr = bf >> cbits;
+            unsigned lo_bits = pr & ((1u << st) - 1);
+            unsigned l0 = ((pr >> st) << (st + 1)) | lo_bits, l1 = l0 | (1u << st);
+            Fe<F> w = lt[lo_bits << (ns - st - 1)];
+            Fe<F> u = sh[(l0 << cbits) | c], x = fe_mul<F>(sh[(l1 << cbits) | c], w);
+            sh[(l0 << cbits) | c] = fe_add<F>(u, x);
+            sh[(l1 << cbits) | c] = fe_sub<F>(u, x);
         }
         __syncthreads();
     }
-    for (unsigned l = threadIdx.x; l < tile_n; l += NTT_BLOCK) {
-        Fe<F> v = sh[l];
+    for (unsigned e = threadIdx.x; e < tile_n; e += NTT_PASS_BLOCK) {
+        unsigned c = e & (C - 1), l = e >> cbits;
+        Fe<F> v = sh[e];
         if (do_scale) v = fe_mul<F>(v, scale);
         if (out_canonical) v = fe_from_mont<F>(v);
-        a[gidx(l)] = v;
+        out[(H << (s0 + ns)) | ((size_t)l << s0) | (tbase + c)] = v;
     }
 }
 
@@ -132,22 +172,34 @@ static void ntt_device(void* d_data, unsigned log_n, bool inverse, hipStream_t s
     NttPlan& plan = ntt_plan<F>(log_n, inverse, s);
     std::lock_guard<std::mutex> lk(plan.mu);  // one transform at a time per plan (shared scratch)
     Fe<F>* tmp = plan.tmp.template as<Fe<F>>();
+    Fe<F>* data = (Fe<F>*)d_data;
     const Fe<F>* tw = plan.tw.template as<Fe<F>>();
+    static bool attr = false;
+    if (!attr) {
+        LURK_HIP_CHECK(hipFuncSetAttribute((const void*)ntt_pass_kernel<PallasFp>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        LURK_HIP_CHECK(hipFuncSetAttribute((const void*)ntt_pass_kernel<PallasFq>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
     ProfScope ps("ntt", s);
-    hipLaunchKernelGGL((ntt_bitrev_kernel<F>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Fe<F>*)d_data, tmp, log_n);
+    if (log_n >= 10) hipLaunchKernelGGL((ntt_bitrev_tiled_kernel<F>), dim3((unsigned)(n >> 10)), dim3(256), 0, s, data, tmp, log_n);
+    else hipLaunchKernelGGL((ntt_bitrev_kernel<F>), dim3(div_up(n, 256)), dim3(256), 0, s, data, tmp, log_n);
     Fe<F> scale = fe_one<F>();
     if (inverse) scale = fe_inv<F>(fe_from_u64<F>((uint64_t)n));
+    // pass plan: first pass as deep as the tile allows, the rest in passes of <= 9 stages (C >= 4: rows of >= 128 B)
     unsigned s0 = 0;
-    if (log_n == 0) hipLaunchKernelGGL((ntt_stages_kernel<F>), dim3(1), dim3(NTT_BLOCK), 32, s, tmp, tw, log_n, 0u, 0u, scale, 0, 1);
-    while (s0 < log_n) {
-        unsigned ns = log_n - s0 < (unsigned)NTT_LDS_LOG ? log_n - s0 : NTT_LDS_LOG;
+    bool first = true;
+    do {
+        unsigned left = log_n - s0;
+        unsigned ns = first ? (left < (unsigned)NTT_TILE_LOG ? left : NTT_TILE_LOG) : (left <= 9 ? left : ((left + 1) / 2 < 8 ? (left + 1) / 2 : 8));
+        unsigned cbits = first ? 0 : (NTT_TILE_LOG - ns < s0 ? NTT_TILE_LOG - ns : s0);
         bool last = s0 + ns == log_n;
-        hipLaunchKernelGGL((ntt_stages_kernel<F>), dim3((unsigned)(n >> ns)), dim3(NTT_BLOCK), ((size_t)32 << ns), s, tmp, tw, log_n, s0, ns,
-                           scale, (last && inverse) ? 1 : 0, last ? 1 : 0);
+        size_t lds = (((size_t)1 << (ns + cbits)) + ((size_t)1 << ns) / 2 + 1) * sizeof(Fe<F>);
+        hipLaunchKernelGGL((ntt_pass_kernel<F>), dim3((unsigned)(n >> (ns + cbits))), dim3(NTT_PASS_BLOCK), lds, s, tmp, last ? data : tmp, tw,
+                           log_n, s0, ns, cbits, scale, (last && inverse) ? 1 : 0, last ? 1 : 0);
         s0 += ns;
-    }
+        first = false;
+    } while (s0 < log_n);
     LURK_HIP_CHECK(hipGetLastError());
-    LURK_HIP_CHECK(hipMemcpyAsync(d_data, tmp, n * 32, hipMemcpyDeviceToDevice, s));
     LURK_HIP_CHECK(hipStreamSynchronize(s));  // the plan's scratch is released to the next caller
 }
 
