@@ -407,6 +407,108 @@ LURK_HD Fe<P> fe_mul(const Fe<P>& a, const Fe<P>& b) {
     return fe_mul_inline<P>(a, b);
 #endif
 }
+// ---- inner product with ONE Montgomery reduction -----------------------------------------------
+// sum_{i<T} a[i]*b[i] / R mod p.  Every partial product a_i[j]*b_i[l] is added to the private
+// accumulator of column j+l (64-bit mad destination + carry word), so operands are consumed one at a
+// time and the 16 columns are propagated and reduced once at the end: T*64 + 40 (Pasta) multiply-adds
+// instead of T*104 - the dense and sparse layers of Poseidon are all inner products with constants.
+// The unreduced result is < p*(T*p/R + 1) <= 3.25 p for T <= 9: two conditional subtractions.
+template <class P>
+LURK_HD void fe_cond_sub2(uint32_t* t) {  // t -= 2p if t >= 2p   (2p < 2^256 for every modulus here)
+    uint32_t d[8];
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint32_t twop = (P::mod(i) << 1) | (i ? (P::mod(i - 1) >> 31) : 0u);
+        d[i] = subb32(t[i], twop, borrow);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = borrow ? t[i] : d[i];
+}
+
+template <class P>
+struct DotAcc {
+    uint64_t col[15];
+    uint32_t h[15];
+};
+template <class P>
+LURK_HD void dot_init(DotAcc<P>& A) {
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        A.col[k] = 0;
+        A.h[k] = 0;
+    }
+}
+// A += a*b (64 multiply-adds, carries folded per column)
+template <class P>
+LURK_HD void dot_mac(DotAcc<P>& A, const Fe<P>& a, const Fe<P>& b) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint64_t cm[8];
+#pragma unroll
+        for (int l = 0; l < 8; l++) mad_c(A.col[j + l], cm[l], a.l[j], b.l[l]);
+        column_fence();
+#pragma unroll
+        for (int l = 0; l < 8; l++) fold_carry(A.h[j + l], cm[l]);
+    }
+}
+// portable Montgomery reduction of a 16-limb value: t = (v + m*p) / 2^256 (< 2^256, not yet < p)
+template <class P>
+LURK_HD void fe_redc16_portable(uint32_t* t, const uint32_t* vin) {
+    uint32_t v[17];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = vin[i];
+    v[16] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        uint32_t m = v[k] * P::INV;
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint64_t x = (uint64_t)m * P::mod(j) + v[k + j] + c;
+            v[k + j] = (uint32_t)x;
+            c = x >> 32;
+        }
+#pragma unroll
+        for (int j = k + 8; j < 17; j++) {
+            uint64_t x = (uint64_t)v[j] + c;
+            v[j] = (uint32_t)x;
+            c = x >> 32;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) t[i] = v[8 + i];
+}
+
+// propagate the columns into a 16-limb integer (two interleaved carry chains), Montgomery-reduce it
+// once, bring the result into [0, p).  The value is < T*p^2 < 2^512 for T <= 9, the quotient < 3.25 p.
+template <class P, int T>
+LURK_HD Fe<P> dot_finish(const DotAcc<P>& A) {
+    // limb k receives: low word of column k, high word of column k-1, carry word of column k-2
+    uint32_t x[16], v[16];
+    uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        uint32_t lo = k < 15 ? (uint32_t)A.col[k] : 0u;
+        uint32_t hi = k >= 1 ? (uint32_t)(A.col[k - 1] >> 32) : 0u;
+        x[k] = addc32(lo, hi, c1);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) v[k] = addc32(x[k], k >= 2 ? A.h[k - 2] : 0u, c2);
+    uint32_t t[8];
+#if defined(__HIP_DEVICE_COMPILE__) && LURK_MUL_IMPL == 2
+    fe_redc16_asm<P>(t, v);
+#else
+    fe_redc16_portable<P>(t, v);
+#endif
+    if (T > 3) fe_cond_sub2<P>(t);
+    fe_cond_sub<P>(t);
+    Fe<P> r;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r.l[i] = t[i];
+    return r;
+}
+
 template <class P>
 LURK_HD Fe<P> fe_sqr(const Fe<P>& a) {
     return fe_mul<P>(a, a);

@@ -135,6 +135,75 @@ def gen_mul(name, modulus, square=False):
     return e.lines
 
 
+def gen_redc(name, modulus):
+    """Montgomery reduction of a 16-limb value v (as produced by the inner-product accumulator):
+    t = (v + m*p) / 2^256, column-wise like the product, with v_k entering column k as v_k * 1."""
+    p = limbs(modulus)
+    inv = (-pow(modulus, -1, 1 << 32)) % (1 << 32)
+    e = Emitter()
+    T = lambda i: f"%{i}"
+    V = lambda i: f"%{8 + i}"
+    M = lambda i: f"v{M_BASE + i}"
+
+    def P(j):
+        return "1" if p[j] == 1 else f"s{P_SGPR_BASE + j}"
+
+    for j in range(8):
+        if p[j] not in (0, 1):
+            e.emit(f"s_mov_b32 s{P_SGPR_BASE + j}, 0x{p[j]:08x}")
+    if inv != 0xFFFFFFFF:
+        e.emit(f"s_mov_b32 s{INV_SGPR}, 0x{inv:08x}")
+    for k in range(16):
+        first_fold = [True]
+        seq = [(V(k), "1")]
+        seq += [(M(i), P(k - i)) for i in range(max(0, k - 7), min(k - 1, 7) + 1) if p[k - i] != 0]
+        if k == 0:
+            x, y = seq.pop(0)
+            pair = e.free.pop(0)
+            e.emit(f"v_mad_u64_u32 v[{ACC_LO}:{ACC_HI}], s[{pair}:{pair + 1}], {x}, {y}, 0")
+            e.writer_pos[pair] = len(e.lines) - 1
+            e.free.append(pair)
+            e.emit(f"v_mov_b32 v{H}, 0")
+            first_fold[0] = False
+        for x, y in seq:
+            e.mad(x, y, first_fold)
+        if k < 8:
+            if inv == 0xFFFFFFFF:
+                e.emit(f"v_sub_u32 {M(k)}, 0, v{ACC_LO}")
+            else:
+                e.emit(f"v_mul_lo_u32 {M(k)}, v{ACC_LO}, s{INV_SGPR}")
+            e.mad(M(k), P(0), first_fold)
+        e.drain(first_fold)
+        if first_fold[0]:
+            e.emit(f"v_mov_b32 v{H}, 0")
+        if k >= 8:
+            e.emit(f"v_mov_b32 {T(k - 8)}, v{ACC_LO}")
+        if k < 15:
+            e.emit(f"v_mov_b32 v{ACC_LO}, v{ACC_HI}")
+            e.emit(f"v_mov_b32 v{ACC_HI}, v{H}")
+    return e.lines
+
+
+def cxx_redc(name, modulus):
+    lines = gen_redc(name, modulus)
+    nmad = sum(1 for l in lines if l.startswith("v_mad"))
+    body = "\n".join(f'        "{l}\\n\\t"' for l in lines)
+    outs = ", ".join(f'"=&v"(t[{i}])' for i in range(8))
+    ins = ", ".join(f'"v"(v[{i}])' for i in range(16))
+    vclob = ", ".join(f'"v{r}"' for r in range(ACC_LO, M_BASE + 8))
+    sclob = ", ".join(f'"s{r}"' for r in range(P_SGPR_BASE, CARRY_PAIRS[-1] + 2))
+    return f"""// {name}: Montgomery reduction of a 16-limb value, {nmad} v_mad_u64_u32; result < 2^256, NOT yet in [0, p)
+template <>
+__device__ __forceinline__ void fe_redc16_asm<{name}>(uint32_t* t, const uint32_t* v) {{
+    asm(
+{body}
+        : {outs}
+        : {ins}
+        : {vclob}, {sclob}, "vcc");
+}}
+"""
+
+
 def cxx(name, modulus):
     lines = gen_mul(name, modulus)
     nmad = sum(1 for l in lines if l.startswith("v_mad"))
@@ -168,10 +237,12 @@ def main():
         "#if defined(__HIP_DEVICE_COMPILE__)",
         "namespace lurk {",
         "template <class P> __device__ __forceinline__ Fe<P> fe_mul_asm(const Fe<P>& a, const Fe<P>& b);",
+        "template <class P> __device__ __forceinline__ void fe_redc16_asm(uint32_t* t, const uint32_t* v);",
         "",
     ]
     for name, mod in FIELDS.items():
         out.append(cxx(name, mod))
+        out.append(cxx_redc(name, mod))
     out += ["}  // namespace lurk", "#else", "namespace lurk {",
             "// host pass: same name, portable arithmetic (kernels that name fe_mul_asm must still parse)",
             "template <class P> LURK_HD Fe<P> fe_mul_asm(const Fe<P>& a, const Fe<P>& b) { return fe_mul_fips<P>(a, b); }",

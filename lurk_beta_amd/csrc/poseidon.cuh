@@ -51,10 +51,12 @@ LURK_HD void poseidon_dense(Fe<P>* s, const Fe<P>* mat) {
     Fe<P> u[T];
 #pragma unroll
     for (int j = 0; j < T; j++) {
-        Fe<P> acc = fe_mul<P>(s[0], ld_const<P>(mat + j * T));
+        // one row = one inner product with a single Montgomery reduction (field.cuh: dot_mac)
+        DotAcc<P> A;
+        dot_init<P>(A);
 #pragma unroll
-        for (int i = 1; i < T; i++) acc = fe_add<P>(acc, fe_mul<P>(s[i], ld_const<P>(mat + j * T + i)));
-        u[j] = acc;
+        for (int i = 0; i < T; i++) dot_mac<P>(A, s[i], ld_const<P>(mat + j * T + i));
+        u[j] = dot_finish<P, T>(A);
     }
 #pragma unroll
     for (int j = 0; j < T; j++) s[j] = u[j];
@@ -80,13 +82,15 @@ LURK_HD void poseidon_permute(Fe<P>* s, const Fe<P>* img, int rf, int rp) {
     for (int p = 0; p < rp; p++) {
         const Fe<P>* sp = img + L.sp() + p * (2 * T - 1);
         Fe<P> x = fe_pow5<P>(fe_add<P>(s[0], ld_const<P>(img + L.pk() + p)));
-        Fe<P> acc = fe_mul<P>(x, ld_const<P>(sp));
+        DotAcc<P> A;
+        dot_init<P>(A);
+        dot_mac<P>(A, x, ld_const<P>(sp));
 #pragma unroll
         for (int i = 1; i < T; i++) {
-            acc = fe_add<P>(acc, fe_mul<P>(s[i], ld_const<P>(sp + i)));
+            dot_mac<P>(A, s[i], ld_const<P>(sp + i));
             s[i] = fe_add<P>(s[i], fe_mul<P>(x, ld_const<P>(sp + T - 1 + i)));
         }
-        s[0] = acc;
+        s[0] = dot_finish<P, T>(A);
     }
     // full rounds h+rp .. rf+rp-1 (the first one takes the constants that absorbed the partial rounds')
 #pragma unroll 1

@@ -26,6 +26,26 @@ static void mul_n(const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n, i
         for (int k = 0; k < 8; k++) o[8 * i + k] = r.l[k];
     }
 }
+// inner product with one reduction: sum_i a[i]*b[i] over T operands (T = 3, 5, 9)
+template <class P, int T>
+static void dot_t(const uint32_t* a, const uint32_t* b, uint32_t* o) {
+    DotAcc<P> A;
+    dot_init<P>(A);
+    for (int i = 0; i < T; i++) {
+        Fe<P> x, y;
+        for (int k = 0; k < 8; k++) { x.l[k] = a[8 * i + k]; y.l[k] = b[8 * i + k]; }
+        dot_mac<P>(A, x, y);
+    }
+    Fe<P> r = dot_finish<P, T>(A);
+    for (int k = 0; k < 8; k++) o[k] = r.l[k];
+}
+extern "C" void hh_fe_dot(int field, int T, const uint32_t* a, const uint32_t* b, uint32_t* o) {
+#define DOT_CASE(P)                                   \
+    if (T == 3) dot_t<P, 3>(a, b, o);                 \
+    else if (T == 5) dot_t<P, 5>(a, b, o);            \
+    else dot_t<P, 9>(a, b, o);
+    if (field == 0) { DOT_CASE(PallasFp) } else if (field == 1) { DOT_CASE(PallasFq) } else { DOT_CASE(Bn254Fr) }
+}
 extern "C" void hh_fe_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
     if (field == 0) mul_n<PallasFp>(a, b, o, n, op);
     else if (field == 1) mul_n<PallasFq>(a, b, o, n, op);

@@ -89,3 +89,20 @@ def test_xyzz_group_law_with_exceptional_cases(cn, c):
     out = np.zeros(8, dtype=np.uint64)
     L.hh_curve_sum(c, 2, vp(B), vp(ks), ctypes.c_size_t(12), vp(out))
     assert C.affine_to_ints(c, out)[0] == want
+
+
+@pytest.mark.parametrize("f", [0, 1, 2])
+@pytest.mark.parametrize("T", [3, 5, 9])
+def test_inner_product_with_single_reduction(f, T):
+    """fe_dot (dot_mac / dot_finish): sum a_i*b_i / R mod p, including the worst case (all p-1)."""
+    p = R.modulus(f)
+    Ri = pow(1 << 256, -1, p)
+    cases = [([R.uniform_fe(40 + k, i, p) for i in range(T)], [R.uniform_fe(50 + k, i, p) for i in range(T)]) for k in range(20)]
+    cases.append(([p - 1] * T, [p - 1] * T))
+    cases.append(([0] * T, [p - 1] * T))
+    cases.append(([1] + [0] * (T - 1), [1] + [0] * (T - 1)))
+    for a, b in cases:
+        A, B = C.ints_to_limbs(a), C.ints_to_limbs(b)
+        O = np.zeros(4, dtype=np.uint64)
+        H.lib().hh_fe_dot(f, T, vp(A), vp(B), vp(O))
+        assert C.limbs_to_ints(O)[0] == sum(x * y for x, y in zip(a, b)) * Ri % p
