@@ -202,3 +202,40 @@ def test_full_size_dlog_checksum(hip, log_n, dist, precompute):
     want = C.jac_to_affine(0, C.gen_mul(0, C.dot(1, k, s)))
     assert got == want
     ck.close()
+
+
+def test_thread_safety(hip):
+    """Entry points are called from rayon worker threads in the reference: concurrent
+    commits on one context, on two contexts, and concurrent Poseidon batches must all be exact."""
+    import threading
+
+    from lurk_beta_amd import CommitmentKey, point_to_affine, poseidon_batch
+
+    n = 1 << 13
+    B = C.synth_bases(0, n)
+    cks = [CommitmentKey(0, B), CommitmentKey(0, B, precompute=True)]
+    scal = [C.synth_scalars(1, 20 + j, j % 2, n) for j in range(6)]
+    want = [C.jac_to_affine(0, C.msm_pippenger(0, B, s)) for s in scal]
+    pre = C.synth_scalars(1, 30, 0, 8 * 4000).reshape(4000, 8, 4)
+    want_h = C.poseidon_batch(1, 8, pre)
+    errors = []
+
+    def work(j):
+        try:
+            for _ in range(3):
+                got = point_to_affine(0, cks[j % 2].commit(scal[j]))
+                if got != want[j]:
+                    errors.append(("msm", j))
+                if not np.array_equal(poseidon_batch(1, 8, pre), want_h):
+                    errors.append(("poseidon", j))
+        except Exception as e:  # noqa: BLE001
+            errors.append((j, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(j,)) for j in range(6)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for ck in cks:
+        ck.close()
