@@ -7,6 +7,7 @@
 #include <functional>
 #define LURK_MUL_FORCE_INLINE_OFF
 #include "../lurk_beta_amd/csrc/field.cuh"
+#include "../lurk_beta_amd/csrc/field29.cuh"
 using namespace lurk;
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
@@ -122,6 +123,21 @@ __global__ void k_femul(const Fe<P>* in, Fe<P>* out, int iters) {
     }
     out[i] = x;
 }
+// radix-2^29 layer: in/out in the C-ABI Montgomery(2^256) form, the chain runs in F29
+template <class P>
+__global__ void k_f29mul(const Fe<P>* in, Fe<P>* out, int iters) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    F29<P> x = f29_from_mont256<P>(in[2 * i]), y = f29_from_mont256<P>(in[2 * i + 1]);
+    for (int k = 0; k < iters; k++) x = f29_mul<P>(x, y);
+    out[i] = f29_to_mont256<P>(x);
+}
+template <class P>
+__global__ void k_f29addsub(const Fe<P>* in, Fe<P>* out, int iters) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    F29<P> x = f29_from_mont256<P>(in[2 * i]), y = f29_from_mont256<P>(in[2 * i + 1]);
+    for (int k = 0; k < iters; k++) { x = f29_carry<P>(f29_sub<P>(x, y)); y = f29_carry<P>(f29_add<P>(y, x)); }
+    out[i] = f29_to_mont256<P>(f29_add<P>(x, y));
+}
 template <class P>
 __global__ void k_feadd(const Fe<P>* in, Fe<P>* out, int iters) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
@@ -191,9 +207,23 @@ int main() {
         for (size_t i = 0; i < n * 8; i++) { bad1 += r0[i] != r1[i]; bad2 += r0[i] != r2[i]; }
         printf("  Pallas: fips vs cios mismatching words: %zu, noinline vs cios: %zu (of %zu)\n", bad1, bad2, n * 8);
     }
+    { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29mul<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o1, MI); });
+      printf("%-28s %8.3f ms  %8.2f G field-mul/s\n", "f29_mul Pallas (radix 2^29)", ms, (double)n * MI / ms / 1e6);
+      std::vector<uint32_t> r0(n * 8), r1(n * 8);
+      CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (size_t i = 0; i < n * 8; i++) bad += r0[i] != r1[i];
+      printf("  Pallas: radix-2^29 chain vs cios chain mismatching words: %zu (of %zu)\n", bad, n * 8); }
+    { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29addsub<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });
+      printf("%-28s %8.3f ms  %8.2f G (add|sub)+carry /s\n", "f29 sub+carry, add+carry", ms, (double)n * MI * 2 / ms / 1e6); }
     RUN_MUL(Bn254Fr, 0, d_o0, "fe_mul BN254 cios(compiler)");
     RUN_MUL(Bn254Fr, 1, d_o1, "fe_mul BN254 fips(asm)");
     RUN_MUL(Bn254Fr, 3, d_o1, "fe_mul BN254 asm-block");
+    { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29mul<Bn254Fr>), dim3(blocks), dim3(threads), 0, 0, (const Fe<Bn254Fr>*)d_in, (Fe<Bn254Fr>*)d_o2, MI); });
+      printf("%-28s %8.3f ms  %8.2f G field-mul/s\n", "f29_mul BN254 (radix 2^29)", ms, (double)n * MI / ms / 1e6);
+      std::vector<uint32_t> r0(n * 8), r1(n * 8);
+      CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o2, n * 32, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (size_t i = 0; i < n * 8; i++) bad += r0[i] != r1[i];
+      printf("  BN254: radix-2^29 chain vs cios chain mismatching words: %zu (of %zu)\n", bad, n * 8); }
     {
         std::vector<uint32_t> r0(n * 8), r1(n * 8);
         CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost));

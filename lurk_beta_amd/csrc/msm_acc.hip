@@ -1,9 +1,16 @@
-// msm_acc.hip - the dominant kernel of the MSM (bucket accumulation), in its own translation unit so
-// that it alone is built with the Montgomery multiplier inlined: a mixed addition is ten products,
-// and calling the multiplier costs ~24 argument moves per product (~5 % of the kernel).
+// msm_acc.hip - the dominant kernel of the MSM (bucket accumulation), in its own translation unit.
+// The accumulator lives on the radix-2^29 layer (curve29.cuh: products without carry folds, lazy
+// reduction); LURK_ACC_RADIX29=0 builds the 8 x 32-bit Montgomery version with the multiplier inlined
+// (kept for A/B measurements).
+#ifndef LURK_ACC_RADIX29
+#define LURK_ACC_RADIX29 1
+#endif
+#if !LURK_ACC_RADIX29
 #define LURK_MUL_FORCE_INLINE
+#endif
 #include "common.hpp"
 #include "msm_core.cuh"
+#include "curve29.cuh"
 
 namespace lurk {
 
@@ -18,7 +25,11 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uin
     if (i >= group_task_base[NG]) return;
     uint32_t t = order[i];
     uint2 ti = task_info[t];
+#if LURK_ACC_RADIX29
+    partials[t] = msm_task_accumulate29<P>(sorted, ti.x, ti.y, table);
+#else
     partials[t] = msm_task_accumulate<P>(sorted, ti.x, ti.y, table);
+#endif
 }
 
 

@@ -104,17 +104,23 @@ extern "C" int hh_poseidon_params(int field, int arity, int* rf, int* rp, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-#include "../../lurk_beta_amd/csrc/curve.cuh"
+#define LURK_F29_CHECK 1
+#include "../../lurk_beta_amd/csrc/curve29.cuh"
 
 // mode 0: acc = sum (+/-) P_i with xyzz_madd; mode 1: pairwise xyzz_add of xyzz_from_affine;
-// mode 2: sum k_i * P_i with xyzz_mul_small (k_i = signs[i] as small integer).  Output: affine Montgomery.
+// mode 2: sum k_i * P_i with xyzz_mul_small (k_i = signs[i] as small integer); mode 3: as mode 0 on the
+// radix-2^29 layer (xyzz29_madd, bound assertions enabled).  Output: affine Montgomery.
 template <class P>
 static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, size_t n, uint32_t* out) {
     Xyzz<P> acc = xyzz_identity<P>();
+    Xyzz29<P> acc29;
+    acc29.x = acc29.y = acc29.zz = acc29.zzz = f29_zero<P>();
+    bool acc29_id = true;
     for (size_t i = 0; i < n; i++) {
         Affine<P> a;
         for (int k = 0; k < 8; k++) { a.x.l[k] = bases[i * 16 + k]; a.y.l[k] = bases[i * 16 + 8 + k]; }
-        if (mode == 0) xyzz_madd<P>(acc, a, signs[i] != 0);
+        if (mode == 3) xyzz29_madd<P>(acc29, acc29_id, a, signs[i] != 0);
+        else if (mode == 0) xyzz_madd<P>(acc, a, signs[i] != 0);
         else if (mode == 1) {
             Xyzz<P> q = xyzz_from_affine<P>(a);
             if (signs[i]) q.y = fe_neg<P>(q.y);
@@ -124,6 +130,7 @@ static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, si
             xyzz_add<P>(acc, q);
         }
     }
+    if (mode == 3) acc = xyzz29_to_xyzz<P>(acc29, acc29_id);
     Affine<P> r = xyzz_to_affine<P>(acc);
     // round-trip through the Jacobian helpers as well
     Jacobian<P> j = jacobian_from_affine<P>(r);
@@ -133,4 +140,41 @@ static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, si
 extern "C" void hh_curve_sum(int curve, int mode, const uint32_t* bases, const uint32_t* signs, size_t n, uint32_t* out) {
     if (curve == 0) curve_sum<PallasFp>(mode, bases, signs, n, out);
     else curve_sum<PallasFq>(mode, bases, signs, n, out);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+#include "../../lurk_beta_amd/csrc/field29.cuh"
+// radix-2^29 layer: op 0: to_mont256(from_mont256(a)); 1: mul; 2: add; 3: sub; 4: sub then sqr (loose operand,
+// carried); 5: chain a*b - a + b via lazy ops.  Inputs/outputs are 8 x 32 Montgomery(2^256) values.
+template <class P>
+static void f29_ops(int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        Fe<P> x, y;
+        for (int k = 0; k < 8; k++) { x.l[k] = a[8 * i + k]; y.l[k] = b[8 * i + k]; }
+        F29<P> X = f29_from_mont256<P>(x), Y = f29_from_mont256<P>(y), Rz;
+        switch (op) {
+            case 0: Rz = X; break;
+            case 1: Rz = f29_mul<P>(X, Y); break;
+            case 2: Rz = f29_add<P>(X, Y); break;
+            case 3: Rz = f29_sub<P>(X, Y); break;
+            case 4: { F29<P> d = f29_carry<P>(f29_sub<P>(X, Y)); Rz = f29_mul<P>(d, d); break; }
+            default: { F29<P> m = f29_mul<P>(X, Y); Rz = f29_add<P>(f29_carry<P>(f29_sub<P>(m, X)), Y); break; }
+        }
+        Fe<P> r = f29_to_mont256<P>(Rz);
+        for (int k = 0; k < 8; k++) o[8 * i + k] = r.l[k];
+    }
+}
+extern "C" void hh_f29_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
+    if (field == 0) f29_ops<PallasFp>(op, a, b, o, n);
+    else if (field == 1) f29_ops<PallasFq>(op, a, b, o, n);
+    else f29_ops<Bn254Fr>(op, a, b, o, n);
+}
+
+// f29_reduce on raw limb patterns: in = 9 limbs (tight, top limb arbitrary); out = 9 limbs
+extern "C" void hh_f29_reduce(int field, const uint32_t* in, uint32_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        if (field == 0) { F29<PallasFp> v; for (int k = 0; k < 9; k++) v.l[k] = in[9 * i + k]; v = f29_reduce<PallasFp>(v); for (int k = 0; k < 9; k++) out[9 * i + k] = v.l[k]; }
+        else { F29<PallasFq> v; for (int k = 0; k < 9; k++) v.l[k] = in[9 * i + k]; v = f29_reduce<PallasFq>(v); for (int k = 0; k < 9; k++) out[9 * i + k] = v.l[k]; }
+    }
 }

@@ -72,15 +72,25 @@ def test_xyzz_group_law_with_exceptional_cases(cn, c):
     want = None
     for pt, s in zip(pts, signs):
         want = R.ec_add(cn, want, R.ec_neg(cn, pt) if s else pt)
-    for mode in (0, 1):
+    for mode in (0, 1, 3):  # 3 = radix-2^29 accumulator (the bucket-accumulation kernel's inner loop)
         out = np.zeros(8, dtype=np.uint64)
         L.hh_curve_sum(c, mode, vp(B), vp(signs), ctypes.c_size_t(12), vp(out))
         assert C.affine_to_ints(c, out)[0] == want, mode
     # chain that ends on the identity
     B2 = np.concatenate([B[:1], B[:1]])
-    out = np.zeros(8, dtype=np.uint64)
-    L.hh_curve_sum(c, 0, vp(B2), vp(np.array([0, 1], dtype=np.uint32)), ctypes.c_size_t(2), vp(out))
-    assert C.affine_to_ints(c, out)[0] == (0, 0)
+    for mode in (0, 3):
+        out = np.zeros(8, dtype=np.uint64)
+        L.hh_curve_sum(c, mode, vp(B2), vp(np.array([0, 1], dtype=np.uint32)), ctypes.c_size_t(2), vp(out))
+        assert C.affine_to_ints(c, out)[0] == (0, 0)
+    # starts with a negated point, then doubles it, then keeps going
+    B3 = np.concatenate([B[:1], B[:1], B[1:4]])
+    s3 = np.array([1, 1, 0, 1, 1], dtype=np.uint32)
+    outs = []
+    for mode in (0, 3):
+        out = np.zeros(8, dtype=np.uint64)
+        L.hh_curve_sum(c, mode, vp(B3), vp(s3), ctypes.c_size_t(5), vp(out))
+        outs.append(C.affine_to_ints(c, out)[0])
+    assert outs[0] == outs[1]
     # small-scalar multiples
     ks = np.array([0, 1, 2, 3, 17, 255, 32768, 65535, 1, 0, 5, 6], dtype=np.uint32)
     want = None
@@ -106,3 +116,64 @@ def test_inner_product_with_single_reduction(f, T):
         O = np.zeros(4, dtype=np.uint64)
         H.lib().hh_fe_dot(f, T, vp(A), vp(B), vp(O))
         assert C.limbs_to_ints(O)[0] == sum(x * y for x, y in zip(a, b)) * Ri % p
+
+
+@pytest.mark.parametrize("f", [0, 1, 2])
+def test_radix29_layer(f):
+    """field29.cuh (9 x 29-bit limbs, R' = 2^261, lazy reduction) against big integers; I/O in the C-ABI form."""
+    p = R.modulus(f)
+    Rm = 1 << 256
+    Ri = pow(Rm, -1, p)
+    a = [R.uniform_fe(60, i, p) for i in range(200)] + [0, 1, p - 1, p - 1, 0, 5]
+    b = [R.uniform_fe(61, i, p) for i in range(200)] + [0, p - 1, p - 1, 1, 7, p - 2]
+    A, B = C.ints_to_limbs(a), C.ints_to_limbs(b)
+
+    def run(op):
+        O = np.zeros_like(A)
+        H.lib().hh_f29_op(f, op, vp(A), vp(B), vp(O), ctypes.c_size_t(len(a)))
+        return C.limbs_to_ints(O)
+
+    assert run(0) == a                                                       # round trip
+    assert run(1) == [x * y * Ri % p for x, y in zip(a, b)]                  # Montgomery product semantics preserved
+    assert run(2) == [(x + y) % p for x, y in zip(a, b)]
+    assert run(3) == [(x - y) % p for x, y in zip(a, b)]
+    assert run(4) == [(x - y) * (x - y) * Ri % p for x, y in zip(a, b)]
+    assert run(5) == [(x * y * Ri - x + y) % p for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("c", [0, 1])
+def test_radix29_accumulator_long_chains(c):
+    """xyzz29_madd against xyzz_madd over long random chains (bounds are asserted inside the harness build)."""
+    L = H.lib()
+    n = 3000
+    B = C.synth_bases(c, n)
+    rng = np.random.default_rng(5)
+    signs = rng.integers(0, 2, n).astype(np.uint32)
+    for lo, hi in [(0, 64), (64, 1000), (1000, 3000)]:
+        outs = []
+        for mode in (0, 3):
+            out = np.zeros(8, dtype=np.uint64)
+            L.hh_curve_sum(c, mode, vp(B[lo:hi].copy()), vp(signs[lo:hi].copy()), ctypes.c_size_t(hi - lo), vp(out))
+            outs.append(C.affine_to_ints(c, out)[0])
+        assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("f", [0, 1])
+def test_radix29_partial_reduction(f):
+    """f29_reduce: same residue, result < 2^255.1 with tight limbs, for extreme limb patterns."""
+    p = R.modulus(f)
+    M = (1 << 29) - 1
+    rng = np.random.default_rng(9)
+    rows = [[M] * 8 + [(1 << 31) - 1], [0] * 9, [0] * 8 + [1 << 22], [M] * 8 + [(1 << 22) - 1], [0] * 8 + [(1 << 31) - 1],
+            [0] * 8 + [(1 << 22) + 5], [1] + [0] * 7 + [1 << 23]]
+    for _ in range(300):
+        rows.append([int(x) for x in rng.integers(0, M + 1, 8)] + [int(rng.integers(0, 1 << 31))])
+    I = np.array(rows, dtype=np.uint32)
+    O = np.zeros_like(I)
+    H.lib().hh_f29_reduce(f, vp(I), vp(O), ctypes.c_size_t(len(rows)))
+    for r_in, r_out in zip(rows, O.tolist()):
+        vin = sum(x << (29 * i) for i, x in enumerate(r_in))
+        vout = sum(x << (29 * i) for i, x in enumerate(r_out))
+        assert vout % p == vin % p
+        assert all(x <= M for x in r_out[:8]) and r_out[8] < (1 << 23) + 1
+        assert vout < (1 << 255) + (1 << 254)
