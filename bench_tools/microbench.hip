@@ -132,6 +132,13 @@ __global__ void k_f29mul(const Fe<P>* in, Fe<P>* out, int iters) {
     out[i] = f29_to_mont256<P>(x);
 }
 template <class P>
+__global__ void k_f29sqr(const Fe<P>* in, Fe<P>* out, int iters) {
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    F29<P> x = f29_from_mont256<P>(in[2 * i]);
+    for (int k = 0; k < iters; k++) x = f29_sqr<P>(x);
+    out[i] = f29_to_mont256<P>(x);
+}
+template <class P>
 __global__ void k_f29addsub(const Fe<P>* in, Fe<P>* out, int iters) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     F29<P> x = f29_from_mont256<P>(in[2 * i]), y = f29_from_mont256<P>(in[2 * i + 1]);
@@ -213,6 +220,8 @@ int main() {
       CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost));
       size_t bad = 0; for (size_t i = 0; i < n * 8; i++) bad += r0[i] != r1[i];
       printf("  Pallas: radix-2^29 chain vs cios chain mismatching words: %zu (of %zu)\n", bad, n * 8); }
+    { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29sqr<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });
+      printf("%-28s %8.3f ms  %8.2f G field-sqr/s\n", "f29_sqr Pallas (radix 2^29)", ms, (double)n * MI / ms / 1e6); }
     { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29addsub<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });
       printf("%-28s %8.3f ms  %8.2f G (add|sub)+carry /s\n", "f29 sub+carry, add+carry", ms, (double)n * MI * 2 / ms / 1e6); }
     RUN_MUL(Bn254Fr, 0, d_o0, "fe_mul BN254 cios(compiler)");

@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblurk_hip.so")
+LIB_PATH = os.environ.get("LURK_HIP_LIB") or os.path.join(_HERE, "liblurk_hip.so")  # override: A/B builds only
 _lib = None
 
 c_void_p, c_size_t, c_int, c_uint, c_u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64

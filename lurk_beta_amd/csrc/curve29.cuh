@@ -29,6 +29,10 @@
 #define F29_ASSERT_TOP(v, bits, what) ((void)0)
 #endif
 
+#ifndef LURK_ACC_PREFETCH
+#define LURK_ACC_PREFETCH 0
+#endif
+
 namespace lurk {
 
 // signed carry pass: limbs are int32 in (-2^31, 2^31); result tight, top limb keeps the rest (must be >= 0)
@@ -120,9 +124,9 @@ LURK_HD __attribute__((noinline)) Xyzz29<P> xyzz29_double_affine(F29<P> qx, F29<
     const F29<P> v = f29_mul<P>(u, u);                           // < 2^259 + p
     const F29<P> w = f29_mul<P>(u, v);
     const F29<P> s = f29_mul<P>(qx, v);
-    const F29<P> xx = f29_mul<P>(qx, qx);
+    const F29<P> xx = f29_sqr<P>(qx);
     const F29<P> m = f29_carry<P>(f29_add<P>(f29_dbl<P>(xx), xx));  // 3 x^2, tight
-    const F29<P> m2 = f29_mul<P>(m, m);
+    const F29<P> m2 = f29_sqr<P>(m);
     Xyzz29<P> r;
     r.x = f29_reduce<P>(f29_carry<P>(f29_sub<P>(m2, f29_dbl<P>(s))));
     const F29<P> t1 = f29_mul<P>(m, f29_sub<P>(s, r.x));
@@ -169,10 +173,10 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
         }
         return;
     }
-    const F29<P> pp = f29_mul<P>(p, p);          // < 2^259.7
+    const F29<P> pp = f29_sqr<P>(p);          // < 2^259.7
     const F29<P> ppp = f29_mul<P>(p, pp);        // < 2^259.1
     const F29<P> qq = f29_mul<P>(acc.x, pp);     // < 2^257.8
-    const F29<P> r2 = f29_mul<P>(r, r);          // < 2^259.7
+    const F29<P> r2 = f29_sqr<P>(r);          // < 2^259.7
     // X3 = R^2 - PPP - 2Q   (two lazy subtractions: limbs < 2^32, value < 2^261.5)
     F29<P> x3 = f29_sub<P>(f29_sub<P>(r2, ppp), f29_dbl<P>(qq));
     x3 = f29_reduce<P>(f29_carry<P>(x3));        // < 2^255.1, tight
@@ -196,10 +200,22 @@ LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, ui
     Xyzz29<P> acc;
     acc.x = acc.y = acc.zz = acc.zzz = f29_zero<P>();
     bool acc_id = true;
+    if (first >= last) return xyzz_identity<P>();
+    // the next base is gathered while the current addition runs (~11k cycles: covers the HBM latency)
+    uint32_t e = sorted[first];
+    Affine<P> q = table[e & 0x7fffffffu];
     for (uint32_t j = first; j < last; j++) {
-        uint32_t e = sorted[j];
-        Affine<P> q = table[e & 0x7fffffffu];
-        xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);
+        const uint32_t e_cur = e;
+        const Affine<P> q_cur = q;
+        if (LURK_ACC_PREFETCH && j + 1 < last) {
+            e = sorted[j + 1];
+            q = table[e & 0x7fffffffu];
+        }
+        xyzz29_madd<P>(acc, acc_id, q_cur, (e_cur & 0x80000000u) != 0);
+        if (!LURK_ACC_PREFETCH && j + 1 < last) {
+            e = sorted[j + 1];
+            q = table[e & 0x7fffffffu];
+        }
     }
     return xyzz29_to_xyzz<P>(acc, acc_id);
 }

@@ -141,9 +141,14 @@ LURK_HD F29<P> f29_mul(const F29<P>& a, const F29<P>& b) {
     return f29_mul_portable<P>(a, b);
 #endif
 }
+// a must be tight (the squaring block multiplies a by its doubled copy)
 template <class P>
 LURK_HD F29<P> f29_sqr(const F29<P>& a) {
-    return f29_mul<P>(a, a);
+#if defined(__HIP_DEVICE_COMPILE__)
+    return f29_sqr_asm<P>(a);
+#else
+    return f29_mul_portable<P>(a, a);
+#endif
 }
 
 // 8 x 32 Montgomery(2^256) -> 9 x 29 Montgomery(2^261): value * 32, i.e. limbs of (x << 5); tight.
