@@ -21,7 +21,7 @@
 
 namespace lurk {
 
-constexpr int MSM_P = 1024;        // coarse partitions of the key space (pass 1 of the sort): write heads per CU
+constexpr int MSM_P = 2048;        // coarse partitions of the key space (pass 1 of the sort)
 constexpr int MSM_NB1 = 256;       // workgroups of pass 1 (one per CU)
 constexpr int MSM_SORT_BLOCK = 1024;
 constexpr int MSM_S = 64;          // sorted entries per accumulation task
@@ -59,7 +59,7 @@ template <class SF>
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ block_hist,
                                                                      MsmShape sh, size_t chunk, int is_mont) {
     __shared__ uint32_t h[MSM_P];
-    if (threadIdx.x < MSM_P) h[threadIdx.x] = 0;
+    for (int p = threadIdx.x; p < MSM_P; p += MSM_SORT_BLOCK) h[p] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
     for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_BLOCK) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* 
         }
     }
     __syncthreads();
-    if (threadIdx.x < MSM_P) block_hist[(size_t)blockIdx.x * MSM_P + threadIdx.x] = h[threadIdx.x];
+    for (int p = threadIdx.x; p < MSM_P; p += MSM_SORT_BLOCK) block_hist[(size_t)blockIdx.x * MSM_P + p] = h[p];
 }
 
 // block p: exclusive scan of partition p's counts over the MSM_NB1 pass-1 blocks
@@ -90,68 +90,146 @@ __global__ __launch_bounds__(MSM_NB1) void msm_scan1_kernel(uint32_t* __restrict
     block_hist[(size_t)t * MSM_P + p] = sh[t] - v;
     if (t == MSM_NB1 - 1) part_cnt[p] = sh[t];
 }
-// single block: part_start[0..P] = exclusive scan of part_cnt
-__global__ __launch_bounds__(MSM_P) void msm_part_start_kernel(const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ part_start) {
-    __shared__ uint32_t sh[MSM_P];
-    const int t = threadIdx.x;
-    uint32_t v = part_cnt[t];
-    sh[t] = v;
-    __syncthreads();
-    for (int off = 1; off < MSM_P; off <<= 1) {
-        uint32_t a = t >= off ? sh[t - off] : 0;
-        __syncthreads();
-        sh[t] += a;
-        __syncthreads();
+
+// Exclusive scan over the 1024 threads of a sort block (wave scans + one scan of the 16 wave totals).
+// scr: >= 17 words of LDS; returns the exclusive prefix of v, *total = sum over the block.
+__device__ __forceinline__ uint32_t msm_block_scan(uint32_t v, uint32_t* scr, uint32_t* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
     }
-    part_start[t] = sh[t] - v;
-    if (t == MSM_P - 1) part_start[MSM_P] = sh[t];
+    if (lane == 63) scr[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        uint32_t w = threadIdx.x < MSM_SORT_BLOCK / 64 ? scr[threadIdx.x] : 0, winc = w;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            uint32_t o = __shfl_up(winc, off);
+            if (lane >= off) winc += o;
+        }
+        if (threadIdx.x < MSM_SORT_BLOCK / 64) scr[threadIdx.x] = winc - w;
+        if (threadIdx.x == MSM_SORT_BLOCK / 64 - 1) scr[16] = winc;
+    }
+    __syncthreads();
+    uint32_t ex = scr[wave] + inc - v;
+    *total = scr[16];
+    __syncthreads();  // scr may be reused at once
+    return ex;
 }
 
+// single block: part_start[0..P] = exclusive scan of part_cnt
+__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part_start_kernel(const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ part_start) {
+    __shared__ uint32_t scr[32];
+    constexpr int PER = MSM_P / MSM_SORT_BLOCK;
+    const int t = threadIdx.x;
+    uint32_t c[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; j++) { c[j] = part_cnt[t * PER + j]; sum += c[j]; }
+    uint32_t total;
+    uint32_t run = msm_block_scan(sum, scr, &total);
+#pragma unroll
+    for (int j = 0; j < PER; j++) { part_start[t * PER + j] = run; run += c[j]; }
+    if (t == 0) part_start[MSM_P] = total;
+}
+
+// Scatter of pass 1.  A tile of 1024 scalars yields <= W*1024 entries; they are first grouped by partition in
+// LDS (a block-local counting sort) and then copied out slot by slot, so that neighbouring lanes write
+// neighbouring addresses: the entries of one partition leave as one run instead of as isolated 8-byte stores
+// (which cost a 32-byte sector each: rocprof showed 3.9x write amplification for the direct scatter).
+// Entry = (key, table index | sign); pass 2 uses the low LB bits of the key.
 template <class SF>
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint4* __restrict__ scalars,
                                                                         const uint32_t* __restrict__ block_off,
                                                                         const uint32_t* __restrict__ part_start, uint2* __restrict__ inter,
                                                                         MsmShape sh, size_t chunk, int is_mont) {
-    __shared__ uint32_t off[MSM_P];
-    if (threadIdx.x < MSM_P) off[threadIdx.x] = part_start[threadIdx.x] + block_off[(size_t)blockIdx.x * MSM_P + threadIdx.x];
+    extern __shared__ uint32_t lds[];
+    constexpr int PER = MSM_P / MSM_SORT_BLOCK;
+    uint32_t* goff = lds;              // [P] where this block's next entry of partition p goes
+    uint32_t* cnt = goff + MSM_P;      // [P] entries of the current tile, then the placement cursor
+    uint32_t* start = cnt + MSM_P;     // [P] exclusive scan of cnt
+    uint32_t* scr = start + MSM_P;     // [32]
+    uint2* stage = reinterpret_cast<uint2*>(scr + 32);  // [W * 1024]
+    const int t = threadIdx.x;
+    for (int p = t; p < MSM_P; p += MSM_SORT_BLOCK) {
+        goff[p] = part_start[p] + block_off[(size_t)blockIdx.x * MSM_P + p];
+        cnt[p] = 0;
+    }
     __syncthreads();
-    const uint32_t low_mask = (1u << sh.LB) - 1u;
     size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_BLOCK) {
-        Fe<SF> s = msm_load_scalar<SF>(scalars, i, is_mont);
-        uint32_t carry = 0;
-        for (int w = 0; w < sh.W; w++) {
-            uint32_t d = msm_digit_step(s.l, w, sh.c, carry);
-            uint32_t mag = d & ~MSM_SIGN;
-            if (mag) {
-                uint32_t key = msm_key(sh, (uint32_t)w, mag);
-                uint32_t pos = atomicAdd(&off[key >> sh.LB], 1u);
-                inter[pos] = make_uint2(key & low_mask, ((uint32_t)((size_t)w * sh.stride) + (uint32_t)i) | (d & MSM_SIGN));
+    for (size_t base = lo; base < hi; base += MSM_SORT_BLOCK) {
+        const size_t i = base + t;
+        const bool live = i < hi;
+        Fe<SF> s;
+        if (live) {
+            s = msm_load_scalar<SF>(scalars, i, is_mont);
+            uint32_t carry = 0;
+            for (int w = 0; w < sh.W; w++) {
+                uint32_t mag = msm_digit_step(s.l, w, sh.c, carry) & ~MSM_SIGN;
+                if (mag) atomicAdd(&cnt[msm_key(sh, (uint32_t)w, mag) >> sh.LB], 1u);
             }
         }
+        __syncthreads();
+        uint32_t c[PER], sum = 0, total;
+#pragma unroll
+        for (int j = 0; j < PER; j++) { c[j] = cnt[t * PER + j]; sum += c[j]; }
+        uint32_t run = msm_block_scan(sum, scr, &total);
+#pragma unroll
+        for (int j = 0; j < PER; j++) { start[t * PER + j] = run; run += c[j]; cnt[t * PER + j] = 0; }
+        __syncthreads();
+        if (live) {
+            uint32_t carry = 0;
+            for (int w = 0; w < sh.W; w++) {
+                uint32_t d = msm_digit_step(s.l, w, sh.c, carry);
+                uint32_t mag = d & ~MSM_SIGN;
+                if (mag) {
+                    uint32_t key = msm_key(sh, (uint32_t)w, mag);
+                    uint32_t p = key >> sh.LB;
+                    uint32_t slot = start[p] + atomicAdd(&cnt[p], 1u);
+                    stage[slot] = make_uint2(key, ((uint32_t)((size_t)w * sh.stride) + (uint32_t)i) | (d & MSM_SIGN));
+                }
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = t; j < total; j += MSM_SORT_BLOCK) {
+            uint2 e = stage[j];
+            uint32_t p = e.x >> sh.LB;
+            inter[goff[p] + (j - start[p])] = e;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; j++) { goff[t * PER + j] += c[j]; cnt[t * PER + j] = 0; }
+        __syncthreads();
     }
 }
+static size_t msm_scatter1_lds(int W) { return (size_t)(3 * MSM_P + 32) * 4 + (size_t)W * MSM_SORT_BLOCK * 8; }
 
 // ---- 2b. sort pass 2: block p sorts partition p by the low key bits ---------------------------------
-// Emits the final sorted entry list, the bucket sizes and the bucket starts of its 2^LB keys.
+// Emits the final sorted entry list, the bucket sizes and the bucket starts of its 2^LB keys.  A partition of
+// <= cap entries is sorted into LDS and leaves as one contiguous copy; a larger one (very skewed scalars,
+// or more entries than 2048 partitions can split) falls back to scattering straight to global memory.
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part2_kernel(const uint2* __restrict__ inter, const uint32_t* __restrict__ part_start,
                                                                      uint32_t* __restrict__ sorted, uint32_t* __restrict__ cnt,
-                                                                     uint32_t* __restrict__ bucket_start, MsmShape sh) {
-    extern __shared__ uint32_t lds[];  // [2^LB] counters, then [MSM_SORT_BLOCK] scan scratch
+                                                                     uint32_t* __restrict__ bucket_start, MsmShape sh, uint32_t cap) {
+    extern __shared__ uint32_t lds[];  // [2^LB] counters, [32] scan scratch, [cap] staged output
     const int p = blockIdx.x, t = threadIdx.x;
-    const uint32_t nbins = 1u << sh.LB;
+    const uint32_t nbins = 1u << sh.LB, low_mask = nbins - 1u;
     uint32_t* h = lds;
     uint32_t* scr = lds + nbins;
+    uint32_t* stage = scr + 32;
     for (uint32_t b = t; b < nbins; b += MSM_SORT_BLOCK) h[b] = 0;
     __syncthreads();
     const uint32_t lo = part_start[p], hi = part_start[p + 1];
+    const bool staged = hi - lo <= cap;
     constexpr int U = 8;  // independent loads in flight per lane: the sweeps are latency bound otherwise
     for (uint32_t base = lo; base < hi; base += MSM_SORT_BLOCK * U) {
         uint32_t k[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             uint32_t e = base + u * MSM_SORT_BLOCK + t;
-            k[u] = e < hi ? inter[e].x : 0xffffffffu;
+            k[u] = e < hi ? (inter[e].x & low_mask) : 0xffffffffu;
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
@@ -165,15 +243,8 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part2_kernel(const uint2* 
         uint32_t b = t * per + j;
         if (b < nbins) sum += h[b];
     }
-    scr[t] = sum;
-    __syncthreads();
-    for (int off = 1; off < MSM_SORT_BLOCK; off <<= 1) {
-        uint32_t a = t >= off ? scr[t - off] : 0;
-        __syncthreads();
-        scr[t] += a;
-        __syncthreads();
-    }
-    uint32_t run = lo + scr[t] - sum;
+    uint32_t total;
+    uint32_t run = lo + msm_block_scan(sum, scr, &total);
     for (uint32_t j = 0; j < per; j++) {
         uint32_t b = t * per + j;
         if (b < nbins) {
@@ -196,12 +267,24 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part2_kernel(const uint2* 
         }
 #pragma unroll
         for (int u = 0; u < U; u++)
-            if (v[u].x != 0xffffffffu) pos[u] = atomicAdd(&h[v[u].x], 1u);
+            if (v[u].x != 0xffffffffu) pos[u] = atomicAdd(&h[v[u].x & low_mask], 1u);
+        if (staged) {
 #pragma unroll
-        for (int u = 0; u < U; u++)
-            if (v[u].x != 0xffffffffu) sorted[pos[u]] = v[u].y;
+            for (int u = 0; u < U; u++)
+                if (v[u].x != 0xffffffffu) stage[pos[u] - lo] = v[u].y;
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (v[u].x != 0xffffffffu) sorted[pos[u]] = v[u].y;
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t j = t; j < hi - lo; j += MSM_SORT_BLOCK) sorted[lo + j] = stage[j];
     }
 }
+constexpr size_t MSM_LDS_BYTES = 160 * 1024;  // per workgroup on gfx950
+static size_t msm_part2_cap(int LB) { return (MSM_LDS_BYTES - (((size_t)1 << LB) + 32) * 4) / 4; }
 
 // ---- 3. task planning ------------------------------------------------------------------------
 // block g (group of MSM_GRP keys), 1024 threads x 32 keys: task starts inside the group + group total
@@ -595,20 +678,27 @@ struct MsmCtx : MsmCtxBase {
         ensure_workspace(wk, sh);
         const size_t chunk = (n + MSM_NB1 - 1) / MSM_NB1;
         const size_t nt = ntask_max(sh);
+        static const bool lds_opt_in = [] {  // > 64 KB of dynamic LDS has to be requested once per kernel
+            LURK_HIP_CHECK(hipFuncSetAttribute((const void*)msm_scatter1_kernel<SF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_LDS_BYTES));
+            LURK_HIP_CHECK(hipFuncSetAttribute((const void*)msm_part2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_LDS_BYTES));
+            return true;
+        }();
+        (void)lds_opt_in;
+        LURK_REQUIRE(msm_scatter1_lds(sh.W) <= MSM_LDS_BYTES, "pass-1 tile does not fit the LDS");
         {
             ProfScope ps("msm_sort", s);
             hipLaunchKernelGGL((msm_hist1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, (const uint4*)d_scalars,
                                wk.block_hist.template as<uint32_t>(), sh, chunk, is_mont);
             hipLaunchKernelGGL(msm_scan1_kernel, dim3(MSM_P), dim3(MSM_NB1), 0, s, wk.block_hist.template as<uint32_t>(),
                                wk.part_cnt.template as<uint32_t>());
-            hipLaunchKernelGGL(msm_part_start_kernel, dim3(1), dim3(MSM_P), 0, s, wk.part_cnt.template as<uint32_t>(),
+            hipLaunchKernelGGL(msm_part_start_kernel, dim3(1), dim3(MSM_SORT_BLOCK), 0, s, wk.part_cnt.template as<uint32_t>(),
                                wk.part_start.template as<uint32_t>());
-            hipLaunchKernelGGL((msm_scatter1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, (const uint4*)d_scalars,
+            hipLaunchKernelGGL((msm_scatter1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), msm_scatter1_lds(sh.W), s, (const uint4*)d_scalars,
                                wk.block_hist.template as<uint32_t>(), wk.part_start.template as<uint32_t>(), wk.inter.template as<uint2>(), sh,
                                chunk, is_mont);
-            hipLaunchKernelGGL(msm_part2_kernel, dim3(MSM_P), dim3(MSM_SORT_BLOCK), (((size_t)1 << sh.LB) + MSM_SORT_BLOCK) * 4, s,
-                               wk.inter.template as<uint2>(), wk.part_start.template as<uint32_t>(), wk.sorted.template as<uint32_t>(),
-                               wk.cnt.template as<uint32_t>(), wk.bucket_start.template as<uint32_t>(), sh);
+            hipLaunchKernelGGL(msm_part2_kernel, dim3(MSM_P), dim3(MSM_SORT_BLOCK), MSM_LDS_BYTES, s, wk.inter.template as<uint2>(),
+                               wk.part_start.template as<uint32_t>(), wk.sorted.template as<uint32_t>(), wk.cnt.template as<uint32_t>(),
+                               wk.bucket_start.template as<uint32_t>(), sh, (uint32_t)msm_part2_cap(sh.LB));
         }
         {
             ProfScope ps("msm_tasks", s);
