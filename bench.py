@@ -323,10 +323,11 @@ def msm_windows(args):
 
 def other_workloads(args, lib, world, rank):
     """Poseidon arity-8 tree (BASELINE configs[2]: 2^24 Pallas-Fq leaves) and the radix-2 NTT, same timing
-    contract: inputs resident in HBM, K timed steps.  Replicas only for N > 1 (no exchange step is modelled;
-    SURVEY.md section 8e describes the 8-root gather for a sharded tree)."""
+    contract: inputs resident in HBM, K timed steps.  N > 1: the tree is ONE tree sharded by subtrees with a
+    single 8 x 32-byte all-gather (SURVEY.md section 8e, strong scaling); the NTT runs replicas."""
     import numpy as np
     import torch
+    import torch.distributed as dist
 
     import lurk_beta_amd as L
     from lurk_beta_amd import _lib, synth
@@ -336,14 +337,43 @@ def other_workloads(args, lib, world, rank):
     if args.workload == "poseidon_tree":
         log_n = args.log_n if args.log_n % 3 == 0 else 24
         n = 1 << log_n
-        d_leaves = synth.scalars(F, 2, 0, n)
-        d_levels = torch.empty(((n - 1) // 7, 4), dtype=torch.int64, device="cuda")
+        scaling, parallelism = "weak", "single"
+        if world == 1:
+            d_leaves = synth.scalars(F, 2, 0, n)
+            d_levels = torch.empty(((n - 1) // 7, 4), dtype=torch.int64, device="cuda")
 
-        def step():
-            _lib.check(lib.lurk_hip_poseidon_tree8_dev(F, _lib.ptr(d_leaves), n, _lib.ptr(d_levels), _lib.ptr(stream)))
+            def step():
+                _lib.check(lib.lurk_hip_poseidon_tree8_dev(F, _lib.ptr(d_leaves), n, _lib.ptr(d_levels), _lib.ptr(stream)))
 
-        unit, per_step_units, kname = "Mleaves/s", n, "poseidon_batch"
-        alg_bytes = 32.0 * n + 64.0 * ((n - 1) // 7)  # leaves read once; every internal node written once and read once
+            per_step_units = n
+        else:
+            # ONE tree of n leaves; the 8 subtrees below the root are dealt to the ranks, each rank
+            # reduces its subtrees, the 8 x 32-byte roots are all-gathered (RCCL) and hashed once more everywhere
+            assert world in (2, 4, 8) and n >= 64, "an arity-8 tree shards over 2, 4 or 8 ranks"
+            scaling, parallelism = "strong", f"subtrees{world}"
+            per_rank, sub = 8 // world, n // 8
+            d_leaves = synth.scalars(F, 2, 0, per_rank * sub, first=rank * per_rank * sub)
+            d_levels = [torch.empty(((sub - 1) // 7, 4), dtype=torch.int64, device="cuda") for _ in range(per_rank)]
+            d_roots = torch.empty((per_rank, 4), dtype=torch.int64, device="cuda")
+            d_all = torch.empty((8, 4), dtype=torch.int64, device="cuda")
+            d_root = torch.empty((1, 4), dtype=torch.int64, device="cuda")
+
+            def step():
+                for j in range(per_rank):
+                    _lib.check(lib.lurk_hip_poseidon_tree8_dev(F, _lib.ptr(d_leaves[j * sub:]), sub, _lib.ptr(d_levels[j]), _lib.ptr(stream)))
+                    d_roots[j].copy_(d_levels[j][-1])
+                if args.backend == "nccl":
+                    dist.all_gather_into_tensor(d_all, d_roots)
+                else:
+                    parts = [torch.empty((per_rank, 4), dtype=torch.int64) for _ in range(world)]
+                    dist.all_gather(parts, d_roots.cpu())
+                    d_all.copy_(torch.cat(parts))
+                _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 8, _lib.ptr(d_all), 1, _lib.ptr(d_root), _lib.ptr(stream)))
+
+            per_step_units = n / world  # the value line multiplies by world: n leaves per step in total
+
+        unit, kname = "Mleaves/s", "poseidon_batch"
+        alg_bytes = (32.0 * n + 64.0 * ((n - 1) // 7)) / world  # leaves read once; every internal node written once and read once
         workload = f"Poseidon arity-8 tree over 2^{log_n} Pallas-Fq leaves ({(n - 1) // 7} hash8)"
     else:
         log_n = args.log_n
@@ -353,6 +383,7 @@ def other_workloads(args, lib, world, rank):
         def step():
             _lib.check(lib.lurk_hip_ntt_dev(F, _lib.ptr(d_data), log_n, 0, _lib.ptr(stream)))
 
+        scaling, parallelism = "weak", "single" if world == 1 else f"replicas{world}"
         unit, per_step_units, kname = "Melements/s", n, "ntt"
         left, passes = max(0, log_n - 11), 2  # bit-reversal pass + the 11-stage pass ...
         while left > 0:                        # ... + later passes of <= 9 stages (mirrors ntt.hip)
@@ -367,12 +398,28 @@ def other_workloads(args, lib, world, rank):
     lib.lurk_hip_profile_enable(1)
     lib.lurk_hip_profile_reset()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     elapsed = time.perf_counter() - t0
     lib.lurk_hip_profile_enable(0)
+    if world > 1:  # the job is as slow as its slowest rank
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if args.verify and args.workload == "poseidon_tree" and rank == 0:
+        from oracle import coracle as C
+
+        assert n <= 1 << 18, "--verify recomputes the tree on the CPU: use --log-n <= 18"
+        want = [int(x) for x in np.asarray(C.poseidon_tree8(1, C.synth_scalars(1, 2, 0, n))).reshape(-1)[:4]]
+        got_t = d_levels[-1] if world == 1 else d_root[0]
+        got = [int(x) for x in got_t.cpu().numpy().view(np.uint64).reshape(-1)[:4]]
+        assert got == want, "tree root differs from the oracle"
     tot, cnt = ctypes.c_double(), ctypes.c_uint64()
     _lib.check(lib.lurk_hip_profile_get(kname.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
     if rank == 0:
@@ -381,8 +428,8 @@ def other_workloads(args, lib, world, rank):
         out = {
             "metric": f"{args.workload} throughput", "value": round(per_step_units * world / (elapsed / args.steps) / 1e6, 3), "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (255-bit Montgomery, integer VALU)",
-            "data": "synthetic", "config": {"workload": workload, "parallelism": "single" if world == 1 else f"replicas{world}"},
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32x8 (255-bit Montgomery, integer VALU)",
+            "data": "synthetic", "config": {"workload": workload, "parallelism": parallelism},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel_ms_per_step": round(kernel_ms_per_step, 4),
                          "algorithmic_bytes_per_step": alg_bytes},

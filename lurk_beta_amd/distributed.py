@@ -7,6 +7,10 @@ its slice of the witness.  The only exchange is the gather of the 96-byte partia
 the group sum on every rank - never a reduction of bucket arrays (RCCL cannot
 reduce elliptic-curve points, and bucket arrays are ~100 MB per GPU).
 
+The dense arity-8 Poseidon tree shards the same way (sharded_tree8_root): the 8 subtrees below the root are
+dealt to the ranks, each rank reduces its subtrees to their roots on its own GPU, the 8 x 32-byte roots are
+all-gathered and every rank hashes them once more.
+
 Folding steps themselves do not shard: each prove_step mutates the running instance
 (/root/reference/src/proof/nova.rs:282-295); what shards is the work inside one commitment."""
 from __future__ import annotations
@@ -60,3 +64,46 @@ class ShardedCommitmentKey:
 
     def close(self):
         self.ck.close()
+
+
+def _all_gather_rows(rows: np.ndarray, group=None) -> np.ndarray:
+    """all_gather of a small (k, 4) uint64 array per rank -> (world * k, 4), rank order."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(np.ascontiguousarray(rows, dtype=np.uint64).view(np.int64).copy())
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t, group=group)
+    return torch.cat(out).cpu().numpy().view(np.uint64).reshape(-1, 4)
+
+
+def sharded_tree8_root(field_id: int, local_leaves: np.ndarray, group=None, tree_root=None, hash8=None) -> np.ndarray:
+    """Root of the dense arity-8 Poseidon tree whose 8^h leaves are dealt contiguously to the ranks
+    (world in {1, 2, 4, 8}: rank r holds the 8/world subtrees number r*8/world ...).  One exchange of
+    8 x 32 bytes.  `tree_root(field, leaves) -> root` and
+    `hash8(field, preimages(k,8,4)) -> digests(k,4)` default to the HIP kernels; the CPU tests inject
+    the oracle."""
+    import torch.distributed as dist
+
+    from . import poseidon as _p
+
+    tree_root = tree_root or _p.poseidon_tree8
+    hash8 = hash8 or (lambda f, pre: _p.poseidon_batch(f, 8, pre))
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world not in (1, 2, 4, 8):
+        raise ValueError("an arity-8 tree shards over 1, 2, 4 or 8 ranks")
+    lv = np.ascontiguousarray(local_leaves, dtype=np.uint64).reshape(-1, 4)
+    per_rank = 8 // world
+    n_sub, rem = divmod(lv.shape[0], per_rank)
+    if rem or n_sub < 1 or (n_sub & (n_sub - 1)) or (n_sub.bit_length() - 1) % 3:
+        raise ValueError("each rank must hold 8/world subtrees of 8^k leaves")
+    if n_sub == 1:  # the leaves are the root's children themselves
+        roots = lv
+    else:
+        roots = np.stack([np.asarray(tree_root(field_id, lv[i * n_sub:(i + 1) * n_sub])).reshape(4) for i in range(per_rank)])
+    if world > 1:
+        roots = _all_gather_rows(roots, group)
+    return np.asarray(hash8(field_id, roots.reshape(1, 8, 4))).reshape(4)

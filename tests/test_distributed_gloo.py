@@ -73,3 +73,44 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def _tree_worker(rank, world, port, log_n, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from lurk_beta_amd.distributed import shard_range, sharded_tree8_root
+        from oracle import coracle as C
+
+        n = 1 << log_n
+        lo, hi = shard_range(n, world, rank)
+        leaves = C.synth_scalars(1, 2, 0, n)[lo:hi]  # this rank's contiguous leaves
+        # the oracle stands in for the HIP kernels (no GPU here); the sharding, gather and final hash8 are the code under test
+        root = sharded_tree8_root(1, leaves, tree_root=lambda f, lv: C.poseidon_tree8(f, lv),
+                                  hash8=lambda f, pre: C.poseidon_batch(f, 8, pre.reshape(-1, 4)))
+        q.put((rank, [int(x) for x in np.asarray(root).reshape(4)]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        q.put((rank, repr(e)))
+        raise
+
+
+@pytest.mark.parametrize("log_n", [3, 9])
+def test_sharded_poseidon_tree_world2_gloo(log_n):
+    from oracle import coracle as C
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tree_worker, args=(r, world, port, log_n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [int(x) for x in np.asarray(C.poseidon_tree8(1, C.synth_scalars(1, 2, 0, 1 << log_n))).reshape(-1)[:4]]
+    assert got[0] == want and got[1] == want

@@ -69,6 +69,18 @@ def test_tree8_matches_oracle(hip, f, height):
         poseidon_tree8(f, np.zeros((12, 4), dtype=np.uint64))  # not a power of 8
 
 
+def test_sharded_tree_single_rank_equals_dense_tree(hip):
+    """distributed.sharded_tree8_root with no process group (world 1): 8 subtrees + one hash8 == the dense tree."""
+    from lurk_beta_amd import poseidon_tree8
+    from lurk_beta_amd.distributed import sharded_tree8_root
+
+    for n in (8, 512):
+        leaves = C.synth_scalars(1, 2, 0, n)
+        assert np.array_equal(sharded_tree8_root(1, leaves), poseidon_tree8(1, leaves))
+    with pytest.raises(ValueError):
+        sharded_tree8_root(1, C.synth_scalars(1, 2, 0, 16))
+
+
 def test_tree8_empty_roots_are_the_trie_kats(hip):
     """A dense tree of zero leaves reproduces the trie's empty roots (trie/mod.rs:464-481)."""
     from lurk_beta_amd import poseidon_tree8
