@@ -12,23 +12,6 @@
 #include "curve.cuh"
 #include "field29.cuh"
 
-#if defined(LURK_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
-#include <cstdio>
-#include <cstdlib>
-#define F29_ASSERT_LIMBS(v, bits, what)                                                        \
-    do {                                                                                       \
-        for (int _i = 0; _i < 9; _i++)                                                         \
-            if ((uint64_t)(v).l[_i] >> (bits)) { printf("F29 bound violated: %s limb %d = %u (>= 2^%d)\n", what, _i, (v).l[_i], bits); abort(); } \
-    } while (0)
-#define F29_ASSERT_TOP(v, bits, what)                                                          \
-    do {                                                                                       \
-        if ((uint64_t)(v).l[8] >> (bits)) { printf("F29 bound violated: %s top limb = %u (>= 2^%d)\n", what, (v).l[8], bits); abort(); } \
-    } while (0)
-#else
-#define F29_ASSERT_LIMBS(v, bits, what) ((void)0)
-#define F29_ASSERT_TOP(v, bits, what) ((void)0)
-#endif
-
 #ifndef LURK_ACC_PREFETCH
 #define LURK_ACC_PREFETCH 0
 #endif

@@ -16,6 +16,35 @@
 #pragma once
 #include "field.cuh"
 
+// LURK_F29_CHECK (host builds of the test harness only): every limb / accumulator bound the radix-2^29
+// code relies on is asserted at run time.
+#if defined(LURK_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+#include <cstdio>
+#include <cstdlib>
+#define F29_ASSERT_LIMBS(v, bits, what)                                                        \
+    do {                                                                                       \
+        for (int _i = 0; _i < 9; _i++)                                                         \
+            if ((uint64_t)(v).l[_i] >> (bits)) { printf("F29 bound violated: %s limb %d = %u (>= 2^%d)\n", what, _i, (v).l[_i], bits); abort(); } \
+    } while (0)
+#define F29_ASSERT(cond, what)                                                                 \
+    do {                                                                                       \
+        if (!(cond)) { printf("F29 bound violated: %s\n", what); abort(); }                     \
+    } while (0)
+#define F29_ASSERT_TOP(v, bits, what)                                                          \
+    do {                                                                                       \
+        if ((uint64_t)(v).l[8] >> (bits)) { printf("F29 bound violated: %s top limb = %u (>= 2^%d)\n", what, (v).l[8], bits); abort(); } \
+    } while (0)
+#else
+#define F29_ASSERT_LIMBS(v, bits, what) ((void)0)
+#define F29_ASSERT(cond, what)                                                                 \
+    do {                                                                                       \
+        if (!(cond)) { printf("F29 bound violated: %s\n", what); abort(); }                     \
+    } while (0)
+#define F29_ASSERT_TOP(v, bits, what) ((void)0)
+#define F29_ASSERT(cond, what) ((void)0)
+#endif
+
+
 namespace lurk {
 
 template <class P>
@@ -111,6 +140,14 @@ LURK_HD F29<P> f29_mul_portable(const F29<P>& a, const F29<P>& b) {
     uint32_t m[9];
     F29<P> t;
     uint64_t acc = 0;
+#if defined(LURK_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    {
+        uint64_t ma = 0, mb = 0;
+        for (int i = 0; i < 9; i++) { ma = a.l[i] > ma ? a.l[i] : ma; mb = b.l[i] > mb ? b.l[i] : mb; }
+        // 9 products + 9 reduction terms (< 2^58 each) + the running carry must fit 64 bits
+        F29_ASSERT((unsigned __int128)ma * mb * 9 + ((unsigned __int128)10 << 58) < ((unsigned __int128)1 << 64), "f29_mul column overflow");
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < 17; k++) {
 #pragma unroll

@@ -1,7 +1,7 @@
 // poseidon.hip - Poseidon batch hasher and dense arity-8 tree builder for gfx950.
 //
-// Kernel shape (north_star): one Poseidon state per lane (t x 8 VGPRs), the whole constant image
-// (round constants, MDS, pre-sparse and sparse matrices; <= 40 KiB for t = 9) staged once per
+// Kernel shape (north_star): one Poseidon state per lane (t x 9 VGPRs: radix-2^29 limbs, poseidon29.cuh),
+// the whole constant image (round constants, MDS, pre-sparse and sparse matrices; 59 KiB for t = 9) staged once per
 // workgroup in LDS and read back as wave-uniform broadcasts (every lane of a wave is in the same
 // round, so every ds_read hits one address: conflict-free).  No MFMA: the work is 255-bit modular
 // multiplication on the integer VALU (v_mad_u64_u32), ~2.1k field multiplications per hash8.
@@ -12,6 +12,7 @@
 
 #include "common.hpp"
 #include "poseidon.cuh"
+#include "poseidon29.cuh"
 #include "poseidon_params.hpp"
 
 namespace lurk {
@@ -26,11 +27,12 @@ __global__ __launch_bounds__(POSEIDON_BLOCK) void poseidon_batch_kernel(const ui
     extern __shared__ uint4 lds[];
     for (int i = threadIdx.x; i < img_vec4; i += POSEIDON_BLOCK) lds[i] = img[i];
     __syncthreads();
-    const Fe<P>* C = reinterpret_cast<const Fe<P>*>(lds);
+    const uint32_t* C = reinterpret_cast<const uint32_t*>(lds);
+    const uint32_t* mont2 = C + (size_t)PoseidonLayout<T>(rf, rp).total() * P29_STRIDE;  // 2^522 mod p
     constexpr int A = T - 1;
     for (size_t h = (size_t)blockIdx.x * POSEIDON_BLOCK + threadIdx.x; h < n; h += (size_t)gridDim.x * POSEIDON_BLOCK) {
-        Fe<P> s[T];
-        s[0] = C[0];
+        F29<P> s[T];
+        s[0] = ld_const29<P>(C);
         const uint4* src = pre + h * (A * 2);
 #pragma unroll
         for (int i = 0; i < A; i++) {
@@ -38,10 +40,10 @@ __global__ __launch_bounds__(POSEIDON_BLOCK) void poseidon_batch_kernel(const ui
             Fe<P> x;
             x.l[0] = lo.x; x.l[1] = lo.y; x.l[2] = lo.z; x.l[3] = lo.w;
             x.l[4] = hi.x; x.l[5] = hi.y; x.l[6] = hi.z; x.l[7] = hi.w;
-            s[i + 1] = (flags & PF_IN_MONT) ? x : fe_to_mont<P>(x);
+            s[i + 1] = (flags & PF_IN_MONT) ? f29_from_mont256<P>(x) : poseidon29_from_canonical<P>(x.l, mont2);
         }
-        poseidon_permute<P, T>(s, C, rf, rp);
-        Fe<P> d = (flags & PF_OUT_MONT) ? s[1] : fe_from_mont<P>(s[1]);
+        poseidon29_permute<P, T>(s, C, rf, rp);
+        Fe<P> d = (flags & PF_OUT_MONT) ? f29_to_mont256<P>(s[1]) : poseidon29_to_canonical<P>(s[1]);
         out[2 * h] = make_uint4(d.l[0], d.l[1], d.l[2], d.l[3]);
         out[2 * h + 1] = make_uint4(d.l[4], d.l[5], d.l[6], d.l[7]);
     }
@@ -64,7 +66,7 @@ static std::unique_ptr<PoseidonConsts> build_consts(int arity) {
     pc->rf = pp.rf;
     pc->rp = pp.rp;
     pc->t = pp.t;
-    pc->image = poseidon_device_image<P>(pp);
+    pc->image = poseidon29_image<P>(poseidon_device_image<P>(pp));  // radix-2^29 form, 12 words per constant
     for (auto& x : pp.rc) {
         Fe<P> c = fe_from_mont<P>(x);
         for (int i = 0; i < 8; i++) pc->rc_canon.push_back(c.l[i]);

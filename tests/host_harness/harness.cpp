@@ -55,11 +55,25 @@ extern "C" void hh_fe_op(int field, int op, const uint32_t* a, const uint32_t* b
 // ---------------------------------------------------------------------------------------------
 #include "../../lurk_beta_amd/csrc/poseidon.cuh"
 #include "../../lurk_beta_amd/csrc/poseidon_params.hpp"
+#include "../../lurk_beta_amd/csrc/poseidon29.cuh"
 
 template <class P, int T>
 static void poseidon_n(int mode, const uint32_t* pre, size_t n, uint32_t* out) {
     PoseidonParams<P> pp = make_poseidon_params<P>(T - 1);
     std::vector<uint32_t> img = poseidon_device_image<P>(pp);
+    if (mode == 2) {  // the radix-2^29 permutation the kernels run
+        std::vector<uint32_t> img29 = poseidon29_image<P>(img);
+        const PoseidonLayout<T> L(pp.rf, pp.rp);
+        for (size_t h = 0; h < n; h++) {
+            F29<P> s[T];
+            s[0] = ld_const29<P>(img29.data());
+            for (int i = 1; i < T; i++) s[i] = poseidon29_from_canonical<P>(pre + (h * (T - 1) + (i - 1)) * 8, img29.data() + (size_t)L.total() * P29_STRIDE);
+            poseidon29_permute<P, T>(s, img29.data(), pp.rf, pp.rp);
+            Fe<P> d = poseidon29_to_canonical<P>(s[1]);
+            for (int k = 0; k < 8; k++) out[h * 8 + k] = d.l[k];
+        }
+        return;
+    }
     for (size_t h = 0; h < n; h++) {
         Fe<P> s[T];
         s[0] = pp.domain_tag;

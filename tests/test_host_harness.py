@@ -54,7 +54,7 @@ def test_poseidon_params_and_sparse_schedule(f, arity):
     pre = [[R.uniform_fe(2, i * arity + j, p) for j in range(arity)] for i in range(4)] + [[0] * arity, [p - 1] * arity]
     PRE = C.ints_to_limbs([x for r in pre for x in r])
     want = C.limbs_to_ints(C.poseidon_batch(f, arity, PRE))
-    for mode in (0, 1):  # 0 = sparse schedule (what the kernel runs), 1 = plain schedule
+    for mode in (0, 1, 2):  # 0 = sparse schedule, 1 = plain schedule, 2 = sparse schedule on the radix-2^29 layer (what the kernel runs)
         out = np.zeros((len(pre), 4), dtype=np.uint64)
         L.hh_poseidon(f, arity, mode, vp(PRE), ctypes.c_size_t(len(pre)), vp(out))
         assert C.limbs_to_ints(out) == want, (f, arity, mode)
