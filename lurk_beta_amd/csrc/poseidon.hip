@@ -21,7 +21,7 @@ constexpr int POSEIDON_BLOCK = 256;
 enum : int { PF_IN_MONT = 1, PF_OUT_MONT = 2 };
 
 template <class P, int T>
-__global__ __launch_bounds__(POSEIDON_BLOCK) void poseidon_batch_kernel(const uint4* __restrict__ pre, uint4* __restrict__ out,
+__global__ __launch_bounds__(POSEIDON_BLOCK) __attribute__((amdgpu_waves_per_eu(2, 2))) void poseidon_batch_kernel(const uint4* __restrict__ pre, uint4* __restrict__ out,
                                                                           size_t n, const uint4* __restrict__ img, int img_vec4,
                                                                           int rf, int rp, int flags) {
     extern __shared__ uint4 lds[];
