@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round measurement sweep (through gpurun): one JSON line per configuration into gpurun_out/sweep_<tag>.jsonl
+TAG=${1:-r01}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/sweep_$TAG.jsonl; : > $OUT
+run() { python bench.py "$@" 2>/dev/null | tail -1 >> $OUT; }
+run --steps 12 --warmup 3                                         # headline: 2^22 table, 2 in flight (+cpu baseline)
+run --steps 12 --warmup 3 --no-cpu-baseline --pipeline 3
+run --steps 10 --warmup 3 --no-cpu-baseline --pipeline 1
+run --steps 10 --warmup 3 --no-cpu-baseline --pipeline 1 --precompute 0
+run --steps 10 --warmup 3 --no-cpu-baseline --dist witness
+run --steps 20 --warmup 3 --no-cpu-baseline --log-n 20 --pipeline 3
+run --steps 20 --warmup 3 --no-cpu-baseline --log-n 20 --pipeline 1
+run --steps 20 --warmup 3 --no-cpu-baseline --log-n 20 --pipeline 1 --precompute 0
+run --steps 20 --warmup 3 --no-cpu-baseline --log-n 20 --pipeline 1 --precompute 0 --dist witness
+run --steps 10 --warmup 2 --no-cpu-baseline --log-n 22 --verify
+run --workload fold_step --steps 10 --warmup 2
+run --workload fold_step --steps 5 --warmup 2 --rc 900 --no-cpu-baseline
+run --workload poseidon_tree --steps 3 --warmup 1
+run --workload ntt --log-n 24 --steps 10 --warmup 2
+run --workload ntt --log-n 20 --steps 20 --warmup 2 --no-cpu-baseline
+python - <<PY
+import json
+for l in open("$OUT"):
+    try: d=json.loads(l)
+    except Exception as e: print("bad line", l[:100]); continue
+    print(d["config"].get("workload","")[:70], "|", d["config"].get("commitments_in_flight",""), "|", d["value"], d["unit"], "|", d["ms_per_step"], "ms", "| verified" if d.get("verified") else "")
+PY
