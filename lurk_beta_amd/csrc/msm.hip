@@ -40,12 +40,15 @@ struct MsmShape {
 // Both sweeps of sort pass 1 read the scalars themselves (32 B each) and recode them on the fly:
 // cheaper than materialising W digits per scalar (4 W bytes written once and read twice).
 template <class SF>  // scalar field
-__device__ __forceinline__ Fe<SF> msm_load_scalar(const uint4* __restrict__ scalars, size_t i, int is_mont) {
-    uint4 lo = scalars[2 * i], hi = scalars[2 * i + 1];
+__device__ __forceinline__ Fe<SF> msm_scalar_from_words(const uint4& lo, const uint4& hi, int is_mont) {
     Fe<SF> s;
     s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
     s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
     return is_mont ? fe_from_mont<SF>(s) : s;
+}
+template <class SF>
+__device__ __forceinline__ Fe<SF> msm_load_scalar(const uint4* __restrict__ scalars, size_t i, int is_mont) {
+    return msm_scalar_from_words<SF>(scalars[2 * i], scalars[2 * i + 1], is_mont);
 }
 
 // entry (w, i) -> key = space * B + |d| - 1 (space = w in plain mode, 0 with the table)
@@ -62,8 +65,13 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* 
     for (int p = threadIdx.x; p < MSM_P; p += MSM_SORT_BLOCK) h[p] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
-    for (size_t i = lo + threadIdx.x; i < hi; i += MSM_SORT_BLOCK) {
-        Fe<SF> s = msm_load_scalar<SF>(scalars, i, is_mont);
+    // the next scalar is in flight while the current one is recoded (16 waves per CU do not hide the load otherwise)
+    size_t i = lo + threadIdx.x;
+    uint4 nlo = make_uint4(0, 0, 0, 0), nhi = nlo;
+    if (i < hi) { nlo = scalars[2 * i]; nhi = scalars[2 * i + 1]; }
+    for (; i < hi; i += MSM_SORT_BLOCK) {
+        Fe<SF> s = msm_scalar_from_words<SF>(nlo, nhi, is_mont);
+        if (i + MSM_SORT_BLOCK < hi) { nlo = scalars[2 * (i + MSM_SORT_BLOCK)]; nhi = scalars[2 * (i + MSM_SORT_BLOCK) + 1]; }
         uint32_t carry = 0;
         for (int w = 0; w < sh.W; w++) {
             uint32_t mag = msm_digit_step(s.l, w, sh.c, carry) & ~MSM_SIGN;
