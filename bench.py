@@ -234,15 +234,43 @@ def main():
         dist.destroy_process_group()
 
 
+def synth_r1cs_shape(field_id, p, num_cons, num_vars, num_io, seed=7):
+    """Synthetic CSR triple shaped like the Lurk step circuit (3-4 entries per row, one row in 300 a 255-entry
+    bit decomposition, coefficients mostly +-1 / small): the bench's own generator (numpy), values in Montgomery form."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    ncols = num_vars + 1 + num_io
+    table_ints = [1, p - 1, 2, p - 2, 3, 4, 8, 16, 256, 1 << 32, p - (1 << 16)] + [int(rng.integers(1, 1 << 62)) ** 4 % p for _ in range(21)]
+    table = np.array([[(v << 256) % p >> (64 * w) & 0xFFFFFFFFFFFFFFFF for w in range(4)] for v in table_ints], dtype=np.uint64)
+    weights = np.array([40, 25, 5, 2, 2, 1, 1, 1, 1, 1, 1] + [1] * 21, dtype=np.float64)
+    weights /= weights.sum()
+
+    def sparse(one_per_row=False):
+        cnt = np.ones(num_cons, dtype=np.uint64) if one_per_row else rng.integers(3, 5, num_cons).astype(np.uint64)
+        if not one_per_row:
+            cnt[rng.integers(0, num_cons, max(1, num_cons // 300))] = min(ncols, 255)
+        indptr = np.zeros(num_cons + 1, dtype=np.uint64)
+        np.cumsum(cnt, out=indptr[1:])
+        nnz = int(indptr[-1])
+        indices = np.full(nnz, num_vars, dtype=np.uint64) if one_per_row else rng.integers(0, ncols, nnz).astype(np.uint64)
+        data = np.ascontiguousarray(table[rng.choice(len(table_ints), size=nnz, p=weights)])
+        return indptr, indices, data
+
+    return sparse(), sparse(), sparse(one_per_row=True)
+
+
 def fold_step_workload(args, lib, world, rank):
     """Synthetic stand-in for the device work of ONE Nova folding step of benches/fibonacci.rs on the
     Pallas cycle (the bench itself needs cargo + arecibo and cannot run here):
       commit(W): n_vars  ~ 9 119 * rc points, witness-like scalars   (src/lem/eval.rs:1966)
-      commit(T): n_cons  ~ 11 141 * rc points, uniform scalars       (src/lem/eval.rs:1967)
+      NIFS cross term T over n_cons ~ 11 141 * rc rows (sparse A, B, C times z1, z2; device-resident, fold.hip)
+      commit(T): n_cons points                                       (src/lem/eval.rs:1967)
+      fold W <- W1 + r W2, E <- E1 + r T                             (device-resident)
       slot-witness Poseidon batch: 21 hashes per frame (14 hash4 + 6 hash8 + 1 hash3, eval.rs:1960-1964)
     Reported as "equivalent Lurk iterations/s" = rc / t(step).  It leaves out what stays on the CPU in the
-    reference (sparse mat-vec, transcript, circuit synthesis): an upper bound on the end-to-end rate, flagged
-    synthetic."""
+    reference (transcript, circuit synthesis, the small secondary-curve fold): an upper bound on the end-to-end
+    rate, flagged synthetic."""
     import numpy as np
     import torch
 
@@ -250,47 +278,85 @@ def fold_step_workload(args, lib, world, rank):
     from lurk_beta_amd import _lib, synth
 
     rc = args.rc
-    n_w, n_t = 9119 * rc, 11141 * rc
+    n_w, n_t, n_io = 9119 * rc, 11141 * rc, 2
     n_key = max(n_w, n_t)
+    F = L.FIELD_PALLAS_FQ
+    q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
     stream = torch.cuda.current_stream().cuda_stream
     d_bases = synth.bases(L.CURVE_PALLAS, n_key)
-    d_w = synth.scalars(L.FIELD_PALLAS_FQ, 1, 1, n_w, mont=True)
-    d_t = synth.scalars(L.FIELD_PALLAS_FQ, 2, 0, n_t, mont=True)
-    pre4 = synth.scalars(L.FIELD_PALLAS_FQ, 3, 1, 14 * rc * 4)
-    pre8 = synth.scalars(L.FIELD_PALLAS_FQ, 4, 1, 6 * rc * 8)
-    pre3 = synth.scalars(L.FIELD_PALLAS_FQ, 5, 1, 1 * rc * 3)
+    d_z1 = synth.scalars(F, 1, 1, n_w + 1 + n_io, mont=True)   # running instance [W1 | u1 | X1] (witness-like values)
+    d_z2 = synth.scalars(F, 6, 1, n_w + 1 + n_io, mont=True)   # fresh instance   [W2 | u2 | X2]
+    d_e1 = synth.scalars(F, 2, 0, n_t, mont=True)              # running error vector E1 (uniform, like any folded T)
+    d_t = torch.empty((n_t, 4), dtype=torch.int64, device="cuda")
+    d_z = torch.empty_like(d_z1)
+    d_e = torch.empty_like(d_e1)
+    pre4 = synth.scalars(F, 3, 1, 14 * rc * 4)
+    pre8 = synth.scalars(F, 4, 1, 6 * rc * 8)
+    pre3 = synth.scalars(F, 5, 1, 1 * rc * 3)
     out = torch.empty((21 * rc, 4), dtype=torch.int64, device="cuda")
+    t_setup = time.perf_counter()
+    shape = L.R1CSShape(F, n_t, n_w, n_io, *synth_r1cs_shape(F, q, n_t, n_w, n_io))
+    shape_setup_s = time.perf_counter() - t_setup
+    info = shape.info()
+    r_mont = np.array([0x1234567890ABCDEF, 0x0FEDCBA098765432, 0x1111111122222222, 0x0333333344444444], dtype=np.uint64)  # stands in for the transcript's challenge
     torch.cuda.synchronize()
     ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
-    F = L.FIELD_PALLAS_FQ
 
     def step():
-        ck.submit_device(0, d_w, n_w, is_mont=True, stream=stream)
-        ck.submit_device(1, d_t, n_t, is_mont=True, stream=stream)
+        ck.submit_device(0, d_z2, n_w, is_mont=True, stream=stream)          # commit(W2)
+        shape.cross_term(d_z1, d_z2, out=d_t, stream=stream)                  # T
+        ck.submit_device(1, d_t, n_t, is_mont=True, stream=stream)           # commit(T)
         _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 4, _lib.ptr(pre4), 14 * rc, _lib.ptr(out), _lib.ptr(stream)))
         _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 8, _lib.ptr(pre8), 6 * rc, _lib.ptr(out[14 * rc:]), _lib.ptr(stream)))
         _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 3, _lib.ptr(pre3), rc, _lib.ptr(out[20 * rc:]), _lib.ptr(stream)))
-        cw, ct = ck.wait(0), ck.wait(1)
+        cw, ct = ck.wait(0), ck.wait(1)                                       # the transcript needs both commitments
+        L.fold_vec(F, d_z1, d_z2, r_mont, out=d_z, stream=stream)             # [W | u | X] <- z1 + r z2
+        L.fold_vec(F, d_e1, d_t, r_mont, out=d_e, stream=stream)              # E <- E1 + r T
         torch.cuda.synchronize()
         return cw, ct
 
     for _ in range(args.warmup):
         step()
+    lib.lurk_hip_profile_enable(1)
+    lib.lurk_hip_profile_reset()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    lib.lurk_hip_profile_enable(0)
+
+    def kernel_ms(name):
+        tot, cnt = ctypes.c_double(), ctypes.c_uint64()
+        _lib.check(lib.lurk_hip_profile_get(name.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
+        return tot.value / max(cnt.value, 1), cnt.value
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
+        nnz = sum(info["nnz"])
+        ct_ms, _ = kernel_ms("r1cs_cross_term")
+        fv_ms, _ = kernel_ms("fold_vec")
+        # algorithmic HBM bytes of the cross-term kernel: 8 B per CSR record + 4 B per row pointer, two 32-byte gathers
+        # per record (z1, z2), 32 B of T per row; fold_vec: two reads + one write of 32 B per element
+        ct_bytes = nnz * 8.0 + 3 * 4.0 * n_t + 2 * 32.0 * nnz + 32.0 * n_t
+        fv_bytes = 96.0 * ((n_w + 1 + n_io) + n_t) / 2
         res = {
             "metric": "equivalent Lurk iterations/s (synthetic stand-in for one Nova folding step, Pallas)",
             "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
-            "config": {"workload": f"fold-step stand-in rc={rc}: MSM(W) {n_w} pts witness-like + MSM(T) {n_t} pts uniform + {21 * rc} Poseidon slot hashes",
-                       "note": "device work only (commitments + slot hashes); sparse mat-vec / transcript / synthesis not modelled"},
+            "config": {"workload": f"fold-step stand-in rc={rc}: MSM(W) {n_w} pts witness-like + cross term over {n_t} rows ({nnz} non-zeros, "
+                                   f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) {n_t} pts + fold of W and E + {21 * rc} Poseidon slot hashes",
+                       "note": "device work only; transcript / synthesis / the small secondary-curve fold not modelled",
+                       "shape_setup_s_once": round(shape_setup_s, 2)},
+            "fold_kernels": {
+                "r1cs_cross_term": {"ms": round(ct_ms, 4), "algorithmic_bytes": ct_bytes, "achieved_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms else None,
+                                    "hbm_frac": round(ct_bytes / (ct_ms * 1e-3) / 8e12, 4) if ct_ms else None},
+                "fold_vec": {"ms_per_launch": round(fv_ms, 4), "algorithmic_bytes_per_launch": fv_bytes,
+                             "achieved_GBps": round(fv_bytes / (fv_ms * 1e-3) / 1e9, 1) if fv_ms else None,
+                             "hbm_frac": round(fv_bytes / (fv_ms * 1e-3) / 8e12, 4) if fv_ms else None},
+            },
         }
         if not args.no_cpu_baseline:
             from oracle import coracle as C
@@ -303,9 +369,10 @@ def fold_step_workload(args, lib, world, rank):
             dt = time.perf_counter() - t1
             scale = (n_w + n_t) / (min(n_w, m) + m)
             res["cpu_baseline"] = {"value": round(rc / (dt * scale), 2), "unit": "iterations/s", "cores": C.lib().orc_num_threads(), "kind": "port",
-                                   "sample": f"both MSMs truncated to <= 2^20 points ({dt:.2f} s), scaled linearly to the full step; oracle/oracle.c OpenMP Pippenger"}
+                                   "sample": f"both MSMs truncated to <= 2^20 points ({dt:.2f} s), scaled linearly to the full step; oracle/oracle.c OpenMP Pippenger (fold arithmetic not included)"}
         print(json.dumps(res), flush=True)
     ck.close()
+    shape.close()
 
 
 def valu_roofline(acc_ms, mixed_adds):

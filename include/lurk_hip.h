@@ -139,6 +139,34 @@ int lurk_hip_poseidon_constants(int field_id, int arity, int* rf, int* rp, void*
 int lurk_hip_ntt(int field_id, void* inout, unsigned log_n, int inverse);
 int lurk_hip_ntt_dev(int field_id, void* d_inout, unsigned log_n, int inverse, void* stream);
 
+/* ---- relaxed-R1CS folding -----------------------------------------------
+ * The arithmetic arecibo's NIFS::prove runs on the CPU between the two commitments of a folding step
+ * (caller: RecursiveSNARK::prove_step, /root/reference/src/proof/nova.rs:291-293; arecibo is the
+ * un-vendored `nova` dependency, /root/reference/Cargo.toml:128): with these the witness vectors
+ * stay in HBM from commit(W) through commit(T) to the next step.
+ * Shape = the three CSR matrices as arecibo's SparseMatrix {data, indices, indptr} holds them:
+ * indptr (num_cons + 1) x usize, indices nnz x usize (column into z = [W | u | X], i.e.
+ * num_vars + 1 + num_io columns), data nnz x 32 B Montgomery.  Copied to the device at creation
+ * (coefficients de-duplicated into a dictionary); the host arrays are only borrowed for the call. */
+typedef struct lurk_hip_r1cs lurk_hip_r1cs;
+int lurk_hip_r1cs_create(lurk_hip_r1cs** shape, int field_id, size_t num_cons, size_t num_vars,
+                         size_t num_io, const uint64_t* a_indptr, const uint64_t* a_indices,
+                         const void* a_data, const uint64_t* b_indptr, const uint64_t* b_indices,
+                         const void* b_data, const uint64_t* c_indptr, const uint64_t* c_indices,
+                         const void* c_data);
+int lurk_hip_r1cs_destroy(lurk_hip_r1cs* shape);
+int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b, size_t* nnz_c,
+                       size_t* distinct_coefficients);
+/* R1CSShape::multiply_vec: (A z, B z, C z); d_z has num_vars + 1 + num_io elements, outputs num_cons */
+int lurk_hip_r1cs_multiply_vec_dev(const lurk_hip_r1cs* shape, const void* d_z, void* d_az, void* d_bz,
+                                   void* d_cz, void* stream);
+/* R1CSShape::commit_T's vector: T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1 (u_i = z_i[num_vars]) */
+int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const void* d_z2, void* d_t,
+                                 void* stream);
+/* RelaxedR1CSWitness::fold: out = a + r b over n elements (W1 + r W2, E1 + r T); r: 32 B Montgomery, host */
+int lurk_hip_fold_vec_dev(int field_id, const void* d_a, const void* d_b, const void* r32_mont, size_t n,
+                          void* d_out, void* stream);
+
 /* ---- synthetic inputs (bench / tests) -------------------------------------
  * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */
 int lurk_hip_synth_scalars_dev(int field_id, uint64_t stream_id, int dist, size_t first, size_t n,

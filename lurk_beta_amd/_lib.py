@@ -48,6 +48,12 @@ SIGNATURES = {
     "lurk_hip_poseidon_constants": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p]),
     "lurk_hip_ntt": (c_int, [c_int, c_void_p, c_uint, c_int]),
     "lurk_hip_ntt_dev": (c_int, [c_int, c_void_p, c_uint, c_int, c_void_p]),
+    "lurk_hip_r1cs_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_size_t, c_size_t, c_size_t] + [c_void_p] * 9),
+    "lurk_hip_r1cs_destroy": (c_int, [c_void_p]),
+    "lurk_hip_r1cs_info": (c_int, [c_void_p] + [ctypes.POINTER(c_size_t)] * 4),
+    "lurk_hip_r1cs_multiply_vec_dev": (c_int, [c_void_p] * 6),
+    "lurk_hip_r1cs_cross_term_dev": (c_int, [c_void_p] * 5),
+    "lurk_hip_fold_vec_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
 }

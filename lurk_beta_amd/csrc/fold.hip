@@ -1,0 +1,490 @@
+// fold.hip - the device-resident part of one relaxed-R1CS folding step.
+//
+// Replaces, for the arithmetic only, what arecibo's NIFS::prove does on the CPU between the two commitments
+// of a step (caller: RecursiveSNARK::prove_step, /root/reference/src/proof/nova.rs:291-293; arecibo itself is
+// an un-vendored git dependency, /root/reference/Cargo.toml:128, so this follows the published Nova
+// construction and oracle/oracle.c restates it - parity unpinned, no golden vectors upstream):
+//   R1CSShape::multiply_vec   (A z, B z, C z)                          -> lurk_hip_r1cs_multiply_vec_dev
+//   R1CSShape::commit_T       T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1 -> lurk_hip_r1cs_cross_term_dev
+//   RelaxedR1CSWitness::fold  W <- W1 + r W2,  E <- E1 + r T            -> lurk_hip_fold_vec_dev
+// With these the witness vectors never leave HBM between commit(W), commit(T) and the next step.
+//
+// Layout.  A shape keeps its three CSR matrices resident: row pointers (u32), and per non-zero ONE 8-byte
+// record {column, coefficient id}.  R1CS coefficients repeat massively (+-1, small constants), so the 32-byte
+// values are replaced by ids into a dictionary of distinct coefficients built once at creation (radix-2^29
+// limbs, 48-byte records, read through L2): 8 B per non-zero instead of 36 B.  z = [W | u | X] as arecibo lays
+// it out; all field elements cross the ABI as 32-byte Montgomery(2^256) values.
+//
+// Kernels: one lane per row (the step circuit's rows hold 3-4 entries; neighbouring lanes read neighbouring
+// CSR records); the few long rows (bit decompositions: ~255 entries) go to a second launch with one wave per row.  A row's inner product is accumulated in 17 unreduced 64-bit columns (poseidon29.cuh: Dot29)
+// and reduced once.  The cross-term kernel runs the six inner products of a row (A, B, C times z1, z2) from one
+// pass over the matrices and finishes T as a four-term lazy row: AZ1*BZ2 + AZ2*BZ1 + (-u1)*CZ2 + (-u2)*CZ1.
+// Both kernels are bound by the random 32-byte gathers from z (HBM / L2), not by arithmetic.
+#include <memory>
+#include <unordered_map>
+
+#include "common.hpp"
+#include "poseidon29.cuh"
+
+namespace lurk {
+
+constexpr int FOLD_BLOCK = 256;
+
+struct CsrDev {
+    DevBuf rowptr;  // u32 x (rows + 1)
+    DevBuf ent;     // uint2 {col, coefficient id} x nnz
+    size_t nnz = 0;
+};
+
+struct R1csShape {
+    int field_id = 0;
+    size_t num_cons = 0, num_vars = 0, num_io = 0;
+    CsrDev m[3];
+    DevBuf dict;  // distinct coefficients, P29_STRIDE words each (canonical Montgomery-2^261 limbs)
+    size_t dict_size = 0;
+    DevBuf long_rows;  // u32 row ids with more than FOLD_LONG entries in A, B or C
+    size_t n_long = 0;
+    int device = 0;
+};
+
+// ---- rows --------------------------------------------------------------------------------------------------
+// Lazy accumulator of one row value: terms a*b (both tight) are added as unreduced 17-column products.
+// 45 products per column fit 64 bits: the columns are normalised every fourth term.  Every term adds < 2^253
+// to the value: every 64 terms the reduced partial sum re-enters as one term (times the Montgomery one) so that
+// rows of any length stay below 2^261.
+template <class P>
+struct RowAcc {
+    Dot29<P> acc;
+    uint32_t since, terms;
+};
+template <class P>
+__device__ __forceinline__ void row_init(RowAcc<P>& r) {
+    dot29_init<P>(r.acc);
+    r.since = 0;
+    r.terms = 0;
+}
+template <class P>
+__device__ __forceinline__ void row_mac(RowAcc<P>& r, const F29<P>& a, const F29<P>& b, const uint32_t* one29) {
+    if (r.terms == 64) {
+        F29<P> part = dot29_finish<P>(r.acc);
+        dot29_init<P>(r.acc);
+        dot29_mac<P>(r.acc, part, ld_const29<P>(one29));
+        r.terms = 1;
+        r.since = 1;
+    }
+    if (r.since == 4) {
+        dot29_carry<P>(r.acc);
+        r.since = 0;
+    }
+    dot29_mac<P>(r.acc, a, b);
+    r.since++;
+    r.terms++;
+}
+
+constexpr uint32_t FOLD_LONG = 32;  // rows with more entries (in any of A, B, C) go to the wave-per-row kernel
+constexpr int FOLD_BATCH = 4;       // entries whose loads are issued together by one lane
+
+struct CsrView {
+    const uint32_t* rowptr;
+    const uint2* ent;
+};
+
+// one lane, one (short) row of one matrix, NV vectors: entries are fetched FOLD_BATCH at a time so that the
+// dependent loads (record -> coefficient, z values) of a batch are in flight together
+template <class P, int NV>
+__device__ __forceinline__ void fold_row_lane(const CsrView& m, const uint32_t* __restrict__ dict, const uint32_t* __restrict__ one29,
+                                              uint32_t lo, uint32_t hi, const Fe<P>* const* z, F29<P>* out) {
+    RowAcc<P> acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) row_init<P>(acc[v]);
+    for (uint32_t k = lo; k < hi; k += FOLD_BATCH) {
+        uint2 e[FOLD_BATCH];
+#pragma unroll
+        for (int u = 0; u < FOLD_BATCH; u++) e[u] = k + u < hi ? m.ent[k + u] : make_uint2(0u, 0u);
+        F29<P> c[FOLD_BATCH];
+        Fe<P> zz[FOLD_BATCH][NV];
+#pragma unroll
+        for (int u = 0; u < FOLD_BATCH; u++) {
+            c[u] = ld_const29<P>(dict + (size_t)e[u].y * P29_STRIDE);
+#pragma unroll
+            for (int v = 0; v < NV; v++) zz[u][v] = z[v][e[u].x];
+        }
+#pragma unroll
+        for (int u = 0; u < FOLD_BATCH; u++)
+            if (k + u < hi) {
+#pragma unroll
+                for (int v = 0; v < NV; v++) row_mac<P>(acc[v], c[u], f29_from_mont256<P>(zz[u][v]), one29);
+            }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) out[v] = dot29_finish<P>(acc[v].acc);
+}
+
+// one wave, one long row of one matrix: chunks of 64 x FOLD_BATCH entries; per chunk every lane accumulates its
+// <= FOLD_BATCH terms, the normalised columns are summed across the wave and lane 0 adds the reduced chunk
+// value to the row as one term.  Result valid on lane 0.
+template <class P, int NV>
+__device__ __forceinline__ void fold_row_wave(const CsrView& m, const uint32_t* __restrict__ dict, const uint32_t* __restrict__ one29,
+                                              uint32_t lo, uint32_t hi, const Fe<P>* const* z, F29<P>* out) {
+    const uint32_t lane = threadIdx.x & 63;
+    RowAcc<P> row[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) row_init<P>(row[v]);
+    for (uint32_t base = lo; base < hi; base += 64 * FOLD_BATCH) {
+        Dot29<P> acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; v++) dot29_init<P>(acc[v]);
+#pragma unroll
+        for (int u = 0; u < FOLD_BATCH; u++) {
+            const uint32_t k = base + u * 64 + lane;
+            if (k < hi) {
+                const uint2 e = m.ent[k];
+                const F29<P> c = ld_const29<P>(dict + (size_t)e.y * P29_STRIDE);
+#pragma unroll
+                for (int v = 0; v < NV; v++) dot29_mac<P>(acc[v], c, f29_from_mont256<P>(z[v][e.x]));
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NV; v++) {
+            dot29_carry<P>(acc[v]);  // columns < 2^29 (the top one < 2^35): 64 of them sum without overflow
+#pragma unroll
+            for (int kcol = 0; kcol < 17; kcol++) {
+                uint64_t x = acc[v].c[kcol];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off);
+                acc[v].c[kcol] = x;
+            }
+            if (lane == 0) row_mac<P>(row[v], dot29_finish<P>(acc[v]), ld_const29<P>(one29), one29);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < NV; v++) out[v] = dot29_finish<P>(row[v].acc);
+}
+
+template <class P>
+__device__ __forceinline__ void fold_store(Fe<P>* dst, const F29<P>& v) {
+    *dst = f29_to_mont256<P>(v);
+}
+
+struct R1csDev {
+    CsrView a, b, c;
+    const uint32_t* dict;
+    size_t dict_size;
+    size_t rows;
+    const uint32_t* long_rows;  // rows with > FOLD_LONG entries in A, B or C
+    uint32_t n_long;
+};
+
+__device__ __forceinline__ bool fold_is_long(const R1csDev& s, size_t row, uint32_t* lo, uint32_t* hi) {
+    lo[0] = s.a.rowptr[row]; hi[0] = s.a.rowptr[row + 1];
+    lo[1] = s.b.rowptr[row]; hi[1] = s.b.rowptr[row + 1];
+    lo[2] = s.c.rowptr[row]; hi[2] = s.c.rowptr[row + 1];
+    return hi[0] - lo[0] > FOLD_LONG || hi[1] - lo[1] > FOLD_LONG || hi[2] - lo[2] > FOLD_LONG;
+}
+
+// LONG = false: one lane per row, long rows skipped;  LONG = true: one wave per entry of long_rows
+template <class P, bool LONG>
+__global__ __launch_bounds__(FOLD_BLOCK) void r1cs_multiply_vec_kernel(R1csDev s, const Fe<P>* __restrict__ z, Fe<P>* __restrict__ az,
+                                                                         Fe<P>* __restrict__ bz, Fe<P>* __restrict__ cz) {
+    const uint32_t* one29 = s.dict + s.dict_size * P29_STRIDE;  // the Montgomery one closes the dictionary
+    const Fe<P>* zs[1] = {z};
+    uint32_t lo[3], hi[3];
+    F29<P> r;
+    if (!LONG) {
+        size_t row = (size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x;
+        if (row >= s.rows || fold_is_long(s, row, lo, hi)) return;
+        fold_row_lane<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &r);
+        fold_store<P>(az + row, r);
+        fold_row_lane<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &r);
+        fold_store<P>(bz + row, r);
+        fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &r);
+        fold_store<P>(cz + row, r);
+    } else {
+        size_t w = ((size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x) >> 6;
+        if (w >= s.n_long) return;
+        size_t row = s.long_rows[w];
+        fold_is_long(s, row, lo, hi);
+        const bool lead = (threadIdx.x & 63) == 0;
+        fold_row_wave<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &r);
+        if (lead) fold_store<P>(az + row, r);
+        fold_row_wave<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &r);
+        if (lead) fold_store<P>(bz + row, r);
+        fold_row_wave<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &r);
+        if (lead) fold_store<P>(cz + row, r);
+    }
+}
+
+// neg_u: [-u1, -u2] as radix-2^29 limbs (2 x P29_STRIDE words), prepared by a one-lane kernel from z1, z2
+template <class P>
+__global__ void r1cs_neg_u_kernel(const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2, size_t u_index, uint32_t* __restrict__ neg_u) {
+    if (threadIdx.x >= 2 || blockIdx.x) return;
+    Fe<P> u = fe_neg<P>(threadIdx.x == 0 ? z1[u_index] : z2[u_index]);
+    F29<P> f = f29_from_mont256<P>(u);  // 32 * (-u) * 2^256: lazy Montgomery-2^261 form, tight, < 2^259
+    for (int i = 0; i < 9; i++) neg_u[threadIdx.x * P29_STRIDE + i] = f.l[i];
+}
+
+template <class P, bool LONG>
+__global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2,
+                                                                       const uint32_t* __restrict__ neg_u, Fe<P>* __restrict__ t) {
+    const uint32_t* one29 = s.dict + s.dict_size * P29_STRIDE;
+    const Fe<P>* zs[2] = {z1, z2};
+    uint32_t lo[3], hi[3];
+    F29<P> a[2], b[2], c[2];
+    size_t row;
+    if (!LONG) {
+        row = (size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x;
+        if (row >= s.rows || fold_is_long(s, row, lo, hi)) return;
+        // one vector at a time: the second pass re-reads the 8-byte records (L2) but halves the live accumulators
+#pragma unroll
+        for (int v = 0; v < 2; v++) {
+            fold_row_lane<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs + v, a + v);
+            fold_row_lane<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs + v, b + v);
+            fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs + v, c + v);
+        }
+    } else {
+        size_t w = ((size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x) >> 6;
+        if (w >= s.n_long) return;
+        row = s.long_rows[w];
+        fold_is_long(s, row, lo, hi);
+#pragma unroll
+        for (int v = 0; v < 2; v++) {
+            fold_row_wave<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs + v, a + v);
+            fold_row_wave<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs + v, b + v);
+            fold_row_wave<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs + v, c + v);
+        }
+        if (threadIdx.x & 63) return;
+    }
+    Dot29<P> acc;
+    dot29_init<P>(acc);
+    dot29_mac<P>(acc, a[0], b[1]);
+    dot29_mac<P>(acc, a[1], b[0]);
+    dot29_mac<P>(acc, ld_const29<P>(neg_u), c[1]);
+    dot29_mac<P>(acc, ld_const29<P>(neg_u + P29_STRIDE), c[0]);
+    fold_store<P>(t + row, dot29_finish<P>(acc));
+}
+
+// out = a + r b (r: Montgomery 2^256, broadcast)
+template <class P>
+__global__ __launch_bounds__(FOLD_BLOCK) void fold_vec_kernel(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ b, Fe<P> r, size_t n,
+                                                                Fe<P>* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * FOLD_BLOCK)
+        out[i] = fe_add<P>(a[i], fe_mul<P>(r, b[i]));
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+struct Key32 {
+    uint64_t w[4];
+    bool operator==(const Key32& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+};
+struct Key32Hash {
+    size_t operator()(const Key32& k) const {
+        uint64_t h = k.w[0] * 0x9E3779B97F4A7C15ull;
+        h ^= (k.w[1] + 0xBF58476D1CE4E5B9ull) * 0x94D049BB133111EBull;
+        h ^= (k.w[2] + 0x2545F4914F6CDD1Dull) * 0xD6E8FEB86659FD93ull;
+        h ^= (k.w[3] + 0x9E3779B97F4A7C15ull) * 0xC2B2AE3D27D4EB4Full;
+        return (size_t)(h ^ (h >> 29));
+    }
+};
+
+template <class P>
+static void dict_record(const uint64_t* mont256, uint32_t* rec) {
+    Fe<P> v;
+    for (int i = 0; i < 4; i++) { v.l[2 * i] = (uint32_t)mont256[i]; v.l[2 * i + 1] = (uint32_t)(mont256[i] >> 32); }
+    for (int d = 0; d < 5; d++) v = fe_add<P>(v, v);  // c 2^256 -> c 2^261 mod p, canonical
+    F29<P> f = f29_from_plain<P>(v.l);
+    for (int i = 0; i < P29_STRIDE; i++) rec[i] = i < 9 ? f.l[i] : 0u;
+}
+
+static void upload_matrix(R1csShape& sh, int which, const uint64_t* indptr, const uint64_t* indices, const void* data, size_t ncols,
+                          std::unordered_map<Key32, uint32_t, Key32Hash>& ids, std::vector<uint32_t>& dict_words) {
+    const size_t rows = sh.num_cons;
+    LURK_REQUIRE(indptr && indptr[0] == 0, "indptr must start at 0");
+    const size_t nnz = indptr[rows];
+    LURK_REQUIRE(nnz < ((size_t)1 << 32), "more than 2^32 - 1 non-zeros");
+    LURK_REQUIRE(nnz == 0 || (indices && data), "null indices / data");
+    std::vector<uint32_t> rp(rows + 1);
+    for (size_t i = 0; i <= rows; i++) {
+        LURK_REQUIRE(i == 0 || indptr[i] >= indptr[i - 1], "indptr must be non-decreasing");
+        rp[i] = (uint32_t)indptr[i];
+    }
+    std::vector<uint2> ent(nnz);
+    const uint64_t* d = (const uint64_t*)data;
+    for (size_t k = 0; k < nnz; k++) {
+        LURK_REQUIRE(indices[k] < ncols, "column index out of range");
+        Key32 key{{d[4 * k], d[4 * k + 1], d[4 * k + 2], d[4 * k + 3]}};
+        auto it = ids.find(key);
+        if (it == ids.end()) {
+            uint32_t id = (uint32_t)ids.size();
+            it = ids.emplace(key, id).first;
+            dict_words.resize(dict_words.size() + P29_STRIDE);
+            uint32_t* rec = dict_words.data() + (size_t)id * P29_STRIDE;
+            if (sh.field_id == 0) dict_record<PallasFp>(key.w, rec);
+            else if (sh.field_id == 1) dict_record<PallasFq>(key.w, rec);
+            else dict_record<Bn254Fr>(key.w, rec);
+        }
+        ent[k] = make_uint2((uint32_t)indices[k], it->second);
+    }
+    CsrDev& m = sh.m[which];
+    m.nnz = nnz;
+    m.rowptr.alloc(rp.size() * 4);
+    m.ent.alloc(nnz * 8);
+    LURK_HIP_CHECK(hipMemcpy(m.rowptr.p, rp.data(), rp.size() * 4, hipMemcpyHostToDevice));
+    if (nnz) LURK_HIP_CHECK(hipMemcpy(m.ent.p, ent.data(), nnz * 8, hipMemcpyHostToDevice));
+}
+
+static R1csDev dev_view(const R1csShape& sh) {
+    R1csDev d;
+    d.a = CsrView{sh.m[0].rowptr.as<uint32_t>(), sh.m[0].ent.as<uint2>()};
+    d.b = CsrView{sh.m[1].rowptr.as<uint32_t>(), sh.m[1].ent.as<uint2>()};
+    d.c = CsrView{sh.m[2].rowptr.as<uint32_t>(), sh.m[2].ent.as<uint2>()};
+    d.dict = sh.dict.as<uint32_t>();
+    d.dict_size = sh.dict_size;
+    d.rows = sh.num_cons;
+    d.long_rows = sh.long_rows.as<uint32_t>();
+    d.n_long = (uint32_t)sh.n_long;
+    return d;
+}
+
+template <class P>
+static void multiply_vec(const R1csShape& sh, const void* d_z, void* az, void* bz, void* cz, hipStream_t s) {
+    if (!sh.num_cons) return;
+    ProfScope ps("r1cs_multiply_vec", s);
+    const R1csDev d = dev_view(sh);
+    hipLaunchKernelGGL((r1cs_multiply_vec_kernel<P, false>), dim3(div_up(sh.num_cons, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z,
+                       (Fe<P>*)az, (Fe<P>*)bz, (Fe<P>*)cz);
+    if (sh.n_long)
+        hipLaunchKernelGGL((r1cs_multiply_vec_kernel<P, true>), dim3(div_up(sh.n_long * 64, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
+                           (const Fe<P>*)d_z, (Fe<P>*)az, (Fe<P>*)bz, (Fe<P>*)cz);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+template <class P>
+static void cross_term(const R1csShape& sh, const void* d_z1, const void* d_z2, void* d_t, void* d_neg_u, hipStream_t s) {
+    if (!sh.num_cons) return;
+    ProfScope ps("r1cs_cross_term", s);
+    const R1csDev d = dev_view(sh);
+    hipLaunchKernelGGL((r1cs_neg_u_kernel<P>), dim3(1), dim3(64), 0, s, (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, sh.num_vars, (uint32_t*)d_neg_u);
+    hipLaunchKernelGGL((r1cs_cross_term_kernel<P, false>), dim3(div_up(sh.num_cons, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z1,
+                       (const Fe<P>*)d_z2, (const uint32_t*)d_neg_u, (Fe<P>*)d_t);
+    if (sh.n_long)
+        hipLaunchKernelGGL((r1cs_cross_term_kernel<P, true>), dim3(div_up(sh.n_long * 64, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
+                           (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, (const uint32_t*)d_neg_u, (Fe<P>*)d_t);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+template <class P>
+static void fold_vec(const void* a, const void* b, const void* r32, size_t n, void* out, hipStream_t s) {
+    if (!n) return;
+    Fe<P> r;
+    memcpy(r.l, r32, 32);
+    ProfScope ps("fold_vec", s);
+    unsigned blocks = div_up(n, FOLD_BLOCK);
+    unsigned cap = (unsigned)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL((fold_vec_kernel<P>), dim3(blocks), dim3(FOLD_BLOCK), 0, s, (const Fe<P>*)a, (const Fe<P>*)b, r, n, (Fe<P>*)out);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lurk
+
+using namespace lurk;
+
+struct lurk_hip_r1cs {
+    R1csShape sh;
+    DevBuf neg_u;  // scratch of cross_term
+    std::mutex mu;
+};
+
+extern "C" {
+
+int lurk_hip_r1cs_create(lurk_hip_r1cs** out, int field_id, size_t num_cons, size_t num_vars, size_t num_io, const uint64_t* a_indptr,
+                         const uint64_t* a_indices, const void* a_data, const uint64_t* b_indptr, const uint64_t* b_indices, const void* b_data,
+                         const uint64_t* c_indptr, const uint64_t* c_indices, const void* c_data) {
+    return guarded([&] {
+        LURK_REQUIRE(out, "null output handle");
+        *out = nullptr;
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(num_vars + 1 + num_io < ((size_t)1 << 32), "z has more than 2^32 - 1 entries");
+        auto h = std::make_unique<lurk_hip_r1cs>();
+        R1csShape& sh = h->sh;
+        sh.field_id = field_id;
+        sh.num_cons = num_cons;
+        sh.num_vars = num_vars;
+        sh.num_io = num_io;
+        LURK_HIP_CHECK(hipGetDevice(&sh.device));
+        std::unordered_map<Key32, uint32_t, Key32Hash> ids;
+        std::vector<uint32_t> dict_words;
+        const size_t ncols = num_vars + 1 + num_io;
+        upload_matrix(sh, 0, a_indptr, a_indices, a_data, ncols, ids, dict_words);
+        upload_matrix(sh, 1, b_indptr, b_indices, b_data, ncols, ids, dict_words);
+        upload_matrix(sh, 2, c_indptr, c_indices, c_data, ncols, ids, dict_words);
+        sh.dict_size = ids.size();
+        {   // closing record: the Montgomery one (1 * 2^256 mod p as the ABI stores it)
+            dict_words.resize(dict_words.size() + P29_STRIDE);
+            uint32_t* rec = dict_words.data() + sh.dict_size * P29_STRIDE;
+            uint64_t one[4];
+            if (field_id == 0) { Fe<PallasFp> o = fe_one<PallasFp>(); memcpy(one, o.l, 32); dict_record<PallasFp>(one, rec); }
+            else if (field_id == 1) { Fe<PallasFq> o = fe_one<PallasFq>(); memcpy(one, o.l, 32); dict_record<PallasFq>(one, rec); }
+            else { Fe<Bn254Fr> o = fe_one<Bn254Fr>(); memcpy(one, o.l, 32); dict_record<Bn254Fr>(one, rec); }
+        }
+        {   // rows the lane-per-row kernels leave to the wave-per-row ones
+            std::vector<uint32_t> lr;
+            for (size_t i = 0; i < num_cons; i++)
+                if (a_indptr[i + 1] - a_indptr[i] > FOLD_LONG || b_indptr[i + 1] - b_indptr[i] > FOLD_LONG || c_indptr[i + 1] - c_indptr[i] > FOLD_LONG)
+                    lr.push_back((uint32_t)i);
+            sh.n_long = lr.size();
+            sh.long_rows.alloc(lr.size() * 4);
+            if (!lr.empty()) LURK_HIP_CHECK(hipMemcpy(sh.long_rows.p, lr.data(), lr.size() * 4, hipMemcpyHostToDevice));
+        }
+        sh.dict.alloc(dict_words.size() * 4);
+        if (!dict_words.empty()) LURK_HIP_CHECK(hipMemcpy(sh.dict.p, dict_words.data(), dict_words.size() * 4, hipMemcpyHostToDevice));
+        h->neg_u.alloc(2 * P29_STRIDE * 4);
+        *out = h.release();
+    });
+}
+
+int lurk_hip_r1cs_destroy(lurk_hip_r1cs* shape) {
+    return guarded([&] { delete shape; });
+}
+
+int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b, size_t* nnz_c, size_t* distinct_coefficients) {
+    return guarded([&] {
+        LURK_REQUIRE(shape, "null shape");
+        if (nnz_a) *nnz_a = shape->sh.m[0].nnz;
+        if (nnz_b) *nnz_b = shape->sh.m[1].nnz;
+        if (nnz_c) *nnz_c = shape->sh.m[2].nnz;
+        if (distinct_coefficients) *distinct_coefficients = shape->sh.dict_size;
+    });
+}
+
+int lurk_hip_r1cs_multiply_vec_dev(const lurk_hip_r1cs* shape, const void* d_z, void* d_az, void* d_bz, void* d_cz, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(shape && d_z && d_az && d_bz && d_cz, "null argument");
+        const R1csShape& sh = shape->sh;
+        if (sh.field_id == 0) multiply_vec<PallasFp>(sh, d_z, d_az, d_bz, d_cz, (hipStream_t)stream);
+        else if (sh.field_id == 1) multiply_vec<PallasFq>(sh, d_z, d_az, d_bz, d_cz, (hipStream_t)stream);
+        else multiply_vec<Bn254Fr>(sh, d_z, d_az, d_bz, d_cz, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const void* d_z2, void* d_t, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(shape && d_z1 && d_z2 && d_t, "null argument");
+        std::lock_guard<std::mutex> lk(shape->mu);  // the -u scratch is per shape
+        const R1csShape& sh = shape->sh;
+        if (sh.field_id == 0) cross_term<PallasFp>(sh, d_z1, d_z2, d_t, shape->neg_u.p, (hipStream_t)stream);
+        else if (sh.field_id == 1) cross_term<PallasFq>(sh, d_z1, d_z2, d_t, shape->neg_u.p, (hipStream_t)stream);
+        else cross_term<Bn254Fr>(sh, d_z1, d_z2, d_t, shape->neg_u.p, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_fold_vec_dev(int field_id, const void* d_a, const void* d_b, const void* r32_mont, size_t n, void* d_out, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(n == 0 || (d_a && d_b && d_out), "null buffer");
+        LURK_REQUIRE(r32_mont, "null challenge");
+        if (field_id == 0) fold_vec<PallasFp>(d_a, d_b, r32_mont, n, d_out, (hipStream_t)stream);
+        else if (field_id == 1) fold_vec<PallasFq>(d_a, d_b, r32_mont, n, d_out, (hipStream_t)stream);
+        else fold_vec<Bn254Fr>(d_a, d_b, r32_mont, n, d_out, (hipStream_t)stream);
+    });
+}
+
+}  // extern "C"

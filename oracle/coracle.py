@@ -198,3 +198,76 @@ def ntt(field: int, data: np.ndarray, inverse: bool = False) -> np.ndarray:
     assert 1 << log_n == a.shape[0]
     lib().orc_ntt(field, _p(a), log_n, int(inverse))
     return a
+
+
+# ---- relaxed-R1CS folding ------------------------------------------------------
+def spmv(field: int, indptr: np.ndarray, indices: np.ndarray, data: np.ndarray, z: np.ndarray) -> np.ndarray:
+    """CSR (arecibo SparseMatrix {data, indices, indptr}) times z; everything canonical."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.uint64)
+    indices = np.ascontiguousarray(indices, dtype=np.uint64)
+    data = np.ascontiguousarray(data, dtype=np.uint64)
+    z = np.ascontiguousarray(z, dtype=np.uint64)
+    rows = indptr.size - 1
+    out = np.empty((rows, 4), dtype=np.uint64)
+    lib().orc_spmv(field, ctypes.c_size_t(rows), _p(indptr), _p(indices), _p(data), _p(z), _p(out))
+    return out
+
+
+def cross_term(field: int, az1, bz1, cz1, az2, bz2, cz2, u1: int, u2: int) -> np.ndarray:
+    arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (az1, bz1, cz1, az2, bz2, cz2)]
+    rows = arrs[0].size // 4
+    out = np.empty((rows, 4), dtype=np.uint64)
+    lib().orc_cross_term(field, ctypes.c_size_t(rows), *[_p(a) for a in arrs], _p(ints_to_limbs([u1])), _p(ints_to_limbs([u2])), _p(out))
+    return out
+
+
+def axpy(field: int, a: np.ndarray, b: np.ndarray, r: int) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_axpy(field, ctypes.c_size_t(a.size // 4), _p(a), _p(b), _p(ints_to_limbs([r])), _p(out))
+    return out
+
+
+def relaxed_residual(field: int, az, bz, cz, u: int, e) -> np.ndarray:
+    arrs = [np.ascontiguousarray(a, dtype=np.uint64) for a in (az, bz, cz)]
+    e = np.ascontiguousarray(e, dtype=np.uint64)
+    out = np.empty_like(arrs[0])
+    lib().orc_relaxed_residual(field, ctypes.c_size_t(arrs[0].size // 4), *[_p(a) for a in arrs], _p(ints_to_limbs([u])), _p(e), _p(out))
+    return out
+
+
+def synth_r1cs(field: int, num_cons: int, num_vars: int, num_io: int, seed: int = 7):
+    """Synthetic R1CS shape of the kind the Lurk step circuit produces (3-4 entries per row, mostly +-1 and small
+    coefficients, a few long rows) together with a strictly satisfying z2 = [W2 | 1 | X2]:
+    A, B random sparse; C has one entry per row, on the u column, equal to (A z2)_i (B z2)_i.
+    Returns (A, B, C, z2) with each matrix = (indptr u64, indices u64, data canonical (nnz, 4) u64)."""
+    from . import pyref as R
+
+    p = R.modulus(field)
+    rng = np.random.default_rng(seed)
+    ncols = num_vars + 1 + num_io
+    table_ints = [1, p - 1, 2, p - 2, 3, 4, 8, 16, 256, 1 << 32, p - (1 << 16)] + [R.uniform_fe(90 + seed, i, p) for i in range(21)]
+    table = ints_to_limbs(table_ints)
+    weights = np.array([40, 25, 5, 2, 2, 1, 1, 1, 1, 1, 1] + [1] * 21, dtype=np.float64)
+    weights /= weights.sum()
+
+    def sparse():
+        cnt = rng.integers(3, 5, num_cons).astype(np.uint64)
+        long_rows = rng.integers(0, num_cons, max(1, num_cons // 300))  # bit-decomposition-like rows
+        cnt[long_rows] = min(ncols, 255)
+        indptr = np.zeros(num_cons + 1, dtype=np.uint64)
+        np.cumsum(cnt, out=indptr[1:])
+        nnz = int(indptr[-1])
+        indices = rng.integers(0, ncols, nnz).astype(np.uint64)
+        data = table[rng.choice(len(table_ints), size=nnz, p=weights)]
+        return indptr, indices, np.ascontiguousarray(data)
+
+    A, B = sparse(), sparse()
+    z2 = synth_scalars(field, 6, 0, ncols, first=seed * 1000003)
+    z2[num_vars] = (1, 0, 0, 0)
+    az, bz = spmv(field, *A, z2), spmv(field, *B, z2)
+    cdata = np.empty((num_cons, 4), dtype=np.uint64)
+    lib().orc_mul_canonical(field, _p(az), _p(bz), _p(cdata), ctypes.c_size_t(num_cons))
+    C = (np.arange(num_cons + 1, dtype=np.uint64), np.full(num_cons, num_vars, dtype=np.uint64), cdata)
+    return A, B, C, z2

@@ -458,3 +458,18 @@ def ntt_recursive(p: int, a: list[int], inverse: bool = False) -> list[int]:
         ninv = pow(n, p - 2, p)
         out = [x * ninv % p for x in out]
     return out
+
+
+# ---- relaxed-R1CS folding: the published Nova equations on Python ints ----------
+# (arecibo, an un-vendored dependency of the reference - Cargo.toml:128 - implements them in
+#  R1CSShape::multiply_vec / commit_T and NIFS::prove; caller: /root/reference/src/proof/nova.rs:291-293)
+def spmv(p, indptr, indices, data, z):
+    return [sum(data[k] * z[indices[k]] for k in range(indptr[i], indptr[i + 1])) % p for i in range(len(indptr) - 1)]
+
+
+def cross_term(p, az1, bz1, cz1, az2, bz2, cz2, u1, u2):
+    return [(a1 * b2 + a2 * b1 - u1 * c2 - u2 * c1) % p for a1, b1, c1, a2, b2, c2 in zip(az1, bz1, cz1, az2, bz2, cz2)]
+
+
+def axpy(p, a, b, r):
+    return [(x + r * y) % p for x, y in zip(a, b)]

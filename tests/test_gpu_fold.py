@@ -1,0 +1,129 @@
+"""GPU parity for the device-resident fold through the C ABI: multiply_vec, cross term and
+fold against the oracle on synthetic R1CS shapes, plus the size-independent folding identity at step-circuit
+size (the folded (z, E) satisfies the relaxed instance).  Parity unpinned upstream (no vectors exist)."""
+import numpy as np
+import pytest
+
+from oracle import coracle as C
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def _shape(f, A, B, Cm, m, nv, nio):
+    from lurk_beta_amd import R1CSShape
+
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    return R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+
+
+@pytest.mark.parametrize("f", [0, 1, 2])
+def test_multiply_vec_cross_term_fold_match_oracle(hip, f):
+    from lurk_beta_amd import fold_vec
+
+    p = R.modulus(f)
+    m, nv, nio = 3000, 2500, 2
+    A, B, Cm, z2 = C.synth_r1cs(f, m, nv, nio, seed=11)
+    sh = _shape(f, A, B, Cm, m, nv, nio)
+    info = sh.info()
+    assert info["nnz"] == (A[1].size, B[1].size, Cm[1].size) and info["distinct_coefficients"] <= 32 + m
+    z1 = C.synth_scalars(f, 8, 0, nv + 1 + nio)
+    d_z1, d_z2 = _dev(C.to_mont(f, z1)), _dev(C.to_mont(f, z2))
+    got = [C.from_mont(f, _host(x)) for x in sh.multiply_vec(d_z1)]
+    want = [C.spmv(f, *M, z1) for M in (A, B, Cm)]
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+    az2, bz2, cz2 = (C.spmv(f, *M, z2) for M in (A, B, Cm))
+    t_want = C.cross_term(f, *want, az2, bz2, cz2, u1, 1)
+    d_t = sh.cross_term(d_z1, d_z2)
+    assert np.array_equal(C.from_mont(f, _host(d_t)), t_want)
+    r = R.uniform_fe(72, f, p)
+    r_mont = C.to_mont(f, C.ints_to_limbs([r]))
+    assert np.array_equal(C.from_mont(f, _host(fold_vec(f, d_z1, d_z2, r_mont))), C.axpy(f, z1, z2, r))
+    sh.close()
+
+
+def test_edge_shapes(hip):
+    """Empty rows, a row longer than the 64-term re-entry period, zero coefficients, all-(p-1) operands, empty shape."""
+    from lurk_beta_amd import R1CSShape, fold_vec
+
+    f = 1
+    p = R.modulus(f)
+    ncols = 700
+    rng = np.random.default_rng(2)
+    lens = np.array([0, 1, 700, 0, 65, 64, 129, 5], dtype=np.uint64)
+    indptr = np.zeros(len(lens) + 1, dtype=np.uint64)
+    np.cumsum(lens, out=indptr[1:])
+    nnz = int(indptr[-1])
+    indices = rng.integers(0, ncols, nnz).astype(np.uint64)
+    vals = [p - 1] * nnz
+    for k in range(0, nnz, 7):
+        vals[k] = 0
+    for k in range(3, nnz, 5):
+        vals[k] = R.uniform_fe(73, k, p)
+    data = C.ints_to_limbs(vals)
+    M = (indptr, indices, data)
+    z = C.ints_to_limbs([p - 1] * ncols)
+    z[::3] = C.synth_scalars(f, 9, 0, ncols)[::3]
+    nv = ncols - 3
+    sh = R1CSShape(f, len(lens), nv, 2, *[(indptr, indices, C.to_mont(f, data))] * 3)
+    got = [C.from_mont(f, _host(x)) for x in sh.multiply_vec(_dev(C.to_mont(f, z)))]
+    want = C.spmv(f, *M, z)
+    assert all(np.array_equal(g, want) for g in got)
+    sh.close()
+    empty = (np.zeros(1, dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64))
+    sh0 = R1CSShape(f, 0, 4, 1, empty, empty, empty)
+    assert sh0.info()["nnz"] == (0, 0, 0)
+    sh0.close()
+    import torch
+
+    e = torch.empty((0, 4), dtype=torch.int64, device="cuda")
+    assert fold_vec(f, e, e, C.ints_to_limbs([5])).shape[0] == 0
+
+
+def test_bad_arguments(hip):
+    from lurk_beta_amd import LurkHipError, R1CSShape
+
+    ip = np.array([0, 1], dtype=np.uint64)
+    with pytest.raises(LurkHipError):  # column out of range
+        R1CSShape(1, 1, 2, 1, *[(ip, np.array([9], dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64))] * 3)
+    with pytest.raises(LurkHipError):  # indptr not starting at 0
+        R1CSShape(1, 1, 2, 1, *[(np.array([1, 1], dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64))] * 3)
+
+
+def test_folding_identity_at_step_circuit_size(hip):
+    """rc = 100 step-circuit size (~1.11 M constraints, ~0.91 M variables): fold a relaxed
+    instance with a strictly satisfied one on the GPU, then check (Az o Bz) = u Cz + E row by row."""
+    from lurk_beta_amd import fold_vec
+
+    f, m, nv, nio = 1, 1114100, 911900, 2
+    p = R.modulus(f)
+    A, B, Cm, z2 = C.synth_r1cs(f, m, nv, nio, seed=13)
+    sh = _shape(f, A, B, Cm, m, nv, nio)
+    z1 = C.synth_scalars(f, 8, 0, nv + 1 + nio)
+    u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+    d_z1, d_z2 = _dev(C.to_mont(f, z1)), _dev(C.to_mont(f, z2))
+    zero = np.zeros((m, 4), dtype=np.uint64)
+    az1, bz1, cz1 = [C.from_mont(f, _host(x)) for x in sh.multiply_vec(d_z1)]
+    e1 = C.relaxed_residual(f, az1, bz1, cz1, u1, zero)       # E1 := Az1 o Bz1 - u1 Cz1 makes (z1, E1) a relaxed witness
+    d_t = sh.cross_term(d_z1, d_z2)
+    r = R.uniform_fe(74, 0, p)
+    r_mont = C.to_mont(f, C.ints_to_limbs([r]))
+    d_z = fold_vec(f, d_z1, d_z2, r_mont)
+    d_e = fold_vec(f, _dev(C.to_mont(f, e1)), d_t, r_mont)
+    az, bz, cz = [C.from_mont(f, _host(x)) for x in sh.multiply_vec(d_z)]
+    u = C.limbs_to_ints(C.from_mont(f, _host(d_z[nv:nv + 1])))[0]
+    assert u == (u1 + r) % p
+    assert not C.relaxed_residual(f, az, bz, cz, u, C.from_mont(f, _host(d_e))).any()
+    sh.close()
