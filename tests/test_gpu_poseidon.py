@@ -155,3 +155,52 @@ def test_store_hydration_level_batches(hip):
     nodes2 = [("atom", R.TAG_SYM, 11), ("atom", R.TAG_NUM, 22), ("atom", R.TAG_ENV, 0), ("compact", R.TAG_ENV, 0, 1, 2)]
     d2 = hydrate(PoseidonCache(1), nodes2)
     assert d2[3] == R.poseidon_hash(1, [11, R.TAG_NUM, 22, 0])
+
+
+def test_full_size_tree_2_24(hip):
+    """BASELINE configs[2] size (8^8 = 2^24 leaves, 2 396 745 hash8) through size-independent properties:
+    (i) over BN254, a tree of zero leaves must reproduce element 8 of the trie's empty-root chain - the chain the
+        reference's golden vectors pin at elements 1..4 and 85 (trie/mod.rs:464-481, eval_tests.rs:3868);
+    (ii) over Pallas Fq with random leaves, 600 nodes sampled from every level satisfy node = hash8(children)
+        when recomputed by the oracle, and the root equals the hash8 of the 8 subtree roots."""
+    import torch
+
+    from lurk_beta_amd import _lib, synth
+
+    lib = _lib.load()
+    n = 8 ** 8
+    stream = torch.cuda.current_stream().cuda_stream
+    d_levels = torch.empty(((n - 1) // 7, 4), dtype=torch.int64, device="cuda")
+    # (i)
+    d_zero = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    _lib.check(lib.lurk_hip_poseidon_tree8_dev(kat.BN, _lib.ptr(d_zero), n, _lib.ptr(d_levels), _lib.ptr(stream)))
+    torch.cuda.synchronize()
+    cur, chain = 0, []
+    for _ in range(8):
+        cur = R.poseidon_hash(kat.BN, [cur] * 8)
+        chain.append(cur)
+    assert chain[1] == kat.golden_int("empty_root_2") and chain[3] == kat.golden_int("empty_root_4")
+    assert C.limbs_to_ints(d_levels[-1:].cpu().numpy().view(np.uint64))[0] == chain[7]
+    del d_zero
+    # (ii)
+    f = 1
+    d_leaves = synth.scalars(f, 2, 0, n)
+    _lib.check(lib.lurk_hip_poseidon_tree8_dev(f, _lib.ptr(d_leaves), n, _lib.ptr(d_levels), _lib.ptr(stream)))
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(4)
+    starts, sizes, off, m = [], [], 0, n // 8
+    while m >= 1:
+        starts.append(off)
+        sizes.append(m)
+        off += m
+        m //= 8
+    pre, want_idx = [], []
+    for lvl, (st, sz) in enumerate(zip(starts, sizes)):
+        for j in rng.integers(0, sz, 75).tolist():
+            child = d_leaves[8 * j:8 * j + 8] if lvl == 0 else d_levels[starts[lvl - 1] + 8 * j: starts[lvl - 1] + 8 * j + 8]
+            pre.append(child.cpu().numpy().view(np.uint64))
+            want_idx.append(st + j)
+    got = d_levels[torch.tensor(want_idx, device="cuda")].cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, C.poseidon_batch(f, 8, np.stack(pre)))
+    top8 = d_levels[starts[-2]:starts[-2] + 8].cpu().numpy().view(np.uint64)
+    assert np.array_equal(d_levels[-1].cpu().numpy().view(np.uint64), C.poseidon_batch(f, 8, top8.reshape(1, 8, 4))[0])
