@@ -120,9 +120,9 @@ __device__ __forceinline__ void fold_row_lane(const CsrView& m, const uint32_t* 
     for (int v = 0; v < NV; v++) out[v] = dot29_finish<P>(acc[v].acc);
 }
 
-// one wave, one long row of one matrix: chunks of 64 x FOLD_BATCH entries; per chunk every lane accumulates its
-// <= FOLD_BATCH terms, the normalised columns are summed across the wave and lane 0 adds the reduced chunk
-// value to the row as one term.  Result valid on lane 0.
+// one wave, one long row of one matrix: chunks of 64 x FOLD_BATCH entries; per chunk every lane accumulates and
+// reduces its <= FOLD_BATCH terms, the reduced values are summed across the wave and lane 0 adds the chunk value
+// to the row as one term.  Result valid on lane 0.
 template <class P, int NV>
 __device__ __forceinline__ void fold_row_wave(const CsrView& m, const uint32_t* __restrict__ dict, const uint32_t* __restrict__ one29,
                                               uint32_t lo, uint32_t hi, const Fe<P>* const* z, F29<P>* out) {
@@ -146,15 +146,17 @@ __device__ __forceinline__ void fold_row_wave(const CsrView& m, const uint32_t* 
         }
 #pragma unroll
         for (int v = 0; v < NV; v++) {
-            dot29_carry<P>(acc[v]);  // columns < 2^29 (the top one < 2^35): 64 of them sum without overflow
+            // every lane reduces its own <= FOLD_BATCH terms (value < 2^254.4, tight limbs), then the nine limbs
+            // are summed across the wave: two butterfly steps at a time (4 x 2^29 < 2^32), a carry pass in between;
+            // the chunk value stays < 64 * 2^254.4 < 2^261
+            F29<P> part = dot29_finish<P>(acc[v]);
 #pragma unroll
-            for (int kcol = 0; kcol < 17; kcol++) {
-                uint64_t x = acc[v].c[kcol];
+            for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) x += __shfl_down(x, off);
-                acc[v].c[kcol] = x;
+                for (int i = 0; i < 9; i++) part.l[i] += __shfl_down(part.l[i], off);
+                if (off == 16 || off == 4 || off == 1) part = f29_carry<P>(part);
             }
-            if (lane == 0) row_mac<P>(row[v], dot29_finish<P>(acc[v]), ld_const29<P>(one29), one29);
+            if (lane == 0) row_mac<P>(row[v], part, ld_const29<P>(one29), one29);
         }
     }
 #pragma unroll
@@ -231,16 +233,22 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
     uint32_t lo[3], hi[3];
     F29<P> a[2], b[2], c[2];
     size_t row;
+    Dot29<P> acc;
+    dot29_init<P>(acc);
     if (!LONG) {
         row = (size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x;
         if (row >= s.rows || fold_is_long(s, row, lo, hi)) return;
-        // one vector at a time: the second pass re-reads the 8-byte records (L2) but halves the live accumulators
+        // one vector at a time (a second pass re-reads the 8-byte records from L2 but halves the live accumulators:
+        // 3 waves/SIMD instead of 2 with spills); T is built up as the row values arrive
 #pragma unroll
         for (int v = 0; v < 2; v++) {
             fold_row_lane<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs + v, a + v);
             fold_row_lane<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs + v, b + v);
-            fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs + v, c + v);
         }
+        dot29_mac<P>(acc, a[0], b[1]);
+        dot29_mac<P>(acc, a[1], b[0]);
+#pragma unroll
+        for (int v = 0; v < 2; v++) fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs + v, c + v);
     } else {
         size_t w = ((size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x) >> 6;
         if (w >= s.n_long) return;
@@ -253,11 +261,9 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
             fold_row_wave<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs + v, c + v);
         }
         if (threadIdx.x & 63) return;
+        dot29_mac<P>(acc, a[0], b[1]);
+        dot29_mac<P>(acc, a[1], b[0]);
     }
-    Dot29<P> acc;
-    dot29_init<P>(acc);
-    dot29_mac<P>(acc, a[0], b[1]);
-    dot29_mac<P>(acc, a[1], b[0]);
     dot29_mac<P>(acc, ld_const29<P>(neg_u), c[1]);
     dot29_mac<P>(acc, ld_const29<P>(neg_u + P29_STRIDE), c[0]);
     fold_store<P>(t + row, dot29_finish<P>(acc));
