@@ -36,10 +36,6 @@
     } while (0)
 #else
 #define F29_ASSERT_LIMBS(v, bits, what) ((void)0)
-#define F29_ASSERT(cond, what)                                                                 \
-    do {                                                                                       \
-        if (!(cond)) { printf("F29 bound violated: %s\n", what); abort(); }                     \
-    } while (0)
 #define F29_ASSERT_TOP(v, bits, what) ((void)0)
 #define F29_ASSERT(cond, what) ((void)0)
 #endif
