@@ -18,6 +18,7 @@
 namespace lurk {
 
 constexpr int POSEIDON_BLOCK = 256;
+constexpr size_t POSEIDON_WIDE_MAX = 8192;  // batches up to this size run one state across T lanes (latency), larger ones one per lane
 enum : int { PF_IN_MONT = 1, PF_OUT_MONT = 2 };
 
 template <class P, int T>
@@ -44,6 +45,104 @@ __global__ __launch_bounds__(POSEIDON_BLOCK) __attribute__((amdgpu_waves_per_eu(
         }
         poseidon29_permute<P, T>(s, C, rf, rp);
         Fe<P> d = (flags & PF_OUT_MONT) ? f29_to_mont256<P>(s[1]) : poseidon29_to_canonical<P>(s[1]);
+        out[2 * h] = make_uint4(d.l[0], d.l[1], d.l[2], d.l[3]);
+        out[2 * h + 1] = make_uint4(d.l[4], d.l[5], d.l[6], d.l[7]);
+    }
+}
+
+// ---- small batches: one state across T lanes -----------------------------------------------------------------
+// A single lane needs ~1 600 dependent products per hash8 (0.57 ms), so a batch that does not fill the chip
+// (the top levels of a tree, a trie path, a store-hydration level) is latency-bound.  Here lane e of a group of
+// T lanes owns state element e (64 / T hashes per wave):
+//   full round     S-boxes in parallel; row e of the matrix is accumulated by lane e from the group's elements
+//                  (fetched lane to lane), one reduction
+//   partial round  x = sbox(s_0) is broadcast; lane e forms its term of the sparse row (x n00 | s_e v_e), the T
+//                  reduced terms are summed across the group into lane 0; lane e >= 1 adds x w_e to its element
+// ~450 product-times per hash instead of ~1 600.  Same constants, same image, bit-identical digests.
+template <class P>
+__device__ __forceinline__ F29<P> grp_fetch(const F29<P>& v, int src_lane) {
+    F29<P> r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) r.l[k] = __shfl(v.l[k], src_lane);
+    return r;
+}
+
+constexpr int POSEIDON_WIDE_BLOCK = 256;
+
+template <class P, int T>
+__global__ __launch_bounds__(POSEIDON_WIDE_BLOCK) void poseidon_wide_kernel(const uint4* __restrict__ pre, uint4* __restrict__ out, size_t n,
+                                                                              const uint4* __restrict__ img, int img_vec4, int rf, int rp,
+                                                                              int flags) {
+    extern __shared__ uint4 lds[];
+    for (int i = threadIdx.x; i < img_vec4; i += POSEIDON_WIDE_BLOCK) lds[i] = img[i];
+    __syncthreads();
+    const uint32_t* C = reinterpret_cast<const uint32_t*>(lds);
+    const PoseidonLayout<T> L(rf, rp);
+    const uint32_t* mont2 = C + (size_t)L.total() * P29_STRIDE;
+    constexpr int G = 64 / T, A = T - 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool in_group = lane < G * T;
+    const int g = in_group ? lane / T : 0, e = in_group ? lane % T : 0;  // spare lanes shadow lane 0 and never store
+    const int base = g * T;
+    const size_t h = ((size_t)blockIdx.x * (POSEIDON_WIDE_BLOCK / 64) + wave) * G + g;
+    const bool live = in_group && h < n;
+
+    F29<P> s;
+    if (e == 0) {
+        s = ld_const29<P>(C);
+    } else {
+        Fe<P> x = fe_zero<P>();
+        if (live) {
+            const uint4* src = pre + (h * A + (e - 1)) * 2;
+            uint4 lo = src[0], hi = src[1];
+            x.l[0] = lo.x; x.l[1] = lo.y; x.l[2] = lo.z; x.l[3] = lo.w;
+            x.l[4] = hi.x; x.l[5] = hi.y; x.l[6] = hi.z; x.l[7] = hi.w;
+        }
+        s = (flags & PF_IN_MONT) ? f29_from_mont256<P>(x) : poseidon29_from_canonical<P>(x.l, mont2);
+    }
+
+    auto full_round = [&](const uint32_t* rc, const uint32_t* mat) {
+        s = f29_pow5<P>(f29_add<P>(s, ld_const29<P>(rc + e * P29_STRIDE)));
+        Dot29<P> acc;
+        dot29_init<P>(acc);
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            if (T > 5 && i == 4) dot29_carry<P>(acc);
+            dot29_mac<P>(acc, grp_fetch<P>(s, base + i), ld_const29<P>(mat + (e * T + i) * P29_STRIDE));
+        }
+        s = dot29_finish<P>(acc);
+    };
+
+    const uint32_t* mds = C + L.mds() * P29_STRIDE;
+#pragma unroll 1
+    for (int r = 0; r < L.h; r++) full_round(C + (L.rc1() + r * T) * P29_STRIDE, r == L.h - 1 ? C + L.pre() * P29_STRIDE : mds);
+#pragma unroll 1
+    for (int p = 0; p < rp; p++) {
+        const uint32_t* sp = C + (L.sp() + p * (2 * T - 1)) * P29_STRIDE;
+        const F29<P> xl = f29_pow5<P>(f29_add<P>(s, ld_const29<P>(C + (L.pk() + p) * P29_STRIDE)));  // meaningful on e == 0
+        const F29<P> x = grp_fetch<P>(xl, base);
+        F29<P> a;
+#pragma unroll
+        for (int k = 0; k < 9; k++) a.l[k] = e == 0 ? x.l[k] : s.l[k];
+        F29<P> term = f29_mul<P>(a, ld_const29<P>(sp + e * P29_STRIDE));  // tight, < 2^254.2
+#pragma unroll
+        for (int off = 1; off < T; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                uint32_t t = __shfl_down(term.l[k], off);
+                if (e + off < T) term.l[k] += t;
+            }
+            if (off == 2 || off * 2 >= T) term = f29_carry<P>(term);  // at most 4 tight values between carries
+        }
+        const F29<P> upd = f29_carry<P>(f29_add<P>(s, f29_mul<P>(x, ld_const29<P>(sp + (T - 1 + e) * P29_STRIDE))));
+#pragma unroll
+        for (int k = 0; k < 9; k++) s.l[k] = e == 0 ? term.l[k] : upd.l[k];
+    }
+#pragma unroll 1
+    for (int r = 0; r < L.h; r++) full_round(r == 0 ? C + L.after() * P29_STRIDE : C + (L.rc2() + (r - 1) * T) * P29_STRIDE, mds);
+
+    if (live && e == 1) {
+        Fe<P> d = (flags & PF_OUT_MONT) ? f29_to_mont256<P>(s) : poseidon29_to_canonical<P>(s);
         out[2 * h] = make_uint4(d.l[0], d.l[1], d.l[2], d.l[3]);
         out[2 * h + 1] = make_uint4(d.l[4], d.l[5], d.l[6], d.l[7]);
     }
@@ -117,6 +216,16 @@ static void launch_batch(const void* d_pre, void* d_out, size_t n, PoseidonConst
     auto kern = poseidon_batch_kernel<P, T>;
     LURK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     (void)attr_set;
+    if (n <= POSEIDON_WIDE_MAX) {  // does not fill the chip: trade throughput for latency
+        auto wide = poseidon_wide_kernel<P, T>;
+        LURK_HIP_CHECK(hipFuncSetAttribute((const void*)wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        constexpr size_t per_block = (size_t)(POSEIDON_WIDE_BLOCK / 64) * (64 / T);
+        ProfScope ps("poseidon_batch", s);
+        hipLaunchKernelGGL(wide, dim3(div_up(n, per_block)), dim3(POSEIDON_WIDE_BLOCK), lds_bytes, s, (const uint4*)d_pre, (uint4*)d_out, n, img,
+                           img_vec4, pc.rf, pc.rp, flags);
+        LURK_HIP_CHECK(hipGetLastError());
+        return;
+    }
     unsigned blocks = div_up(n, POSEIDON_BLOCK);
     unsigned cap = (unsigned)num_cus() * 2;  // 2 workgroups (8 waves) per CU, grid-stride beyond
     if (blocks > cap) blocks = cap;
