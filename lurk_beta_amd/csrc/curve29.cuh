@@ -12,10 +12,6 @@
 #include "curve.cuh"
 #include "field29.cuh"
 
-#ifndef LURK_ACC_PREFETCH
-#define LURK_ACC_PREFETCH 0
-#endif
-
 namespace lurk {
 
 // signed carry pass: limbs are int32 in (-2^31, 2^31); result tight, top limb keeps the rest (must be >= 0)
@@ -183,22 +179,12 @@ LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, ui
     Xyzz29<P> acc;
     acc.x = acc.y = acc.zz = acc.zzz = f29_zero<P>();
     bool acc_id = true;
-    if (first >= last) return xyzz_identity<P>();
-    // the next base is gathered while the current addition runs (~11k cycles: covers the HBM latency)
-    uint32_t e = sorted[first];
-    Affine<P> q = table[e & 0x7fffffffu];
+    // (gathering the next base ahead of the current addition was measured: no gain, the other waves of the SIMD
+    // already cover the load)
     for (uint32_t j = first; j < last; j++) {
-        const uint32_t e_cur = e;
-        const Affine<P> q_cur = q;
-        if (LURK_ACC_PREFETCH && j + 1 < last) {
-            e = sorted[j + 1];
-            q = table[e & 0x7fffffffu];
-        }
-        xyzz29_madd<P>(acc, acc_id, q_cur, (e_cur & 0x80000000u) != 0);
-        if (!LURK_ACC_PREFETCH && j + 1 < last) {
-            e = sorted[j + 1];
-            q = table[e & 0x7fffffffu];
-        }
+        const uint32_t e = sorted[j];
+        const Affine<P> q = table[e & 0x7fffffffu];
+        xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);
     }
     return xyzz29_to_xyzz<P>(acc, acc_id);
 }

@@ -13,7 +13,7 @@
 //   partials        128 B x (NB + W*n/S)                         XYZZ task sums
 //   buckets, planes 128 B x NB (x3)
 // Algorithmic HBM bytes per call: 96 B per point (32 B scalar + 64 B base) - the dominant kernel is
-// bound by the integer VALU (v_mad_u64_u32 + carry folds), not by HBM.
+// bound by the integer VALU (v_mad_u64_u32 issue), not by HBM.
 #include <memory>
 
 #include "common.hpp"

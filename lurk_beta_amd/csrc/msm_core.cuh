@@ -5,11 +5,13 @@
 // Pipeline (c-bit signed windows, W = ceil(256/c) windows, B = 2^(c-1) buckets per key space):
 //   1. digits      scalar -> W signed digits d_w in [-2^(c-1), 2^(c-1)]        (msm_scalar_digits)
 //   2. sort        two-pass partitioned counting sort of (point, sign) entries by key
-//                  (key = space*B + |d|-1): 256 coarse partitions, then the low key bits inside
-//                  each partition; LDS counters only, every global write lands in a region small
-//                  enough for the L2 to merge lines                             (msm.hip)
+//                  (key = space*B + |d|-1): 2048 coarse partitions, then the low key bits inside
+//                  each partition; LDS counters only, both passes stage their output in LDS and
+//                  write it back in runs                                        (msm.hip)
 //   3. accumulate  buckets are cut into tasks of <= S sorted entries, ordered longest first; one
-//                  lane per task runs XYZZ mixed additions over gathered bases  (msm_task_accumulate)
+//                  lane per task runs XYZZ mixed additions over gathered bases on the radix-2^29
+//                  layer (curve29.cuh: msm_task_accumulate29; msm_task_accumulate below is the
+//                  32-bit-limb statement of the same loop, kept for A/B runs and the host harness)
 //   4. finalize    per bucket: sum of its task partials (hot buckets by a workgroup tree)
 //   5. reduce      sum_b b*B_b = S + sum_k 2^k P_k: bit-plane merge tree (c-1 levels of depth one
 //                  addition) + Horner                                           (msm.hip)
