@@ -208,7 +208,7 @@ def main():
                 "mixed_additions_per_launch": (13 if args.precompute and not args.window_bits else msm_windows(args)) * n,
                 "note": "integer-VALU bound (v_mad_u64_u32 issue), not HBM bound: see roofline_valu and DESIGN.md",
             },
-            # the honest ceiling for this kernel is VALU issue, not HBM: a mixed addition needs 1278 v_mad_u64_u32
+            # the honest ceiling for this kernel is VALU issue, not HBM: a mixed addition needs 1224 v_mad_u64_u32
             # (4.6 cycles per wave-instruction per SIMD, measured: profiles/r01_microbench_instr_rates.txt) on
             # 1024 SIMDs at the ~2.15 GHz the chip sustains here; shifts/masks/lazy adds come on top
             "roofline_valu": valu_roofline(acc_avg_ms, msm_windows(args) * n),
@@ -376,8 +376,9 @@ def fold_step_workload(args, lib, world, rank):
 
 
 def valu_roofline(acc_ms, mixed_adds):
-    # radix-2^29 XYZZ mixed addition (curve29.cuh): 8 products of 135 + 2 squarings of 99 v_mad_u64_u32
-    cycles_per_wave_madd = (8 * 135 + 2 * 99) * 4.6
+    # radix-2^29 XYZZ mixed addition (curve29.cuh): 8 products of 135 + 2 squarings of 99 v_mad_u64_u32, minus the
+    # one reduction (54) saved by forming Y3 as a two-term lazy row
+    cycles_per_wave_madd = (8 * 135 + 2 * 99 - 54) * 4.6
     peak = 1024 * 2.15e9 * 64 / cycles_per_wave_madd  # mixed additions / s if the SIMDs issued nothing but those mads
     ach = mixed_adds / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
     return {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(ach / 1e9, 3), "peak": round(peak / 1e9, 3),

@@ -132,6 +132,20 @@ __global__ void k_f29mul(const Fe<P>* in, Fe<P>* out, int iters) {
     out[i] = f29_to_mont256<P>(x);
 }
 template <class P>
+__global__ void k_f29dotmul(const Fe<P>* in, Fe<P>* out, int iters) {  // one product as a one-term lazy row (compiler-scheduled mads)
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    F29<P> x = f29_from_mont256<P>(in[2 * i]), y = f29_from_mont256<P>(in[2 * i + 1]);
+    for (int k = 0; k < iters; k++) { Dot29<P> a; dot29_init<P>(a); dot29_mac<P>(a, x, y); x = dot29_finish<P>(a); }
+    out[i] = f29_to_mont256<P>(x);
+}
+template <class P>
+__global__ void k_f29dot2(const Fe<P>* in, Fe<P>* out, int iters) {  // two-term row: x = (x*y + y*y) / R
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    F29<P> x = f29_from_mont256<P>(in[2 * i]), y = f29_from_mont256<P>(in[2 * i + 1]);
+    for (int k = 0; k < iters; k++) { Dot29<P> a; dot29_init<P>(a); dot29_mac<P>(a, x, y); dot29_mac<P>(a, y, y); x = dot29_finish<P>(a); }
+    out[i] = f29_to_mont256<P>(x);
+}
+template <class P>
 __global__ void k_f29sqr(const Fe<P>* in, Fe<P>* out, int iters) {
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     F29<P> x = f29_from_mont256<P>(in[2 * i]);
@@ -220,6 +234,14 @@ int main() {
       CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost));
       size_t bad = 0; for (size_t i = 0; i < n * 8; i++) bad += r0[i] != r1[i];
       printf("  Pallas: radix-2^29 chain vs cios chain mismatching words: %zu (of %zu)\n", bad, n * 8); }
+    { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29dotmul<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });
+      printf("%-28s %8.3f ms  %8.2f G field-mul/s\n", "f29 1-term lazy row (C++)", ms, (double)n * MI / ms / 1e6);
+      std::vector<uint32_t> r0(n * 8), r1(n * 8);
+      CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o2, n * 32, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (size_t i = 0; i < n * 8; i++) bad += r0[i] != r1[i];
+      printf("  Pallas: 1-term row chain vs cios chain mismatching words: %zu\n", bad); }
+    { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29dot2<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });
+      printf("%-28s %8.3f ms  %8.2f G rows/s (2 products each)\n", "f29 2-term lazy row (C++)", ms, (double)n * MI / ms / 1e6); }
     { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29sqr<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });
       printf("%-28s %8.3f ms  %8.2f G field-sqr/s\n", "f29_sqr Pallas (radix 2^29)", ms, (double)n * MI / ms / 1e6); }
     { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29addsub<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });

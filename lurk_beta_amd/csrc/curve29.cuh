@@ -12,6 +12,10 @@
 #include "curve.cuh"
 #include "field29.cuh"
 
+#ifndef LURK_ACC_Y3_ROW
+#define LURK_ACC_Y3_ROW 1
+#endif
+
 namespace lurk {
 
 // signed carry pass: limbs are int32 in (-2^31, 2^31); result tight, top limb keeps the rest (must be >= 0)
@@ -164,9 +168,19 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
 #pragma unroll
     for (int i = 0; i < 9; i++)
         d.l[i] = negate ? x3.l[i] + (f29_bias<P>(i) - qq.l[i]) : qq.l[i] + (f29_bias<P>(i) - x3.l[i]);
+#if LURK_ACC_Y3_ROW
+    // Y3 = R D - Y1 PPP as ONE lazy row: R * D + (64p - Y1) * PPP, a single Montgomery reduction
+    // (operands tight: 18 products of < 2^58 per column); value < 2^259.7 + p
+    Dot29<P> row;
+    dot29_init<P>(row);
+    dot29_mac<P>(row, r, f29_carry<P>(d));
+    dot29_mac<P>(row, f29_carry<P>(f29_sub<P>(f29_zero<P>(), acc.y)), ppp);
+    F29<P> y3 = f29_reduce<P>(dot29_finish<P>(row));
+#else
     const F29<P> t1 = f29_mul<P>(r, d);          // r tight (< 2^260.3), d loose (< 2^260.1): < 2^259.5
     const F29<P> t2 = f29_mul<P>(acc.y, ppp);    // < 2^257.2
     F29<P> y3 = f29_reduce<P>(f29_carry<P>(f29_sub<P>(t1, t2)));
+#endif
     acc.x = x3;
     acc.y = y3;
     acc.zz = f29_mul<P>(acc.zz, pp);             // < 2^257.8

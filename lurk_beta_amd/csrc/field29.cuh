@@ -184,6 +184,73 @@ LURK_HD F29<P> f29_sqr(const F29<P>& a) {
 #endif
 }
 
+// ---- lazy inner products: sum_i a_i * b_i with ONE Montgomery reduction -------------------------------
+// 17 unreduced 64-bit column sums take the 81 partial products of every term with no carry handling; 45
+// products of tight limbs (< 2^58 each) fit a column together with the reduction's own terms.
+template <class P>
+struct Dot29 {
+    uint64_t c[17];
+#if defined(LURK_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    unsigned __int128 shadow[17];  // exact column sums: the 64-bit ones must never wrap
+#endif
+};
+template <class P>
+LURK_HD void dot29_init(Dot29<P>& A) {
+#pragma unroll
+    for (int k = 0; k < 17; k++) A.c[k] = 0;
+#if defined(LURK_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    for (int k = 0; k < 17; k++) A.shadow[k] = 0;
+#endif
+}
+// A += a * b  (both tight: 81 products of < 2^58)
+template <class P>
+LURK_HD void dot29_mac(Dot29<P>& A, const F29<P>& a, const F29<P>& b) {
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+        for (int j = 0; j < 9; j++) A.c[i + j] += (uint64_t)a.l[i] * b.l[j];
+#if defined(LURK_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    for (int i = 0; i < 9; i++)
+        for (int j = 0; j < 9; j++) A.shadow[i + j] += (unsigned __int128)a.l[i] * b.l[j];
+    // room for the reduction's own terms (9 products < 2^58 + carry) must remain
+    for (int k = 0; k < 17; k++) F29_ASSERT(A.shadow[k] + ((unsigned __int128)10 << 58) < ((unsigned __int128)1 << 64), "dot29 column overflow");
+#endif
+}
+// push every column's excess above 29 bits into the next column (value unchanged)
+template <class P>
+LURK_HD void dot29_carry(Dot29<P>& A) {
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        A.c[k + 1] += A.c[k] >> 29;
+        A.c[k] &= F29_MASK;
+    }
+#if defined(LURK_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
+    for (int k = 0; k < 17; k++) A.shadow[k] = A.c[k];
+#endif
+}
+// t = A / 2^261 mod p, tight, value < A / 2^261 + p
+template <class P>
+LURK_HD F29<P> dot29_finish(const Dot29<P>& A) {
+    uint32_t m[9];
+    F29<P> t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+        acc += A.c[k];
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k - 1 < 8 ? k - 1 : 8); i++) acc += (uint64_t)m[i] * f29_mod<P>(k - i);
+        if (k <= 8) {
+            m[k] = ((uint32_t)acc * f29_inv<P>()) & F29_MASK;
+            acc += (uint64_t)m[k] * f29_mod<P>(0);
+        } else {
+            t.l[k - 9] = (uint32_t)acc & F29_MASK;
+        }
+        acc >>= 29;
+    }
+    t.l[8] = (uint32_t)acc;
+    return t;
+}
+
 // 8 x 32 Montgomery(2^256) -> 9 x 29 Montgomery(2^261): value * 32, i.e. limbs of (x << 5); tight.
 template <class P>
 LURK_HD F29<P> f29_from_mont256(const Fe<P>& x) {
