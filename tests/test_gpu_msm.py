@@ -183,10 +183,12 @@ def test_point_sum(hip):
     assert point_to_affine(0, point_sum(0, parts)) == C.jac_to_affine(0, C.msm_pippenger(0, B, S))
 
 
-@pytest.mark.parametrize("log_n,dist,precompute", [(20, 0, False), (20, 1, False), (20, 1, True), (22, 0, False), (22, 1, True)])
+@pytest.mark.parametrize("log_n,dist,precompute", [(20, 0, False), (20, 1, False), (20, 1, True), (22, 0, False), (22, 1, True), (22, 0, True),
+                                                   (23, 0, True), (23, 1, False)])
 def test_full_size_dlog_checksum(hip, log_n, dist, precompute):
-    """BASELINE.json sizes (2^20, 2^22): inputs generated in HBM, result checked bit-exactly by the
-    size-independent identity  sum_i s_i [k_i]G = [sum_i s_i k_i mod q] G."""
+    """BASELINE.json sizes (2^20, 2^22) and one size beyond (2^23: the rc = 900 step circuit, where the partitions
+    of sort pass 2 no longer fit their LDS stage and take the direct-scatter path): inputs generated in HBM, result
+    checked bit-exactly by the size-independent identity  sum_i s_i [k_i]G = [sum_i s_i k_i mod q] G."""
     import torch
 
     from lurk_beta_amd import CommitmentKey, point_to_affine, synth
