@@ -21,6 +21,9 @@ is pinned against the reference's own golden vectors (see tests/test_oracle_kat.
     double-and-add; the C oracle's Pippenger is cross-checked against this.
   * NTT: PARITY UNPINNED - no NTT exists anywhere in the reference.
     Oracle = O(n^2) DFT and a recursive radix-2 NTT.
+  * Fold (relaxed-R1CS folding arithmetic of arecibo's NIFS::prove): PARITY UNPINNED - arecibo is an
+    un-vendored dependency and no vectors exist upstream.  Oracle = the published Nova equations on Python
+    ints; the folding identity (folded (z, E) satisfies the relaxed instance) is the size-independent check.
 
 Reference call sites restated here:
   PoseidonCache::hash3/4/6/8        /root/reference/src/hash.rs:180-204
