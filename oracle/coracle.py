@@ -237,6 +237,24 @@ def relaxed_residual(field: int, az, bz, cz, u: int, e) -> np.ndarray:
     return out
 
 
+def _frame_structured_columns(rng, row_of_entry, num_cons, num_vars, num_io):
+    """Column pattern of the Lurk step circuit: W = [globals | frame 0 aux | frame 1 aux | ...] (frames are
+    synthesized independently and their aux concatenated, /root/reference/src/lem/multiframe.rs:699-702, 11 141
+    constraints and 9 119 aux per frame, src/lem/eval.rs:1966-1967), so frame f's rows touch frame f's block (88 %),
+    the globals at the front (6 %), the previous frame's block (4 %: its outputs) and the constant-one column u (2 %)."""
+    import numpy as np
+
+    nf = max(1, num_cons // 11141)
+    cons_pf, vars_pf = -(-num_cons // nf), max(1, num_vars // nf)
+    frame = np.minimum(row_of_entry // cons_pf, nf - 1)
+    kind = rng.random(row_of_entry.size)
+    local = frame * vars_pf + rng.integers(0, vars_pf, row_of_entry.size)
+    prev = np.maximum(frame - 1, 0) * vars_pf + rng.integers(0, vars_pf, row_of_entry.size)
+    glob = rng.integers(0, min(256, num_vars), row_of_entry.size)
+    cols = np.where(kind < 0.88, local, np.where(kind < 0.94, glob, np.where(kind < 0.98, prev, num_vars)))
+    return np.minimum(cols, num_vars + num_io).astype(np.uint64)
+
+
 def synth_r1cs(field: int, num_cons: int, num_vars: int, num_io: int, seed: int = 7):
     """Synthetic R1CS shape of the kind the Lurk step circuit produces (3-4 entries per row, mostly +-1 and small
     coefficients, a few long rows) together with a strictly satisfying z2 = [W2 | 1 | X2]:
@@ -259,7 +277,8 @@ def synth_r1cs(field: int, num_cons: int, num_vars: int, num_io: int, seed: int 
         indptr = np.zeros(num_cons + 1, dtype=np.uint64)
         np.cumsum(cnt, out=indptr[1:])
         nnz = int(indptr[-1])
-        indices = rng.integers(0, ncols, nnz).astype(np.uint64)
+        rows = np.repeat(np.arange(num_cons, dtype=np.int64), cnt.astype(np.int64))
+        indices = _frame_structured_columns(rng, rows, num_cons, num_vars, num_io)
         data = table[rng.choice(len(table_ints), size=nnz, p=weights)]
         return indptr, indices, np.ascontiguousarray(data)
 
