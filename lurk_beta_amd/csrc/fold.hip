@@ -16,7 +16,7 @@
 // it out; all field elements cross the ABI as 32-byte Montgomery(2^256) values.
 //
 // Kernels: one lane per row (the step circuit's rows hold 3-4 entries; neighbouring lanes read neighbouring
-// CSR records); the few long rows (bit decompositions: ~255 entries) go to a second launch with one wave per row.  A row's inner product is accumulated in 17 unreduced 64-bit columns (poseidon29.cuh: Dot29)
+// CSR records); the few long rows (bit decompositions: ~255 entries) go to a second launch with 16 lanes per row.  A row's inner product is accumulated in 17 unreduced 64-bit columns (poseidon29.cuh: Dot29)
 // and reduced once.  The cross-term kernel runs the six inner products of a row (A, B, C times z1, z2) from one
 // pass over the matrices and finishes T as a four-term lazy row: AZ1*BZ2 + AZ2*BZ1 + (-u1)*CZ2 + (-u2)*CZ1.
 // Both kernels are bound by the random 32-byte gathers from z (HBM / L2), not by arithmetic.
@@ -120,47 +120,57 @@ __device__ __forceinline__ void fold_row_lane(const CsrView& m, const uint32_t* 
     for (int v = 0; v < NV; v++) out[v] = dot29_finish<P>(acc[v].acc);
 }
 
-// one wave, one long row of one matrix: chunks of 64 x FOLD_BATCH entries; per chunk every lane accumulates and
-// reduces its <= FOLD_BATCH terms, the reduced values are summed across the wave and lane 0 adds the chunk value
-// to the row as one term.  Result valid on lane 0.
+// FOLD_GROUP lanes, one long row of one matrix (64 / FOLD_GROUP rows per wave): lane g of the group runs a RowAcc
+// over the entries lo + g, lo + g + FOLD_GROUP, ... and reduces it; the reduced values are then summed across
+// the group - limb-wise (two butterfly steps between carry passes: 4 x 2^29 < 2^32) while the row is short enough
+// for the sum to stay below 2^261 (<= 256 entries: < 256 * 2^252 + 16 p), otherwise one by one into the group
+// leader's accumulator (times the Montgomery one).  Result valid on the group leader.
+constexpr int FOLD_GROUP = 16;
+
 template <class P, int NV>
 __device__ __forceinline__ void fold_row_wave(const CsrView& m, const uint32_t* __restrict__ dict, const uint32_t* __restrict__ one29,
                                               uint32_t lo, uint32_t hi, const Fe<P>* const* z, F29<P>* out) {
-    const uint32_t lane = threadIdx.x & 63;
-    RowAcc<P> row[NV];
+    static_assert(NV == 1, "one vector per pass");
+    const uint32_t gl = threadIdx.x & (FOLD_GROUP - 1);
+    RowAcc<P> acc;
+    row_init<P>(acc);
+    for (uint32_t k = lo + gl; k < hi; k += FOLD_GROUP * FOLD_BATCH) {  // FOLD_BATCH entries' loads in flight together
+        uint2 e[FOLD_BATCH];
 #pragma unroll
-    for (int v = 0; v < NV; v++) row_init<P>(row[v]);
-    for (uint32_t base = lo; base < hi; base += 64 * FOLD_BATCH) {
-        Dot29<P> acc[NV];
-#pragma unroll
-        for (int v = 0; v < NV; v++) dot29_init<P>(acc[v]);
+        for (int u = 0; u < FOLD_BATCH; u++) e[u] = k + u * FOLD_GROUP < hi ? m.ent[k + u * FOLD_GROUP] : make_uint2(0u, 0u);
+        F29<P> c[FOLD_BATCH];
+        Fe<P> zz[FOLD_BATCH];
 #pragma unroll
         for (int u = 0; u < FOLD_BATCH; u++) {
-            const uint32_t k = base + u * 64 + lane;
-            if (k < hi) {
-                const uint2 e = m.ent[k];
-                const F29<P> c = ld_const29<P>(dict + (size_t)e.y * P29_STRIDE);
-#pragma unroll
-                for (int v = 0; v < NV; v++) dot29_mac<P>(acc[v], c, f29_from_mont256<P>(z[v][e.x]));
-            }
+            c[u] = ld_const29<P>(dict + (size_t)e[u].y * P29_STRIDE);
+            zz[u] = z[0][e[u].x];
         }
 #pragma unroll
-        for (int v = 0; v < NV; v++) {
-            // every lane reduces its own <= FOLD_BATCH terms (value < 2^254.4, tight limbs), then the nine limbs
-            // are summed across the wave: two butterfly steps at a time (4 x 2^29 < 2^32), a carry pass in between;
-            // the chunk value stays < 64 * 2^254.4 < 2^261
-            F29<P> part = dot29_finish<P>(acc[v]);
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-                for (int i = 0; i < 9; i++) part.l[i] += __shfl_down(part.l[i], off);
-                if (off == 16 || off == 4 || off == 1) part = f29_carry<P>(part);
-            }
-            if (lane == 0) row_mac<P>(row[v], part, ld_const29<P>(one29), one29);
-        }
+        for (int u = 0; u < FOLD_BATCH; u++)
+            if (k + u * FOLD_GROUP < hi) row_mac<P>(acc, c[u], f29_from_mont256<P>(zz[u]), one29);
     }
+    F29<P> part = dot29_finish<P>(acc.acc);  // tight, < 2^258.1
+    if (hi - lo <= 256) {
 #pragma unroll
-    for (int v = 0; v < NV; v++) out[v] = dot29_finish<P>(row[v].acc);
+        for (int off = FOLD_GROUP / 2; off >= 1; off >>= 1) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) part.l[i] += __shfl_down(part.l[i], off);
+            if (off == FOLD_GROUP / 4 || off == 1) part = f29_carry<P>(part);
+        }
+        out[0] = part;
+    } else {
+        RowAcc<P> tot;
+        row_init<P>(tot);
+        const int leader = (threadIdx.x & 63) & ~(FOLD_GROUP - 1);
+#pragma unroll 1
+        for (int g = 0; g < FOLD_GROUP; g++) {
+            F29<P> v;
+#pragma unroll
+            for (int i = 0; i < 9; i++) v.l[i] = __shfl(part.l[i], leader + g);
+            row_mac<P>(tot, v, ld_const29<P>(one29), one29);
+        }
+        out[0] = dot29_finish<P>(tot.acc);
+    }
 }
 
 template <class P>
@@ -184,7 +194,7 @@ __device__ __forceinline__ bool fold_is_long(const R1csDev& s, size_t row, uint3
     return hi[0] - lo[0] > FOLD_LONG || hi[1] - lo[1] > FOLD_LONG || hi[2] - lo[2] > FOLD_LONG;
 }
 
-// LONG = false: one lane per row, long rows skipped;  LONG = true: one wave per entry of long_rows
+// LONG = false: one lane per row, long rows skipped;  LONG = true: FOLD_GROUP lanes per entry of long_rows
 template <class P, bool LONG>
 __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_multiply_vec_kernel(R1csDev s, const Fe<P>* __restrict__ z, Fe<P>* __restrict__ az,
                                                                          Fe<P>* __restrict__ bz, Fe<P>* __restrict__ cz) {
@@ -202,11 +212,11 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_multiply_vec_kernel(R1csDev s
         fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &r);
         fold_store<P>(cz + row, r);
     } else {
-        size_t w = ((size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x) >> 6;
-        if (w >= s.n_long) return;
-        size_t row = s.long_rows[w];
+        size_t w = ((size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x) / FOLD_GROUP;
+        const bool live = w < s.n_long;  // a group without a row shadows the last one (the shuffles need every lane)
+        size_t row = s.long_rows[live ? w : s.n_long - 1];
         fold_is_long(s, row, lo, hi);
-        const bool lead = (threadIdx.x & 63) == 0;
+        const bool lead = live && (threadIdx.x & (FOLD_GROUP - 1)) == 0;
         fold_row_wave<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &r);
         if (lead) fold_store<P>(az + row, r);
         fold_row_wave<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &r);
@@ -250,9 +260,9 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
 #pragma unroll
         for (int v = 0; v < 2; v++) fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs + v, c + v);
     } else {
-        size_t w = ((size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x) >> 6;
-        if (w >= s.n_long) return;
-        row = s.long_rows[w];
+        size_t w = ((size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x) / FOLD_GROUP;
+        const bool live = w < s.n_long;  // a group without a row shadows the last one (the shuffles need every lane)
+        row = s.long_rows[live ? w : s.n_long - 1];
         fold_is_long(s, row, lo, hi);
 #pragma unroll
         for (int v = 0; v < 2; v++) {
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
             fold_row_wave<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs + v, b + v);
             fold_row_wave<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs + v, c + v);
         }
-        if (threadIdx.x & 63) return;
+        if (!live || (threadIdx.x & (FOLD_GROUP - 1))) return;
         dot29_mac<P>(acc, a[0], b[1]);
         dot29_mac<P>(acc, a[1], b[0]);
     }
@@ -356,11 +366,11 @@ static void multiply_vec(const R1csShape& sh, const void* d_z, void* az, void* b
     if (!sh.num_cons) return;
     ProfScope ps("r1cs_multiply_vec", s);
     const R1csDev d = dev_view(sh);
+    if (sh.n_long)  // first: its few latency-bound waves then run beside the lane-per-row launch that follows
+        hipLaunchKernelGGL((r1cs_multiply_vec_kernel<P, true>), dim3(div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
+                           (const Fe<P>*)d_z, (Fe<P>*)az, (Fe<P>*)bz, (Fe<P>*)cz);
     hipLaunchKernelGGL((r1cs_multiply_vec_kernel<P, false>), dim3(div_up(sh.num_cons, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z,
                        (Fe<P>*)az, (Fe<P>*)bz, (Fe<P>*)cz);
-    if (sh.n_long)
-        hipLaunchKernelGGL((r1cs_multiply_vec_kernel<P, true>), dim3(div_up(sh.n_long * 64, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
-                           (const Fe<P>*)d_z, (Fe<P>*)az, (Fe<P>*)bz, (Fe<P>*)cz);
     LURK_HIP_CHECK(hipGetLastError());
 }
 template <class P>
@@ -369,11 +379,11 @@ static void cross_term(const R1csShape& sh, const void* d_z1, const void* d_z2, 
     ProfScope ps("r1cs_cross_term", s);
     const R1csDev d = dev_view(sh);
     hipLaunchKernelGGL((r1cs_neg_u_kernel<P>), dim3(1), dim3(64), 0, s, (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, sh.num_vars, (uint32_t*)d_neg_u);
+    if (sh.n_long)
+        hipLaunchKernelGGL((r1cs_cross_term_kernel<P, true>), dim3(div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
+                           (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, (const uint32_t*)d_neg_u, (Fe<P>*)d_t);
     hipLaunchKernelGGL((r1cs_cross_term_kernel<P, false>), dim3(div_up(sh.num_cons, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z1,
                        (const Fe<P>*)d_z2, (const uint32_t*)d_neg_u, (Fe<P>*)d_t);
-    if (sh.n_long)
-        hipLaunchKernelGGL((r1cs_cross_term_kernel<P, true>), dim3(div_up(sh.n_long * 64, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
-                           (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, (const uint32_t*)d_neg_u, (Fe<P>*)d_t);
     LURK_HIP_CHECK(hipGetLastError());
 }
 template <class P>
@@ -396,7 +406,7 @@ using namespace lurk;
 struct lurk_hip_r1cs {
     R1csShape sh;
     DevBuf neg_u;  // scratch of cross_term
-    std::mutex mu;
+    mutable std::mutex mu;  // the -u scratch is per shape
 };
 
 extern "C" {
@@ -464,6 +474,7 @@ int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b,
 int lurk_hip_r1cs_multiply_vec_dev(const lurk_hip_r1cs* shape, const void* d_z, void* d_az, void* d_bz, void* d_cz, void* stream) {
     return guarded([&] {
         LURK_REQUIRE(shape && d_z && d_az && d_bz && d_cz, "null argument");
+        std::lock_guard<std::mutex> lk(shape->mu);
         const R1csShape& sh = shape->sh;
         if (sh.field_id == 0) multiply_vec<PallasFp>(sh, d_z, d_az, d_bz, d_cz, (hipStream_t)stream);
         else if (sh.field_id == 1) multiply_vec<PallasFq>(sh, d_z, d_az, d_bz, d_cz, (hipStream_t)stream);
@@ -474,7 +485,7 @@ int lurk_hip_r1cs_multiply_vec_dev(const lurk_hip_r1cs* shape, const void* d_z, 
 int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const void* d_z2, void* d_t, void* stream) {
     return guarded([&] {
         LURK_REQUIRE(shape && d_z1 && d_z2 && d_t, "null argument");
-        std::lock_guard<std::mutex> lk(shape->mu);  // the -u scratch is per shape
+        std::lock_guard<std::mutex> lk(shape->mu);
         const R1csShape& sh = shape->sh;
         if (sh.field_id == 0) cross_term<PallasFp>(sh, d_z1, d_z2, d_t, shape->neg_u.p, (hipStream_t)stream);
         else if (sh.field_id == 1) cross_term<PallasFq>(sh, d_z1, d_z2, d_t, shape->neg_u.p, (hipStream_t)stream);
