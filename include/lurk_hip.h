@@ -166,6 +166,10 @@ int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const v
 /* RelaxedR1CSWitness::fold: out = a + r b over n elements (W1 + r W2, E1 + r T); r: 32 B Montgomery, host */
 int lurk_hip_fold_vec_dev(int field_id, const void* d_a, const void* d_b, const void* r32_mont, size_t n,
                           void* d_out, void* stream);
+/* host-pointer forms of the three calls above (copy in, run, copy out): small inputs and tests */
+int lurk_hip_r1cs_multiply_vec(const lurk_hip_r1cs* shape, const void* z, void* az, void* bz, void* cz);
+int lurk_hip_r1cs_cross_term(lurk_hip_r1cs* shape, const void* z1, const void* z2, void* t);
+int lurk_hip_fold_vec(int field_id, const void* a, const void* b, const void* r32_mont, size_t n, void* out);
 
 /* ---- synthetic inputs (bench / tests) -------------------------------------
  * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */

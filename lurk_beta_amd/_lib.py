@@ -54,6 +54,9 @@ SIGNATURES = {
     "lurk_hip_r1cs_multiply_vec_dev": (c_int, [c_void_p] * 6),
     "lurk_hip_r1cs_cross_term_dev": (c_int, [c_void_p] * 5),
     "lurk_hip_fold_vec_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_r1cs_multiply_vec": (c_int, [c_void_p] * 5),
+    "lurk_hip_r1cs_cross_term": (c_int, [c_void_p] * 4),
+    "lurk_hip_fold_vec": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
 }

@@ -493,6 +493,50 @@ int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const v
     });
 }
 
+// host-pointer forms (small inputs, tests, the C++ mirror): copy in, run, copy out
+int lurk_hip_r1cs_multiply_vec(const lurk_hip_r1cs* shape, const void* z, void* az, void* bz, void* cz) {
+    return guarded([&] {
+        LURK_REQUIRE(shape && z && az && bz && cz, "null argument");
+        const R1csShape& sh = shape->sh;
+        const size_t ncols = sh.num_vars + 1 + sh.num_io, m = sh.num_cons;
+        DevBuf d_z(ncols * 32), d_a(m * 32), d_b(m * 32), d_c(m * 32);
+        LURK_HIP_CHECK(hipMemcpy(d_z.p, z, ncols * 32, hipMemcpyHostToDevice));
+        LURK_REQUIRE(lurk_hip_r1cs_multiply_vec_dev(shape, d_z.p, d_a.p, d_b.p, d_c.p, nullptr) == 0, lurk_hip_last_error());
+        LURK_HIP_CHECK(hipDeviceSynchronize());
+        LURK_HIP_CHECK(hipMemcpy(az, d_a.p, m * 32, hipMemcpyDeviceToHost));
+        LURK_HIP_CHECK(hipMemcpy(bz, d_b.p, m * 32, hipMemcpyDeviceToHost));
+        LURK_HIP_CHECK(hipMemcpy(cz, d_c.p, m * 32, hipMemcpyDeviceToHost));
+    });
+}
+
+int lurk_hip_r1cs_cross_term(lurk_hip_r1cs* shape, const void* z1, const void* z2, void* t) {
+    return guarded([&] {
+        LURK_REQUIRE(shape && z1 && z2 && t, "null argument");
+        const R1csShape& sh = shape->sh;
+        const size_t ncols = sh.num_vars + 1 + sh.num_io, m = sh.num_cons;
+        DevBuf d_z1(ncols * 32), d_z2(ncols * 32), d_t(m * 32);
+        LURK_HIP_CHECK(hipMemcpy(d_z1.p, z1, ncols * 32, hipMemcpyHostToDevice));
+        LURK_HIP_CHECK(hipMemcpy(d_z2.p, z2, ncols * 32, hipMemcpyHostToDevice));
+        LURK_REQUIRE(lurk_hip_r1cs_cross_term_dev(shape, d_z1.p, d_z2.p, d_t.p, nullptr) == 0, lurk_hip_last_error());
+        LURK_HIP_CHECK(hipDeviceSynchronize());
+        LURK_HIP_CHECK(hipMemcpy(t, d_t.p, m * 32, hipMemcpyDeviceToHost));
+    });
+}
+
+int lurk_hip_fold_vec(int field_id, const void* a, const void* b, const void* r32_mont, size_t n, void* out) {
+    return guarded([&] {
+        LURK_REQUIRE(n == 0 || (a && b && out), "null buffer");
+        DevBuf d_a(n * 32), d_b(n * 32), d_o(n * 32);
+        if (n) {
+            LURK_HIP_CHECK(hipMemcpy(d_a.p, a, n * 32, hipMemcpyHostToDevice));
+            LURK_HIP_CHECK(hipMemcpy(d_b.p, b, n * 32, hipMemcpyHostToDevice));
+        }
+        LURK_REQUIRE(lurk_hip_fold_vec_dev(field_id, d_a.p, d_b.p, r32_mont, n, d_o.p, nullptr) == 0, lurk_hip_last_error());
+        LURK_HIP_CHECK(hipDeviceSynchronize());
+        if (n) LURK_HIP_CHECK(hipMemcpy(out, d_o.p, n * 32, hipMemcpyDeviceToHost));
+    });
+}
+
 int lurk_hip_fold_vec_dev(int field_id, const void* d_a, const void* d_b, const void* r32_mont, size_t n, void* d_out, void* stream) {
     return guarded([&] {
         LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");

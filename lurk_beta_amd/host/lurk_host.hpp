@@ -5,6 +5,7 @@
 //   lurk::host::PoseidonCache   <- PoseidonCache<F>::hash3/4/6/8, compute_hash  (/root/reference/src/hash.rs:86-204)
 //   lurk::host::Trie            <- coprocessor::trie::Trie<F, 8, HEIGHT>        (/root/reference/src/coprocessor/trie/mod.rs:328-800)
 //   lurk::host::CommitmentKey   <- arecibo CommitmentKey + CE::commit(ck, v)     (callers /root/reference/src/proof/nova.rs:287-293)
+//   lurk::host::R1CSShape       <- arecibo R1CSShape::multiply_vec / commit_T cross term / witness fold (nova.rs:291-293)
 //
 // Field elements are 32-byte canonical little-endian values (Fe); points use the repr-c layouts.
 #pragma once
@@ -165,6 +166,52 @@ class CommitmentKey {
   private:
     int curve_;
     lurk_hip_msm_ctx* ctx_ = nullptr;
+};
+
+// R1CS shape resident on the GPU: the arithmetic of one folding step between its two commitments
+// (arecibo R1CSShape::multiply_vec / commit_T's cross term / RelaxedR1CSWitness::fold, as reached from
+// /root/reference/src/proof/nova.rs:291-293).  Matrices as arecibo's SparseMatrix {data, indices, indptr}.
+struct SparseMatrix {
+    std::vector<Fe> data;           // Montgomery values
+    std::vector<uint64_t> indices;  // column into z = [W | u | X]
+    std::vector<uint64_t> indptr;   // num_cons + 1
+};
+
+class R1CSShape {
+  public:
+    R1CSShape(int field, size_t num_cons, size_t num_vars, size_t num_io, const SparseMatrix& a, const SparseMatrix& b, const SparseMatrix& c)
+        : field_(field), num_cons_(num_cons), num_cols_(num_vars + 1 + num_io) {
+        check(lurk_hip_r1cs_create(&h_, field, num_cons, num_vars, num_io, a.indptr.data(), a.indices.data(), a.data.data(), b.indptr.data(),
+                                   b.indices.data(), b.data.data(), c.indptr.data(), c.indices.data(), c.data.data()));
+    }
+    ~R1CSShape() { lurk_hip_r1cs_destroy(h_); }
+    R1CSShape(const R1CSShape&) = delete;
+    // (A z, B z, C z)
+    std::array<std::vector<Fe>, 3> multiply_vec(const std::vector<Fe>& z) const {
+        if (z.size() != num_cols_) throw std::invalid_argument("z must have num_vars + 1 + num_io entries");
+        std::array<std::vector<Fe>, 3> out{std::vector<Fe>(num_cons_), std::vector<Fe>(num_cons_), std::vector<Fe>(num_cons_)};
+        check(lurk_hip_r1cs_multiply_vec(h_, z.data(), out[0].data(), out[1].data(), out[2].data()));
+        return out;
+    }
+    // T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1
+    std::vector<Fe> cross_term(const std::vector<Fe>& z1, const std::vector<Fe>& z2) const {
+        if (z1.size() != num_cols_ || z2.size() != num_cols_) throw std::invalid_argument("z must have num_vars + 1 + num_io entries");
+        std::vector<Fe> t(num_cons_);
+        check(lurk_hip_r1cs_cross_term(h_, z1.data(), z2.data(), t.data()));
+        return t;
+    }
+    // a + r b
+    std::vector<Fe> fold(const std::vector<Fe>& a, const std::vector<Fe>& b, const Fe& r) const {
+        if (a.size() != b.size()) throw std::invalid_argument("length mismatch");
+        std::vector<Fe> out(a.size());
+        check(lurk_hip_fold_vec(field_, a.data(), b.data(), &r, a.size(), out.data()));
+        return out;
+    }
+
+  private:
+    int field_;
+    size_t num_cons_, num_cols_;
+    lurk_hip_r1cs* h_ = nullptr;
 };
 
 }  // namespace host

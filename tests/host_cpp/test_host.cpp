@@ -83,6 +83,32 @@ int main() {
         check(lurk_hip_msm_pallas(&oneshot, ck.data(), 64, a.data(), 0));
         EXPECT(key.to_affine(oneshot) == key.to_affine(ca));  // ctx path == pasta-msm-shaped path
     }
+    // Device-resident fold over Pallas Fq.  Montgomery values are built from the Montgomery one with
+    // the library's own fold (a + 1 * b): no host field arithmetic needed.
+    {
+        const int FQ = LURK_FIELD_PALLAS_FQ;
+        Fe one;  // 2^256 mod q
+        one.l = {0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL};
+        const Fe zero;
+        SparseMatrix A, B, C;  // row 0: x * x = y ; row 1: (x + y) * u = (x + y);  z = [x, y | u]
+        A.indptr = {0, 1, 3}; A.indices = {0, 0, 1}; A.data = {one, one, one};
+        B.indptr = {0, 1, 2}; B.indices = {0, 2};    B.data = {one, one};
+        C.indptr = {0, 1, 3}; C.indices = {1, 0, 1}; C.data = {one, one, one};
+        R1CSShape shape(FQ, 2, 2, 0, A, B, C);
+        auto add = [&](const Fe& a, const Fe& b) { return shape.fold({a}, {b}, one)[0]; };
+        Fe two = add(one, one), three = add(two, one), four = add(two, two), six = add(three, three), nine = add(six, three), twelve = add(nine, three);
+        std::vector<Fe> z1{three, nine, one}, z2{two, four, one};
+        auto m = shape.multiply_vec(z1);
+        EXPECT(m[0][0] == three && m[0][1] == twelve);   // A z
+        EXPECT(m[1][0] == three && m[1][1] == one);      // B z
+        EXPECT(m[2][0] == nine && m[2][1] == twelve);    // C z
+        auto t_self = shape.cross_term(z1, z1);          // satisfied instance with itself: 2 (Az o Bz - u Cz) = 0
+        EXPECT(t_self[0] == zero && t_self[1] == zero);
+        auto t = shape.cross_term(z1, z2);               // row 0: 3*2 + 2*3 - 4 - 9 = -1 ; row 1: 12 + 6 - 6 - 12 = 0
+        EXPECT(add(t[0], one) == zero && t[1] == zero);
+        auto zf = shape.fold(z1, z2, two);               // z1 + 2 z2 = [7, 17, 3]
+        EXPECT(zf[0] == add(six, one) && zf[2] == three);
+    }
     printf("host mirror ok\n");
     return 0;
 }
