@@ -21,7 +21,9 @@
 
 namespace lurk {
 
-constexpr int MSM_P = 2048;        // coarse partitions of the key space (pass 1 of the sort)
+constexpr int MSM_P_MIN = 2048;    // coarse partitions of the key space (pass 1 of the sort): 2048 up to n = 2^22, then
+constexpr int MSM_P_MAX = 8192;    // doubled until a partition fits the LDS stage of pass 2 (MsmCtx::shape)
+constexpr int MSM_P_PER_MAX = MSM_P_MAX / 1024;
 constexpr int MSM_NB1 = 256;       // workgroups of pass 1 (one per CU)
 constexpr int MSM_SORT_BLOCK = 1024;
 constexpr int MSM_S = 64;          // sorted entries per accumulation task
@@ -31,7 +33,9 @@ constexpr int MSM_ACC_BLOCK = 256;
 struct MsmShape {
     int c, W, G;           // window bits, windows, key spaces
     uint32_t B, NB;        // buckets per space, total keys
-    int LB;                // low key bits sorted in pass 2 (NB >> LB == MSM_P)
+    int P;                 // coarse partitions of pass 1 (power of two, MSM_P_MIN .. MSM_P_MAX)
+    int tile;              // scalars per pass-1 scatter tile (1024, or less when P counters + W*tile entries exceed the LDS)
+    int LB;                // low key bits sorted in pass 2 (NB >> LB == P)
     int NG;                // scan groups of MSM_GRP keys
     size_t n, stride;      // scalars in this call; table stride per window (0 in plain mode)
 };
@@ -61,8 +65,8 @@ __device__ __forceinline__ uint32_t msm_key(const MsmShape& sh, uint32_t w, uint
 template <class SF>
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ block_hist,
                                                                      MsmShape sh, size_t chunk, int is_mont) {
-    __shared__ uint32_t h[MSM_P];
-    for (int p = threadIdx.x; p < MSM_P; p += MSM_SORT_BLOCK) h[p] = 0;
+    extern __shared__ uint32_t h[];  // [P]
+    for (int p = threadIdx.x; p < sh.P; p += MSM_SORT_BLOCK) h[p] = 0;
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
     // the next scalar is in flight while the current one is recoded (16 waves per CU do not hide the load otherwise)
@@ -79,14 +83,14 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* 
         }
     }
     __syncthreads();
-    for (int p = threadIdx.x; p < MSM_P; p += MSM_SORT_BLOCK) block_hist[(size_t)blockIdx.x * MSM_P + p] = h[p];
+    for (int p = threadIdx.x; p < sh.P; p += MSM_SORT_BLOCK) block_hist[(size_t)blockIdx.x * sh.P + p] = h[p];
 }
 
 // block p: exclusive scan of partition p's counts over the MSM_NB1 pass-1 blocks
-__global__ __launch_bounds__(MSM_NB1) void msm_scan1_kernel(uint32_t* __restrict__ block_hist, uint32_t* __restrict__ part_cnt) {
+__global__ __launch_bounds__(MSM_NB1) void msm_scan1_kernel(uint32_t* __restrict__ block_hist, uint32_t* __restrict__ part_cnt, int P) {
     __shared__ uint32_t sh[MSM_NB1];
     const int p = blockIdx.x, t = threadIdx.x;
-    uint32_t v = block_hist[(size_t)t * MSM_P + p];
+    uint32_t v = block_hist[(size_t)t * P + p];
     sh[t] = v;
     __syncthreads();
     for (int off = 1; off < MSM_NB1; off <<= 1) {
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(MSM_NB1) void msm_scan1_kernel(uint32_t* __restrict
         sh[t] += a;
         __syncthreads();
     }
-    block_hist[(size_t)t * MSM_P + p] = sh[t] - v;
+    block_hist[(size_t)t * P + p] = sh[t] - v;
     if (t == MSM_NB1 - 1) part_cnt[p] = sh[t];
 }
 
@@ -129,21 +133,23 @@ __device__ __forceinline__ uint32_t msm_block_scan(uint32_t v, uint32_t* scr, ui
 }
 
 // single block: part_start[0..P] = exclusive scan of part_cnt
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part_start_kernel(const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ part_start) {
+__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part_start_kernel(const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ part_start,
+                                                                          int P) {
     __shared__ uint32_t scr[32];
-    constexpr int PER = MSM_P / MSM_SORT_BLOCK;
+    const int PER = P / MSM_SORT_BLOCK;  // 2, 4 or 8 counters per thread
     const int t = threadIdx.x;
-    uint32_t c[PER], sum = 0;
+    uint32_t c[MSM_P_PER_MAX], sum = 0;
 #pragma unroll
-    for (int j = 0; j < PER; j++) { c[j] = part_cnt[t * PER + j]; sum += c[j]; }
+    for (int j = 0; j < MSM_P_PER_MAX; j++) { c[j] = j < PER ? part_cnt[t * PER + j] : 0u; sum += c[j]; }
     uint32_t total;
     uint32_t run = msm_block_scan(sum, scr, &total);
 #pragma unroll
-    for (int j = 0; j < PER; j++) { part_start[t * PER + j] = run; run += c[j]; }
-    if (t == 0) part_start[MSM_P] = total;
+    for (int j = 0; j < MSM_P_PER_MAX; j++)
+        if (j < PER) { part_start[t * PER + j] = run; run += c[j]; }
+    if (t == 0) part_start[P] = total;
 }
 
-// Scatter of pass 1.  A tile of 1024 scalars yields <= W*1024 entries; they are first grouped by partition in
+// Scatter of pass 1.  A tile of sh.tile (1024) scalars yields <= W*tile entries; they are first grouped by partition in
 // LDS (a block-local counting sort) and then copied out slot by slot, so that neighbouring lanes write
 // neighbouring addresses: the entries of one partition leave as one run instead of as isolated 8-byte stores
 // (which cost a 32-byte sector each: rocprof showed 3.9x write amplification for the direct scatter).
@@ -154,22 +160,22 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
                                                                         const uint32_t* __restrict__ part_start, uint2* __restrict__ inter,
                                                                         MsmShape sh, size_t chunk, int is_mont) {
     extern __shared__ uint32_t lds[];
-    constexpr int PER = MSM_P / MSM_SORT_BLOCK;
-    uint32_t* goff = lds;              // [P] where this block's next entry of partition p goes
-    uint32_t* cnt = goff + MSM_P;      // [P] entries of the current tile, then the placement cursor
-    uint32_t* start = cnt + MSM_P;     // [P] exclusive scan of cnt
-    uint32_t* scr = start + MSM_P;     // [32]
-    uint2* stage = reinterpret_cast<uint2*>(scr + 32);  // [W * 1024]
+    const int P = sh.P, PER = P / MSM_SORT_BLOCK;
+    uint32_t* goff = lds;          // [P] where this block's next entry of partition p goes
+    uint32_t* cnt = goff + P;      // [P] entries of the current tile, then the placement cursor
+    uint32_t* start = cnt + P;     // [P] exclusive scan of cnt
+    uint32_t* scr = start + P;     // [32]
+    uint2* stage = reinterpret_cast<uint2*>(scr + 32);  // [W * tile]
     const int t = threadIdx.x;
-    for (int p = t; p < MSM_P; p += MSM_SORT_BLOCK) {
-        goff[p] = part_start[p] + block_off[(size_t)blockIdx.x * MSM_P + p];
+    for (int p = t; p < P; p += MSM_SORT_BLOCK) {
+        goff[p] = part_start[p] + block_off[(size_t)blockIdx.x * P + p];
         cnt[p] = 0;
     }
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
-    for (size_t base = lo; base < hi; base += MSM_SORT_BLOCK) {
+    for (size_t base = lo; base < hi; base += sh.tile) {
         const size_t i = base + t;
-        const bool live = i < hi;
+        const bool live = t < sh.tile && i < hi;
         Fe<SF> s;
         if (live) {
             s = msm_load_scalar<SF>(scalars, i, is_mont);
@@ -180,12 +186,13 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
             }
         }
         __syncthreads();
-        uint32_t c[PER], sum = 0, total;
+        uint32_t c[MSM_P_PER_MAX], sum = 0, total;
 #pragma unroll
-        for (int j = 0; j < PER; j++) { c[j] = cnt[t * PER + j]; sum += c[j]; }
+        for (int j = 0; j < MSM_P_PER_MAX; j++) { c[j] = j < PER ? cnt[t * PER + j] : 0u; sum += c[j]; }
         uint32_t run = msm_block_scan(sum, scr, &total);
 #pragma unroll
-        for (int j = 0; j < PER; j++) { start[t * PER + j] = run; run += c[j]; cnt[t * PER + j] = 0; }
+        for (int j = 0; j < MSM_P_PER_MAX; j++)
+            if (j < PER) { start[t * PER + j] = run; run += c[j]; cnt[t * PER + j] = 0; }
         __syncthreads();
         if (live) {
             uint32_t carry = 0;
@@ -208,11 +215,12 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < PER; j++) { goff[t * PER + j] += c[j]; cnt[t * PER + j] = 0; }
+        for (int j = 0; j < MSM_P_PER_MAX; j++)
+            if (j < PER) { goff[t * PER + j] += c[j]; cnt[t * PER + j] = 0; }
         __syncthreads();
     }
 }
-static size_t msm_scatter1_lds(int W) { return (size_t)(3 * MSM_P + 32) * 4 + (size_t)W * MSM_SORT_BLOCK * 8; }
+static size_t msm_scatter1_lds(int P, int W, int tile) { return (size_t)(3 * P + 32) * 4 + (size_t)W * tile * 8; }
 
 // ---- 2b. sort pass 2: block p sorts partition p by the low key bits ---------------------------------
 // Emits the final sorted entry list, the bucket sizes and the bucket starts of its 2^LB keys.  A partition of
@@ -612,8 +620,19 @@ struct MsmCtx : MsmCtxBase {
         sh.G = precomputed ? 1 : sh.W;
         sh.B = 1u << (c - 1);
         sh.NB = (uint32_t)sh.G * sh.B;
+        // partitions: as few as let an average partition (W n / P entries) fit the LDS stage of pass 2 with 15 % to
+        // spare - 2048 up to n = 2^22, 4096 for the rc = 900 step circuit (n ~ 10^7), 8192 beyond
+        sh.P = MSM_P_MIN;
+        while (sh.P < MSM_P_MAX && (uint32_t)sh.P < sh.NB) {
+            int lb = 0;
+            while ((sh.NB >> lb) > (uint32_t)sh.P) lb++;
+            if ((double)sh.W * (double)n / sh.P <= 0.85 * (double)msm_part2_cap(lb)) break;
+            sh.P *= 2;
+        }
         sh.LB = 0;
-        while ((sh.NB >> sh.LB) > (uint32_t)MSM_P) sh.LB++;
+        while ((sh.NB >> sh.LB) > (uint32_t)sh.P) sh.LB++;
+        sh.tile = MSM_SORT_BLOCK;
+        while (sh.tile > 64 && msm_scatter1_lds(sh.P, sh.W, sh.tile) > MSM_LDS_BYTES) sh.tile /= 2;
         sh.NG = (int)(sh.NB / MSM_GRP);
         sh.n = n;
         sh.stride = precomputed ? npoints : 0;
@@ -658,9 +677,9 @@ struct MsmCtx : MsmCtxBase {
         const size_t entries = (size_t)sh.W * sh.n, nt = ntask_max(sh);
         wk.inter.ensure(entries * 8);
         wk.sorted.ensure(entries * 4);
-        wk.block_hist.ensure((size_t)MSM_NB1 * MSM_P * 4);
-        wk.part_cnt.ensure(MSM_P * 4);
-        wk.part_start.ensure((MSM_P + 1) * 4);
+        wk.block_hist.ensure((size_t)MSM_NB1 * MSM_P_MAX * 4);
+        wk.part_cnt.ensure(MSM_P_MAX * 4);
+        wk.part_start.ensure((MSM_P_MAX + 1) * 4);
         wk.cnt.ensure((size_t)sh.NB * 4);
         wk.bucket_start.ensure((size_t)sh.NB * 4);
         wk.task_start.ensure((size_t)sh.NG * (MSM_GRP + 1) * 4);
@@ -692,19 +711,19 @@ struct MsmCtx : MsmCtxBase {
             return true;
         }();
         (void)lds_opt_in;
-        LURK_REQUIRE(msm_scatter1_lds(sh.W) <= MSM_LDS_BYTES, "pass-1 tile does not fit the LDS");
+        LURK_REQUIRE(msm_scatter1_lds(sh.P, sh.W, sh.tile) <= MSM_LDS_BYTES, "pass-1 tile does not fit the LDS");
         {
             ProfScope ps("msm_sort", s);
-            hipLaunchKernelGGL((msm_hist1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), 0, s, (const uint4*)d_scalars,
+            hipLaunchKernelGGL((msm_hist1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), (size_t)sh.P * 4, s, (const uint4*)d_scalars,
                                wk.block_hist.template as<uint32_t>(), sh, chunk, is_mont);
-            hipLaunchKernelGGL(msm_scan1_kernel, dim3(MSM_P), dim3(MSM_NB1), 0, s, wk.block_hist.template as<uint32_t>(),
-                               wk.part_cnt.template as<uint32_t>());
+            hipLaunchKernelGGL(msm_scan1_kernel, dim3(sh.P), dim3(MSM_NB1), 0, s, wk.block_hist.template as<uint32_t>(),
+                               wk.part_cnt.template as<uint32_t>(), sh.P);
             hipLaunchKernelGGL(msm_part_start_kernel, dim3(1), dim3(MSM_SORT_BLOCK), 0, s, wk.part_cnt.template as<uint32_t>(),
-                               wk.part_start.template as<uint32_t>());
-            hipLaunchKernelGGL((msm_scatter1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), msm_scatter1_lds(sh.W), s, (const uint4*)d_scalars,
-                               wk.block_hist.template as<uint32_t>(), wk.part_start.template as<uint32_t>(), wk.inter.template as<uint2>(), sh,
-                               chunk, is_mont);
-            hipLaunchKernelGGL(msm_part2_kernel, dim3(MSM_P), dim3(MSM_SORT_BLOCK), MSM_LDS_BYTES, s, wk.inter.template as<uint2>(),
+                               wk.part_start.template as<uint32_t>(), sh.P);
+            hipLaunchKernelGGL((msm_scatter1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), msm_scatter1_lds(sh.P, sh.W, sh.tile), s,
+                               (const uint4*)d_scalars, wk.block_hist.template as<uint32_t>(), wk.part_start.template as<uint32_t>(),
+                               wk.inter.template as<uint2>(), sh, chunk, is_mont);
+            hipLaunchKernelGGL(msm_part2_kernel, dim3(sh.P), dim3(MSM_SORT_BLOCK), MSM_LDS_BYTES, s, wk.inter.template as<uint2>(),
                                wk.part_start.template as<uint32_t>(), wk.sorted.template as<uint32_t>(), wk.cnt.template as<uint32_t>(),
                                wk.bucket_start.template as<uint32_t>(), sh, (uint32_t)msm_part2_cap(sh.LB));
         }
