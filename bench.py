@@ -52,7 +52,19 @@ def main():
                     help="check the final commitment of the timed loop against the oracle's discrete-log checksum (rank 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20)
+    ap.add_argument("--pmc", choices=["auto", "off"], default="auto",
+                    help="auto = after the timed region, re-run two synchronous commitments under `rocprofv3 --pmc` (FETCH_SIZE and "
+                         "WRITE_SIZE in separate passes) and report the dominant kernel's HBM traffic per launch in roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-plain-leg", action="store_true", help="skip the plain-key synchronous sub-record (plain_sync)")
     args = ap.parse_args()
+
+    # N > 1 without a launcher: become the launcher (one rank per GPU, the same command line the driver uses)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE', '1')}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or drop WORLD_SIZE")
 
     import numpy as np
     import torch
@@ -69,6 +81,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if world > torch.cuda.device_count() and args.backend == "nccl":
+        sys.exit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s): RCCL needs one GPU per rank "
+                 "(--backend gloo shares GPU 0 between the ranks: functional check only)")
     dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev)
     lib = _lib.load()
@@ -126,6 +141,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.pmc_child:  # under rocprofv3 --pmc: a few synchronous commitments, no timing, no JSON line
+        for _ in range(1 + args.steps):
+            ck.commit_device(d_scalars, n, is_mont=True, stream=stream)
+        torch.cuda.synchronize()
+        ck.close()
+        return
+
     result = run_steps(args.warmup)
     lib.lurk_hip_profile_enable(1)
     lib.lurk_hip_profile_reset()
@@ -163,16 +185,23 @@ def main():
         acc_avg_ms = acc_ms / max(acc_cnt, 1)
         alg_bytes = 96.0 * n  # per launch: one rank's shard
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9 if acc_avg_ms > 0 else 0.0
-        traffic = None
+        # HBM traffic of the dominant kernel, measured by THIS run: two rocprofv3 --pmc passes over a short synchronous
+        # re-run of the same workload (after the timed region).  When that is not possible (no rocprofv3, N > 1, --pmc off)
+        # traffic stays null and the last committed profile is quoted under its own name and tag.
+        traffic, traffic_detail = None, None
+        if args.pmc == "auto" and world == 1:
+            traffic, traffic_detail = collect_traffic(args)
+        traffic_from_profile = None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_msm_accumulate.json")
-        if os.path.exists(pmc_path):
+        if traffic is None and os.path.exists(pmc_path):
             try:
                 with open(pmc_path) as f:
                     pmc = json.load(f)
                 if pmc.get("log_n") == args.log_n:
-                    traffic = pmc.get("hbm_bytes_per_launch")
+                    traffic_from_profile = {"hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch"), "tag": pmc.get("tag"),
+                                            "note": "static file from an earlier lease, NOT measured by this run"}
             except Exception:
-                traffic = None
+                traffic_from_profile = None
         out = {
             "metric": "MSM Mscalar-mul/s (Pallas Pedersen commitment, bases+scalars resident in HBM)",
             "value": round(value, 3),
@@ -203,6 +232,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / 8000.0, 6),
                 "traffic": traffic,
+                "traffic_detail": traffic_detail,
+                "traffic_from_profile": traffic_from_profile,
                 "avg_launch_ms": round(acc_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "mixed_additions_per_launch": (13 if args.precompute and not args.window_bits else msm_windows(args)) * n,
@@ -216,6 +247,8 @@ def main():
             "sync_ms_per_commit": round(sync_ms, 4),
             "setup_ms_once": round(setup_ms, 1),
         }
+        if not args.no_plain_leg and world == 1 and args.precompute:
+            out["plain_sync"] = plain_sync_leg(args, d_bases, d_scalars, n, stream)
         if args.verify:
             # sum_i s_i [k_i]G == [sum_i s_i k_i] G over ALL ranks' points (bases have known discrete logs)
             from oracle import coracle as C
@@ -392,6 +425,89 @@ def fold_step_workload(args, lib, world, rank):
         print(json.dumps(res), flush=True)
     ck.close()
     shape.close()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher in the environment: re-run this command line under
+    torch.distributed.run with one rank per GPU (rendezvous on 127.0.0.1); rank 0 of that job prints the JSON line."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def plain_sync_leg(args, d_bases, d_scalars, n, stream):
+    """The same workload through what the literal pasta-msm drop-in does minus PCIe: a plain 64 B/point key (no
+    precomputed table, nothing to amortise), one synchronous commitment at a time."""
+    import torch
+
+    import lurk_beta_amd as L
+
+    ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n, device=True, precompute=False)
+    for _ in range(max(1, args.warmup)):
+        ck.commit_device(d_scalars, n, is_mont=True, stream=stream)
+    torch.cuda.synchronize()
+    k = max(3, args.steps)
+    t0 = time.perf_counter()
+    for _ in range(k):
+        ck.commit_device(d_scalars, n, is_mont=True, stream=stream)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    ck.close()
+    return {"value": round(n / dt / 1e6, 3), "unit": "Mscalar-mul/s", "ms_per_commit": round(dt * 1e3, 4), "steps": k,
+            "config": "plain resident key (64 B/point, 16-bit windows), synchronous: one commitment at a time, result on the host after each"}
+
+
+def collect_traffic(args):
+    """HBM bytes per launch of msm_accumulate_kernel from the PMC counters, as MI355X_MICROARCH.md section HBM prescribes:
+    FETCH_SIZE and WRITE_SIZE in separate rocprofv3 passes (they do not fit one), both in KiB, FETCH_SIZE doubled on
+    gfx950 (128-byte requests tallied as 64).  Returns (bytes_per_launch or None, detail or None)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not on PATH"}
+    child = [sys.executable, os.path.abspath(__file__), "--pmc-child", "--pmc", "off", "--steps", "2", "--no-cpu-baseline",
+             "--log-n", str(args.log_n), "--dist", args.dist, "--precompute", str(args.precompute), "--window-bits", str(args.window_bits)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    work = tempfile.mkdtemp(prefix="lurk_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            outdir = os.path.join(work, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", outdir, "--"] + child
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            except Exception as e:  # noqa: BLE001
+                return None, {"error": f"rocprofv3 --pmc {counter} failed: {type(e).__name__}"}
+            per = []
+            for f in glob.glob(os.path.join(outdir, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if "msm_accumulate_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                            per.append(float(r["Counter_Value"]))
+            if not per:
+                return None, {"error": f"no {counter} rows for msm_accumulate_kernel"}
+            vals[counter] = (sum(per) / len(per), len(per))
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    fetch_kib, write_kib = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    total = (2.0 * fetch_kib + write_kib) * 1024.0
+    return total, {"source": "live: rocprofv3 --pmc over a synchronous re-run of this workload, separate passes",
+                   "fetch_size_kib_raw": round(fetch_kib, 1), "write_size_kib": round(write_kib, 1), "launches": vals["FETCH_SIZE"][1],
+                   "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests as 64 B; calibrated for streaming reads only, so an upper "
+                                 "estimate for the 64-B gathers of this kernel), WRITE_SIZE as is"}
 
 
 def valu_roofline(acc_ms, mixed_adds):

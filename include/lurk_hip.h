@@ -105,6 +105,25 @@ int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_s
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out_jacobian96);
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx);
 
+/* One process, several GPUs.  arecibo's prover is a single process (/root/reference/src/proof/nova.rs:304-326: one
+ * witness-producer thread, rayon inside), so the multi-GPU form of the commitment is a context that owns a list
+ * of devices: the key is cut into len(devices) contiguous slices (the first npoints % n_dev slices hold one more
+ * point), every slice stays resident on its device, and a commit runs the slices concurrently (one host thread
+ * per device inside the library), brings the 96-byte partial commitments back and sums them on the host.  A
+ * device id may appear more than once (two slices on one GPU).  flags as for lurk_hip_msm_ctx_create.
+ * commit takes the whole scalar vector in host memory; commit_dev takes one device pointer per slice (slice i's
+ * scalars resident on slice i's device; entries of slices beyond nscalars are ignored). */
+typedef struct lurk_hip_msm_multi lurk_hip_msm_multi;
+int lurk_hip_msm_multi_create(lurk_hip_msm_multi** ctx, int curve, const void* bases_affine64, size_t npoints,
+                              const int* devices, int n_dev, int flags);
+int lurk_hip_msm_multi_num_shards(const lurk_hip_msm_multi* ctx);
+int lurk_hip_msm_multi_shard(const lurk_hip_msm_multi* ctx, int index, int* device, size_t* first, size_t* count);
+int lurk_hip_msm_multi_commit(lurk_hip_msm_multi* ctx, void* out_jacobian96, const void* scalars32, size_t nscalars,
+                              int is_mont);
+int lurk_hip_msm_multi_commit_dev(lurk_hip_msm_multi* ctx, void* out_jacobian96, const void* const* d_scalars32,
+                                  size_t nscalars, int is_mont);
+int lurk_hip_msm_multi_destroy(lurk_hip_msm_multi* ctx);
+
 /* Group helpers used by the multi-GPU gather (sum of per-rank partial commitments) and by tests:
  * out = sum of `count` Jacobian points (host memory, 96 B each). */
 int lurk_hip_point_sum(int curve, void* out_jacobian96, const void* points_jacobian96, size_t count);

@@ -39,6 +39,12 @@ SIGNATURES = {
     "lurk_hip_msm_ctx_submit_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lurk_hip_msm_ctx_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lurk_hip_msm_ctx_destroy": (c_int, [c_void_p]),
+    "lurk_hip_msm_multi_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, ctypes.POINTER(c_int), c_int, c_int]),
+    "lurk_hip_msm_multi_num_shards": (c_int, [c_void_p]),
+    "lurk_hip_msm_multi_shard": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
+    "lurk_hip_msm_multi_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
+    "lurk_hip_msm_multi_commit_dev": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_size_t, c_int]),
+    "lurk_hip_msm_multi_destroy": (c_int, [c_void_p]),
     "lurk_hip_point_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     "lurk_hip_point_to_affine_canonical": (c_int, [c_int, c_void_p, c_void_p]),
     "lurk_hip_poseidon_batch": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),

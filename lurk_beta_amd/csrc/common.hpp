@@ -7,9 +7,13 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/lurk_hip.h"
@@ -41,6 +45,30 @@ struct HipFailure {
 
 // Fails loudly (no CPU fallback) unless a gfx950 device is usable.
 void require_device();
+
+// Every handle (MSM context, R1CS shape, NTT plan) records the device it was created on; its entry points run
+// under a DeviceGuard, so a handle may be used from any host thread whatever that thread's current device is
+// (hipSetDevice is per thread).
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        LURK_HIP_CHECK(hipGetDevice(&prev));
+        if (prev != dev) {
+            LURK_HIP_CHECK(hipSetDevice(dev));
+            switched = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+int current_device();
+
+// More than 64 KB of dynamic LDS has to be requested per kernel and per device; done once for each pair.
+void allow_dynamic_lds(const void* kernel, int bytes);
 
 // Wraps the body of a C-ABI entry point: converts exceptions to error codes.
 template <class F>
@@ -99,31 +127,54 @@ class Profiler {
     void enable(bool on) { enabled_ = on; }
     bool enabled() const { return enabled_; }
     void reset();
-    void begin(const char* name, hipStream_t s);
-    void end(hipStream_t s);
+    hipEvent_t begin(hipStream_t s);                          // records and returns the opening event
+    void end(const char* name, hipEvent_t a, hipStream_t s);  // records the closing event
     void query(const char* prefix, double* total_ms, uint64_t* launches);
 
   private:
-    struct Rec { std::string name; hipEvent_t a, b; };
+    struct Rec { std::string name; hipEvent_t a, b; int device; };
     std::mutex mu_;
     bool enabled_ = false;
     std::vector<Rec> recs_;
-    std::vector<hipEvent_t> pool_;
-    hipEvent_t open_a_ = nullptr;
-    std::string open_name_;
+    std::map<int, std::vector<hipEvent_t>> pool_;  // events belong to the device they were created on
     std::map<std::string, std::pair<double, uint64_t>> done_;
-    hipEvent_t get_event();
+    hipEvent_t get_event(int device);
 };
 
+// scopes may be open on several host threads / devices at once (the multi-device MSM): the opening event travels
+// with the scope
 struct ProfScope {
     hipStream_t s;
-    bool on;
-    ProfScope(const char* name, hipStream_t st) : s(st), on(Profiler::get().enabled()) {
-        if (on) Profiler::get().begin(name, s);
+    const char* name;
+    hipEvent_t a = nullptr;
+    ProfScope(const char* nm, hipStream_t st) : s(st), name(nm) {
+        if (Profiler::get().enabled()) a = Profiler::get().begin(s);
     }
     ~ProfScope() {
-        if (on) Profiler::get().end(s);
+        if (a) Profiler::get().end(name, a, s);
     }
+};
+
+// One host thread bound to one device: the multi-device entry points post their per-device work here so that
+// the devices are driven concurrently from a single-process caller (arecibo's prover is one process,
+// /root/reference/src/proof/nova.rs:304-326).
+class DeviceWorker {
+  public:
+    explicit DeviceWorker(int device);
+    ~DeviceWorker();
+    void post(std::function<void()> job);  // one job at a time: post, then wait
+    void wait();                           // blocks until the job is done; rethrows its HipFailure
+    int device() const { return device_; }
+
+  private:
+    void loop();
+    int device_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    bool has_job_ = false, busy_ = false, stop_ = false, failed_ = false;
+    HipFailure err_{0, ""};
+    std::thread th_;
 };
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }

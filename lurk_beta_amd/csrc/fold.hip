@@ -226,18 +226,11 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_multiply_vec_kernel(R1csDev s
     }
 }
 
-// neg_u: [-u1, -u2] as radix-2^29 limbs (2 x P29_STRIDE words), prepared by a one-lane kernel from z1, z2
-template <class P>
-__global__ void r1cs_neg_u_kernel(const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2, size_t u_index, uint32_t* __restrict__ neg_u) {
-    if (threadIdx.x >= 2 || blockIdx.x) return;
-    Fe<P> u = fe_neg<P>(threadIdx.x == 0 ? z1[u_index] : z2[u_index]);
-    F29<P> f = f29_from_mont256<P>(u);  // 32 * (-u) * 2^256: lazy Montgomery-2^261 form, tight, < 2^259
-    for (int i = 0; i < 9; i++) neg_u[threadIdx.x * P29_STRIDE + i] = f.l[i];
-}
-
+// -u1, -u2 (u_i = z_i[num_vars]) are negated and converted by every lane that finishes a row: two broadcast loads and two
+// limb repackings, so that a call keeps no state outside its arguments (concurrent calls on one shape are independent)
 template <class P, bool LONG>
 __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2,
-                                                                       const uint32_t* __restrict__ neg_u, Fe<P>* __restrict__ t) {
+                                                                       size_t u_index, Fe<P>* __restrict__ t) {
     const uint32_t* one29 = s.dict + s.dict_size * P29_STRIDE;
     const Fe<P>* zs[2] = {z1, z2};
     uint32_t lo[3], hi[3];
@@ -274,8 +267,8 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
         dot29_mac<P>(acc, a[0], b[1]);
         dot29_mac<P>(acc, a[1], b[0]);
     }
-    dot29_mac<P>(acc, ld_const29<P>(neg_u), c[1]);
-    dot29_mac<P>(acc, ld_const29<P>(neg_u + P29_STRIDE), c[0]);
+    dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(z1[u_index])), c[1]);  // 32 (-u) 2^256: lazy Montgomery-2^261 form, tight, < 2^259
+    dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(z2[u_index])), c[0]);
     fold_store<P>(t + row, dot29_finish<P>(acc));
 }
 
@@ -374,16 +367,15 @@ static void multiply_vec(const R1csShape& sh, const void* d_z, void* az, void* b
     LURK_HIP_CHECK(hipGetLastError());
 }
 template <class P>
-static void cross_term(const R1csShape& sh, const void* d_z1, const void* d_z2, void* d_t, void* d_neg_u, hipStream_t s) {
+static void cross_term(const R1csShape& sh, const void* d_z1, const void* d_z2, void* d_t, hipStream_t s) {
     if (!sh.num_cons) return;
     ProfScope ps("r1cs_cross_term", s);
     const R1csDev d = dev_view(sh);
-    hipLaunchKernelGGL((r1cs_neg_u_kernel<P>), dim3(1), dim3(64), 0, s, (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, sh.num_vars, (uint32_t*)d_neg_u);
     if (sh.n_long)
         hipLaunchKernelGGL((r1cs_cross_term_kernel<P, true>), dim3(div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
-                           (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, (const uint32_t*)d_neg_u, (Fe<P>*)d_t);
+                           (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, sh.num_vars, (Fe<P>*)d_t);
     hipLaunchKernelGGL((r1cs_cross_term_kernel<P, false>), dim3(div_up(sh.num_cons, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z1,
-                       (const Fe<P>*)d_z2, (const uint32_t*)d_neg_u, (Fe<P>*)d_t);
+                       (const Fe<P>*)d_z2, sh.num_vars, (Fe<P>*)d_t);
     LURK_HIP_CHECK(hipGetLastError());
 }
 template <class P>
@@ -404,9 +396,7 @@ static void fold_vec(const void* a, const void* b, const void* r32, size_t n, vo
 using namespace lurk;
 
 struct lurk_hip_r1cs {
-    R1csShape sh;
-    DevBuf neg_u;  // scratch of cross_term
-    mutable std::mutex mu;  // the -u scratch is per shape
+    R1csShape sh;  // immutable after creation: calls on one shape from any thread / stream are independent
 };
 
 extern "C" {
@@ -452,13 +442,16 @@ int lurk_hip_r1cs_create(lurk_hip_r1cs** out, int field_id, size_t num_cons, siz
         }
         sh.dict.alloc(dict_words.size() * 4);
         if (!dict_words.empty()) LURK_HIP_CHECK(hipMemcpy(sh.dict.p, dict_words.data(), dict_words.size() * 4, hipMemcpyHostToDevice));
-        h->neg_u.alloc(2 * P29_STRIDE * 4);
         *out = h.release();
     });
 }
 
 int lurk_hip_r1cs_destroy(lurk_hip_r1cs* shape) {
-    return guarded([&] { delete shape; });
+    if (!shape) return 0;
+    return guarded([&] {
+        DeviceGuard dg(shape->sh.device);
+        delete shape;
+    });
 }
 
 int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b, size_t* nnz_c, size_t* distinct_coefficients) {
@@ -474,7 +467,7 @@ int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b,
 int lurk_hip_r1cs_multiply_vec_dev(const lurk_hip_r1cs* shape, const void* d_z, void* d_az, void* d_bz, void* d_cz, void* stream) {
     return guarded([&] {
         LURK_REQUIRE(shape && d_z && d_az && d_bz && d_cz, "null argument");
-        std::lock_guard<std::mutex> lk(shape->mu);
+        DeviceGuard dg(shape->sh.device);
         const R1csShape& sh = shape->sh;
         if (sh.field_id == 0) multiply_vec<PallasFp>(sh, d_z, d_az, d_bz, d_cz, (hipStream_t)stream);
         else if (sh.field_id == 1) multiply_vec<PallasFq>(sh, d_z, d_az, d_bz, d_cz, (hipStream_t)stream);
@@ -485,11 +478,11 @@ int lurk_hip_r1cs_multiply_vec_dev(const lurk_hip_r1cs* shape, const void* d_z, 
 int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const void* d_z2, void* d_t, void* stream) {
     return guarded([&] {
         LURK_REQUIRE(shape && d_z1 && d_z2 && d_t, "null argument");
-        std::lock_guard<std::mutex> lk(shape->mu);
+        DeviceGuard dg(shape->sh.device);
         const R1csShape& sh = shape->sh;
-        if (sh.field_id == 0) cross_term<PallasFp>(sh, d_z1, d_z2, d_t, shape->neg_u.p, (hipStream_t)stream);
-        else if (sh.field_id == 1) cross_term<PallasFq>(sh, d_z1, d_z2, d_t, shape->neg_u.p, (hipStream_t)stream);
-        else cross_term<Bn254Fr>(sh, d_z1, d_z2, d_t, shape->neg_u.p, (hipStream_t)stream);
+        if (sh.field_id == 0) cross_term<PallasFp>(sh, d_z1, d_z2, d_t, (hipStream_t)stream);
+        else if (sh.field_id == 1) cross_term<PallasFq>(sh, d_z1, d_z2, d_t, (hipStream_t)stream);
+        else cross_term<Bn254Fr>(sh, d_z1, d_z2, d_t, (hipStream_t)stream);
     });
 }
 
@@ -497,6 +490,7 @@ int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const v
 int lurk_hip_r1cs_multiply_vec(const lurk_hip_r1cs* shape, const void* z, void* az, void* bz, void* cz) {
     return guarded([&] {
         LURK_REQUIRE(shape && z && az && bz && cz, "null argument");
+        DeviceGuard dg(shape->sh.device);
         const R1csShape& sh = shape->sh;
         const size_t ncols = sh.num_vars + 1 + sh.num_io, m = sh.num_cons;
         DevBuf d_z(ncols * 32), d_a(m * 32), d_b(m * 32), d_c(m * 32);
@@ -512,6 +506,7 @@ int lurk_hip_r1cs_multiply_vec(const lurk_hip_r1cs* shape, const void* z, void* 
 int lurk_hip_r1cs_cross_term(lurk_hip_r1cs* shape, const void* z1, const void* z2, void* t) {
     return guarded([&] {
         LURK_REQUIRE(shape && z1 && z2 && t, "null argument");
+        DeviceGuard dg(shape->sh.device);
         const R1csShape& sh = shape->sh;
         const size_t ncols = sh.num_vars + 1 + sh.num_io, m = sh.num_cons;
         DevBuf d_z1(ncols * 32), d_z2(ncols * 32), d_t(m * 32);

@@ -579,6 +579,7 @@ constexpr int MSM_SLOTS = 3;  // commitments in flight per context (independent 
 
 struct MsmCtxBase {
     int curve = 0;
+    int device = 0;  // the device the context lives on: every entry point runs under a DeviceGuard for it
     size_t npoints = 0;
     bool precomputed = false;
     int c = MSM_C_PLAIN;
@@ -649,7 +650,8 @@ struct MsmCtx : MsmCtxBase {
         LURK_REQUIRE(c >= 16 && c <= 20, "window bits must be in 16..20");
         LURK_REQUIRE(precompute || c == MSM_C_PLAIN, "the plain mode uses 16-bit windows");
         const int W = msm_num_windows(c);
-        LURK_REQUIRE(n < ((size_t)1 << 31) / (precompute ? W : 1), "too many points for 31-bit table indices");
+        // sorted entries carry a 31-bit table index (+ sign bit); the sort's offsets are 32-bit over the W n entries
+        LURK_REQUIRE((size_t)W * n < ((size_t)1 << 31), "too many points: windows x points must stay below 2^31");
         if (precompute) {
             own_bases.alloc((size_t)W * n * sizeof(Affine<P>));
             if (n) {
@@ -705,12 +707,8 @@ struct MsmCtx : MsmCtxBase {
         ensure_workspace(wk, sh);
         const size_t chunk = (n + MSM_NB1 - 1) / MSM_NB1;
         const size_t nt = ntask_max(sh);
-        static const bool lds_opt_in = [] {  // > 64 KB of dynamic LDS has to be requested once per kernel
-            LURK_HIP_CHECK(hipFuncSetAttribute((const void*)msm_scatter1_kernel<SF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_LDS_BYTES));
-            LURK_HIP_CHECK(hipFuncSetAttribute((const void*)msm_part2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MSM_LDS_BYTES));
-            return true;
-        }();
-        (void)lds_opt_in;
+        allow_dynamic_lds((const void*)msm_scatter1_kernel<SF>, (int)MSM_LDS_BYTES);
+        allow_dynamic_lds((const void*)msm_part2_kernel, (int)MSM_LDS_BYTES);
         LURK_REQUIRE(msm_scatter1_lds(sh.P, sh.W, sh.tile) <= MSM_LDS_BYTES, "pass-1 tile does not fit the LDS");
         {
             ProfScope ps("msm_sort", s);
@@ -845,6 +843,7 @@ static MsmCtxBase* new_ctx(int curve) {
     LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
     MsmCtxBase* c = curve == LURK_CURVE_PALLAS ? (MsmCtxBase*)new MsmCtx<PallasFp, PallasFq>() : (MsmCtxBase*)new MsmCtx<PallasFq, PallasFp>();
     c->curve = curve;
+    c->device = current_device();
     return c;
 }
 static void ctx_set_bases(MsmCtxBase* c, const void* d_bases, size_t n, bool copy, int flags, hipStream_t s) {
@@ -892,6 +891,65 @@ struct lurk_hip_msm_ctx {
     std::unique_ptr<MsmCtxBase> impl;
 };
 
+// A commitment key cut into contiguous slices, one per device of the list, driven from ONE host process:
+// each slice has its own context (resident in that device's HBM) and its own host thread bound to the device, so
+// the devices sort / accumulate concurrently; the 96-byte partial commitments come back to the host and are
+// summed with the host group law.  No bucket array ever crosses a link.
+struct lurk_hip_msm_multi {
+    struct Shard {
+        size_t lo = 0, hi = 0;
+        std::unique_ptr<DeviceWorker> worker;
+        std::unique_ptr<MsmCtxBase> ctx;  // created, used and destroyed on the worker thread
+        DevBuf staged;                    // device copy of this shard's scalars (host-pointer commits)
+        Jacobian<PallasFp> partial;       // both curves share the 96-byte layout
+    };
+    int curve = 0;
+    size_t npoints = 0;
+    std::vector<std::unique_ptr<Shard>> shards;
+    std::mutex mu;  // one commitment at a time per multi-context
+
+    // f(shard, count) on every shard that owns some of the first n scalars; waits for all of them
+    template <class F>
+    void for_shards(size_t n, F&& f) {
+        std::vector<Shard*> live;
+        for (auto& sp : shards) {
+            Shard& sh = *sp;
+            if (sh.lo >= n || sh.lo == sh.hi) continue;
+            size_t cnt = (sh.hi < n ? sh.hi : n) - sh.lo;
+            Shard* shp = &sh;
+            sh.worker->post([shp, cnt, &f] { f(*shp, cnt); });
+            live.push_back(shp);
+        }
+        std::unique_ptr<HipFailure> first;
+        for (Shard* shp : live) {
+            try {
+                shp->worker->wait();
+            } catch (const HipFailure& e) {
+                if (!first) first.reset(new HipFailure(e));
+            }
+        }
+        if (first) throw *first;
+    }
+    void sum(size_t n, void* out) {
+        std::vector<Jacobian<PallasFp>> parts;
+        for (auto& sp : shards)
+            if (sp->lo < n && sp->lo != sp->hi) parts.push_back(sp->partial);
+        if (curve == LURK_CURVE_PALLAS) point_sum_host<PallasFp>(parts.data(), parts.size(), out);
+        else point_sum_host<PallasFq>(parts.data(), parts.size(), out);
+    }
+    ~lurk_hip_msm_multi() {
+        for (auto& sp : shards) {
+            Shard* shp = sp.get();
+            if (!shp->worker) continue;
+            shp->worker->post([shp] {
+                shp->ctx.reset();
+                shp->staged.release();
+            });
+            try { shp->worker->wait(); } catch (...) {}
+        }
+    }
+};
+
 extern "C" {
 
 int lurk_hip_msm_pallas(void* out, const void* bases, size_t n, const void* scalars, int is_mont) {
@@ -925,6 +983,7 @@ int lurk_hip_msm_ctx_run(lurk_hip_msm_ctx* ctx, void* out, const void* scalars, 
     return guarded([&] {
         LURK_REQUIRE(ctx && out, "null argument");
         LURK_REQUIRE(n == 0 || scalars, "null scalars");
+        DeviceGuard dg(ctx->impl->device);
         DevBuf ds(n * 32);
         if (n) LURK_HIP_CHECK(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
         ctx->impl->run(ds.p, n, is_mont, nullptr, out);
@@ -934,6 +993,7 @@ int lurk_hip_msm_ctx_run_dev(lurk_hip_msm_ctx* ctx, void* out, const void* d_sca
     return guarded([&] {
         LURK_REQUIRE(ctx && out, "null argument");
         LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
+        DeviceGuard dg(ctx->impl->device);
         ctx->impl->run(d_scalars, n, is_mont, (hipStream_t)stream, out);
     });
 }
@@ -941,18 +1001,102 @@ int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_s
     return guarded([&] {
         LURK_REQUIRE(ctx, "null ctx");
         LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
+        DeviceGuard dg(ctx->impl->device);
         ctx->impl->submit(slot, d_scalars, n, is_mont, (hipStream_t)stream);
     });
 }
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out) {
     return guarded([&] {
         LURK_REQUIRE(ctx && out, "null argument");
+        DeviceGuard dg(ctx->impl->device);
         ctx->impl->wait(slot, out);
     });
 }
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx) {
-    delete ctx;
-    return 0;
+    if (!ctx) return 0;
+    return guarded([&] {
+        DeviceGuard dg(ctx->impl->device);
+        delete ctx;
+    });
+}
+
+// ---- one process, several devices --------------------------------------------------------------
+int lurk_hip_msm_multi_create(lurk_hip_msm_multi** out, int curve, const void* bases, size_t n, const int* devices, int n_dev, int flags) {
+    return guarded([&] {
+        LURK_REQUIRE(out, "null ctx pointer");
+        *out = nullptr;
+        LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
+        LURK_REQUIRE(n == 0 || bases, "null bases");
+        LURK_REQUIRE(devices && n_dev >= 1 && n_dev <= 64, "device list must hold 1..64 entries");
+        const int have = lurk_hip_device_count();
+        for (int i = 0; i < n_dev; i++) LURK_REQUIRE(devices[i] >= 0 && devices[i] < have, "device id out of range");
+        auto m = std::make_unique<lurk_hip_msm_multi>();
+        m->curve = curve;
+        m->npoints = n;
+        const size_t base = n / n_dev, extra = n % n_dev;  // the first n % n_dev shards hold one more point
+        for (int i = 0; i < n_dev; i++) {
+            auto sh = std::make_unique<lurk_hip_msm_multi::Shard>();
+            sh->lo = (size_t)i * base + ((size_t)i < extra ? (size_t)i : extra);
+            sh->hi = sh->lo + base + ((size_t)i < extra ? 1 : 0);
+            sh->worker = std::make_unique<DeviceWorker>(devices[i]);
+            m->shards.push_back(std::move(sh));
+        }
+        const char* hb = (const char*)bases;
+        m->for_shards(n, [&](lurk_hip_msm_multi::Shard& sh, size_t cnt) {
+            sh.ctx.reset(new_ctx(curve));
+            DevBuf tmp(cnt * 64);
+            LURK_HIP_CHECK(hipMemcpy(tmp.p, hb + sh.lo * 64, cnt * 64, hipMemcpyHostToDevice));
+            ctx_set_bases(sh.ctx.get(), tmp.p, cnt, /*copy=*/true, flags, nullptr);
+        });
+        *out = m.release();
+    });
+}
+int lurk_hip_msm_multi_shard(const lurk_hip_msm_multi* m, int index, int* device, size_t* first, size_t* count) {
+    return guarded([&] {
+        LURK_REQUIRE(m, "null ctx");
+        LURK_REQUIRE(index >= 0 && (size_t)index < m->shards.size(), "shard index out of range");
+        const auto& sh = *m->shards[index];
+        if (device) *device = sh.worker->device();
+        if (first) *first = sh.lo;
+        if (count) *count = sh.hi - sh.lo;
+    });
+}
+int lurk_hip_msm_multi_num_shards(const lurk_hip_msm_multi* m) { return m ? (int)m->shards.size() : 0; }
+
+int lurk_hip_msm_multi_commit(lurk_hip_msm_multi* m, void* out, const void* scalars, size_t n, int is_mont) {
+    return guarded([&] {
+        LURK_REQUIRE(m && out, "null argument");
+        LURK_REQUIRE(n <= m->npoints, "more scalars than bases in the context");
+        LURK_REQUIRE(n == 0 || scalars, "null scalars");
+        std::lock_guard<std::mutex> lk(m->mu);
+        const char* hs = (const char*)scalars;
+        m->for_shards(n, [&](lurk_hip_msm_multi::Shard& sh, size_t cnt) {
+            sh.staged.ensure(cnt * 32);
+            LURK_HIP_CHECK(hipMemcpy(sh.staged.p, hs + sh.lo * 32, cnt * 32, hipMemcpyHostToDevice));
+            sh.ctx->run(sh.staged.p, cnt, is_mont, nullptr, &sh.partial);
+        });
+        m->sum(n, out);
+    });
+}
+int lurk_hip_msm_multi_commit_dev(lurk_hip_msm_multi* m, void* out, const void* const* d_scalars, size_t n, int is_mont) {
+    return guarded([&] {
+        LURK_REQUIRE(m && out, "null argument");
+        LURK_REQUIRE(n <= m->npoints, "more scalars than bases in the context");
+        LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
+        std::lock_guard<std::mutex> lk(m->mu);
+        for (size_t i = 0; i < m->shards.size(); i++)
+            LURK_REQUIRE(m->shards[i]->lo >= n || m->shards[i]->lo == m->shards[i]->hi || d_scalars[i], "null shard pointer");
+        m->for_shards(n, [&](lurk_hip_msm_multi::Shard& sh, size_t cnt) {
+            size_t idx = 0;
+            while (m->shards[idx].get() != &sh) idx++;
+            sh.ctx->run(d_scalars[idx], cnt, is_mont, nullptr, &sh.partial);
+        });
+        m->sum(n, out);
+    });
+}
+int lurk_hip_msm_multi_destroy(lurk_hip_msm_multi* m) {
+    if (!m) return 0;
+    return guarded([&] { delete m; });
 }
 
 // host-side group helpers (a handful of points: partial commitments gathered from the ranks)

@@ -136,8 +136,7 @@ static Fe<F> host_omega(unsigned log_n, bool inverse) {
 // Twiddle tables and the bit-reversal scratch buffer are cached per (device, field, log_n, direction):
 // generating n/2 powers costs more field multiplications than the transform itself.
 struct NttPlan {
-    DevBuf tw, tmp;
-    std::mutex mu;
+    DevBuf tw;
 };
 static std::mutex g_plan_mu;
 static std::map<std::tuple<int, int, unsigned, bool>, std::unique_ptr<NttPlan>> g_plans;
@@ -153,7 +152,6 @@ static NttPlan& ntt_plan(unsigned log_n, bool inverse, hipStream_t s) {
         const size_t n = (size_t)1 << log_n;
         auto plan = std::make_unique<NttPlan>();
         plan->tw.alloc((n / 2 ? n / 2 : 1) * 32);
-        plan->tmp.alloc(n * 32);
         if (n > 1) {
             Fe<F> omega = host_omega<F>(log_n, inverse);
             hipLaunchKernelGGL((ntt_twiddle_kernel<F>), dim3(div_up(n / 2, 256)), dim3(256), 0, s, omega, n / 2, plan->tw.template as<Fe<F>>());
@@ -170,16 +168,13 @@ static void ntt_device(void* d_data, unsigned log_n, bool inverse, hipStream_t s
     LURK_REQUIRE(log_n <= 28, "log_n too large");
     const size_t n = (size_t)1 << log_n;
     NttPlan& plan = ntt_plan<F>(log_n, inverse, s);
-    std::lock_guard<std::mutex> lk(plan.mu);  // one transform at a time per plan (shared scratch)
-    Fe<F>* tmp = plan.tmp.template as<Fe<F>>();
+    // the ping-pong scratch is stream-ordered (allocated and freed on `s`): concurrent transforms on one plan never
+    // share it and the call does not synchronise
+    Fe<F>* tmp = nullptr;
+    LURK_HIP_CHECK(hipMallocAsync((void**)&tmp, n * 32, s));
     Fe<F>* data = (Fe<F>*)d_data;
     const Fe<F>* tw = plan.tw.template as<Fe<F>>();
-    static bool attr = false;
-    if (!attr) {
-        LURK_HIP_CHECK(hipFuncSetAttribute((const void*)ntt_pass_kernel<PallasFp>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        LURK_HIP_CHECK(hipFuncSetAttribute((const void*)ntt_pass_kernel<PallasFq>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    allow_dynamic_lds((const void*)ntt_pass_kernel<F>, 160 * 1024);
     ProfScope ps("ntt", s);
     if (log_n >= 10) hipLaunchKernelGGL((ntt_bitrev_tiled_kernel<F>), dim3((unsigned)(n >> 10)), dim3(256), 0, s, data, tmp, log_n);
     else hipLaunchKernelGGL((ntt_bitrev_kernel<F>), dim3(div_up(n, 256)), dim3(256), 0, s, data, tmp, log_n);
@@ -199,8 +194,9 @@ static void ntt_device(void* d_data, unsigned log_n, bool inverse, hipStream_t s
         s0 += ns;
         first = false;
     } while (s0 < log_n);
-    LURK_HIP_CHECK(hipGetLastError());
-    LURK_HIP_CHECK(hipStreamSynchronize(s));  // the plan's scratch is released to the next caller
+    hipError_t launch_err = hipGetLastError();
+    (void)hipFreeAsync(tmp, s);
+    LURK_HIP_CHECK(launch_err);
 }
 
 }  // namespace lurk
@@ -227,6 +223,7 @@ int lurk_hip_ntt(int field_id, void* inout, unsigned log_n, int inverse) {
         LURK_HIP_CHECK(hipMemcpy(d.p, inout, n * 32, hipMemcpyHostToDevice));
         if (field_id == 0) ntt_device<PallasFp>(d.p, log_n, inverse != 0, nullptr);
         else ntt_device<PallasFq>(d.p, log_n, inverse != 0, nullptr);
+        LURK_HIP_CHECK(hipStreamSynchronize(nullptr));
         LURK_HIP_CHECK(hipMemcpy(inout, d.p, n * 32, hipMemcpyDeviceToHost));
     });
 }

@@ -212,13 +212,10 @@ static void launch_batch(const void* d_pre, void* d_out, size_t n, PoseidonConst
     const uint4* img = device_image(pc, s);
     int img_vec4 = (int)(pc.image.size() / 4);
     size_t lds_bytes = (size_t)img_vec4 * 16;
-    static bool attr_set = false;
     auto kern = poseidon_batch_kernel<P, T>;
-    LURK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    (void)attr_set;
     if (n <= POSEIDON_WIDE_MAX) {  // does not fill the chip: trade throughput for latency
         auto wide = poseidon_wide_kernel<P, T>;
-        LURK_HIP_CHECK(hipFuncSetAttribute((const void*)wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        allow_dynamic_lds((const void*)wide, (int)lds_bytes);
         constexpr size_t per_block = (size_t)(POSEIDON_WIDE_BLOCK / 64) * (64 / T);
         ProfScope ps("poseidon_batch", s);
         hipLaunchKernelGGL(wide, dim3(div_up(n, per_block)), dim3(POSEIDON_WIDE_BLOCK), lds_bytes, s, (const uint4*)d_pre, (uint4*)d_out, n, img,
@@ -226,6 +223,7 @@ static void launch_batch(const void* d_pre, void* d_out, size_t n, PoseidonConst
         LURK_HIP_CHECK(hipGetLastError());
         return;
     }
+    allow_dynamic_lds((const void*)kern, (int)lds_bytes);
     unsigned blocks = div_up(n, POSEIDON_BLOCK);
     unsigned cap = (unsigned)num_cus() * 2;  // 2 workgroups (8 waves) per CU, grid-stride beyond
     if (blocks > cap) blocks = cap;

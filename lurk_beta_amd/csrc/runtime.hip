@@ -48,39 +48,62 @@ void require_device() {
 
 int num_cus() { return g_num_cus > 0 ? g_num_cus : 256; }
 
+int current_device() {
+    int dev = 0;
+    LURK_HIP_CHECK(hipGetDevice(&dev));
+    return dev;
+}
+
+void allow_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, int> done;  // (kernel, device) -> bytes granted
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    int& have = done[std::make_pair(kernel, dev)];
+    if (have >= bytes) return;
+    LURK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+}
+
 Profiler& Profiler::get() {
     static Profiler p;
     return p;
 }
-hipEvent_t Profiler::get_event() {
-    if (!pool_.empty()) {
-        hipEvent_t e = pool_.back();
-        pool_.pop_back();
+hipEvent_t Profiler::get_event(int device) {
+    auto& pool = pool_[device];
+    if (!pool.empty()) {
+        hipEvent_t e = pool.back();
+        pool.pop_back();
         return e;
     }
     hipEvent_t e;
     LURK_HIP_CHECK(hipEventCreate(&e));
     return e;
 }
-void Profiler::begin(const char* name, hipStream_t s) {
-    std::lock_guard<std::mutex> lk(mu_);
-    open_a_ = get_event();
-    open_name_ = name;
-    LURK_HIP_CHECK(hipEventRecord(open_a_, s));
+hipEvent_t Profiler::begin(hipStream_t s) {
+    const int dev = current_device();
+    hipEvent_t a;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        a = get_event(dev);
+    }
+    LURK_HIP_CHECK(hipEventRecord(a, s));
+    return a;
 }
-void Profiler::end(hipStream_t s) {
+void Profiler::end(const char* name, hipEvent_t a, hipStream_t s) {
+    const int dev = current_device();
     std::lock_guard<std::mutex> lk(mu_);
-    hipEvent_t b = get_event();
-    LURK_HIP_CHECK(hipEventRecord(b, s));
-    recs_.push_back({open_name_, open_a_, b});
-    open_a_ = nullptr;
+    hipEvent_t b = get_event(dev);
+    (void)hipEventRecord(b, s);  // called from a destructor: never throws
+    recs_.push_back({name, a, b, dev});
 }
 void Profiler::reset() {
     std::lock_guard<std::mutex> lk(mu_);
     for (auto& r : recs_) {
+        DeviceGuard g(r.device);
         (void)hipEventSynchronize(r.b);
-        pool_.push_back(r.a);
-        pool_.push_back(r.b);
+        pool_[r.device].push_back(r.a);
+        pool_[r.device].push_back(r.b);
     }
     recs_.clear();
     done_.clear();
@@ -88,14 +111,15 @@ void Profiler::reset() {
 void Profiler::query(const char* prefix, double* total_ms, uint64_t* launches) {
     std::lock_guard<std::mutex> lk(mu_);
     for (auto& r : recs_) {
+        DeviceGuard g(r.device);
         LURK_HIP_CHECK(hipEventSynchronize(r.b));
         float ms = 0;
         LURK_HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
         auto& d = done_[r.name];
         d.first += ms;
         d.second += 1;
-        pool_.push_back(r.a);
-        pool_.push_back(r.b);
+        pool_[r.device].push_back(r.a);
+        pool_[r.device].push_back(r.b);
     }
     recs_.clear();
     double tot = 0;
@@ -108,6 +132,66 @@ void Profiler::query(const char* prefix, double* total_ms, uint64_t* launches) {
         }
     *total_ms = tot;
     *launches = cnt;
+}
+
+DeviceWorker::DeviceWorker(int device) : device_(device), th_([this] { loop(); }) {}
+DeviceWorker::~DeviceWorker() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    if (th_.joinable()) th_.join();
+}
+void DeviceWorker::loop() {
+    bool bound = hipSetDevice(device_) == hipSuccess;
+    for (;;) {
+        std::function<void()> job;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [this] { return has_job_ || stop_; });
+            if (stop_ && !has_job_) return;
+            job = std::move(job_);
+            has_job_ = false;
+        }
+        bool failed = false;
+        HipFailure err{0, ""};
+        try {
+            if (!bound) throw HipFailure{LURK_HIP_ERR_HIP, "hipSetDevice(" + std::to_string(device_) + ") failed on the worker thread"};
+            job();
+        } catch (const HipFailure& e) {
+            failed = true;
+            err = e;
+        } catch (const std::exception& e) {
+            failed = true;
+            err = HipFailure{LURK_HIP_ERR_HIP, e.what()};
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            failed_ = failed;
+            err_ = err;
+            busy_ = false;
+        }
+        cv_.notify_all();
+    }
+}
+void DeviceWorker::post(std::function<void()> job) {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return !busy_; });
+    job_ = std::move(job);
+    has_job_ = true;
+    busy_ = true;
+    failed_ = false;
+    lk.unlock();
+    cv_.notify_all();
+}
+void DeviceWorker::wait() {
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [this] { return !busy_; });
+    if (failed_) {
+        failed_ = false;
+        throw err_;
+    }
 }
 
 }  // namespace lurk

@@ -168,6 +168,36 @@ class CommitmentKey {
     lurk_hip_msm_ctx* ctx_ = nullptr;
 };
 
+// The same key cut across a list of devices and driven from this one process (arecibo's prover is a single process,
+// /root/reference/src/proof/nova.rs:304-326): slice i of ck lives on devices[i], a commit runs the slices
+// concurrently and sums the 96-byte partial commitments on the host.
+class MultiCommitmentKey {
+  public:
+    MultiCommitmentKey(int curve, const std::vector<Affine>& ck, const std::vector<int>& devices, bool precompute) : curve_(curve) {
+        check(lurk_hip_msm_multi_create(&ctx_, curve, ck.data(), ck.size(), devices.data(), (int)devices.size(),
+                                        precompute ? LURK_MSM_FLAG_PRECOMPUTE : 0));
+    }
+    ~MultiCommitmentKey() { lurk_hip_msm_multi_destroy(ctx_); }
+    MultiCommitmentKey(const MultiCommitmentKey&) = delete;
+    Jacobian commit(const std::vector<Fe>& scalars, bool is_mont) const {
+        Jacobian out;
+        check(lurk_hip_msm_multi_commit(ctx_, &out, scalars.data(), scalars.size(), is_mont ? 1 : 0));
+        return out;
+    }
+    int num_shards() const { return lurk_hip_msm_multi_num_shards(ctx_); }
+    // (device, first point, point count) of slice i
+    std::array<size_t, 3> shard(int i) const {
+        int dev = 0;
+        size_t first = 0, count = 0;
+        check(lurk_hip_msm_multi_shard(ctx_, i, &dev, &first, &count));
+        return {(size_t)dev, first, count};
+    }
+
+  private:
+    int curve_;
+    lurk_hip_msm_multi* ctx_ = nullptr;
+};
+
 // R1CS shape resident on the GPU: the arithmetic of one folding step between its two commitments
 // (arecibo R1CSShape::multiply_vec / commit_T's cross term / RelaxedR1CSWitness::fold, as reached from
 // /root/reference/src/proof/nova.rs:291-293).  Matrices as arecibo's SparseMatrix {data, indices, indptr}.

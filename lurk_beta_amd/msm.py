@@ -107,3 +107,58 @@ class CommitmentKey:
             self.close()
         except Exception:
             pass
+
+
+class MultiCommitmentKey:
+    """``lurk_hip_msm_multi_*``: one process, a list of devices.  The key is cut into ``len(devices)`` contiguous
+    slices (slice i resident on ``devices[i]``); ``commit`` runs the slices concurrently inside the library (one host
+    thread per device) and sums the 96-byte partial commitments on the host.  This is the form a single-process
+    prover binds (/root/reference/src/proof/nova.rs:304-326); ``distributed.ShardedCommitmentKey`` is the
+    one-process-per-GPU form of the same sharding."""
+
+    def __init__(self, curve: int, bases: np.ndarray, devices, precompute: bool = False, window_bits: int = 0):
+        lib = _lib.load()
+        self.curve = curve
+        bases = np.ascontiguousarray(bases, dtype=np.uint64)
+        self.n = bases.size // 8
+        self.devices = list(devices)
+        devs = (ctypes.c_int * len(self.devices))(*self.devices)
+        flags = (1 if precompute else 0) | ((window_bits & 0xFF) << 8)
+        self._ctx = ctypes.c_void_p()
+        _lib.check(lib.lurk_hip_msm_multi_create(ctypes.byref(self._ctx), curve, _lib.ptr(bases), self.n, devs, len(self.devices), flags))
+
+    def shards(self) -> list[tuple[int, int, int]]:
+        """(device, first point, count) per slice."""
+        lib = _lib.load()
+        out = []
+        for i in range(lib.lurk_hip_msm_multi_num_shards(self._ctx)):
+            d, f, c = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(lib.lurk_hip_msm_multi_shard(self._ctx, i, ctypes.byref(d), ctypes.byref(f), ctypes.byref(c)))
+            out.append((d.value, f.value, c.value))
+        return out
+
+    def commit(self, scalars: np.ndarray, is_mont: bool = False) -> np.ndarray:
+        lib = _lib.load()
+        scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.lurk_hip_msm_multi_commit(self._ctx, _lib.ptr(out), _lib.ptr(scalars), scalars.size // 4, int(is_mont)))
+        return out
+
+    def commit_device(self, d_slices, n: int, is_mont: bool = False) -> np.ndarray:
+        """``d_slices[i]``: slice i's scalars resident on slice i's device (torch tensors or raw pointers)."""
+        lib = _lib.load()
+        ptrs = (ctypes.c_void_p * len(d_slices))(*[_lib.ptr(x) for x in d_slices])
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.lurk_hip_msm_multi_commit_dev(self._ctx, _lib.ptr(out), ptrs, n, int(is_mont)))
+        return out
+
+    def close(self):
+        if self._ctx:
+            _lib.load().lurk_hip_msm_multi_destroy(self._ctx)
+            self._ctx = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -83,6 +83,28 @@ int main() {
         check(lurk_hip_msm_pallas(&oneshot, ck.data(), 64, a.data(), 0));
         EXPECT(key.to_affine(oneshot) == key.to_affine(ca));  // ctx path == pasta-msm-shaped path
     }
+    // One process, several devices (here: the one GPU listed two and three times): slices of ck on each entry of the
+    // device list, partial commitments summed on the host == the single-context commitment; prefix commits that end
+    // inside the first slice, on a slice boundary and in the last slice.
+    for (bool pre : {false, true}) {
+        CommitmentKey key(LURK_CURVE_PALLAS, ck, pre);
+        std::vector<Fe> a(64);
+        for (int i = 0; i < 64; i++) a[i] = Fe(0x9e3779b97f4a7c15ull * (i + 1));
+        for (std::vector<int> devs : {std::vector<int>{0, 0}, std::vector<int>{0, 0, 0}, std::vector<int>{0}}) {
+            MultiCommitmentKey mk(LURK_CURVE_PALLAS, ck, devs, pre);
+            EXPECT(mk.num_shards() == (int)devs.size());
+            size_t covered = 0;
+            for (int i = 0; i < mk.num_shards(); i++) { auto sh = mk.shard(i); EXPECT(sh[0] == 0 && sh[1] == covered); covered += sh[2]; }
+            EXPECT(covered == 64);
+            for (size_t n : {(size_t)64, (size_t)5, (size_t)32, (size_t)44, (size_t)0}) {
+                std::vector<Fe> v(a.begin(), a.begin() + n);
+                EXPECT(key.to_affine(mk.commit(v, false)) == key.to_affine(key.commit(v, false)));
+            }
+        }
+        bool bad = false;  // a device id the box does not have
+        try { MultiCommitmentKey mk(LURK_CURVE_PALLAS, ck, {0, 1000}, pre); } catch (const std::runtime_error&) { bad = true; }
+        EXPECT(bad);
+    }
     // Device-resident fold over Pallas Fq.  Montgomery values are built from the Montgomery one with
     // the library's own fold (a + 1 * b): no host field arithmetic needed.
     {

@@ -102,12 +102,40 @@ def test_bad_arguments(hip):
         R1CSShape(1, 1, 2, 1, *[(np.array([1, 1], dtype=np.uint64), np.zeros(0, dtype=np.uint64), np.zeros((0, 4), dtype=np.uint64))] * 3)
 
 
-def test_folding_identity_at_step_circuit_size(hip):
-    """rc = 100 step-circuit size (~1.11 M constraints, ~0.91 M variables): fold a relaxed
-    instance with a strictly satisfied one on the GPU, then check (Az o Bz) = u Cz + E row by row."""
+def test_cross_term_two_streams_one_shape(hip):
+    """Calls on one shape keep no state outside their arguments: two cross terms with different (z1, z2) enqueued
+    back to back on two streams, several rounds, every result exact."""
+    import torch
+
+    f, m, nv, nio = 1, 60000, 50000, 2
+    A, B, Cm, z2 = C.synth_r1cs(f, m, nv, nio, seed=17)
+    sh = _shape(f, A, B, Cm, m, nv, nio)
+    zs = [C.synth_scalars(f, 80 + k, k % 2, nv + 1 + nio) for k in range(4)]
+    mats = [[C.spmv(f, *M, z) for M in (A, B, Cm)] for z in zs]
+    us = [C.limbs_to_ints(z[nv:nv + 1])[0] for z in zs]
+    pairs = [(0, 1), (2, 3)]
+    want = [C.cross_term(f, *mats[a], *mats[b], us[a], us[b]) for a, b in pairs]
+    d = [_dev(C.to_mont(f, z)) for z in zs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [torch.empty((m, 4), dtype=torch.int64, device="cuda") for _ in pairs]
+    torch.cuda.synchronize()
+    for _ in range(20):
+        for k, (a, b) in enumerate(pairs):
+            sh.cross_term(d[a], d[b], out=outs[k], stream=streams[k].cuda_stream)
+    torch.cuda.synchronize()
+    for k in range(2):
+        assert np.array_equal(C.from_mont(f, _host(outs[k])), want[k])
+    sh.close()
+
+
+@pytest.mark.parametrize("rc", [100, 900])
+def test_folding_identity_at_step_circuit_size(hip, rc):
+    """Step-circuit sizes of BASELINE configs[0] and [3] (rc = 100: ~1.11 M constraints, ~0.91 M variables; rc = 900:
+    ~10.0 M / ~8.2 M): fold a relaxed instance with a strictly satisfied one on the GPU, then check
+    (Az o Bz) = u Cz + E row by row."""
     from lurk_beta_amd import fold_vec
 
-    f, m, nv, nio = 1, 1114100, 911900, 2
+    f, m, nv, nio = 1, 11141 * rc, 9119 * rc, 2
     p = R.modulus(f)
     A, B, Cm, z2 = C.synth_r1cs(f, m, nv, nio, seed=13)
     sh = _shape(f, A, B, Cm, m, nv, nio)

@@ -96,63 +96,68 @@ def test_edge_cases(hip, cn, c):
     assert point_to_affine(c, msm(c, B3, S3)) == C.jac_to_affine(c, C.msm_naive(c, B3, S3))
 
 
+@pytest.mark.parametrize("cn,c", CURVES)
 @pytest.mark.parametrize("dist", [0, 1])
 @pytest.mark.parametrize("log_n", [14, 16])
-def test_medium_msm_matches_oracle_pippenger(hip, dist, log_n):
+def test_medium_msm_matches_oracle_pippenger(hip, cn, c, dist, log_n):
     from lurk_beta_amd import msm, point_to_affine
 
     n = 1 << log_n
-    B = C.synth_bases(0, n)
-    S = C.synth_scalars(1, 1, dist, n)
-    assert point_to_affine(0, msm(0, B, S)) == C.jac_to_affine(0, C.msm_pippenger(0, B, S))
+    B = C.synth_bases(c, n)
+    S = C.synth_scalars(_sf(c), 1, dist, n)
+    assert point_to_affine(c, msm(c, B, S)) == C.jac_to_affine(c, C.msm_pippenger(c, B, S))
 
 
-def test_commitment_key_prefix_and_precompute(hip):
+@pytest.mark.parametrize("cn,c", CURVES)
+def test_commitment_key_prefix_and_precompute(hip, cn, c):
     """CE::commit(ck, v) uses ck[..v.len()]; the precomputed-table context must agree bit for bit."""
     from lurk_beta_amd import CommitmentKey, point_to_affine
 
     n = 4096
-    B = C.synth_bases(0, n)
-    ck = CommitmentKey(0, B)
-    ckp = CommitmentKey(0, B, precompute=True)
-    ckw = {c: CommitmentKey(0, B, precompute=True, window_bits=c) for c in (16, 17, 19, 20)}
+    sf = _sf(c)
+    B = C.synth_bases(c, n)
+    ck = CommitmentKey(c, B)
+    ckp = CommitmentKey(c, B, precompute=True)
+    ckw = {w: CommitmentKey(c, B, precompute=True, window_bits=w) for w in (16, 17, 19, 20)}
     for m, dist in ((n, 0), (n, 1), (1000, 0), (1, 0), (0, 0)):
-        S = C.synth_scalars(1, 3, dist, m)
-        want = C.jac_to_affine(0, C.msm_pippenger(0, B[:m], S)) if m else (0, 0)
-        assert point_to_affine(0, ck.commit(S)) == want, (m, dist)
-        assert point_to_affine(0, ckp.commit(S)) == want, ("precompute", m, dist)
-        for c, k in ckw.items():
-            assert point_to_affine(0, k.commit(S)) == want, ("precompute", c, m, dist)
-        assert point_to_affine(0, ck.commit(C.to_mont(1, S), is_mont=True)) == want
+        S = C.synth_scalars(sf, 3, dist, m)
+        want = C.jac_to_affine(c, C.msm_pippenger(c, B[:m], S)) if m else (0, 0)
+        assert point_to_affine(c, ck.commit(S)) == want, (m, dist)
+        assert point_to_affine(c, ckp.commit(S)) == want, ("precompute", m, dist)
+        for w, k in ckw.items():
+            assert point_to_affine(c, k.commit(S)) == want, ("precompute", w, m, dist)
+        assert point_to_affine(c, ck.commit(C.to_mont(sf, S), is_mont=True)) == want
     # scalars that stress the signed-digit recoding at every window width
-    q = R.PALLAS_Q
+    q = R.CURVES[cn]["order"]
     edge = [0, 1, q - 1, (1 << 254) | 0xFFFFF, int("f" * 63, 16) % q, 1 << 19, (1 << 19) + 1, (1 << 17) + 1, 0x80000, 0x7FFFF]
     S = C.ints_to_limbs(edge)
-    want = C.jac_to_affine(0, C.msm_naive(0, B[: len(edge)], S))
+    want = C.jac_to_affine(c, C.msm_naive(c, B[: len(edge)], S))
     for k in [ck, ckp] + list(ckw.values()):
-        assert point_to_affine(0, k.commit(S)) == want
+        assert point_to_affine(c, k.commit(S)) == want
     for k in ckw.values():
         k.close()
     from lurk_beta_amd import LurkHipError
 
     with pytest.raises(LurkHipError):
-        ck.commit(C.synth_scalars(1, 3, 0, n + 1))
+        ck.commit(C.synth_scalars(sf, 3, 0, n + 1))
     ck.close()
     ckp.close()
 
 
-def test_async_slots(hip):
+@pytest.mark.parametrize("cn,c", CURVES)
+def test_async_slots(hip, cn, c):
     """submit/wait: three commitments in flight on one context give the same bytes as the synchronous call."""
     import torch
 
     from lurk_beta_amd import CommitmentKey, LurkHipError, point_to_affine, synth
 
     n = 1 << 14
-    d_bases = synth.bases(0, n)
-    scal = [synth.scalars(1, 10 + j, j % 2, n, mont=True) for j in range(5)]
+    d_bases = synth.bases(c, n)
+    scal = [synth.scalars(_sf(c), 10 + j, j % 2, n, mont=True) for j in range(5)]
     torch.cuda.synchronize()
+    want0 = C.jac_to_affine(c, C.msm_pippenger(c, C.synth_bases(c, n), C.synth_scalars(_sf(c), 10, 0, n)))
     for pre in (False, True):
-        ck = CommitmentKey(0, d_bases, n=n, device=True, precompute=pre)
+        ck = CommitmentKey(c, d_bases, n=n, device=True, precompute=pre)
         want = [ck.commit_device(sc, n, is_mont=True) for sc in scal]
         got = [None] * 5
         for j in range(5):
@@ -163,7 +168,8 @@ def test_async_slots(hip):
         for j in range(2, 5):
             got[j] = ck.wait(j % 3)
         for a, b in zip(got, want):
-            assert point_to_affine(0, a) == point_to_affine(0, b)
+            assert point_to_affine(c, a) == point_to_affine(c, b)
+        assert point_to_affine(c, got[0]) == want0
         with pytest.raises(LurkHipError):
             ck.wait(0)  # nothing pending
         ck.submit_device(1, scal[0], n, is_mont=True)
@@ -183,9 +189,10 @@ def test_point_sum(hip):
     assert point_to_affine(0, point_sum(0, parts)) == C.jac_to_affine(0, C.msm_pippenger(0, B, S))
 
 
-@pytest.mark.parametrize("log_n,dist,precompute", [(20, 0, False), (20, 1, False), (20, 1, True), (22, 0, False), (22, 1, True), (22, 0, True),
-                                                   (23, 0, True), (23, 1, False)])
-def test_full_size_dlog_checksum(hip, log_n, dist, precompute):
+@pytest.mark.parametrize("c,log_n,dist,precompute", [(0, 20, 0, False), (0, 20, 1, False), (0, 20, 1, True), (0, 22, 0, False), (0, 22, 1, True),
+                                                     (0, 22, 0, True), (0, 23, 0, True), (0, 23, 1, False),
+                                                     (1, 20, 0, False), (1, 20, 1, True), (1, 22, 0, True), (1, 22, 1, False)])
+def test_full_size_dlog_checksum(hip, c, log_n, dist, precompute):
     """BASELINE.json sizes (2^20, 2^22) and one size beyond (2^23: the rc = 900 step circuit, where the partitions
     of sort pass 2 no longer fit their LDS stage and take the direct-scatter path): inputs generated in HBM, result
     checked bit-exactly by the size-independent identity  sum_i s_i [k_i]G = [sum_i s_i k_i mod q] G."""
@@ -194,16 +201,78 @@ def test_full_size_dlog_checksum(hip, log_n, dist, precompute):
     from lurk_beta_amd import CommitmentKey, point_to_affine, synth
 
     n = 1 << log_n
-    d_bases = synth.bases(0, n)
-    d_scalars = synth.scalars(1, 1, dist, n, mont=True)
+    sf = _sf(c)
+    d_bases = synth.bases(c, n)
+    d_scalars = synth.scalars(sf, 1, dist, n, mont=True)
     torch.cuda.synchronize()
-    ck = CommitmentKey(0, d_bases, n=n, device=True, precompute=precompute)
-    got = point_to_affine(0, ck.commit_device(d_scalars, n, is_mont=True))
-    k = C.synth_base_scalars(0, n)
-    s = C.synth_scalars(1, 1, dist, n)
-    want = C.jac_to_affine(0, C.gen_mul(0, C.dot(1, k, s)))
+    ck = CommitmentKey(c, d_bases, n=n, device=True, precompute=precompute)
+    got = point_to_affine(c, ck.commit_device(d_scalars, n, is_mont=True))
+    k = C.synth_base_scalars(c, n)
+    s = C.synth_scalars(sf, 1, dist, n)
+    want = C.jac_to_affine(c, C.gen_mul(c, C.dot(sf, k, s)))
     assert got == want
     ck.close()
+
+
+@pytest.mark.parametrize("cn,c", CURVES)
+def test_oneshot_pasta_msm_entry_point_at_2_20(hip, cn, c):
+    """The literal drop-in symbols lurk_hip_msm_{pallas,vesta}(out, points, npoints, scalars, is_mont) - what an
+    unmodified arecibo binds instead of pasta-msm's mult_pippenger_* - with HOST buffers at BASELINE configs[1]'s
+    size, checked by the discrete-log checksum."""
+    from lurk_beta_amd import msm, point_to_affine, synth
+
+    n = 1 << 20
+    sf = _sf(c)
+    B = synth.bases(c, n).cpu().numpy().view(np.uint64)
+    S = C.to_mont(sf, C.synth_scalars(sf, 1, 1, n))
+    got = point_to_affine(c, msm(c, B, S, is_mont=True))
+    want = C.jac_to_affine(c, C.gen_mul(c, C.dot(sf, C.synth_base_scalars(c, n), C.synth_scalars(sf, 1, 1, n))))
+    assert got == want
+
+
+@pytest.mark.parametrize("cn,c", CURVES)
+def test_multi_device_key_one_process(hip, cn, c):
+    """lurk_hip_msm_multi_*: one process, a device list (the single GPU of this box listed 2 and 3 times), slices of
+    the key on every list entry, partials summed on the host == the oracle; host-pointer and device-pointer commits,
+    prefix commits ending inside each slice, plain and table keys."""
+    import torch
+
+    from lurk_beta_amd import LurkHipError, MultiCommitmentKey, point_to_affine
+
+    n = 10007
+    sf = _sf(c)
+    B = C.synth_bases(c, n)
+    S = C.synth_scalars(sf, 41, 1, n)
+    for devices, pre in (([0, 0], False), ([0, 0, 0], True), ([0], False)):
+        mk = MultiCommitmentKey(c, B, devices, precompute=pre)
+        sh = mk.shards()
+        assert [d for d, _, _ in sh] == devices and sh[0][1] == 0 and sum(cnt for _, _, cnt in sh) == n
+        assert all(sh[i][1] + sh[i][2] == sh[i + 1][1] for i in range(len(sh) - 1))
+        for m in (n, 17, sh[0][2], sh[0][2] + 1, n - 1, 0):
+            want = C.jac_to_affine(c, C.msm_pippenger(c, B[:m], S[:m])) if m else (0, 0)
+            assert point_to_affine(c, mk.commit(S[:m])) == want, (devices, pre, m)
+            assert point_to_affine(c, mk.commit(C.to_mont(sf, S[:m]), is_mont=True)) == want
+        d_slices = [torch.from_numpy(np.ascontiguousarray(C.to_mont(sf, S[f:f + cnt])).view(np.int64)).cuda() for _, f, cnt in sh]
+        torch.cuda.synchronize()
+        assert point_to_affine(c, mk.commit_device(d_slices, n, is_mont=True)) == C.jac_to_affine(c, C.msm_pippenger(c, B, S))
+        with pytest.raises(LurkHipError):
+            mk.commit(C.synth_scalars(sf, 41, 0, n + 1))
+        mk.close()
+    with pytest.raises(LurkHipError):
+        MultiCommitmentKey(c, B, [0, 4096])
+
+
+def test_multi_device_full_size(hip):
+    """2^22 points over the device list [0, 0] through the host-pointer commit, dlog checksum."""
+    from lurk_beta_amd import MultiCommitmentKey, point_to_affine, synth
+
+    n = 1 << 22
+    B = synth.bases(0, n).cpu().numpy().view(np.uint64)
+    S = C.synth_scalars(1, 1, 0, n)
+    mk = MultiCommitmentKey(0, B, [0, 0], precompute=True)
+    got = point_to_affine(0, mk.commit(C.to_mont(1, S), is_mont=True))
+    assert got == C.jac_to_affine(0, C.gen_mul(0, C.dot(1, C.synth_base_scalars(0, n), S)))
+    mk.close()
 
 
 def test_thread_safety(hip):
