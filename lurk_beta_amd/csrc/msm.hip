@@ -40,6 +40,20 @@ struct MsmShape {
     size_t n, stride;      // scalars in this call; table stride per window (0 in plain mode)
 };
 
+// Every kernel of a commitment except the bucket accumulation is short and bound by latency, LDS atomics or HBM; with
+// commitments in flight they share the SIMDs with the (older, VALU-saturating) accumulate waves of the previous
+// commitment, and the instruction arbiter serves the oldest wave first: measured 15-18x slowdowns of these kernels.
+// Raising their wave priority lets them issue when they are ready; they need a few percent of the VALU.
+__constant__ int msm_wave_prio[2] = {3, 3};  // [0] sort kernels, [1] plan / finalize / reduce kernels (experiment knob: LURK_MSM_SORT_PRIO, LURK_MSM_TAIL_PRIO)
+__device__ __forceinline__ void msm_set_wave_prio(int cls) {
+    switch (msm_wave_prio[cls]) {
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        default: break;
+    }
+}
+
 // ---- 1. digits ---------------------------------------------------------------------------
 // Both sweeps of sort pass 1 read the scalars themselves (32 B each) and recode them on the fly:
 // cheaper than materialising W digits per scalar (4 W bytes written once and read twice).
@@ -65,6 +79,7 @@ __device__ __forceinline__ uint32_t msm_key(const MsmShape& sh, uint32_t w, uint
 template <class SF>
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ block_hist,
                                                                      MsmShape sh, size_t chunk, int is_mont) {
+    msm_set_wave_prio(0);
     extern __shared__ uint32_t h[];  // [P]
     for (int p = threadIdx.x; p < sh.P; p += MSM_SORT_BLOCK) h[p] = 0;
     __syncthreads();
@@ -88,6 +103,7 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* 
 
 // block p: exclusive scan of partition p's counts over the MSM_NB1 pass-1 blocks
 __global__ __launch_bounds__(MSM_NB1) void msm_scan1_kernel(uint32_t* __restrict__ block_hist, uint32_t* __restrict__ part_cnt, int P) {
+    msm_set_wave_prio(0);
     __shared__ uint32_t sh[MSM_NB1];
     const int p = blockIdx.x, t = threadIdx.x;
     uint32_t v = block_hist[(size_t)t * P + p];
@@ -135,6 +151,7 @@ __device__ __forceinline__ uint32_t msm_block_scan(uint32_t v, uint32_t* scr, ui
 // single block: part_start[0..P] = exclusive scan of part_cnt
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part_start_kernel(const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ part_start,
                                                                           int P) {
+    msm_set_wave_prio(0);
     __shared__ uint32_t scr[32];
     const int PER = P / MSM_SORT_BLOCK;  // 2, 4 or 8 counters per thread
     const int t = threadIdx.x;
@@ -159,6 +176,7 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
                                                                         const uint32_t* __restrict__ block_off,
                                                                         const uint32_t* __restrict__ part_start, uint2* __restrict__ inter,
                                                                         MsmShape sh, size_t chunk, int is_mont) {
+    msm_set_wave_prio(0);
     extern __shared__ uint32_t lds[];
     const int P = sh.P, PER = P / MSM_SORT_BLOCK;
     uint32_t* goff = lds;          // [P] where this block's next entry of partition p goes
@@ -229,6 +247,7 @@ static size_t msm_scatter1_lds(int P, int W, int tile) { return (size_t)(3 * P +
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part2_kernel(const uint2* __restrict__ inter, const uint32_t* __restrict__ part_start,
                                                                      uint32_t* __restrict__ sorted, uint32_t* __restrict__ cnt,
                                                                      uint32_t* __restrict__ bucket_start, MsmShape sh, uint32_t cap) {
+    msm_set_wave_prio(0);
     extern __shared__ uint32_t lds[];  // [2^LB] counters, [32] scan scratch, [cap] staged output
     const int p = blockIdx.x, t = threadIdx.x;
     const uint32_t nbins = 1u << sh.LB, low_mask = nbins - 1u;
@@ -306,6 +325,7 @@ static size_t msm_part2_cap(int LB) { return (MSM_LDS_BYTES - (((size_t)1 << LB)
 // block g (group of MSM_GRP keys), 1024 threads x 32 keys: task starts inside the group + group total
 __global__ __launch_bounds__(1024) void msm_taskscan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ task_start,
                                                               uint32_t* __restrict__ group_tasks) {
+    msm_set_wave_prio(1);
     __shared__ uint32_t sh[1024];
     const int g = blockIdx.x, t = threadIdx.x;
     constexpr int PER = MSM_GRP / 1024;
@@ -343,6 +363,7 @@ __global__ __launch_bounds__(1024) void msm_taskscan_kernel(const uint32_t* __re
 }
 // exclusive scan of the per-group task totals (NG <= 16) -> group_task_base[0..NG]
 __global__ void msm_task_base_kernel(const uint32_t* __restrict__ group_tasks, uint32_t* __restrict__ group_task_base, int NG) {
+    msm_set_wave_prio(1);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint32_t run = 0;
         for (int g = 0; g < NG; g++) {
@@ -356,6 +377,7 @@ __global__ void msm_task_base_kernel(const uint32_t* __restrict__ group_tasks, u
 __global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bucket_start,
                                                           const uint32_t* __restrict__ task_start,
                                                           const uint32_t* __restrict__ group_task_base, int NG, uint2* __restrict__ task_info) {
+    msm_set_wave_prio(1);
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= group_task_base[NG]) return;
     int g = 0;
@@ -377,6 +399,7 @@ __global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restri
 // counted per wave with one ballot instead of one LDS atomic each.
 __global__ __launch_bounds__(1024) void msm_len_hist_kernel(const uint2* __restrict__ task_info, const uint32_t* __restrict__ group_task_base,
                                                               int NG, uint32_t* __restrict__ len_hist) {
+    msm_set_wave_prio(1);
     __shared__ uint32_t sh[MSM_S + 1];
     if (threadIdx.x <= MSM_S) sh[threadIdx.x] = 0;
     __syncthreads();
@@ -399,6 +422,7 @@ __global__ __launch_bounds__(1024) void msm_len_hist_kernel(const uint2* __restr
 }
 // len_hist -> start offset of each length class, longest first (single small block)
 __global__ void msm_len_scan_kernel(uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor) {
+    msm_set_wave_prio(1);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint32_t run = 0;
         for (int l = MSM_S; l >= 0; l--) {
@@ -410,6 +434,7 @@ __global__ void msm_len_scan_kernel(uint32_t* __restrict__ len_hist, uint32_t* _
 __global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __restrict__ task_info,
                                                                  const uint32_t* __restrict__ group_task_base, int NG,
                                                                  uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+    msm_set_wave_prio(1);
     __shared__ uint32_t sh_cnt[MSM_S + 1], sh_base[MSM_S + 1];
     const uint32_t ntasks = group_task_base[NG];
     for (uint32_t base = blockIdx.x * 1024u; base < ntasks; base += gridDim.x * 1024u) {
@@ -446,6 +471,33 @@ __global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __re
 template <class P>
 void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
                            const uint32_t* group_task_base, int NG, Xyzz<P>* partials, size_t nt, hipStream_t s);
+template <class P>
+void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
+                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, int waves_per_simd, bool r128,
+                                      hipStream_t s);
+
+// Tuning switches of the commitments-in-flight path (read once; the defaults are the measured best):
+// the accumulate kernel of a submitted commitment is persistent with ONE wave per SIMD, so that the accumulations of up to
+// three commitments in flight share every SIMD (three dependent mad chains keep the VALU issuing) and the short kernels of
+// the others always find registers and wave slots beside them.
+struct MsmTuning {
+    int persistent, waves, r128, prio, sort_prio, tail_prio;
+    MsmTuning() {
+        auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
+        persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);
+        waves = geti("LURK_MSM_ACC_WAVES", 1);
+        r128 = geti("LURK_MSM_ACC_R128", 0);
+        prio = geti("LURK_MSM_PRIO", 1);
+        sort_prio = geti("LURK_MSM_SORT_PRIO", 3);
+        tail_prio = geti("LURK_MSM_TAIL_PRIO", 3);
+        if (waves < 1) waves = 1;
+        if (waves > 8) waves = 8;
+    }
+};
+static const MsmTuning& msm_tuning() {
+    static const MsmTuning t;
+    return t;
+}
 
 // ---- 5. finalize ---------------------------------------------------------------------------
 template <class P>
@@ -454,6 +506,7 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const Xyzz<P>* __rest
                                                              const uint32_t* __restrict__ group_task_base, uint32_t NB,
                                                              Xyzz<P>* __restrict__ buckets, uint32_t* __restrict__ big_list,
                                                              uint32_t* __restrict__ big_count) {
+    msm_set_wave_prio(1);
     size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (key >= NB) return;
     uint32_t g = (uint32_t)(key / MSM_GRP), b = (uint32_t)(key % MSM_GRP);
@@ -488,6 +541,7 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __re
                                                                const uint32_t* __restrict__ task_start,
                                                                const uint32_t* __restrict__ group_task_base, Xyzz<P>* __restrict__ buckets,
                                                                const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count) {
+    msm_set_wave_prio(1);
     extern __shared__ uint4 lds_raw[];
     Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
     const uint32_t nbig = *big_count;
@@ -513,6 +567,7 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __re
 // level k: in[g][seg][0..k] (segments of 2^k items) -> out[g][seg/2][0..k+1]
 template <class P>
 __global__ __launch_bounds__(256) void msm_planes_kernel(const Xyzz<P>* __restrict__ in, Xyzz<P>* __restrict__ out, int k, int G, uint32_t B) {
+    msm_set_wave_prio(1);
     const size_t nseg_out = (size_t)B >> (k + 1);
     const size_t comps_out = (size_t)k + 2, comps_in = (size_t)k + 1;
     size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -529,10 +584,14 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const Xyzz<P>* __restri
     }
     out[id] = r;
 }
+// (A two-launch form - one workgroup running ten levels on 1024 buckets behind barriers, then one workgroup per key space for
+// the rest - was measured at 0.69 ms against 0.45 ms for the per-level launches: a level is one addition deep, and an addition
+// is fastest when its wave has a SIMD to itself, which only the chip-wide launches give.)
 // plain mode (c = 16): block g, 16 lanes: W_g = S + sum_k 2^k P_k by a tree-shaped Horner
 // (15 doublings + 5 additions deep)
 template <class P>
 __global__ __launch_bounds__(64) void msm_horner16_kernel(const Xyzz<P>* __restrict__ planes, Xyzz<P>* __restrict__ ws) {
+    msm_set_wave_prio(1);
     __shared__ uint4 lds_raw[16 * sizeof(Xyzz<P>) / 16];
     Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
     const int g = blockIdx.x, t = threadIdx.x;
@@ -602,14 +661,19 @@ struct MsmCtx : MsmCtxBase {
             task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, ws;
         Xyzz<P>* host_pts = nullptr;  // pinned: window sums or bit planes for the host tail
         size_t ws_n = 0;
-        hipStream_t stream = nullptr;
-        hipEvent_t ready = nullptr;
+        hipStream_t stream = nullptr;      // slot stream: sort, plan, finalize, reduce (high priority)
+        hipStream_t acc_stream = nullptr;  // the accumulate kernel alone (low priority)
+        hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
+        DevBuf cursor;                     // task cursor of the persistent accumulate kernel
         bool pending = false;
         size_t pending_n = 0;
         ~Work() {
             if (host_pts) (void)hipHostFree(host_pts);
             if (stream) (void)hipStreamDestroy(stream);
+            if (acc_stream) (void)hipStreamDestroy(acc_stream);
             if (ready) (void)hipEventDestroy(ready);
+            if (planned) (void)hipEventDestroy(planned);
+            if (accumulated) (void)hipEventDestroy(accumulated);
         }
     };
     Work work[MSM_SLOTS];
@@ -641,6 +705,10 @@ struct MsmCtx : MsmCtxBase {
     }
 
     void set_bases_device(const void* d_bases, size_t n, bool copy, bool precompute, int c_override, hipStream_t s) {
+        {
+            const int pr[2] = {msm_tuning().sort_prio, msm_tuning().tail_prio};
+            LURK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(msm_wave_prio), pr, sizeof(pr)));
+        }
         npoints = n;
         precomputed = precompute;
         // plain: 16-bit windows (W = 16 key spaces of 2^15 buckets).  With the table every window shares
@@ -694,6 +762,7 @@ struct MsmCtx : MsmCtxBase {
         wk.buckets.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
         wk.big_list.ensure((size_t)sh.NB * 4);
         wk.big_count.ensure(16);
+        wk.cursor.ensure(16);
         wk.planes_a.ensure((size_t)sh.NB * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
         wk.planes_b.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
         wk.ws.ensure(32 * sizeof(Xyzz<P>));
@@ -702,7 +771,8 @@ struct MsmCtx : MsmCtxBase {
     }
 
     // every kernel of one commitment + the D2H of its <= 20 result points, on stream s
-    void enqueue(Work& wk, const void* d_scalars, size_t n, int is_mont, hipStream_t s) {
+    // s_acc: stream of the accumulate kernel (nullptr: same stream, classic launch)
+    void enqueue(Work& wk, const void* d_scalars, size_t n, int is_mont, hipStream_t s, hipStream_t s_acc = nullptr) {
         const MsmShape sh = shape(n);
         ensure_workspace(wk, sh);
         const size_t chunk = (n + MSM_NB1 - 1) / MSM_NB1;
@@ -743,7 +813,26 @@ struct MsmCtx : MsmCtxBase {
             hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
                                wk.group_task_base.template as<uint32_t>(), sh.NG, lh + MSM_S + 1, wk.task_order.template as<uint32_t>());
         }
-        {
+        if (s_acc) {
+            const MsmTuning& tn = msm_tuning();
+            LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4, s));
+            LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
+            LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, wk.planned, 0));
+            {
+                ProfScope ps("msm_accumulate", s_acc);
+                if (tn.persistent)
+                    msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
+                                                        wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
+                                                        wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(), tn.waves, tn.r128 != 0,
+                                                        s_acc);
+                else
+                    msm_launch_accumulate<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
+                                             wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
+                                             wk.partials.template as<Xyzz<P>>(), nt, s_acc);
+            }
+            LURK_HIP_CHECK(hipEventRecord(wk.accumulated, s_acc));
+            LURK_HIP_CHECK(hipStreamWaitEvent(s, wk.accumulated, 0));
+        } else {
             ProfScope ps("msm_accumulate", s);
             msm_launch_accumulate<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
                                      wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
@@ -755,7 +844,7 @@ struct MsmCtx : MsmCtxBase {
                                wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), sh.NB, wk.buckets.template as<Xyzz<P>>(),
                                wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>());
-            hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(512), dim3(256), 256 * sizeof(Xyzz<P>), s, wk.partials.template as<Xyzz<P>>(),
+            hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(128), dim3(256), 256 * sizeof(Xyzz<P>), s, wk.partials.template as<Xyzz<P>>(),
                                wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), wk.buckets.template as<Xyzz<P>>(),
                                wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>());
@@ -810,14 +899,22 @@ struct MsmCtx : MsmCtxBase {
         std::lock_guard<std::mutex> lk(wk.mu);
         LURK_REQUIRE(!wk.pending, "slot is busy: wait for it first");
         if (!wk.stream) {
-            LURK_HIP_CHECK(hipStreamCreateWithFlags(&wk.stream, hipStreamNonBlocking));
+            // the throughput-bound accumulate kernel runs on its own low-priority stream, everything else of the slot on a
+            // high-priority one: the short kernels of the next commitment are dispatched ahead of it as wave slots free up
+            int least = 0, greatest = 0;
+            LURK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const bool prio = msm_tuning().prio != 0;
+            LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.stream, hipStreamNonBlocking, prio ? greatest : 0));
+            LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.acc_stream, hipStreamNonBlocking, prio ? least : 0));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.ready, hipEventDisableTiming));
+            LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.planned, hipEventDisableTiming));
+            LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.accumulated, hipEventDisableTiming));
         }
         if (n) {
             // the scalars were produced on the caller's stream: order the slot stream after it
             LURK_HIP_CHECK(hipEventRecord(wk.ready, after));
             LURK_HIP_CHECK(hipStreamWaitEvent(wk.stream, wk.ready, 0));
-            enqueue(wk, d_scalars, n, is_mont, wk.stream);
+            enqueue(wk, d_scalars, n, is_mont, wk.stream, wk.acc_stream);
         }
         wk.pending = true;
         wk.pending_n = n;

@@ -17,12 +17,9 @@ namespace lurk {
 constexpr int MSM_ACC_BLOCK = 256;
 
 template <class P>
-__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
-                                                                         const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
-                                                                         const uint32_t* __restrict__ group_task_base, int NG,
-                                                                         Xyzz<P>* __restrict__ partials) {
-    uint32_t i = blockIdx.x * MSM_ACC_BLOCK + threadIdx.x;
-    if (i >= group_task_base[NG]) return;
+__device__ __forceinline__ void msm_accumulate_task(uint32_t i, const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
+                                                    const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
+                                                    Xyzz<P>* __restrict__ partials) {
     uint32_t t = order[i];
     uint2 ti = task_info[t];
 #if LURK_ACC_RADIX29
@@ -32,6 +29,47 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uin
 #endif
 }
 
+// One launch covers every task (the hardware dispatcher balances the workgroups).
+template <class P>
+__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
+                                                                         const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
+                                                                         const uint32_t* __restrict__ group_task_base, int NG,
+                                                                         Xyzz<P>* __restrict__ partials) {
+    uint32_t i = blockIdx.x * MSM_ACC_BLOCK + threadIdx.x;
+    if (i >= group_task_base[NG]) return;
+    msm_accumulate_task<P>(i, sorted, table, task_info, order, partials);
+}
+
+// Persistent form for commitments in flight: a fixed number of waves per SIMD (the launch grid), each wave pulls the next
+// 64 tasks of the longest-first order from a global cursor.  The kernel then never holds more than its share of every
+// SIMD's registers and wave slots, so the latency / HBM-bound kernels of the NEXT commitment (sort, plan, bucket
+// reduction: other stream, higher priority) find room on every CU while this one keeps the integer VALU busy.
+#define LURK_ACC_PERSISTENT_BODY                                                                                       \
+    const uint32_t ntasks = group_task_base[NG];                                                                       \
+    const uint32_t lane = threadIdx.x & 63u;                                                                           \
+    for (;;) {                                                                                                         \
+        uint32_t base = 0;                                                                                             \
+        if (lane == 0) base = atomicAdd(cursor, 64u);                                                                  \
+        base = __shfl(base, 0);                                                                                        \
+        if (base >= ntasks) break;                                                                                     \
+        if (base + lane < ntasks) msm_accumulate_task<P>(base + lane, sorted, table, task_info, order, partials);      \
+    }
+template <class P>
+__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_persistent_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
+                                                                                    const uint2* __restrict__ task_info,
+                                                                                    const uint32_t* __restrict__ order,
+                                                                                    const uint32_t* __restrict__ group_task_base, int NG,
+                                                                                    Xyzz<P>* __restrict__ partials, uint32_t* __restrict__ cursor) {
+    LURK_ACC_PERSISTENT_BODY
+}
+// same, compiled for <= 128 VGPRs (4 waves per SIMD of register budget): two of its waves and four 64-register waves of a
+// 1024-thread sort workgroup fit one SIMD's 512 registers together
+template <class P>
+__global__ __launch_bounds__(MSM_ACC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void msm_accumulate_persistent128_kernel(
+    const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table, const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
+    const uint32_t* __restrict__ group_task_base, int NG, Xyzz<P>* __restrict__ partials, uint32_t* __restrict__ cursor) {
+    LURK_ACC_PERSISTENT_BODY
+}
 
 template <class P>
 void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
@@ -39,9 +77,25 @@ void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const
     hipLaunchKernelGGL((msm_accumulate_kernel<P>), dim3(div_up(nt, MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
                        group_task_base, NG, partials);
 }
-template void msm_launch_accumulate<PallasFp>(const uint32_t*, const Affine<PallasFp>*, const uint2*, const uint32_t*, const uint32_t*, int,
-                                              Xyzz<PallasFp>*, size_t, hipStream_t);
-template void msm_launch_accumulate<PallasFq>(const uint32_t*, const Affine<PallasFq>*, const uint2*, const uint32_t*, const uint32_t*, int,
-                                              Xyzz<PallasFq>*, size_t, hipStream_t);
+// waves_per_simd workgroups of 4 waves per CU; cursor must be zero when the kernel starts
+template <class P>
+void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
+                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, int waves_per_simd, bool r128,
+                                      hipStream_t s) {
+    const unsigned blocks = (unsigned)num_cus() * (unsigned)waves_per_simd;
+    if (r128)
+        hipLaunchKernelGGL((msm_accumulate_persistent128_kernel<P>), dim3(blocks), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
+                           group_task_base, NG, partials, cursor);
+    else
+        hipLaunchKernelGGL((msm_accumulate_persistent_kernel<P>), dim3(blocks), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
+                           group_task_base, NG, partials, cursor);
+}
+#define LURK_ACC_INSTANTIATE(P)                                                                                                             \
+    template void msm_launch_accumulate<P>(const uint32_t*, const Affine<P>*, const uint2*, const uint32_t*, const uint32_t*, int, Xyzz<P>*, \
+                                           size_t, hipStream_t);                                                                            \
+    template void msm_launch_accumulate_persistent<P>(const uint32_t*, const Affine<P>*, const uint2*, const uint32_t*, const uint32_t*, int, \
+                                                      Xyzz<P>*, uint32_t*, int, bool, hipStream_t);
+LURK_ACC_INSTANTIATE(PallasFp)
+LURK_ACC_INSTANTIATE(PallasFq)
 
 }  // namespace lurk
