@@ -152,6 +152,36 @@ int lurk_hip_poseidon_tree8_dev(int field_id, const void* d_leaves, size_t n_lea
  * (arity+1)^2; pass NULL to query sizes only */
 int lurk_hip_poseidon_constants(int field_id, int arity, int* rf, int* rp, void* rc, void* mds);
 
+/* ---- slot witnesses: the Poseidon / bit-decomposition part of the witness vector, produced on the device ------------
+ * Replaces generate_slots_witnesses (/root/reference/src/lem/multiframe.rs:520-592), which runs allocate_slot
+ * (/root/reference/src/lem/circuit.rs:242-315) on a WitnessCS per slot: neptune's circuit2::poseidon_hash_allocated for
+ * the Hash4 / Hash6 / Hash8 / Commitment slots (circuit.rs:212-235) and bellpepper's to_bits_le_strict for the BitDecomp
+ * slots (circuit.rs:236-238).  A slot's block in W is, in the circuit's allocation order,
+ *     hash slots:  [preimage (arity) | l^2, l^4, l^5 + key for every S-box | digest]
+ *     bit decomp:  [value | bits of the value from the top, with the AND chain closing every run of 1-bits of p - 1]
+ * as 32-byte Montgomery values: about 85 % of the step circuit's W (7 808 of 9 119 aux per frame on BN254,
+ * /root/reference/src/lem/eval.rs:1960-1966).  With these W is assembled in HBM - [globals | frame 0 | frame 1 | ...],
+ * each frame = its slots' blocks back to back, then the rest of the frame's aux (multiframe.rs:699-702,
+ * circuit.rs:1429-1433) - and handed to lurk_hip_msm_ctx_submit_dev / lurk_hip_r1cs_cross_term_dev without crossing PCIe.
+ * slot_type: the arity for hash slots (LURK_SLOT_COMMITMENT = 3, HASH4 = 4, HASH6 = 6, HASH8 = 8) or LURK_SLOT_BIT_DECOMP. */
+#define LURK_SLOT_BIT_DECOMP 1
+#define LURK_SLOT_COMMITMENT 3
+#define LURK_SLOT_HASH4 4
+#define LURK_SLOT_HASH6 6
+#define LURK_SLOT_HASH8 8
+/* elements per slot block = compute_witness_size (multiframe.rs:503-516); host-only, needs no device */
+int lurk_hip_slot_witness_size(int field_id, int slot_type, size_t* size);
+/* n slots of one type: preimages n x (arity | 1) x 32 B (Montgomery if preimages_mont, else canonical); slot i's block is
+ * written at element d_w[d_offsets[i]] (device array) or, with d_offsets == NULL, at d_w[first + i * stride] */
+int lurk_hip_slot_witness_dev(int field_id, int slot_type, const void* d_preimages, size_t n, int preimages_mont, void* d_w,
+                              const uint64_t* d_offsets, size_t first, size_t stride, void* stream);
+/* host buffers in and out, blocks back to back (n x size x 32 B): small inputs and tests */
+int lurk_hip_slot_witness(int field_id, int slot_type, const void* preimages, size_t n, int preimages_mont, void* w_out);
+/* places n_blocks packed blocks of block_len elements (host or device memory) at d_w[first + b * stride]: the globals and
+ * the non-slot remainder of every frame, which the CPU synthesis still produces */
+int lurk_hip_witness_blocks_dev(void* d_w, size_t first, size_t stride, const void* src, int src_on_host, size_t n_blocks,
+                                size_t block_len, void* stream);
+
 /* ---- NTT ---------------------------------------------------------------------------------
  * No reference counterpart: radix-2 NTT over a Pasta field, natural order in
  * and out, omega = 5^((p-1)/2^32)^(2^(32-log_n)); inverse includes the 1/n scaling. */

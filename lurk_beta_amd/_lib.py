@@ -52,6 +52,10 @@ SIGNATURES = {
     "lurk_hip_poseidon_tree8": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_poseidon_tree8_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_poseidon_constants": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p]),
+    "lurk_hip_slot_witness_size": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
+    "lurk_hip_slot_witness_dev": (c_int, [c_int, c_int, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "lurk_hip_slot_witness": (c_int, [c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_witness_blocks_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_int, c_size_t, c_size_t, c_void_p]),
     "lurk_hip_ntt": (c_int, [c_int, c_void_p, c_uint, c_int]),
     "lurk_hip_ntt_dev": (c_int, [c_int, c_void_p, c_uint, c_int, c_void_p]),
     "lurk_hip_r1cs_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_size_t, c_size_t, c_size_t] + [c_void_p] * 9),

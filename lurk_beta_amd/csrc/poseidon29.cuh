@@ -96,6 +96,43 @@ LURK_HD void poseidon29_permute(F29<P>* s, const uint32_t* img, int rf, int rp) 
         poseidon29_full_round<P, T>(s, r == 0 ? img + L.after() * P29_STRIDE : img + (L.rc2() + (r - 1) * T) * P29_STRIDE, mds);
 }
 
+// The same permutation with the circuit's S-box witnesses handed to `emit(sbox, l2, l4, l5k)` (lazy radix-2^29 values):
+// sbox = position of the S-box in circuit order, l2 = l^2, l4 = l^4, l5k = l^5 + post key (neptune circuit2 allocates
+// exactly these three per S-box).  post: the post keys, one image record per S-box.
+template <class P, class E>
+LURK_HD F29<P> f29_pow5_trace(const F29<P>& l, const uint32_t* post, int sbox, E& emit) {
+    const F29<P> l2 = f29_sqr<P>(l);
+    const F29<P> l4 = f29_sqr<P>(l2);
+    const F29<P> l5 = f29_mul<P>(l4, l);
+    emit(sbox, l2, l4, f29_add<P>(l5, ld_const29<P>(post + (size_t)sbox * P29_STRIDE)));
+    return l5;
+}
+template <class P, int T, class E>
+LURK_HD void poseidon29_permute_trace(F29<P>* s, const uint32_t* img, const uint32_t* post, int rf, int rp, E& emit) {
+    const PoseidonLayout<T> L(rf, rp);
+    const uint32_t* mds = img + L.mds() * P29_STRIDE;
+    int sbox = 0;
+    auto full_round = [&](const uint32_t* rc, const uint32_t* mat) {
+        for (int i = 0; i < T; i++) s[i] = f29_pow5_trace<P>(f29_carry<P>(f29_add<P>(s[i], ld_const29<P>(rc + i * P29_STRIDE))), post, sbox++, emit);
+        poseidon29_dense<P, T>(s, mat);
+    };
+    for (int r = 0; r < L.h; r++) full_round(img + (L.rc1() + r * T) * P29_STRIDE, r == L.h - 1 ? img + L.pre() * P29_STRIDE : mds);
+    for (int p = 0; p < rp; p++) {
+        const uint32_t* sp = img + (L.sp() + p * (2 * T - 1)) * P29_STRIDE;
+        F29<P> x = f29_pow5_trace<P>(f29_carry<P>(f29_add<P>(s[0], ld_const29<P>(img + (L.pk() + p) * P29_STRIDE))), post, sbox++, emit);
+        Dot29<P> A;
+        dot29_init<P>(A);
+        dot29_mac<P>(A, x, ld_const29<P>(sp));
+        for (int i = 1; i < T; i++) {
+            if (T > 5 && i == 4) dot29_carry<P>(A);
+            dot29_mac<P>(A, s[i], ld_const29<P>(sp + i * P29_STRIDE));
+            s[i] = f29_carry<P>(f29_add<P>(s[i], f29_mul<P>(x, ld_const29<P>(sp + (T - 1 + i) * P29_STRIDE))));
+        }
+        s[0] = dot29_finish<P>(A);
+    }
+    for (int r = 0; r < L.h; r++) full_round(r == 0 ? img + L.after() * P29_STRIDE : img + (L.rc2() + (r - 1) * T) * P29_STRIDE, mds);
+}
+
 // plain canonical value (8 x 32) -> state element; mont2 = the image's last element (2^522 mod p)
 template <class P>
 LURK_HD F29<P> poseidon29_from_canonical(const uint32_t* x, const uint32_t* mont2) {
@@ -117,10 +154,11 @@ LURK_HD Fe<P> poseidon29_to_canonical(const F29<P>& a) {
 }
 
 // host: re-express the 8 x 32 image (canonical Montgomery-2^256 elements) in the radix-2^29 form
+// extra256: further canonical Montgomery-2^256 elements appended AFTER the 2^522 record (the trace kernels' post keys)
 template <class P>
-std::vector<uint32_t> poseidon29_image(const std::vector<uint32_t>& img256) {
-    const size_t n = img256.size() / 8;
-    std::vector<uint32_t> out((n + 1) * P29_STRIDE, 0u);
+std::vector<uint32_t> poseidon29_image(const std::vector<uint32_t>& img256, const std::vector<uint32_t>& extra256 = {}) {
+    const size_t n = img256.size() / 8, m = extra256.size() / 8;
+    std::vector<uint32_t> out((n + 1 + m) * P29_STRIDE, 0u);
     auto put = [&](size_t e, const Fe<P>& v) {  // v: canonical value to be stored as plain limbs
         F29<P> f = f29_from_plain<P>(v.l);
         for (int i = 0; i < 9; i++) out[e * P29_STRIDE + i] = f.l[i];
@@ -135,6 +173,12 @@ std::vector<uint32_t> poseidon29_image(const std::vector<uint32_t>& img256) {
     Fe<P> v = fe_one<P>();                       // 2^256 mod p as a plain integer
     for (int d = 0; d < 522 - 256; d++) v = fe_add<P>(v, v);
     put(n, v);
+    for (size_t e = 0; e < m; e++) {
+        Fe<P> x;
+        for (int i = 0; i < 8; i++) x.l[i] = extra256[e * 8 + i];
+        for (int d = 0; d < 5; d++) x = fe_add<P>(x, x);
+        put(n + 1 + e, x);
+    }
     return out;
 }
 

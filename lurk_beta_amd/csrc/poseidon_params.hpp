@@ -241,6 +241,51 @@ PoseidonParams<P> make_poseidon_params(int arity) {
     return pp;
 }
 
+// neptune's `compressed_round_constants` re-expressed as ONE post-S-box key per S-box in circuit order (what
+// circuit2::poseidon_hash_allocated adds to l^5 before it allocates the S-box output): S-box
+// number r*t + e for element e of full round r of the first half, then one per partial round, then the second half;
+// zero for the last round (no key).  Published rule (neptune preprocessing.rs): the constants of round r+1 are pulled
+// back through M^-1 to act after the S-boxes of round r; through the partial rounds only coordinate 0's key stays in
+// its round and the rest moves one round earlier.  The first round's own constants are added BEFORE its S-boxes (they
+// are rc[0..t), already in the image).  The oracle restates the same rule independently (oracle/circuit_ref.py).
+template <class P>
+std::vector<Fe<P>> neptune_post_keys(const PoseidonParams<P>& pp) {
+    const int t = pp.t, h = pp.rf / 2, rp = pp.rp;
+    const std::vector<Fe<P>> minv = mat_inv<P>(pp.mds, t);
+    auto pull = [&](const std::vector<Fe<P>>& v) {  // v * M^-1 (M is symmetric: the same as M^-1 * v)
+        std::vector<Fe<P>> o(t, fe_zero<P>());
+        for (int j = 0; j < t; j++)
+            for (int i = 0; i < t; i++) o[j] = fe_add<P>(o[j], fe_mul<P>(v[i], minv[i * t + j]));
+        return o;
+    };
+    auto keys = [&](int r) { return std::vector<Fe<P>>(pp.rc.begin() + (size_t)r * t, pp.rc.begin() + (size_t)(r + 1) * t); };
+    std::vector<Fe<P>> post;
+    for (int r = 0; r + 1 < h; r++) {
+        auto k = pull(keys(r + 1));
+        post.insert(post.end(), k.begin(), k.end());
+    }
+    std::vector<Fe<P>> partial(rp);
+    std::vector<Fe<P>> acc = keys(h + rp);
+    for (int i = 0; i < rp; i++) {
+        auto inv = pull(acc);
+        partial[rp - 1 - i] = inv[0];
+        inv[0] = fe_zero<P>();
+        auto prev = keys(h + rp - i - 1);
+        for (int j = 0; j < t; j++) acc[j] = fe_add<P>(prev[j], inv[j]);
+    }
+    {
+        auto k = pull(acc);  // keys of the last full round of the first half
+        post.insert(post.end(), k.begin(), k.end());
+    }
+    post.insert(post.end(), partial.begin(), partial.end());
+    for (int r = 1; r < h; r++) {
+        auto k = pull(keys(h + rp + r));
+        post.insert(post.end(), k.begin(), k.end());
+    }
+    post.resize((size_t)t * pp.rf + rp, fe_zero<P>());  // the last round adds nothing
+    return post;
+}
+
 // Flat device image of the sparse schedule, as uint32 words (8 per element):
 //   [0]                      domain tag
 //   [1 .. 1+h*t)             round constants of full rounds 0..h-1

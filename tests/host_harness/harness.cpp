@@ -102,6 +102,54 @@ extern "C" void hh_poseidon(int field, int arity, int mode, const uint32_t* pre,
     else if (field == 1) poseidon_f<PallasFq>(arity, mode, pre, n, out);
     else poseidon_f<Bn254Fr>(arity, mode, pre, n, out);
 }
+// Slot-witness trace of one Poseidon hash on the radix-2^29 layer (poseidon29_permute_trace): per hash
+// [preimage | (l^2, l^4, l^5 + key) per S-box in circuit order | digest], canonical values, (arity + 3 * sboxes + 1) x 8 words
+template <class P, int T>
+static void poseidon_trace_n(const uint32_t* pre, size_t n, uint32_t* out) {
+    PoseidonParams<P> pp = make_poseidon_params<P>(T - 1);
+    std::vector<Fe<P>> post = neptune_post_keys<P>(pp);
+    std::vector<uint32_t> post_words;
+    for (auto& x : post) for (int k = 0; k < 8; k++) post_words.push_back(x.l[k]);
+    std::vector<uint32_t> img29 = poseidon29_image<P>(poseidon_device_image<P>(pp), post_words);
+    const PoseidonLayout<T> L(pp.rf, pp.rp);
+    const uint32_t* mont2 = img29.data() + (size_t)L.total() * P29_STRIDE;
+    const uint32_t* post29 = mont2 + P29_STRIDE;
+    const size_t nsbox = (size_t)T * pp.rf + pp.rp, per = (T - 1) + 3 * nsbox + 1;
+    for (size_t h = 0; h < n; h++) {
+        uint32_t* o = out + h * per * 8;
+        auto put = [&](size_t idx, const F29<P>& v) {
+            Fe<P> d = poseidon29_to_canonical<P>(v);
+            for (int k = 0; k < 8; k++) o[idx * 8 + k] = d.l[k];
+        };
+        F29<P> s[T];
+        s[0] = ld_const29<P>(img29.data());
+        for (int i = 1; i < T; i++) {
+            s[i] = poseidon29_from_canonical<P>(pre + (h * (T - 1) + (i - 1)) * 8, mont2);
+            put(i - 1, s[i]);
+        }
+        auto emit = [&](int sbox, const F29<P>& l2, const F29<P>& l4, const F29<P>& l5k) {
+            put((T - 1) + 3 * (size_t)sbox, l2);
+            put((T - 1) + 3 * (size_t)sbox + 1, l4);
+            put((T - 1) + 3 * (size_t)sbox + 2, l5k);
+        };
+        poseidon29_permute_trace<P, T>(s, img29.data(), post29, pp.rf, pp.rp, emit);
+        put(per - 1, s[1]);
+    }
+}
+template <class P>
+static void poseidon_trace_f(int arity, const uint32_t* pre, size_t n, uint32_t* out) {
+    switch (arity) {
+        case 3: poseidon_trace_n<P, 4>(pre, n, out); break;
+        case 4: poseidon_trace_n<P, 5>(pre, n, out); break;
+        case 6: poseidon_trace_n<P, 7>(pre, n, out); break;
+        case 8: poseidon_trace_n<P, 9>(pre, n, out); break;
+    }
+}
+extern "C" void hh_poseidon_trace(int field, int arity, const uint32_t* pre, size_t n, uint32_t* out) {
+    if (field == 0) poseidon_trace_f<PallasFp>(arity, pre, n, out);
+    else if (field == 1) poseidon_trace_f<PallasFq>(arity, pre, n, out);
+    else poseidon_trace_f<Bn254Fr>(arity, pre, n, out);
+}
 // canonical round constants + mds + (rf, rp) for comparison with the oracle's generator
 template <class P>
 static int params_f(int arity, int* rf, int* rp, uint32_t* rc, uint32_t* mds) {
