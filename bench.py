@@ -286,7 +286,7 @@ def _frame_structured_columns(rng, row_of_entry, num_cons, num_vars, num_io):
     return np.minimum(cols, num_vars + num_io).astype(np.uint64)
 
 
-def synth_r1cs_shape(field_id, p, num_cons, num_vars, num_io, seed=7):
+def synth_r1cs_shape(field_id, p, num_cons, num_vars, num_io, seed=7, uniform_columns=False):
     """Synthetic CSR triple shaped like the Lurk step circuit (3-4 entries per row, one row in 300 a 255-entry
     bit decomposition, coefficients mostly +-1 / small): the bench's own generator (numpy), values in Montgomery form."""
     import numpy as np
@@ -306,7 +306,12 @@ def synth_r1cs_shape(field_id, p, num_cons, num_vars, num_io, seed=7):
         np.cumsum(cnt, out=indptr[1:])
         nnz = int(indptr[-1])
         rows = np.repeat(np.arange(num_cons, dtype=np.int64), cnt.astype(np.int64))
-        indices = np.full(nnz, num_vars, dtype=np.uint64) if one_per_row else _frame_structured_columns(rng, rows, num_cons, num_vars, num_io)
+        if one_per_row:
+            indices = np.full(nnz, num_vars, dtype=np.uint64)
+        elif uniform_columns:
+            indices = rng.integers(0, ncols, nnz).astype(np.uint64)
+        else:
+            indices = _frame_structured_columns(rng, rows, num_cons, num_vars, num_io)
         data = np.ascontiguousarray(table[rng.choice(len(table_ints), size=nnz, p=weights)])
         return indptr, indices, data
 
@@ -314,16 +319,17 @@ def synth_r1cs_shape(field_id, p, num_cons, num_vars, num_io, seed=7):
 
 
 def fold_step_workload(args, lib, world, rank):
-    """Synthetic stand-in for the device work of ONE Nova folding step of benches/fibonacci.rs on the
-    Pallas cycle (the bench itself needs cargo + arecibo and cannot run here):
-      commit(W): n_vars  ~ 9 119 * rc points, witness-like scalars   (src/lem/eval.rs:1966)
-      NIFS cross term T over n_cons ~ 11 141 * rc rows (sparse A, B, C times z1, z2; device-resident, fold.hip)
-      commit(T): n_cons points                                       (src/lem/eval.rs:1967)
-      fold W <- W1 + r W2, E <- E1 + r T                             (device-resident)
-      slot-witness Poseidon batch: 21 hashes per frame (14 hash4 + 6 hash8 + 1 hash3, eval.rs:1960-1964)
-    Reported as "equivalent Lurk iterations/s" = rc / t(step).  It leaves out what stays on the CPU in the
-    reference (transcript, circuit synthesis, the small secondary-curve fold): an upper bound on the end-to-end
-    rate, flagged synthetic."""
+    """Synthetic stand-in for the device work of ONE Nova folding step of benches/fibonacci.rs on the primary (Pallas) curve
+    (the bench itself needs cargo + arecibo and cannot run here), through the step entry points:
+      W2 assembled in HBM: 14 hash4 + 6 hash8 + 1 commitment + 3 bit-decomposition slot blocks per frame written by the trace
+        kernels (lurk_hip_slot_witness_dev), the non-slot remainder of every frame (1 311 aux, what the CPU synthesis produces)
+        copied in over PCIe                                                      (src/lem/multiframe.rs:520-592, 699-702)
+      lurk_hip_fold_step_begin: commit(W2) || cross term T over the step circuit's rows || commit(T)   (nova.rs:287-293)
+      lurk_hip_fold_step_finish(r): [W | u | X] <- z1 + r z2, E <- E1 + r T
+    Sizes on Pallas: 8 951 aux per frame (7 640 slot aux: bit decompositions are 298 instead of BN254's 354; + 1 311) and
+    10 973 constraints per frame (11 141 - 3 x 56), from src/lem/eval.rs:1960-1967 and multiframe.rs:495-497.
+    Reported as "equivalent Lurk iterations/s" = rc / t(step).  Left out: what stays on the CPU in the reference (the transcript,
+    circuit synthesis of the frame bodies, the small secondary-curve fold): an upper bound on the end-to-end rate, flagged synthetic."""
     import numpy as np
     import torch
 
@@ -331,22 +337,21 @@ def fold_step_workload(args, lib, world, rank):
     from lurk_beta_amd import _lib, synth
 
     rc = args.rc
-    n_w, n_t, n_io = 9119 * rc, 11141 * rc, 2
-    n_key = max(n_w, n_t)
     F = L.FIELD_PALLAS_FQ
+    mf = L.MultiFrameWitness(F, rc, globals_len=64, body_len=1311)
+    n_w, n_t, n_io = mf.w_len, 10973 * rc, 6
+    n_key = max(n_w, n_t)
     q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
     stream = torch.cuda.current_stream().cuda_stream
     d_bases = synth.bases(L.CURVE_PALLAS, n_key)
-    d_z1 = synth.scalars(F, 1, 1, n_w + 1 + n_io, mont=True)   # running instance [W1 | u1 | X1] (witness-like values)
-    d_z2 = synth.scalars(F, 6, 1, n_w + 1 + n_io, mont=True)   # fresh instance   [W2 | u2 | X2]
-    d_e1 = synth.scalars(F, 2, 0, n_t, mont=True)              # running error vector E1 (uniform, like any folded T)
-    d_t = torch.empty((n_t, 4), dtype=torch.int64, device="cuda")
-    d_z = torch.empty_like(d_z1)
-    d_e = torch.empty_like(d_e1)
-    pre4 = synth.scalars(F, 3, 1, 14 * rc * 4)
-    pre8 = synth.scalars(F, 4, 1, 6 * rc * 8)
-    pre3 = synth.scalars(F, 5, 1, 1 * rc * 3)
-    out = torch.empty((21 * rc, 4), dtype=torch.int64, device="cuda")
+    pre = {"hash4": synth.scalars(F, 3, 1, 14 * rc * 4, mont=True), "hash8": synth.scalars(F, 4, 1, 6 * rc * 8, mont=True),
+           "commitment": synth.scalars(F, 5, 1, rc * 3, mont=True), "bit_decomp": synth.scalars(F, 6, 1, 3 * rc, mont=True)}
+    globals_host = synth.scalars(F, 7, 1, mf.globals_len, mont=True).cpu().numpy().view(np.uint64)
+    bodies_host = torch.empty((rc, mf.body_len, 4), dtype=torch.int64).pin_memory()
+    bodies_host.copy_(synth.scalars(F, 8, 1, rc * mf.body_len, mont=True).reshape(rc, mf.body_len, 4).cpu())
+    bodies_np = bodies_host.numpy().view(np.uint64)
+    d_w2 = torch.zeros((n_w, 4), dtype=torch.int64, device="cuda")
+    x2 = synth.scalars(F, 9, 0, n_io, mont=True).cpu().numpy().view(np.uint64)
     t_setup = time.perf_counter()
     shape = L.R1CSShape(F, n_t, n_w, n_io, *synth_r1cs_shape(F, q, n_t, n_w, n_io))
     shape_setup_s = time.perf_counter() - t_setup
@@ -354,18 +359,16 @@ def fold_step_workload(args, lib, world, rank):
     r_mont = np.array([0x1234567890ABCDEF, 0x0FEDCBA098765432, 0x1111111122222222, 0x0333333344444444], dtype=np.uint64)  # stands in for the transcript's challenge
     torch.cuda.synchronize()
     ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
+    ctx = L.FoldingContext(L.CURVE_PALLAS, shape, ck)
+    z1 = synth.scalars(F, 1, 1, n_w + 1 + n_io, mont=True).cpu().numpy().view(np.uint64)   # a running instance with witness-like values
+    e1 = synth.scalars(F, 2, 0, n_t, mont=True).cpu().numpy().view(np.uint64)              # a running error vector (uniform, like any folded T)
+    ident = np.zeros(12, dtype=np.uint64)
+    ctx.set_running(z1, e1, ident, ident)
 
     def step():
-        ck.submit_device(0, d_z2, n_w, is_mont=True, stream=stream)          # commit(W2)
-        shape.cross_term(d_z1, d_z2, out=d_t, stream=stream)                  # T
-        ck.submit_device(1, d_t, n_t, is_mont=True, stream=stream)           # commit(T)
-        _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 4, _lib.ptr(pre4), 14 * rc, _lib.ptr(out), _lib.ptr(stream)))
-        _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 8, _lib.ptr(pre8), 6 * rc, _lib.ptr(out[14 * rc:]), _lib.ptr(stream)))
-        _lib.check(lib.lurk_hip_poseidon_batch_dev(F, 3, _lib.ptr(pre3), rc, _lib.ptr(out[20 * rc:]), _lib.ptr(stream)))
-        cw, ct = ck.wait(0), ck.wait(1)                                       # the transcript needs both commitments
-        L.fold_vec(F, d_z1, d_z2, r_mont, out=d_z, stream=stream)             # [W | u | X] <- z1 + r z2
-        L.fold_vec(F, d_e1, d_t, r_mont, out=d_e, stream=stream)              # E <- E1 + r T
-        torch.cuda.synchronize()
+        mf.assemble(d_w2, pre, globals_host, bodies_np, mont=True, stream=stream)   # W2 in HBM (slot traces on the device)
+        cw, ct = ctx.begin(d_w2, x2, stream=stream)                                  # both commitments + the cross term
+        ctx.finish(r_mont)                                                            # the transcript's r would come between
         return cw, ct
 
     for _ in range(args.warmup):
@@ -376,6 +379,7 @@ def fold_step_workload(args, lib, world, rank):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    # (the folds are ordered on the context's own stream; torch.cuda.synchronize() is device-wide)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lib.lurk_hip_profile_enable(0)
@@ -390,6 +394,8 @@ def fold_step_workload(args, lib, world, rank):
         nnz = sum(info["nnz"])
         ct_ms, _ = kernel_ms("r1cs_cross_term")
         fv_ms, _ = kernel_ms("fold_vec")
+        tr_ms, tr_n = kernel_ms("poseidon_trace")
+        bd_ms, _ = kernel_ms("bit_decomp_trace")
         # algorithmic HBM bytes of the cross-term kernel: 8 B per CSR record + 4 B per row pointer, two 32-byte gathers
         # per record (z1, z2), 32 B of T per row; fold_vec: two reads + one write of 32 B per element
         ct_bytes = nnz * 8.0 + 3 * 4.0 * n_t + 2 * 32.0 * nnz + 32.0 * n_t
@@ -399,9 +405,12 @@ def fold_step_workload(args, lib, world, rank):
             "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
-            "config": {"workload": f"fold-step stand-in rc={rc}: MSM(W) {n_w} pts witness-like + cross term over {n_t} rows ({nnz} non-zeros, "
-                                   f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) {n_t} pts + fold of W and E + {21 * rc} Poseidon slot hashes",
-                       "note": "device work only; transcript / synthesis / the small secondary-curve fold not modelled",
+            "config": {"workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_begin/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
+                                   f"slot blocks traced on the device + {rc} x 1311 body aux over PCIe) -> MSM(W2) + cross term over {n_t} rows ({nnz} non-zeros, "
+                                   f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) -> fold of [W|u|X] and E",
+                       "note": "device work only; transcript / body synthesis / the small secondary-curve fold not modelled",
+                       "r1cs_columns": "frame-structured (88 % frame-local, 6 % globals, 4 % previous frame, 2 % u): a builder-chosen model of the step circuit's sparsity, "
+                                       "see fold_kernels.r1cs_cross_term_uniform_columns for the structure-free case",
                        "shape_setup_s_once": round(shape_setup_s, 2)},
             "fold_kernels": {
                 "r1cs_cross_term": {"ms": round(ct_ms, 4), "algorithmic_bytes": ct_bytes, "achieved_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms else None,
@@ -409,8 +418,23 @@ def fold_step_workload(args, lib, world, rank):
                 "fold_vec": {"ms_per_launch": round(fv_ms, 4), "algorithmic_bytes_per_launch": fv_bytes,
                              "achieved_GBps": round(fv_bytes / (fv_ms * 1e-3) / 1e9, 1) if fv_ms else None,
                              "hbm_frac": round(fv_bytes / (fv_ms * 1e-3) / 8e12, 4) if fv_ms else None},
+                "slot_witness_trace": {"poseidon_ms_per_launch": round(tr_ms, 4), "launches_per_step": tr_n // max(args.steps, 1),
+                                       "bit_decomp_ms_per_launch": round(bd_ms, 4), "bytes_written_per_step": mf.slots_len * rc * 32.0},
             },
         }
+        # the same cross term over a structure-free shape (uniformly random columns): the other end of the sparsity range
+        lib.lurk_hip_profile_enable(1)
+        lib.lurk_hip_profile_reset()
+        shape_u = L.R1CSShape(F, n_t, n_w, n_io, *synth_r1cs_shape(F, q, n_t, n_w, n_io, uniform_columns=True))
+        d_z1 = torch.from_numpy(z1.view(np.int64)).cuda()
+        d_t = torch.empty((n_t, 4), dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            shape_u.cross_term(d_z1, torch.cat([d_w2, d_z1[n_w:]]), out=d_t, stream=stream)
+        torch.cuda.synchronize()
+        cu_ms, _ = kernel_ms("r1cs_cross_term")
+        lib.lurk_hip_profile_enable(0)
+        shape_u.close()
+        res["fold_kernels"]["r1cs_cross_term_uniform_columns"] = {"ms": round(cu_ms, 4), "hbm_frac": round(ct_bytes / (cu_ms * 1e-3) / 8e12, 4) if cu_ms else None}
         if not args.no_cpu_baseline:
             from oracle import coracle as C
 
@@ -424,6 +448,7 @@ def fold_step_workload(args, lib, world, rank):
             res["cpu_baseline"] = {"value": round(rc / (dt * scale), 2), "unit": "iterations/s", "cores": C.lib().orc_num_threads(), "kind": "port",
                                    "sample": f"both MSMs truncated to <= 2^20 points ({dt:.2f} s), scaled linearly to the full step; oracle/oracle.c OpenMP Pippenger (fold arithmetic not included)"}
         print(json.dumps(res), flush=True)
+    ctx.close()
     ck.close()
     shape.close()
 

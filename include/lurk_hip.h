@@ -20,7 +20,8 @@
  *     point fails with LURK_HIP_ERR_NO_DEVICE.
  *   - entry points are thread-safe (arecibo commits from rayon worker threads).
  *   - *_dev variants take device pointers and a hipStream_t (as void*; NULL = default stream) and
- *     do not synchronise: inputs stay resident in HBM across calls.
+ *     do not synchronise: inputs stay resident in HBM across calls.  Device buffers of field elements / points must be
+ *     16-byte aligned (anything hipMalloc returns, at any multiple of 32 bytes); host buffers need no alignment.
  */
 #ifndef LURK_HIP_H
 #define LURK_HIP_H
@@ -127,6 +128,8 @@ int lurk_hip_msm_multi_destroy(lurk_hip_msm_multi* ctx);
 /* Group helpers used by the multi-GPU gather (sum of per-rank partial commitments) and by tests:
  * out = sum of `count` Jacobian points (host memory, 96 B each). */
 int lurk_hip_point_sum(int curve, void* out_jacobian96, const void* points_jacobian96, size_t count);
+/* out = [scalar] point on the host (the transcript-side folding of commitments: comm_W1 + r comm_W2, comm_E1 + r comm_T) */
+int lurk_hip_point_mul(int curve, void* out_jacobian96, const void* point_jacobian96, const void* scalar32, int is_mont);
 /* Jacobian (Montgomery) -> canonical affine bytes (x, y), 64 B; identity -> all zero */
 int lurk_hip_point_to_affine_canonical(int curve, void* out_xy64, const void* point_jacobian96);
 
@@ -177,6 +180,12 @@ int lurk_hip_slot_witness_dev(int field_id, int slot_type, const void* d_preimag
                               const uint64_t* d_offsets, size_t first, size_t stride, void* stream);
 /* host buffers in and out, blocks back to back (n x size x 32 B): small inputs and tests */
 int lurk_hip_slot_witness(int field_id, int slot_type, const void* preimages, size_t n, int preimages_mont, void* w_out);
+/* every slot block of a MultiFrame in one call: counts5 / d_preimages5 are indexed (hash4, hash6, hash8, commitment, bit_decomp)
+ * - the order generate_slots_witnesses walks a frame's hints in (multiframe.rs:527-536) - with counts per frame and, per type,
+ * num_frames * count preimages in frame-major order.  Frame f's slot blocks are written back to back from
+ * d_w[first + f * frame_len].  The per-type launches run concurrently inside; ordered after and before `stream`. */
+int lurk_hip_frames_witness_dev(int field_id, size_t num_frames, const size_t* counts5, const void* const* d_preimages5,
+                                int preimages_mont, void* d_w, size_t first, size_t frame_len, void* stream);
 /* places n_blocks packed blocks of block_len elements (host or device memory) at d_w[first + b * stride]: the globals and
  * the non-slot remainder of every frame, which the CPU synthesis still produces */
 int lurk_hip_witness_blocks_dev(void* d_w, size_t first, size_t stride, const void* src, int src_on_host, size_t n_blocks,
@@ -204,6 +213,7 @@ int lurk_hip_r1cs_create(lurk_hip_r1cs** shape, int field_id, size_t num_cons, s
                          const void* b_data, const uint64_t* c_indptr, const uint64_t* c_indices,
                          const void* c_data);
 int lurk_hip_r1cs_destroy(lurk_hip_r1cs* shape);
+int lurk_hip_r1cs_dims(const lurk_hip_r1cs* shape, int* field_id, size_t* num_cons, size_t* num_vars, size_t* num_io);
 int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b, size_t* nnz_c,
                        size_t* distinct_coefficients);
 /* R1CSShape::multiply_vec: (A z, B z, C z); d_z has num_vars + 1 + num_io elements, outputs num_cons */
@@ -219,6 +229,32 @@ int lurk_hip_fold_vec_dev(int field_id, const void* d_a, const void* d_b, const 
 int lurk_hip_r1cs_multiply_vec(const lurk_hip_r1cs* shape, const void* z, void* az, void* bz, void* cz);
 int lurk_hip_r1cs_cross_term(lurk_hip_r1cs* shape, const void* z1, const void* z2, void* t);
 int lurk_hip_fold_vec(int field_id, const void* a, const void* b, const void* r32_mont, size_t n, void* out);
+
+/* ---- one folding step on one curve of the cycle ----------------------------------------------
+ * What RecursiveSNARK::prove_step (/root/reference/src/proof/nova.rs:282-295, SuperNova /root/reference/src/proof/
+ * supernova.rs:231-244) runs per curve through arecibo's NIFS::prove, with the running pair (z1 = [W1 | u1 | X1], E1)
+ * resident in HBM from step to step.  A prover holds one context per curve: Pallas (primary, the Lurk step circuit) and
+ * Vesta (secondary).  shape and key are borrowed (same curve / scalar field, created on the same device) and must outlive
+ * the context; the context uses the key's async slots 0 and 1.  The challenge r comes from the caller's transcript (a
+ * Poseidon sponge over the OTHER field of the cycle, absorbing the two commitments `begin` returns), hence two halves:
+ *   begin:  comm_W2 = commit(W2); T = cross term of (z1, [W2 | 1 | X2]); comm_T = commit(T)   - commitments in flight
+ *   finish: W <- W1 + r W2, u <- u1 + r, X <- X1 + r X2, E <- E1 + r T                         - stream-ordered, no sync
+ * The public IO X2 of a Lurk step is Store::to_scalar_vector's [tag, hash] x 3 (/root/reference/src/lem/store.rs:883-895,
+ * Z1) in Montgomery form.  A new context holds the default (all-zero) relaxed pair, as RecursiveSNARK::new starts from. */
+typedef struct lurk_hip_fold_ctx lurk_hip_fold_ctx;
+int lurk_hip_fold_ctx_create(lurk_hip_fold_ctx** ctx, int curve, lurk_hip_r1cs* shape, lurk_hip_msm_ctx* key);
+int lurk_hip_fold_ctx_destroy(lurk_hip_fold_ctx* ctx);
+/* running pair <- host values (Montgomery): z1 (num_vars + 1 + num_io elements), E1 (num_cons elements) */
+int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* ctx, const void* z1, const void* e1);
+/* w2: num_vars x 32 B Montgomery, host memory or (w2_on_device) device memory produced on w2_stream (NULL = default
+ * stream); x2_mont: num_io x 32 B, host */
+int lurk_hip_fold_step_begin(lurk_hip_fold_ctx* ctx, const void* w2, int w2_on_device, void* w2_stream, const void* x2_mont,
+                             void* comm_w2_jacobian96, void* comm_t_jacobian96);
+int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* ctx, const void* r32_mont);
+/* the running pair where it lives (valid until the next finish) and the stream its updates are ordered on */
+int lurk_hip_fold_ctx_running_dev(lurk_hip_fold_ctx* ctx, void** d_z, void** d_e, void** stream);
+/* copies of the running pair for the host (either may be NULL); synchronises the context's stream */
+int lurk_hip_fold_ctx_read(lurk_hip_fold_ctx* ctx, void* z_host, void* e_host);
 
 /* ---- synthetic inputs (bench / tests) -------------------------------------
  * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */

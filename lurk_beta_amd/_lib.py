@@ -46,6 +46,7 @@ SIGNATURES = {
     "lurk_hip_msm_multi_commit_dev": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_size_t, c_int]),
     "lurk_hip_msm_multi_destroy": (c_int, [c_void_p]),
     "lurk_hip_point_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
+    "lurk_hip_point_mul": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "lurk_hip_point_to_affine_canonical": (c_int, [c_int, c_void_p, c_void_p]),
     "lurk_hip_poseidon_batch": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lurk_hip_poseidon_batch_dev": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -55,11 +56,13 @@ SIGNATURES = {
     "lurk_hip_slot_witness_size": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
     "lurk_hip_slot_witness_dev": (c_int, [c_int, c_int, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "lurk_hip_slot_witness": (c_int, [c_int, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_frames_witness_dev": (c_int, [c_int, c_size_t, ctypes.POINTER(c_size_t), ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_size_t, c_void_p]),
     "lurk_hip_witness_blocks_dev": (c_int, [c_void_p, c_size_t, c_size_t, c_void_p, c_int, c_size_t, c_size_t, c_void_p]),
     "lurk_hip_ntt": (c_int, [c_int, c_void_p, c_uint, c_int]),
     "lurk_hip_ntt_dev": (c_int, [c_int, c_void_p, c_uint, c_int, c_void_p]),
     "lurk_hip_r1cs_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_size_t, c_size_t, c_size_t] + [c_void_p] * 9),
     "lurk_hip_r1cs_destroy": (c_int, [c_void_p]),
+    "lurk_hip_r1cs_dims": (c_int, [c_void_p, ctypes.POINTER(c_int)] + [ctypes.POINTER(c_size_t)] * 3),
     "lurk_hip_r1cs_info": (c_int, [c_void_p] + [ctypes.POINTER(c_size_t)] * 4),
     "lurk_hip_r1cs_multiply_vec_dev": (c_int, [c_void_p] * 6),
     "lurk_hip_r1cs_cross_term_dev": (c_int, [c_void_p] * 5),
@@ -67,6 +70,13 @@ SIGNATURES = {
     "lurk_hip_r1cs_multiply_vec": (c_int, [c_void_p] * 5),
     "lurk_hip_r1cs_cross_term": (c_int, [c_void_p] * 4),
     "lurk_hip_fold_vec": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "lurk_hip_fold_ctx_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "lurk_hip_fold_ctx_destroy": (c_int, [c_void_p]),
+    "lurk_hip_fold_ctx_set_running": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_fold_step_begin": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_fold_step_finish": (c_int, [c_void_p, c_void_p]),
+    "lurk_hip_fold_ctx_running_dev": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
+    "lurk_hip_fold_ctx_read": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
 }

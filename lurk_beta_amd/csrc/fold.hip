@@ -454,6 +454,16 @@ int lurk_hip_r1cs_destroy(lurk_hip_r1cs* shape) {
     });
 }
 
+int lurk_hip_r1cs_dims(const lurk_hip_r1cs* shape, int* field_id, size_t* num_cons, size_t* num_vars, size_t* num_io) {
+    return guarded([&] {
+        LURK_REQUIRE(shape, "null shape");
+        if (field_id) *field_id = shape->sh.field_id;
+        if (num_cons) *num_cons = shape->sh.num_cons;
+        if (num_vars) *num_vars = shape->sh.num_vars;
+        if (num_io) *num_io = shape->sh.num_io;
+    });
+}
+
 int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b, size_t* nnz_c, size_t* distinct_coefficients) {
     return guarded([&] {
         LURK_REQUIRE(shape, "null shape");

@@ -870,18 +870,21 @@ struct MsmCtx : MsmCtxBase {
     }
 
     // host tail over the <= 20 points the device left in pinned memory (stream already synchronised)
-    void host_tail(Work& wk, size_t n, Jacobian<P>* out) {
+    // results go to caller memory without an alignment promise: memcpy
+    static void put_point(void* out, const Jacobian<P>& j) { memcpy(out, &j, sizeof(j)); }
+    static void put_identity(void* out) { put_point(out, jacobian_from_affine<P>(Affine<P>{fe_zero<P>(), fe_zero<P>()})); }
+    void host_tail(Work& wk, size_t n, void* out) {
         const MsmShape sh = shape(n);
         Xyzz<P> total = sh.G > 1 ? msm_combine_windows<P>(wk.host_pts, sh.G, sh.c)  // sum_w 2^(c w) W_w
                                  : msm_planes_horner<P>(wk.host_pts, sh.c);         // one key space: c-1 doublings
-        *out = jacobian_from_affine<P>(xyzz_to_affine<P>(total));
+        put_point(out, jacobian_from_affine<P>(xyzz_to_affine<P>(total)));
     }
 
     void run(const void* d_scalars, size_t n, int is_mont, hipStream_t s, void* out_jac96_host) override {
         LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
-        Jacobian<P>* out = (Jacobian<P>*)out_jac96_host;
+        void* out = out_jac96_host;
         if (n == 0) {
-            *out = jacobian_from_affine<P>(Affine<P>{fe_zero<P>(), fe_zero<P>()});
+            put_identity(out);
             return;
         }
         Work& wk = work[0];
@@ -925,10 +928,10 @@ struct MsmCtx : MsmCtxBase {
         Work& wk = work[slot];
         std::lock_guard<std::mutex> lk(wk.mu);
         LURK_REQUIRE(wk.pending, "nothing was submitted on this slot");
-        Jacobian<P>* out = (Jacobian<P>*)out_jac96_host;
+        void* out = out_jac96_host;
         wk.pending = false;
         if (wk.pending_n == 0) {
-            *out = jacobian_from_affine<P>(Affine<P>{fe_zero<P>(), fe_zero<P>()});
+            put_identity(out);
             return;
         }
         LURK_HIP_CHECK(hipStreamSynchronize(wk.stream));
@@ -952,17 +955,42 @@ static void ctx_set_bases(MsmCtxBase* c, const void* d_bases, size_t n, bool cop
 
 template <class P>
 static void point_sum_host(const void* pts, size_t count, void* out) {
-    const Jacobian<P>* in = (const Jacobian<P>*)pts;
+    // the caller's buffers carry no alignment promise (Fe<P> is 16-byte aligned): go through memcpy
     Xyzz<P> acc = xyzz_identity<P>();
-    for (size_t i = 0; i < count; i++) xyzz_add<P>(acc, xyzz_from_jacobian<P>(in[i]));
-    *(Jacobian<P>*)out = jacobian_from_affine<P>(xyzz_to_affine<P>(acc));
+    for (size_t i = 0; i < count; i++) {
+        Jacobian<P> j;
+        memcpy(&j, (const char*)pts + i * sizeof(Jacobian<P>), sizeof(j));
+        xyzz_add<P>(acc, xyzz_from_jacobian<P>(j));
+    }
+    const Jacobian<P> r = jacobian_from_affine<P>(xyzz_to_affine<P>(acc));
+    memcpy(out, &r, sizeof(r));
 }
 template <class P>
 static void point_affine_canonical_host(const void* pt, void* out) {
-    Affine<P> a = xyzz_to_affine<P>(xyzz_from_jacobian<P>(*(const Jacobian<P>*)pt));
+    Jacobian<P> j;
+    memcpy(&j, pt, sizeof(j));
+    Affine<P> a = xyzz_to_affine<P>(xyzz_from_jacobian<P>(j));
     Fe<P> x = fe_from_mont<P>(a.x), y = fe_from_mont<P>(a.y);
     memcpy(out, x.l, 32);
     memcpy((char*)out + 32, y.l, 32);
+}
+
+// [k] P on the host (double-and-add over the canonical scalar, top bit first): a handful per folding step
+template <class P, class SF>
+static void point_mul_host(const void* pt, const void* scalar32, int is_mont, void* out) {
+    Fe<SF> k;
+    memcpy(k.l, scalar32, 32);
+    if (is_mont) k = fe_from_mont<SF>(k);
+    Jacobian<P> j;
+    memcpy(&j, pt, sizeof(j));
+    const Xyzz<P> base = xyzz_from_jacobian<P>(j);
+    Xyzz<P> acc = xyzz_identity<P>();
+    for (int i = 255; i >= 0; i--) {
+        acc = xyzz_dbl<P>(acc);
+        if ((k.l[i >> 5] >> (i & 31)) & 1u) xyzz_add<P>(acc, base);
+    }
+    const Jacobian<P> r = jacobian_from_affine<P>(xyzz_to_affine<P>(acc));
+    memcpy(out, &r, sizeof(r));
 }
 
 static int msm_oneshot(int curve, void* out, const void* bases, size_t n, const void* scalars, int is_mont) {
@@ -1203,6 +1231,19 @@ int lurk_hip_point_sum(int curve, void* out, const void* points, size_t count) {
         LURK_REQUIRE(out && (count == 0 || points), "null argument");
         if (curve == 0) point_sum_host<PallasFp>(points, count, out);
         else point_sum_host<PallasFq>(points, count, out);
+        set_error(0, "");
+        return 0;
+    } catch (const HipFailure& e) {
+        set_error(e.code, e.msg);
+        return e.code;
+    }
+}
+int lurk_hip_point_mul(int curve, void* out, const void* point, const void* scalar32, int is_mont) {
+    try {
+        LURK_REQUIRE(curve == 0 || curve == 1, "unknown curve id");
+        LURK_REQUIRE(out && point && scalar32, "null argument");
+        if (curve == 0) point_mul_host<PallasFp, PallasFq>(point, scalar32, is_mont, out);
+        else point_mul_host<PallasFq, PallasFp>(point, scalar32, is_mont, out);
         set_error(0, "");
         return 0;
     } catch (const HipFailure& e) {

@@ -167,8 +167,11 @@ __device__ __forceinline__ void trace_store(Fe<P>* __restrict__ w, size_t idx, c
 struct TraceDst {
     void* w;                  // Fe<P>*: the witness vector
     const uint64_t* offsets;  // per-slot element offsets, or null
-    size_t first, stride;     // ... then first + i * stride
-    __device__ __forceinline__ size_t base(size_t i) const { return offsets ? (size_t)offsets[i] : first + i * stride; }
+    size_t first, stride;     // ... then first + (i / group) * group_stride + (i % group) * stride
+    size_t group = ~(size_t)0, group_stride = 0;  // slots per frame and frame length (frame-major slot numbering)
+    __device__ __forceinline__ size_t base(size_t i) const {
+        return offsets ? (size_t)offsets[i] : first + (i / group) * group_stride + (i % group) * stride;
+    }
 };
 
 template <class P, int T>
@@ -584,6 +587,58 @@ void slot_witness_device(int field_id, int slot_type, const void* d_pre, size_t 
     else launch_trace_f<Bn254Fr>(slot_type, d_pre, n, pc, flags, dst, s);
 }
 
+// All slot blocks of a MultiFrame in one call: the (up to five) launches are independent and, at a folding step's sizes,
+// latency-bound (a few hundred waves each), so they run side by side on per-device helper streams forked from and joined
+// back into the caller's stream.
+struct TraceStreams {
+    hipStream_t s[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+static TraceStreams& trace_streams() {
+    static std::mutex mu;
+    static std::map<int, std::unique_ptr<TraceStreams>> per_dev;
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_dev.find(dev);
+    if (it == per_dev.end()) {
+        auto ts = std::make_unique<TraceStreams>();
+        LURK_HIP_CHECK(hipEventCreateWithFlags(&ts->fork, hipEventDisableTiming));
+        for (int k = 0; k < 5; k++) {
+            LURK_HIP_CHECK(hipStreamCreateWithFlags(&ts->s[k], hipStreamNonBlocking));
+            LURK_HIP_CHECK(hipEventCreateWithFlags(&ts->join[k], hipEventDisableTiming));
+        }
+        it = per_dev.emplace(dev, std::move(ts)).first;
+    }
+    return *it->second;
+}
+static std::mutex g_frames_mu;  // the helper streams' events are shared: one frames call at a time per process
+
+void frames_witness_device(int field_id, size_t num_frames, const size_t* counts, const void* const* d_pre, int pre_mont, void* d_w, size_t first,
+                           size_t frame_len, hipStream_t s) {
+    static const int types[5] = {LURK_SLOT_HASH4, LURK_SLOT_HASH6, LURK_SLOT_HASH8, LURK_SLOT_COMMITMENT, LURK_SLOT_BIT_DECOMP};
+    size_t off = 0, sizes[5];
+    for (int k = 0; k < 5; k++) {
+        sizes[k] = counts[k] ? slot_witness_size(field_id, types[k]) : 0;
+        LURK_REQUIRE(counts[k] == 0 || d_pre[k], "null preimage array for a slot type with a non-zero count");
+        off += counts[k] * sizes[k];
+    }
+    LURK_REQUIRE(num_frames <= 1 || frame_len >= off, "frame_len shorter than the frame's slot blocks");
+    if (num_frames == 0) return;
+    std::lock_guard<std::mutex> lk(g_frames_mu);
+    TraceStreams& ts = trace_streams();
+    LURK_HIP_CHECK(hipEventRecord(ts.fork, s));
+    off = 0;
+    for (int k = 0; k < 5; k++) {
+        if (!counts[k]) continue;
+        LURK_HIP_CHECK(hipStreamWaitEvent(ts.s[k], ts.fork, 0));
+        TraceDst dst{d_w, nullptr, first + off, sizes[k], counts[k], frame_len};
+        slot_witness_device(field_id, types[k], d_pre[k], num_frames * counts[k], pre_mont, dst, ts.s[k]);
+        LURK_HIP_CHECK(hipEventRecord(ts.join[k], ts.s[k]));
+        LURK_HIP_CHECK(hipStreamWaitEvent(s, ts.join[k], 0));
+        off += counts[k] * sizes[k];
+    }
+}
+
 static bool is_pow8(size_t n) {
     if (n < 8) return false;
     while (n % 8 == 0) n /= 8;
@@ -664,6 +719,14 @@ int lurk_hip_slot_witness(int field_id, int slot_type, const void* preimages, si
         slot_witness_device(field_id, slot_type, in.p, n, preimages_mont, dst, nullptr);
         LURK_HIP_CHECK(hipStreamSynchronize(nullptr));
         LURK_HIP_CHECK(hipMemcpy(w_out, out.p, n * sz * 32, hipMemcpyDeviceToHost));
+    });
+}
+
+int lurk_hip_frames_witness_dev(int field_id, size_t num_frames, const size_t* counts5, const void* const* d_preimages5, int preimages_mont,
+                                void* d_w, size_t first, size_t frame_len, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(counts5 && d_preimages5 && (num_frames == 0 || d_w), "null argument");
+        frames_witness_device(field_id, num_frames, counts5, d_preimages5, preimages_mont, d_w, first, frame_len, (hipStream_t)stream);
     });
 }
 

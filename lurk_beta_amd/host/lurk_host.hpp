@@ -163,6 +163,8 @@ class CommitmentKey {
         return xy;
     }
 
+    lurk_hip_msm_ctx* handle() const { return ctx_; }
+
   private:
     int curve_;
     lurk_hip_msm_ctx* ctx_ = nullptr;
@@ -238,10 +240,62 @@ class R1CSShape {
         return out;
     }
 
+    lurk_hip_r1cs* handle() const { return h_; }
+    size_t num_cons() const { return num_cons_; }
+    size_t num_cols() const { return num_cols_; }
+
   private:
     int field_;
     size_t num_cons_, num_cols_;
     lurk_hip_r1cs* h_ = nullptr;
+};
+
+// Store::to_scalar_vector (/root/reference/src/lem/store.rs:883-895): the public IO of a step, [tag, hash] per pointer
+inline std::vector<Fe> to_scalar_vector(const std::vector<std::pair<Fe, Fe>>& z_ptrs) {
+    std::vector<Fe> out;
+    for (auto& zp : z_ptrs) { out.push_back(zp.first); out.push_back(zp.second); }
+    return out;
+}
+
+// One curve's half of RecursiveSNARK::prove_step (/root/reference/src/proof/nova.rs:282-295): the running relaxed pair
+// stays on the GPU; begin() returns the commitments the transcript absorbs, finish(r) folds.  The running instance's two
+// commitments are folded here on the host as RelaxedR1CSInstance::fold does.
+class FoldingContext {
+  public:
+    FoldingContext(int curve, R1CSShape& shape, CommitmentKey& key) : curve_(curve), shape_(shape) {
+        check(lurk_hip_fold_ctx_create(&h_, curve, shape.handle(), key.handle()));
+    }
+    ~FoldingContext() { lurk_hip_fold_ctx_destroy(h_); }
+    FoldingContext(const FoldingContext&) = delete;
+    std::array<Jacobian, 2> begin(const std::vector<Fe>& w2_mont, const std::vector<Fe>& x2_mont) {
+        std::array<Jacobian, 2> c;
+        check(lurk_hip_fold_step_begin(h_, w2_mont.data(), 0, nullptr, x2_mont.data(), &c[0], &c[1]));
+        open_ = c;
+        return c;
+    }
+    void finish(const Fe& r_mont) {
+        check(lurk_hip_fold_step_finish(h_, &r_mont));
+        Jacobian rw, rt, pair[2];
+        check(lurk_hip_point_mul(curve_, &rw, &open_[0], &r_mont, 1));
+        check(lurk_hip_point_mul(curve_, &rt, &open_[1], &r_mont, 1));
+        pair[0] = comm_w; pair[1] = rw;
+        check(lurk_hip_point_sum(curve_, &comm_w, pair, 2));
+        pair[0] = comm_e; pair[1] = rt;
+        check(lurk_hip_point_sum(curve_, &comm_e, pair, 2));
+    }
+    // host copies of z = [W | u | X] and E (Montgomery)
+    std::pair<std::vector<Fe>, std::vector<Fe>> read() const {
+        std::vector<Fe> z(shape_.num_cols()), e(shape_.num_cons());
+        check(lurk_hip_fold_ctx_read(h_, z.data(), e.data()));
+        return {z, e};
+    }
+    Jacobian comm_w{}, comm_e{};  // identity (z = 0): RelaxedR1CSInstance::default
+
+  private:
+    int curve_;
+    R1CSShape& shape_;
+    lurk_hip_fold_ctx* h_ = nullptr;
+    std::array<Jacobian, 2> open_{};
 };
 
 }  // namespace host

@@ -68,7 +68,7 @@ class MultiFrameWitness:
             off += cnt * self.sizes[name]
 
     def assemble(self, d_w, d_preimages: dict, globals_host: np.ndarray | None = None, bodies_host: np.ndarray | None = None, mont: bool = True,
-                 stream=None):
+                 stream=None, per_type_offsets: bool = False):
         """d_w: (>= w_len, 4) int64 device tensor.  d_preimages[name]: device tensor with num_frames * count preimages of that
         slot type, frame-major.  globals_host: (globals_len, 4); bodies_host: (num_frames, body_len, 4) - Montgomery values."""
         import torch
@@ -76,15 +76,24 @@ class MultiFrameWitness:
         lib = _lib.load()
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
         assert d_w.shape[0] >= self.w_len
-        for name, st in SLOT_ORDER:
-            cnt = self.counts.get(name, 0)
-            if not cnt:
-                continue
-            pre = d_preimages[name]
-            n = self.num_frames * cnt
-            assert pre.numel() == n * slot_preimage_len(st) * 4
-            _lib.check(lib.lurk_hip_slot_witness_dev(self.field_id, st, _lib.ptr(pre), n, int(mont), _lib.ptr(d_w), _lib.ptr(self.offsets[name]), 0, 0,
-                                                     _lib.ptr(s)))
+        if per_type_offsets:  # the general form: one call per slot type with explicit per-slot offsets
+            for name, st in SLOT_ORDER:
+                cnt = self.counts.get(name, 0)
+                if not cnt:
+                    continue
+                pre = d_preimages[name]
+                n = self.num_frames * cnt
+                assert pre.numel() == n * slot_preimage_len(st) * 4
+                _lib.check(lib.lurk_hip_slot_witness_dev(self.field_id, st, _lib.ptr(pre), n, int(mont), _lib.ptr(d_w), _lib.ptr(self.offsets[name]), 0, 0,
+                                                         _lib.ptr(s)))
+        else:  # every slot block of the MultiFrame in one call (the per-type launches run side by side inside)
+            counts = (ctypes.c_size_t * 5)(*[self.counts.get(name, 0) for name, _ in SLOT_ORDER])
+            ptrs = (ctypes.c_void_p * 5)(*[_lib.ptr(d_preimages[name]) if self.counts.get(name, 0) else None for name, _ in SLOT_ORDER])
+            for name, st in SLOT_ORDER:
+                if self.counts.get(name, 0):
+                    assert d_preimages[name].numel() == self.num_frames * self.counts[name] * slot_preimage_len(st) * 4
+            _lib.check(lib.lurk_hip_frames_witness_dev(self.field_id, self.num_frames, counts, ptrs, int(mont), _lib.ptr(d_w), self.globals_len,
+                                                       self.frame_len, _lib.ptr(s)))
         if globals_host is not None and self.globals_len:
             g = np.ascontiguousarray(globals_host, dtype=np.uint64)
             _lib.check(lib.lurk_hip_witness_blocks_dev(_lib.ptr(d_w), 0, self.globals_len, _lib.ptr(g), 1, 1, self.globals_len, _lib.ptr(s)))

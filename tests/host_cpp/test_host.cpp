@@ -131,6 +131,65 @@ int main() {
         auto zf = shape.fold(z1, z2, two);               // z1 + 2 z2 = [7, 17, 3]
         EXPECT(zf[0] == add(six, one) && zf[2] == three);
     }
+    // Three consecutive folding steps on each curve of the cycle through lurk_hip_fold_step_{begin,finish} (M1): the context's
+    // running pair must equal what the standalone entry points give (cross term of the previous pair with the fresh
+    // instance, a + r b folds), and the host-folded commitments must be the commitments of the folded vectors.
+    for (int curve : {LURK_CURVE_PALLAS, LURK_CURVE_VESTA}) {
+        const int F = curve == LURK_CURVE_PALLAS ? LURK_FIELD_PALLAS_FQ : LURK_FIELD_PALLAS_FP;
+        Fe one;  // 2^256 mod q (Pallas scalars) / mod p (Vesta scalars)
+        if (curve == LURK_CURVE_PALLAS) one.l = {0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL};
+        else one.l = {0x34786d38fffffffdULL, 0x992c350be41914adULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL};
+        const Fe zero;
+        SparseMatrix A, B, C;  // row 0: x * x = y ; row 1: (x + y) * u = (x + y) ; z = [x, y | u | io]  (io unconstrained)
+        A.indptr = {0, 1, 3}; A.indices = {0, 0, 1}; A.data = {one, one, one};
+        B.indptr = {0, 1, 2}; B.indices = {0, 2};    B.data = {one, one};
+        C.indptr = {0, 1, 3}; C.indices = {1, 0, 1}; C.data = {one, one, one};
+        R1CSShape shape(F, 2, 2, 1, A, B, C);
+        auto add = [&](const Fe& a, const Fe& b) { return shape.fold({a}, {b}, one)[0]; };
+        Fe two = add(one, one), three = add(two, one), four = add(two, two), five = add(four, one), nine = add(five, four);
+        Fe twenty_five = add(add(nine, nine), add(five, two));
+        // a 2-point key on this curve: [G, 2G] from the one-shot entry point
+        Affine Gc = G;
+        if (curve == LURK_CURVE_VESTA) {  // Vesta generator (-1, 2) over Fq: x = q - R', y = 2R' mod q with R' = 2^256 mod q
+            const uint64_t Rq[4] = {0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL};
+            const uint64_t Q[4] = {0x8c46eb2100000001ULL, 0x224698fc0994a8ddULL, 0x0ULL, 0x4000000000000000ULL};
+            unsigned __int128 br = 0;
+            for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)Q[i] - Rq[i] - br; Gc.x.l[i] = (uint64_t)d; br = (d >> 64) & 1; }
+            uint64_t t2[4];
+            unsigned __int128 c = 0;
+            for (int i = 0; i < 4; i++) { c += (unsigned __int128)Rq[i] + Rq[i]; t2[i] = (uint64_t)c; c >>= 64; }
+            br = 0;
+            for (int i = 0; i < 4; i++) { unsigned __int128 d = (unsigned __int128)t2[i] - Q[i] - br; Gc.y.l[i] = (uint64_t)d; br = (d >> 64) & 1; }
+        }
+        CommitmentKey k1(curve, {Gc}, false);
+        Jacobian g2 = k1.commit({Fe(2)}, false);
+        CommitmentKey key(curve, {Gc, Affine{g2.x, g2.y}}, false);
+        FoldingContext ctx(curve, shape, key);
+        std::vector<Fe> z_run{zero, zero, zero, zero}, e_run{zero, zero};
+        const std::vector<std::vector<Fe>> fresh{{three, nine}, {two, four}, {five, twenty_five}};
+        const std::vector<Fe> rs{three, five, two};
+        for (int step = 0; step < 3; step++) {
+            std::vector<Fe> io = to_scalar_vector({{Fe(), Fe()}});
+            io.resize(1);
+            io[0] = rs[step];  // any public value
+            auto comms = ctx.begin(fresh[step], io);
+            std::vector<Fe> z2{fresh[step][0], fresh[step][1], one, io[0]};
+            EXPECT(key.to_affine(comms[0]) == key.to_affine(key.commit(fresh[step], true)));
+            auto t = shape.cross_term(z_run, z2);
+            EXPECT(key.to_affine(comms[1]) == key.to_affine(key.commit(t, true)));
+            ctx.finish(rs[step]);
+            z_run = shape.fold(z_run, z2, rs[step]);
+            e_run = shape.fold(e_run, t, rs[step]);
+            auto got = ctx.read();
+            EXPECT(got.first == z_run && got.second == e_run);
+            std::vector<Fe> w(z_run.begin(), z_run.begin() + 2);
+            EXPECT(key.to_affine(ctx.comm_w) == key.to_affine(key.commit(w, true)));      // comm_W1 + r comm_W2 = commit(W1 + r W2)
+            EXPECT(key.to_affine(ctx.comm_e) == key.to_affine(key.commit(e_run, true)));  // comm_E1 + r comm_T  = commit(E1 + r T)
+        }
+        // after three folds of satisfied instances the pair is a relaxed witness: E = A z o B z - u C z.  Row 1 of this shape is
+        // linear in z times u, so E_1 = (x + y) u - u (x + y) = 0 whatever was folded.
+        EXPECT(e_run[1] == zero);
+    }
     printf("host mirror ok\n");
     return 0;
 }

@@ -98,8 +98,12 @@ def test_multiframe_w_is_assembled_on_the_device_and_committed(hip):
     g_host = C.to_mont(f, C.synth_scalars(f, 90, 0, glob))
     b_host = C.to_mont(f, C.synth_scalars(f, 91, 1, frames * body)).reshape(frames, body, 4)
     d_w = torch.zeros((mf.w_len, 4), dtype=torch.int64, device="cuda")
-    mf.assemble(d_w, {k: _dev(C.to_mont(f, v.reshape(-1, 4))) for k, v in pre.items()}, g_host, b_host, mont=True)
+    d_pre = {k: _dev(C.to_mont(f, v.reshape(-1, 4))) for k, v in pre.items()}
+    mf.assemble(d_w, d_pre, g_host, b_host, mont=True)
+    d_w_b = torch.zeros_like(d_w)
+    mf.assemble(d_w_b, d_pre, g_host, b_host, mont=True, per_type_offsets=True)  # explicit per-slot offsets: same vector
     torch.cuda.synchronize()
+    assert torch.equal(d_w, d_w_b)
     got = C.from_mont(f, d_w.cpu().numpy().view(np.uint64))
     want = C.limbs_to_ints(C.from_mont(f, g_host))
     for fr in range(frames):
