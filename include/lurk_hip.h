@@ -105,6 +105,18 @@ int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_s
                                 size_t nscalars, int is_mont, void* stream);
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out_jacobian96);
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx);
+/* Workspaces (sort buffers, task partials, buckets: ~1 GiB per slot at 2^22 points) are allocated on a slot's first use; a
+ * prover that wants no allocation inside its first steps reserves them up front for the largest commitment it will make. */
+int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots);
+int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoints, int* window_bits, int* precomputed);
+/* Key files.  The reference caches its public parameters - mostly the commitment key - on disk and
+ * maps them back (/root/reference/src/public_parameters/mod.rs:33-56, disk_cache.rs:69-77).  save writes the resident key as it
+ * sits in HBM (64-byte header + 64-byte affine Montgomery records; with_table != 0 also the per-window multiples of a
+ * precomputed context); load maps the file and copies it straight into device memory.  load's flags: LURK_MSM_FLAG_PRECOMPUTE
+ * takes the file's table when it has one and rebuilds it on the device otherwise (one inversion per point: faster than
+ * reading 13 x the bytes from disk unless the file is hot in the page cache). */
+int lurk_hip_msm_ctx_save(const lurk_hip_msm_ctx* ctx, const char* path, int with_table);
+int lurk_hip_msm_ctx_load(lurk_hip_msm_ctx** ctx, const char* path, int flags);
 
 /* One process, several GPUs.  arecibo's prover is a single process (/root/reference/src/proof/nova.rs:304-326: one
  * witness-producer thread, rayon inside), so the multi-GPU form of the commitment is a context that owns a list

@@ -39,6 +39,10 @@ SIGNATURES = {
     "lurk_hip_msm_ctx_submit_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lurk_hip_msm_ctx_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lurk_hip_msm_ctx_destroy": (c_int, [c_void_p]),
+    "lurk_hip_msm_ctx_reserve": (c_int, [c_void_p, c_size_t, c_int]),
+    "lurk_hip_msm_ctx_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "lurk_hip_msm_ctx_save": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
+    "lurk_hip_msm_ctx_load": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int]),
     "lurk_hip_msm_multi_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, ctypes.POINTER(c_int), c_int, c_int]),
     "lurk_hip_msm_multi_num_shards": (c_int, [c_void_p]),
     "lurk_hip_msm_multi_shard": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),

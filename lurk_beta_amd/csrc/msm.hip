@@ -14,6 +14,11 @@
 //   buckets, planes 128 B x NB (x3)
 // Algorithmic HBM bytes per call: 96 B per point (32 B scalar + 64 B base) - the dominant kernel is
 // bound by the integer VALU (v_mad_u64_u32 issue), not by HBM.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <memory>
 
 #include "common.hpp"
@@ -617,19 +622,43 @@ __global__ __launch_bounds__(64) void msm_horner16_kernel(const Xyzz<P>* __restr
 }
 
 // ---- precomputed table: T[w*n + i] = 2^(c w) * P_i ----------------------------------------------
+// One inversion per POINT, not per table entry: the W-1 multiples are carried in XYZZ form, their (X, Y) parked in the table,
+// ZZ, ZZZ and the running product of the ZZZ parked in a scratch buffer, then one field inversion and Montgomery's trick walk
+// back over the windows (x = X / ZZ, y = Y / ZZZ, 1/ZZ = (ZZ / ZZZ)^2).  The per-entry inversion (285 dependent products each)
+// was 2/3 of the 189 ms a 2^22-point table took.
 template <class P>
 __global__ __launch_bounds__(256) void msm_precompute_kernel(const Affine<P>* __restrict__ bases, size_t n, Affine<P>* __restrict__ table, int c,
-                                                               int W) {
+                                                               int W, Fe<P>* __restrict__ scratch) {
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    Affine<P> a = bases[i];
+    const Affine<P> a = bases[i];
     table[i] = a;
+    if (affine_is_identity<P>(a)) {
+        for (int w = 1; w < W; w++) table[(size_t)w * n + i] = a;
+        return;
+    }
+    auto slot = [&](int w, int k) -> Fe<P>& { return scratch[((size_t)(w - 1) * 3 + k) * n + i]; };  // k: 0 = ZZ, 1 = ZZZ, 2 = product of ZZZ_1..w
     Xyzz<P> p = xyzz_from_affine<P>(a);
+    Fe<P> prod = fe_one<P>();
     for (int w = 1; w < W; w++) {
         p = xyzz_dbl_n<P>(p, c);
-        Affine<P> q = xyzz_to_affine<P>(p);
+        table[(size_t)w * n + i] = Affine<P>{p.x, p.y};
+        prod = fe_mul<P>(prod, p.zzz);
+        slot(w, 0) = p.zz;
+        slot(w, 1) = p.zzz;
+        slot(w, 2) = prod;
+    }
+    Fe<P> inv = fe_inv<P>(prod);  // 1 / (ZZZ_1 ... ZZZ_{W-1})
+    for (int w = W - 1; w >= 1; w--) {
+        const Fe<P> zzz = slot(w, 1);
+        const Fe<P> zzz_inv = w > 1 ? fe_mul<P>(inv, slot(w - 1, 2)) : inv;
+        inv = fe_mul<P>(inv, zzz);
+        const Fe<P> t = fe_mul<P>(slot(w, 0), zzz_inv);
+        const Fe<P> zz_inv = fe_sqr<P>(t);
+        Affine<P> q = table[(size_t)w * n + i];
+        q.x = fe_mul<P>(q.x, zz_inv);
+        q.y = fe_mul<P>(q.y, zzz_inv);
         table[(size_t)w * n + i] = q;
-        p = xyzz_from_affine<P>(q);  // keep ZZ = 1
     }
 }
 
@@ -648,6 +677,10 @@ struct MsmCtxBase {
     // asynchronous: enqueue on the slot's own stream (after `after`, the stream that produced the scalars)
     virtual void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after) = 0;
     virtual void wait(int slot, void* out_jac96_host) = 0;
+    virtual void reserve(size_t n, int slots) = 0;  // allocate the workspaces of slots 0..slots-1 for n scalars now
+    virtual const void* device_table() const = 0;  // npoints (x windows when precomputed) 64-byte records
+    // adopt a table that is already complete in device memory (loaded from a key file)
+    virtual void adopt_table(DevBuf&& buf, size_t n, bool precomputed_, int c_) = 0;
 };
 
 template <class P, class SF>
@@ -723,10 +756,14 @@ struct MsmCtx : MsmCtxBase {
         if (precompute) {
             own_bases.alloc((size_t)W * n * sizeof(Affine<P>));
             if (n) {
-                ProfScope ps("msm_precompute", s);
-                hipLaunchKernelGGL((msm_precompute_kernel<P>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Affine<P>*)d_bases, n,
-                                   own_bases.as<Affine<P>>(), c, W);
-                LURK_HIP_CHECK(hipGetLastError());
+                DevBuf scratch((size_t)(W - 1) * 3 * n * sizeof(Fe<P>));
+                {
+                    ProfScope ps("msm_precompute", s);
+                    hipLaunchKernelGGL((msm_precompute_kernel<P>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Affine<P>*)d_bases, n,
+                                       own_bases.as<Affine<P>>(), c, W, scratch.as<Fe<P>>());
+                    LURK_HIP_CHECK(hipGetLastError());
+                }
+                LURK_HIP_CHECK(hipStreamSynchronize(s));  // the scratch buffer is released here
             }
             LURK_HIP_CHECK(hipStreamSynchronize(s));
             table = own_bases.as<Affine<P>>();
@@ -738,6 +775,37 @@ struct MsmCtx : MsmCtxBase {
         } else {
             table = (const Affine<P>*)d_bases;  // borrowed
         }
+    }
+
+    void reserve(size_t n, int slots) override {
+        LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
+        LURK_REQUIRE(slots >= 1 && slots <= MSM_SLOTS, "slot count out of range");
+        if (n == 0) return;
+        const MsmShape sh = shape(n);
+        // A slot's first commitment otherwise pays for its two hardware queues and their scratch rings (tens of ms): run one
+        // empty commitment (all-zero scalars: no entries, every kernel launched) through each slot's streams now.
+        const size_t nz = n < 256 ? n : 256;
+        DevBuf zeros(nz * 32);
+        LURK_HIP_CHECK(hipMemset(zeros.p, 0, nz * 32));
+        for (int k = 0; k < slots; k++) {
+            Work& wk = work[k];
+            std::lock_guard<std::mutex> lk(wk.mu);
+            LURK_REQUIRE(!wk.pending, "slot is busy");
+            ensure_workspace(wk, sh);
+            ensure_streams(wk);
+            enqueue(wk, zeros.p, nz, 0, wk.stream, wk.acc_stream);
+            LURK_HIP_CHECK(hipStreamSynchronize(wk.stream));
+        }
+    }
+    const void* device_table() const override { return table; }
+    void adopt_table(DevBuf&& buf, size_t n, bool precomputed_, int c_) override {
+        own_bases = std::move(buf);
+        table = own_bases.as<Affine<P>>();
+        npoints = n;
+        precomputed = precomputed_;
+        c = c_;
+        const int pr[2] = {msm_tuning().sort_prio, msm_tuning().tail_prio};
+        LURK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(msm_wave_prio), pr, sizeof(pr)));
     }
 
     size_t ntask_max(const MsmShape& sh) const { return (size_t)sh.NB + (size_t)sh.W * sh.n / MSM_S + 1; }
@@ -901,6 +969,18 @@ struct MsmCtx : MsmCtxBase {
         Work& wk = work[slot];
         std::lock_guard<std::mutex> lk(wk.mu);
         LURK_REQUIRE(!wk.pending, "slot is busy: wait for it first");
+        ensure_streams(wk);
+        if (n) {
+            // the scalars were produced on the caller's stream: order the slot stream after it
+            LURK_HIP_CHECK(hipEventRecord(wk.ready, after));
+            LURK_HIP_CHECK(hipStreamWaitEvent(wk.stream, wk.ready, 0));
+            enqueue(wk, d_scalars, n, is_mont, wk.stream, wk.acc_stream);
+        }
+        wk.pending = true;
+        wk.pending_n = n;
+    }
+
+    void ensure_streams(Work& wk) {
         if (!wk.stream) {
             // the throughput-bound accumulate kernel runs on its own low-priority stream, everything else of the slot on a
             // high-priority one: the short kernels of the next commitment are dispatched ahead of it as wave slots free up
@@ -913,14 +993,6 @@ struct MsmCtx : MsmCtxBase {
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.planned, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.accumulated, hipEventDisableTiming));
         }
-        if (n) {
-            // the scalars were produced on the caller's stream: order the slot stream after it
-            LURK_HIP_CHECK(hipEventRecord(wk.ready, after));
-            LURK_HIP_CHECK(hipStreamWaitEvent(wk.stream, wk.ready, 0));
-            enqueue(wk, d_scalars, n, is_mont, wk.stream, wk.acc_stream);
-        }
-        wk.pending = true;
-        wk.pending_n = n;
     }
 
     void wait(int slot, void* out_jac96_host) override {
@@ -1142,6 +1214,104 @@ int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx) {
     return guarded([&] {
         DeviceGuard dg(ctx->impl->device);
         delete ctx;
+    });
+}
+
+// ---- key files ----------------------------------------------------------------------------------
+// The reference keeps its public parameters - the commitment key is their bulk - in a disk cache and maps them back
+// (/root/reference/src/public_parameters/mod.rs:33-56 "this clone is VERY expensive", disk_cache.rs:69-77).  A key file is the
+// resident context's image: a 64-byte header, then the 64-byte affine records exactly as they sit in HBM (the bases; with
+// with_table also the per-window multiples), so loading is open + mmap + copies straight into device memory, no parsing.
+struct KeyFileHeader {
+    char magic[8];  // "LURKHIPK"
+    uint32_t version, curve, window_bits, windows;  // windows = 1: bases only
+    uint64_t npoints, reserved[4];
+};
+static_assert(sizeof(KeyFileHeader) == 64, "key file header is 64 bytes");
+
+int lurk_hip_msm_ctx_save(const lurk_hip_msm_ctx* ctx, const char* path, int with_table) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && path, "null argument");
+        const MsmCtxBase& c = *ctx->impl;
+        DeviceGuard dg(c.device);
+        KeyFileHeader h{};
+        memcpy(h.magic, "LURKHIPK", 8);
+        h.version = 1;
+        h.curve = (uint32_t)c.curve;
+        h.window_bits = (uint32_t)c.c;
+        h.windows = (with_table && c.precomputed) ? (uint32_t)msm_num_windows(c.c) : 1u;
+        h.npoints = c.npoints;
+        FILE* f = fopen(path, "wb");
+        LURK_REQUIRE(f, std::string("cannot create ") + path);
+        bool good = fwrite(&h, sizeof(h), 1, f) == 1;
+        const size_t total = (size_t)h.windows * c.npoints * 64, chunk = (size_t)64 << 20;
+        std::vector<char> buf(total < chunk ? total : chunk);
+        for (size_t off = 0; good && off < total; off += chunk) {
+            const size_t len = total - off < chunk ? total - off : chunk;
+            if (hipMemcpy(buf.data(), (const char*)c.device_table() + off, len, hipMemcpyDeviceToHost) != hipSuccess) good = false;
+            else good = fwrite(buf.data(), 1, len, f) == len;
+        }
+        good = (fclose(f) == 0) && good;
+        LURK_REQUIRE(good, std::string("write failed: ") + path);
+    });
+}
+
+int lurk_hip_msm_ctx_load(lurk_hip_msm_ctx** ctx, const char* path, int flags) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && path, "null argument");
+        *ctx = nullptr;
+        const int fd = open(path, O_RDONLY);
+        LURK_REQUIRE(fd >= 0, std::string("cannot open ") + path);
+        struct stat st;
+        KeyFileHeader h{};
+        bool good = fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(h) && pread(fd, &h, sizeof(h), 0) == (ssize_t)sizeof(h);
+        good = good && memcmp(h.magic, "LURKHIPK", 8) == 0 && h.version == 1 && h.curve <= 1 && h.windows >= 1 && h.windows <= MSM_MAX_W &&
+               (h.windows == 1 || (h.window_bits >= 16 && h.window_bits <= 20 && h.windows == (uint32_t)msm_num_windows((int)h.window_bits))) &&
+               h.npoints < ((uint64_t)1 << 31) && (uint64_t)st.st_size == sizeof(h) + (uint64_t)h.windows * h.npoints * 64;
+        if (!good) {
+            close(fd);
+            LURK_REQUIRE(false, std::string("not a lurk-hip key file (or truncated): ") + path);
+        }
+        const size_t n = h.npoints, total = (size_t)h.windows * n * 64;
+        void* map = total ? mmap(nullptr, sizeof(h) + total, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+        close(fd);
+        LURK_REQUIRE(!total || map != MAP_FAILED, std::string("mmap failed: ") + path);
+        std::unique_ptr<MsmCtxBase> c(new_ctx((int)h.curve));
+        try {
+            const bool want_table = (flags & LURK_MSM_FLAG_PRECOMPUTE) != 0;
+            DevBuf buf(total);
+            if (total) LURK_HIP_CHECK(hipMemcpy(buf.p, (const char*)map + sizeof(h), total, hipMemcpyHostToDevice));
+            if (h.windows > 1 && want_table) {
+                c->adopt_table(std::move(buf), n, true, (int)h.window_bits);  // the file's table as it is
+            } else if (want_table) {
+                ctx_set_bases(c.get(), buf.p, n, false, flags, nullptr);      // bases from the file, table rebuilt on the device
+            } else {
+                DevBuf bases(n * 64);  // bases only (drop a table the caller did not ask for)
+                if (n) LURK_HIP_CHECK(hipMemcpy(bases.p, buf.p, n * 64, hipMemcpyDeviceToDevice));
+                c->adopt_table(std::move(bases), n, false, MSM_C_PLAIN);
+            }
+        } catch (...) {
+            if (map) munmap(map, sizeof(h) + total);
+            throw;
+        }
+        if (map) munmap(map, sizeof(h) + total);
+        *ctx = new lurk_hip_msm_ctx{std::move(c)};
+    });
+}
+int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx, "null ctx");
+        DeviceGuard dg(ctx->impl->device);
+        ctx->impl->reserve(nscalars, slots);
+    });
+}
+int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoints, int* window_bits, int* precomputed) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx, "null ctx");
+        if (curve) *curve = ctx->impl->curve;
+        if (npoints) *npoints = ctx->impl->npoints;
+        if (window_bits) *window_bits = ctx->impl->c;
+        if (precomputed) *precomputed = ctx->impl->precomputed ? 1 : 0;
     });
 }
 

@@ -68,6 +68,31 @@ class CommitmentKey:
             self.n = bases.size // 8
             _lib.check(lib.lurk_hip_msm_ctx_create(ctypes.byref(self._ctx), curve, _lib.ptr(bases), self.n, flags))
 
+    @classmethod
+    def load(cls, path: str, precompute: bool = False, window_bits: int = 0) -> "CommitmentKey":
+        """Key file -> resident context (``lurk_hip_msm_ctx_load``): the public-parameter cache of the commitment path
+        (/root/reference/src/public_parameters/mod.rs:33-56)."""
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        self._ctx = ctypes.c_void_p()
+        flags = (1 if precompute else 0) | ((window_bits & 0xFF) << 8)
+        _lib.check(lib.lurk_hip_msm_ctx_load(ctypes.byref(self._ctx), path.encode(), flags))
+        info = self.info()
+        self.curve, self.n = info["curve"], info["npoints"]
+        return self
+
+    def reserve(self, n: int, slots: int = 3) -> None:
+        """Allocate the workspaces of slots 0..slots-1 for n-scalar commitments now instead of on first use."""
+        _lib.check(_lib.load().lurk_hip_msm_ctx_reserve(self._ctx, n, slots))
+
+    def save(self, path: str, with_table: bool = False) -> None:
+        _lib.check(_lib.load().lurk_hip_msm_ctx_save(self._ctx, path.encode(), int(with_table)))
+
+    def info(self) -> dict:
+        c, n, w, p = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.load().lurk_hip_msm_ctx_info(self._ctx, ctypes.byref(c), ctypes.byref(n), ctypes.byref(w), ctypes.byref(p)))
+        return {"curve": c.value, "npoints": n.value, "window_bits": w.value, "precomputed": bool(p.value)}
+
     def commit(self, scalars: np.ndarray, is_mont: bool = False) -> np.ndarray:
         """``CE::commit(ck, v)``: host scalars (len <= n) -> Jacobian commitment."""
         lib = _lib.load()

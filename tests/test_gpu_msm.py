@@ -310,3 +310,45 @@ def test_thread_safety(hip):
     assert not errors, errors
     for ck in cks:
         ck.close()
+
+
+@pytest.mark.parametrize("cn,c", CURVES)
+def test_key_files_round_trip(hip, tmp_path, cn, c):
+    """f4: a resident key saved and mapped back (bases only / with its table; loaded plain / precomputed from either) commits to
+    the same bytes as the oracle; foreign and truncated files are refused."""
+    from lurk_beta_amd import CommitmentKey, LurkHipError, point_to_affine
+
+    n = 5000
+    sf = _sf(c)
+    B = C.synth_bases(c, n)
+    B[7] = 0  # an identity base survives the batched-inversion table build
+    S = C.synth_scalars(sf, 55, 1, n)
+    want = C.jac_to_affine(c, C.msm_pippenger(c, B, S))
+    ck = CommitmentKey(c, B, precompute=True)
+    assert point_to_affine(c, ck.commit(S)) == want
+    bases_only, with_table = str(tmp_path / "ck.bin"), str(tmp_path / "ck_table.bin")
+    ck.save(bases_only)
+    ck.save(with_table, with_table=True)
+    import os
+
+    assert os.path.getsize(bases_only) == 64 + 64 * n and os.path.getsize(with_table) == 64 + 13 * 64 * n
+    for path in (bases_only, with_table):
+        for pre in (False, True):
+            k2 = CommitmentKey.load(path, precompute=pre)
+            info = k2.info()
+            assert (info["curve"], info["npoints"], info["precomputed"]) == (c, n, pre)
+            assert point_to_affine(c, k2.commit(S)) == want, (path, pre)
+            assert point_to_affine(c, k2.commit(S[:777])) == C.jac_to_affine(c, C.msm_pippenger(c, B[:777], S[:777]))
+            k2.close()
+    ck.close()
+    bad = str(tmp_path / "bad.bin")
+    with open(with_table, "rb") as fh, open(bad, "wb") as out:
+        out.write(fh.read()[:-64])  # truncated
+    with pytest.raises(LurkHipError):
+        CommitmentKey.load(bad)
+    with open(bad, "wb") as out:
+        out.write(b"not a key file" * 10)
+    with pytest.raises(LurkHipError):
+        CommitmentKey.load(bad)
+    with pytest.raises(LurkHipError):
+        CommitmentKey.load(str(tmp_path / "missing.bin"))
