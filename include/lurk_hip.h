@@ -167,6 +167,29 @@ int lurk_hip_poseidon_tree8_dev(int field_id, const void* d_leaves, size_t n_lea
  * (arity+1)^2; pass NULL to query sizes only */
 int lurk_hip_poseidon_constants(int field_id, int arity, int* rf, int* rp, void* rc, void* mds);
 
+/* ---- store hydration -----------------------------------------------------------------------
+ * Replaces the recursive, node-by-node hashing of StoreCore::hydrate_z_cache / hash_ptr
+ * (/root/reference/src/lem/store_core.rs:256-269) with the StoreHasher preimage layouts
+ * (/root/reference/src/lem/store.rs:29-78).  nodes: the DAG in topological order (children before parents); the digest of
+ * every node is written to digests32 (n x 32 B canonical; an atom's digest is its value).  Every level is hashed on the
+ * device - one preimage gather + one Poseidon batch per (level, arity) - and nothing crosses PCIe in between.
+ * *levels (optional) receives the depth of the DAG.  Tags are the u16 tag values of /root/reference/src/tag.rs. */
+#define LURK_NODE_ATOM 0    /* digest = values32[value]                                   (store_core.rs:204) */
+#define LURK_NODE_TUPLE2 2  /* hash4(tag_a, h_a, tag_b, h_b)                              (store.rs:32-36) */
+#define LURK_NODE_TUPLE3 3  /* hash6(...)                                                 (store.rs:37-49) */
+#define LURK_NODE_TUPLE4 4  /* hash8(...)                                                 (store.rs:50-65) */
+#define LURK_NODE_COMPACT 5 /* hash4(h_a, tag_b, h_b, h_c)                                (store.rs:75-77) */
+#define LURK_NODE_COMM 6    /* hash3(values32[value] = secret, tag_a, h_a)                (store.rs:70-73) */
+typedef struct {
+    uint32_t kind;     /* LURK_NODE_* */
+    uint32_t tag;      /* the tag a parent's preimage records for this node */
+    uint32_t child[4]; /* indices of earlier nodes (tuple2: 2, tuple3: 3, tuple4: 4, compact: 3, comm: 1) */
+    uint32_t value;    /* atom: index of its value; comm: index of the secret */
+    uint32_t reserved;
+} lurk_hip_store_node;
+int lurk_hip_store_hydrate(int field_id, const lurk_hip_store_node* nodes, size_t n, const void* values32, size_t n_values,
+                           void* digests32, size_t* levels);
+
 /* ---- slot witnesses: the Poseidon / bit-decomposition part of the witness vector, produced on the device ------------
  * Replaces generate_slots_witnesses (/root/reference/src/lem/multiframe.rs:520-592), which runs allocate_slot
  * (/root/reference/src/lem/circuit.rs:242-315) on a WitnessCS per slot: neptune's circuit2::poseidon_hash_allocated for

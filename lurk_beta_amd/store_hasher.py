@@ -55,3 +55,47 @@ def hydrate(cache: PoseidonCache, nodes: list[tuple]) -> list[int]:
             for (i, _), d in zip(items, outs):
                 digest[i] = d
     return digest  # type: ignore[return-value]
+
+
+_KIND = {"atom": 0, "tuple2": 2, "tuple3": 3, "tuple4": 4, "compact": 5, "comm": 6}
+
+
+def hydrate_device(field_id: int, nodes: list[tuple]) -> list[int]:
+    """The same DAG through ``lurk_hip_store_hydrate``: every level hashed on the device, one copy back at the end."""
+    import ctypes
+
+    import numpy as np
+
+    from . import _lib
+
+    lib = _lib.load()
+    n = len(nodes)
+    rec = np.zeros((n, 8), dtype=np.uint32)  # kind, tag, child[4], value, reserved
+    values: list[int] = []
+    tag_of = [0] * n
+    for i, nd in enumerate(nodes):
+        kind = nd[0]
+        rec[i, 0] = _KIND[kind]
+        if kind == "atom":
+            tag_of[i] = nd[1]
+            rec[i, 6] = len(values)
+            values.append(int(nd[2]))
+        elif kind == "comm":
+            tag_of[i] = 8  # ExprTag::Comm
+            rec[i, 2] = nd[2]
+            rec[i, 6] = len(values)
+            values.append(int(nd[1]))
+        else:
+            tag_of[i] = nd[1]
+            for k, c in enumerate(nd[2:]):
+                rec[i, 2 + k] = c
+        rec[i, 1] = tag_of[i]
+    vals = np.zeros((max(len(values), 1), 4), dtype=np.uint64)
+    for k, v in enumerate(values):
+        for w in range(4):
+            vals[k, w] = (v >> (64 * w)) & 0xFFFFFFFFFFFFFFFF
+    out = np.zeros((n, 4), dtype=np.uint64)
+    levels = ctypes.c_size_t()
+    _lib.check(lib.lurk_hip_store_hydrate(field_id, _lib.ptr(rec), n, _lib.ptr(vals), len(values), _lib.ptr(out), ctypes.byref(levels)))
+    hydrate_device.last_levels = levels.value
+    return [int(out[i, 0]) | int(out[i, 1]) << 64 | int(out[i, 2]) << 128 | int(out[i, 3]) << 192 for i in range(n)]

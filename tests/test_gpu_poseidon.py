@@ -155,6 +155,53 @@ def test_store_hydration_level_batches(hip):
     nodes2 = [("atom", R.TAG_SYM, 11), ("atom", R.TAG_NUM, 22), ("atom", R.TAG_ENV, 0), ("compact", R.TAG_ENV, 0, 1, 2)]
     d2 = hydrate(PoseidonCache(1), nodes2)
     assert d2[3] == R.poseidon_hash(1, [11, R.TAG_NUM, 22, 0])
+    # the same DAGs through the C ABI entry point (all levels on the device, no per-level round trip)
+    from lurk_beta_amd.store_hasher import hydrate_device
+
+    assert hydrate_device(kat.BN, nodes) == digests
+    assert hydrate_device.last_levels == max(len("lurk"), len("user"), len("nil")) + 3 + 3  # chars + symbol path + cons, fun, comm
+    assert hydrate_device(1, nodes2) == d2
+    # a few-thousand-node DAG: a list of 400 distinct symbols, a tuple3 and compact bindings on top; node-by-node oracle recursion
+    import time
+
+    big = []
+    syms = [symbol_nodes(big, ["lurk", "user", "sym%d" % k]) for k in range(400)]
+    big.append(("atom", R.TAG_NIL, 0))
+    lst = len(big) - 1
+    for sy in reversed(syms):
+        big.append(("tuple2", R.TAG_CONS, sy, lst))
+        lst = len(big) - 1
+    big.append(("tuple3", R.TAG_THUNK, syms[0], syms[1], lst))
+    big.append(("compact", R.TAG_ENV, syms[2], syms[3], lst))
+    big.append(("comm", 12345, len(big) - 2))
+    t0 = time.perf_counter()
+    got = hydrate_device(1, big)
+    dt = time.perf_counter() - t0
+    memo = {}
+
+    def ref(i):
+        if i in memo:
+            return memo[i]
+        nd = big[i]
+        tag = lambda j: 8 if big[j][0] == "comm" else big[j][1]
+        if nd[0] == "atom":
+            v = nd[2]
+        elif nd[0] == "comm":
+            v = R.poseidon_hash(1, [nd[1], tag(nd[2]), ref(nd[2])])
+        elif nd[0] == "compact":
+            a, b, c = nd[2:]
+            v = R.poseidon_hash(1, [ref(a), tag(b), ref(b), ref(c)])
+        else:
+            v = R.poseidon_hash(1, [x for c in nd[2:] for x in (tag(c), ref(c))])
+        memo[i] = v
+        return v
+
+    import sys
+
+    sys.setrecursionlimit(10000)
+    for i in (len(big) - 1, len(big) - 2, len(big) - 3, lst, syms[17], 5):
+        assert got[i] == ref(i), i
+    print("store hydrate: %d nodes, %d levels, %.1f ms" % (len(big), hydrate_device.last_levels, dt * 1e3))
 
 
 def test_full_size_tree_2_24(hip):
