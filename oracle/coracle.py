@@ -157,6 +157,25 @@ def msm_pippenger(curve: int, bases: np.ndarray, scalars: np.ndarray, nthreads: 
     return out
 
 
+def msm_fast(curve: int, bases: np.ndarray, scalars: np.ndarray, nthreads: int = 0, info: dict | None = None) -> np.ndarray:
+    """The CPU baseline (oracle/msm_fast.c: pasta-msm-shaped Pippenger); same interface and result as msm_pippenger."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64)
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    out = np.empty(12, dtype=np.uint64)
+    if nthreads <= 0:
+        nthreads = lib().orc_num_threads()
+    c, tiles = ctypes.c_int(), ctypes.c_int()
+    lib().orc_msm_fast(curve, _p(bases), _p(scalars), ctypes.c_size_t(scalars.size // 4), nthreads, _p(out), ctypes.byref(c), ctypes.byref(tiles))
+    if info is not None:
+        info.update(window_bits=c.value, tiles=tiles.value, threads=nthreads)
+    return out
+
+
+def fast_mul_ns(curve: int = 0, iters: int = 2_000_000) -> float:
+    lib().orc_fast_mul_ns.restype = ctypes.c_double
+    return float(lib().orc_fast_mul_ns(curve, iters))
+
+
 def jac_to_affine(curve: int, jac: np.ndarray) -> tuple[int, int]:
     """Jacobian Montgomery (12 limbs) -> canonical affine (x, y) ints; identity -> (0, 0)."""
     jac = np.ascontiguousarray(jac, dtype=np.uint64)

@@ -98,3 +98,29 @@ def test_ntt(f):
     assert C.limbs_to_ints(C.ntt(f, C.ints_to_limbs(fw), True)) == a
     w = R.root_of_unity(p, 32)
     assert pow(w, 1 << 32, p) == 1 and pow(w, 1 << 31, p) == p - 1
+
+
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+def test_cpu_baseline_msm_matches_the_slow_oracle(cn, c):
+    """oracle/msm_fast.c (bench.py's cpu_baseline: pasta-msm-shaped Pippenger) == oracle.c's Pippenger == naive, incl. the edge
+    cases of the signed recoding and the exceptional cases of the mixed addition; any thread count."""
+    sf = 1 if c == 0 else 0
+    q = R.CURVES[cn]["order"]
+    for n, dist in ((1, 0), (2, 1), (33, 0), (3000, 1), (1 << 14, 0)):
+        B, S = C.synth_bases(c, n), C.synth_scalars(sf, 1, dist, n)
+        want = C.jac_to_affine(c, C.msm_pippenger(c, B, S))
+        for th in (1, 3, 8):
+            assert C.jac_to_affine(c, C.msm_fast(c, B, S, nthreads=th)) == want, (n, th)
+    n = 300
+    B = C.synth_bases(c, n)
+    B[3] = B[2]
+    B[5] = 0
+    s = [R.uniform_fe(9, i, q) for i in range(n)]
+    s[2] = s[3] = 777          # same point, same bucket: the doubling branch
+    s[10], s[11] = 555, q - 555
+    B[11] = B[10]              # P and -P meet: identity mid-chain
+    s[6], s[7], s[8], s[9] = 0, q - 1, 1, (1 << 254) | 0xFFFF
+    S = C.ints_to_limbs(s)
+    assert C.jac_to_affine(c, C.msm_fast(c, B, S)) == C.jac_to_affine(c, C.msm_naive(c, B, S))
+    assert C.jac_to_affine(c, C.msm_fast(c, B, C.ints_to_limbs([0] * n))) == (0, 0)
+    assert C.jac_to_affine(c, C.msm_fast(c, B[:0], S[:0])) == (0, 0)
