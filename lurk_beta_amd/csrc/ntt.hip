@@ -18,7 +18,8 @@
 #include <tuple>
 
 #include "common.hpp"
-#include "field.cuh"
+#include "curve29.cuh"
+#include "poseidon29.cuh"
 
 namespace lurk {
 
@@ -124,6 +125,208 @@ __global__ __launch_bounds__(NTT_PASS_BLOCK) void ntt_pass_kernel(const Fe<F>* _
     }
 }
 
+
+// ---- wave-resident passes (log_n >= 12) ------------------------------------------------------------------------------------
+// The north-star shape: butterflies in registers and across lanes, LDS only as the tile that turns strided sub-transforms into
+// coalesced rows.  A pass covers stages s0+1 .. s0+ns (ns <= 8) of the same twisted decimation-in-time as ntt_pass_kernel.
+// A workgroup of 8 waves owns a tile of 2048 elements = 2^ns rows (index l inside the sub-transform) x 2^(11-ns) neighbouring
+// columns; a wave owns 256 of them as 4 per lane (slot = lane + 64 k: l = slot mod 2^ns, column = slot >> ns), on the
+// radix-2^29 layer (field29.cuh).  Stage st pairs the slots that differ in bit st:
+//   st < 6   partner lane = lane ^ 2^st.  The two lanes hold 4 butterflies between them; each does the twiddle product of TWO
+//            (lane with the bit clear: k = 0, 1, the other: k = 2, 3), so no lane multiplies for nothing: 2 exchanges to bring
+//            the operands together, 2 to hand the partner its results, 2 products per lane per stage
+//   st >= 6  both slots in the lane's own registers (k ^ 1, k ^ 2).
+// Twiddles of the stages come from a per-workgroup LDS table of omega_{2^ns}^j (radix-2^29 records), the twist between passes
+// from the global omega^i table.  The first pass reads the caller's natural-order, canonical input through the bit-reversed
+// tile addressing (no separate permutation pass) and converts on the fly; between passes values are stored as the packed
+// 256-bit image of the lazily reduced Montgomery-2^261 residue (no conversion products); the last pass multiplies by 1 (or
+// n^-1) on the way out, which is also the conversion to canonical bytes.  2^24: three passes of 8 stages.
+struct NttConst29 {
+    uint32_t in_c[9];   // 2^522 mod p   (canonical -> Montgomery 2^261)
+    uint32_t out_c[9];  // 1 or n^-1, plain (Montgomery 2^261 -> canonical, scaled)
+};
+constexpr int NTT_W_BLOCK = 512;   // 8 waves
+constexpr int NTT_W_TILE_LOG = 11;  // 2048 elements per workgroup
+
+template <class F>
+__device__ __forceinline__ F29<F> f29_lane_xchg(const F29<F>& v, int mask) {
+    F29<F> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = __shfl_xor(v.l[i], mask);
+    return r;
+}
+template <class F>
+__device__ __forceinline__ F29<F> f29_select(bool c, const F29<F>& a, const F29<F>& b) {
+    F29<F> r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+// 4p with its limbs re-balanced like f29_bias (limb_i += 2^30, limb_{i+1} -= 2): subtracting a TIGHT value below 2^256 limb-wise
+// never underflows.  The butterflies' subtrahend is always a fresh product (< 2^255 + p), so this small bias replaces the
+// general 64p one and a value grows by < 2^256.1 per stage: eight stages stay below 2^259.3 with no reduction in between.
+template <class F>
+LURK_HD constexpr uint32_t ntt_bias4(int i) {
+    uint64_t carry = 0;
+    uint32_t limb = 0;
+    for (int k = 0; k <= i; k++) {
+        uint64_t x = (uint64_t)f29_mod<F>(k) * 4u + carry;
+        limb = (uint32_t)(x & F29_MASK);
+        carry = x >> 29;
+        if (k == 8) limb = (uint32_t)x;
+    }
+    uint32_t v = limb;
+    if (i < 8) v += 1u << 30;
+    if (i > 0) v -= 2u;
+    return v;
+}
+// (u, v) <- (u + w v, u - w v): u tight-limbed on entry (value < 2^260), v tight; both results carried (tight limbs), lazily
+// reduced: each grows by < 2^256.1
+template <class F>
+__device__ __forceinline__ void ntt_bfly(F29<F>& u, F29<F>& v, const F29<F>& w) {
+    const F29<F> x = f29_mul<F>(v, w);  // tight, < 2^255 + p
+    F29<F> d;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d.l[i] = u.l[i] + (ntt_bias4<F>(i) - x.l[i]);
+    v = f29_carry<F>(d);
+    u = f29_carry<F>(f29_add<F>(u, x));
+}
+
+template <class F, bool FIRST>
+__global__ __launch_bounds__(NTT_W_BLOCK) void ntt_wave_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
+                                                                      unsigned log_n, unsigned s0, unsigned ns, NttConst29 cst, int last) {
+    extern __shared__ uint32_t lds_w[];
+    const unsigned cbits = NTT_W_TILE_LOG - ns, rows = 1u << ns, cols = 1u << cbits;
+    const unsigned row_words = cols * 8 + 2;  // 8 bytes of padding per row: the column reads of a wave spread over all banks
+    uint32_t* tile = lds_w;
+    uint32_t* lt = lds_w + rows * row_words;  // omega_{2^ns}^j, j < 2^(ns-1), radix-2^29 records
+    const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t half_n = (size_t)1 << (log_n - 1);
+    size_t H = 0, tbase = 0;
+    if (FIRST) {
+        tbase = (size_t)blockIdx.x << cbits;  // 2^cbits consecutive values of rev(H)
+    } else {
+        const size_t groups = ((size_t)1 << s0) >> cbits;
+        H = blockIdx.x / groups;
+        tbase = (blockIdx.x % groups) << cbits;
+    }
+    for (unsigned j = tid; j < rows / 2; j += NTT_W_BLOCK) {
+        const F29<F> w = f29_from_mont256<F>(tw[(size_t)j << (log_n - ns)]);
+#pragma unroll
+        for (int i = 0; i < 9; i++) lt[j * P29_STRIDE + i] = w.l[i];
+    }
+    // ---- tile in: rows of 2^cbits neighbouring elements
+    for (unsigned e = tid; e < (1u << NTT_W_TILE_LOG); e += NTT_W_BLOCK) {
+        const unsigned col = e & (cols - 1), row = e >> cbits;
+        // FIRST: row r holds the natural-order elements (r << (log_n - ns)) | rev(H): it is l = rev_ns(r) of sub-transform H
+        const size_t src = FIRST ? (((size_t)row << (log_n - ns)) | (tbase + col)) : ((H << (s0 + ns)) | ((size_t)row << s0) | (tbase + col));
+        const uint4* g = reinterpret_cast<const uint4*>(in + src);
+        const uint4 lo = g[0], hi = g[1];
+        uint32_t* d = tile + row * row_words + col * 8;
+        d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w; d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
+    }
+    __syncthreads();
+    // ---- registers: 4 slots per lane
+    F29<F> e[4];
+    const unsigned lmask = rows - 1, wave_cols = 1u << (8 - ns);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned slot = lane + 64u * k, l = slot & lmask, col = wave * wave_cols + (slot >> ns);
+        const unsigned row = FIRST ? (__brev(l) >> (32 - ns)) : l;
+        const uint32_t* sp = tile + row * row_words + col * 8;
+        uint32_t x[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) x[i] = sp[i];
+        if (FIRST) {
+            F29<F> c;
+#pragma unroll
+            for (int i = 0; i < 9; i++) c.l[i] = cst.in_c[i];
+            e[k] = f29_mul<F>(f29_from_plain<F>(x), c);
+        } else {
+            e[k] = f29_from_plain<F>(x);
+            const size_t t = tbase + col;
+            const size_t idx = (t * (size_t)(__brev(l) >> (32 - ns))) << (log_n - s0 - ns);
+            Fe<F> w = tw[idx & (half_n - 1)];
+            if (idx & half_n) w = fe_neg<F>(w);
+            e[k] = f29_mul<F>(e[k], f29_from_mont256<F>(w));
+        }
+    }
+    // ---- stages
+#pragma unroll
+    for (unsigned st = 0; st < 6; st++) {
+        if (st >= ns) break;
+        const int bit = 1 << st;
+        const bool hi = (lane & bit) != 0;
+        const unsigned j = lane & (bit - 1);
+        const F29<F> w = ld_const29<F>(lt + (size_t)(j << (ns - st - 1)) * P29_STRIDE);
+        const F29<F> q0 = f29_lane_xchg<F>(f29_select<F>(hi, e[0], e[2]), bit);
+        const F29<F> q1 = f29_lane_xchg<F>(f29_select<F>(hi, e[1], e[3]), bit);
+        F29<F> u0 = f29_select<F>(hi, q0, e[0]), v0 = f29_select<F>(hi, e[2], q0);
+        F29<F> u1 = f29_select<F>(hi, q1, e[1]), v1 = f29_select<F>(hi, e[3], q1);
+        ntt_bfly<F>(u0, v0, w);
+        ntt_bfly<F>(u1, v1, w);
+        // the lane with the bit clear keeps the sums (its k = 0, 1) and receives the partner's sums for k = 2, 3;
+        // the other keeps the differences (its k = 2, 3) and receives the differences for k = 0, 1
+        const F29<F> r0 = f29_lane_xchg<F>(f29_select<F>(hi, u0, v0), bit);
+        const F29<F> r1 = f29_lane_xchg<F>(f29_select<F>(hi, u1, v1), bit);
+        e[0] = f29_select<F>(hi, r0, u0);
+        e[1] = f29_select<F>(hi, r1, u1);
+        e[2] = f29_select<F>(hi, v0, r0);
+        e[3] = f29_select<F>(hi, v1, r1);
+    }
+    if (ns > 6) {  // slots lane and lane + 64: j = lane
+        const F29<F> w = ld_const29<F>(lt + (size_t)(lane << (ns - 7)) * P29_STRIDE);
+        ntt_bfly<F>(e[0], e[1], w);
+        ntt_bfly<F>(e[2], e[3], w);
+    }
+    if (ns > 7) {  // slots differing by 128: j = lane, lane + 64
+        ntt_bfly<F>(e[0], e[2], ld_const29<F>(lt + (size_t)lane * P29_STRIDE));
+        ntt_bfly<F>(e[1], e[3], ld_const29<F>(lt + (size_t)(lane + 64) * P29_STRIDE));
+    }
+    // ---- tile out (each wave rewrites only its own columns), natural l
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned slot = lane + 64u * k, l = slot & lmask, col = wave * wave_cols + (slot >> ns);
+        uint32_t x[8];
+        if (last) {
+            F29<F> c;
+#pragma unroll
+            for (int i = 0; i < 9; i++) c.l[i] = cst.out_c[i];
+            const F29<F> u = f29_mul<F>(e[k], c);  // value / 2^261 (times n^-1): tight, < p + 1
+            f29_pack<F>(u, x);
+            fe_cond_sub<F>(x);
+        } else {
+            f29_pack<F>(f29_reduce<F>(e[k]), x);  // < 2^255.1: the packed image of the lazy residue
+        }
+        uint32_t* d = tile + l * row_words + col * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++) d[i] = x[i];
+    }
+    __syncthreads();
+    for (unsigned e2 = tid; e2 < (1u << NTT_W_TILE_LOG); e2 += NTT_W_BLOCK) {
+        unsigned col, row;
+        size_t dst;
+        if (FIRST) {  // column = one contiguous sub-transform of the (bit-reversed order) working array
+            row = e2 & lmask;
+            col = e2 >> ns;
+            const size_t Hc = __brevll((unsigned long long)(tbase + col)) >> (64 - (log_n - ns));
+            dst = (Hc << ns) | row;
+        } else {
+            col = e2 & (cols - 1);
+            row = e2 >> cbits;
+            dst = (H << (s0 + ns)) | ((size_t)row << s0) | (tbase + col);
+        }
+        const uint32_t* sp = tile + row * row_words + col * 8;
+        uint4* g = reinterpret_cast<uint4*>(out + dst);
+        g[0] = make_uint4(sp[0], sp[1], sp[2], sp[3]);
+        g[1] = make_uint4(sp[4], sp[5], sp[6], sp[7]);
+    }
+}
+static size_t ntt_wave_lds(unsigned ns) {
+    const size_t rows = (size_t)1 << ns, cols = (size_t)1 << (NTT_W_TILE_LOG - ns);
+    return (rows * (cols * 8 + 2) + (rows / 2 + 1) * P29_STRIDE) * 4;
+}
+
 template <class F>
 static Fe<F> host_omega(unsigned log_n, bool inverse) {
     Fe<F> w;
@@ -176,6 +379,40 @@ static void ntt_device(void* d_data, unsigned log_n, bool inverse, hipStream_t s
     const Fe<F>* tw = plan.tw.template as<Fe<F>>();
     allow_dynamic_lds((const void*)ntt_pass_kernel<F>, 160 * 1024);
     ProfScope ps("ntt", s);
+    if (log_n >= 12 && !getenv("LURK_NTT_LDS_PASSES")) {
+        NttConst29 cst;
+        {
+            Fe<F> v = fe_one<F>();  // 2^256 mod p as a plain integer -> 2^522 mod p
+            for (int d = 0; d < 522 - 256; d++) v = fe_add<F>(v, v);
+            const F29<F> a = f29_from_plain<F>(v.l);
+            Fe<F> o = fe_from_mont<F>(inverse ? fe_inv<F>(fe_from_u64<F>((uint64_t)n)) : fe_one<F>());  // plain n^-1 or 1
+            const F29<F> b = f29_from_plain<F>(o.l);
+            for (int i = 0; i < 9; i++) { cst.in_c[i] = a.l[i]; cst.out_c[i] = b.l[i]; }
+        }
+        const unsigned passes = (log_n + 7) / 8;
+        unsigned s0 = 0;
+        for (unsigned p = 0; p < passes; p++) {
+            const unsigned ns = (log_n - s0 + (passes - p) - 1) / (passes - p);  // as even as possible, <= 8
+            const bool first = p == 0, last = p + 1 == passes;
+            const size_t lds = ntt_wave_lds(ns);
+            const Fe<F>* src = first ? data : tmp;
+            Fe<F>* dst = last ? data : tmp;
+            if (first) {
+                allow_dynamic_lds((const void*)ntt_wave_pass_kernel<F, true>, 160 * 1024);
+                hipLaunchKernelGGL((ntt_wave_pass_kernel<F, true>), dim3((unsigned)(n >> NTT_W_TILE_LOG)), dim3(NTT_W_BLOCK), lds, s, src, tmp, tw, log_n, 0u, ns,
+                                   cst, 0);
+            } else {
+                allow_dynamic_lds((const void*)ntt_wave_pass_kernel<F, false>, 160 * 1024);
+                hipLaunchKernelGGL((ntt_wave_pass_kernel<F, false>), dim3((unsigned)(n >> NTT_W_TILE_LOG)), dim3(NTT_W_BLOCK), lds, s, src, dst, tw, log_n, s0, ns,
+                                   cst, last ? 1 : 0);
+            }
+            s0 += ns;
+        }
+        hipError_t launch_err = hipGetLastError();
+        (void)hipFreeAsync(tmp, s);
+        LURK_HIP_CHECK(launch_err);
+        return;
+    }
     if (log_n >= 10) hipLaunchKernelGGL((ntt_bitrev_tiled_kernel<F>), dim3((unsigned)(n >> 10)), dim3(256), 0, s, data, tmp, log_n);
     else hipLaunchKernelGGL((ntt_bitrev_kernel<F>), dim3(div_up(n, 256)), dim3(256), 0, s, data, tmp, log_n);
     Fe<F> scale = fe_one<F>();
