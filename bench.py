@@ -618,13 +618,13 @@ def other_workloads(args, lib, world, rank):
 
         scaling, parallelism = "weak", "single" if world == 1 else f"replicas{world}"
         unit, per_step_units, kname = "Melements/s", n, "ntt"
-        left, passes = max(0, log_n - 11), 2  # bit-reversal pass + the 11-stage pass ...
-        while left > 0:                        # ... + later passes of <= 9 stages (mirrors ntt.hip)
-            ns = left if left <= 9 else min(8, (left + 1) // 2)
-            left -= ns
-            passes += 1
+        if log_n >= 12:  # wave-resident passes of <= 8 stages, bit reversal folded into the first (ntt.hip)
+            passes = (log_n + 7) // 8
+        else:            # small sizes: bit-reversal pass + one LDS pass
+            passes = 2
         alg_bytes = 64.0 * passes * n
-        workload = f"radix-2 NTT, 2^{log_n} Pallas-Fq elements (parity unpinned: no reference counterpart)"
+        workload = f"radix-2 NTT, 2^{log_n} Pallas-Fq elements, {passes} passes over memory (parity unpinned: no reference counterpart)"
+        ntt_mults = n * (log_n / 2.0 + (passes - 1) + 2)  # butterflies + twists between passes + conversion in and out
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
@@ -667,6 +667,13 @@ def other_workloads(args, lib, world, rank):
                          "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel_ms_per_step": round(kernel_ms_per_step, 4),
                          "algorithmic_bytes_per_step": alg_bytes},
         }
+        if args.workload == "ntt" and kernel_ms_per_step > 0:
+            # the honest ceiling: field products on the radix-2^29 layer (135 v_mad_u64_u32 each at 4.6 cycles per wave-instruction,
+            # 1024 SIMDs, ~2.15 GHz: profiles/r01_microbench_instr_rates.txt), not HBM
+            peak = 1024 * 2.15e9 * 64 / (135 * 4.6)
+            ach = ntt_mults / (kernel_ms_per_step * 1e-3)
+            out["roofline_valu"] = {"bound": "valu", "kernel": "ntt_wave_pass_kernel", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 2),
+                                    "unit": "G field-mul/s", "frac": round(ach / peak, 4), "field_muls_per_step": ntt_mults}
         if not args.no_cpu_baseline:
             from oracle import coracle as C
 

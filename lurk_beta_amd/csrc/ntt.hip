@@ -5,7 +5,12 @@
 // omega_n = (5^((p-1)/2^32))^(2^(32-log_n)); natural order in, natural order out; the inverse
 // transform uses omega^-1 and scales by 1/n.
 //
-// Shape: decimation-in-time after a bit-reversal permutation, in passes that each fuse several
+// Two implementations of the same twisted decimation-in-time:
+//   log_n >= 12  wave-resident passes (ntt_wave_pass_kernel below): <= 8 stages per pass with the butterflies in registers and
+//                across lanes (__shfl_xor), radix-2^29 arithmetic, bit reversal folded into the first pass's tile addressing,
+//                LDS only as the transposing tile and the twiddle table: 3 passes over memory at 2^24
+//   smaller      the LDS-stage kernels (also reachable with LURK_NTT_LDS_PASSES=1 for A/B runs):
+// Shape of the LDS-stage path: decimation-in-time after a bit-reversal permutation, in passes that each fuse several
 // radix-2 stages out of an LDS tile:
 //   * the permutation is a 32x32 LDS transpose (both the reads and the writes are 1 KiB rows);
 //   * pass 1 (stages 1..11) works on 2048 contiguous elements;
