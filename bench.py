@@ -539,6 +539,26 @@ def collect_traffic(args):
                                  "estimate for the 64-B gathers of this kernel), WRITE_SIZE as is"}
 
 
+def poseidon_mads_per_hash(arity):
+    """v_mad_u64_u32 per hash of the kernels' schedule (poseidon29.cuh), radix-2^29 layer: product 135, squaring 99, one lazy row
+    of k terms 81 k + 54.  Full round: t S-boxes (2 squarings + 1 product) + t rows of t terms; partial round: 1 S-box + one
+    row of t terms + t - 1 products; canonical in (arity products) and out (1)."""
+    from oracle import pyref as R
+
+    t = arity + 1
+    rf, rp = R.round_numbers(arity)
+    sbox, row = 2 * 99 + 135, 81 * t + 54
+    return rf * (t * sbox + t * row) + rp * (sbox + row + (t - 1) * 135) + (arity + 1) * 135
+
+
+def poseidon_valu_roofline(arity, hashes, kernel_ms):
+    mads = poseidon_mads_per_hash(arity)
+    peak = 1024 * 2.15e9 * 64 / (mads * 4.6)  # hashes / s if the SIMDs issued nothing but those mads (4.6 cycles per wave-instruction, measured)
+    ach = hashes / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+    return {"bound": "valu", "kernel": "poseidon_batch_kernel", "achieved": round(ach / 1e6, 2), "peak": round(peak / 1e6, 2), "unit": f"M hash{arity}/s",
+            "frac": round(ach / peak, 4), "mads_per_hash": mads}
+
+
 def valu_roofline(acc_ms, mixed_adds):
     # radix-2^29 XYZZ mixed addition (curve29.cuh): 8 products of 135 + 2 squarings of 99 v_mad_u64_u32, minus the
     # one reduction (54) saved by forming Y3 as a two-term lazy row
@@ -667,6 +687,8 @@ def other_workloads(args, lib, world, rank):
                          "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel_ms_per_step": round(kernel_ms_per_step, 4),
                          "algorithmic_bytes_per_step": alg_bytes},
         }
+        if args.workload == "poseidon_tree":
+            out["roofline_valu"] = poseidon_valu_roofline(8, ((n - 1) // 7) / world, kernel_ms_per_step)
         if args.workload == "ntt" and kernel_ms_per_step > 0:
             # the honest ceiling: field products on the radix-2^29 layer (135 v_mad_u64_u32 each at 4.6 cycles per wave-instruction,
             # 1024 SIMDs, ~2.15 GHz: profiles/r01_microbench_instr_rates.txt), not HBM

@@ -4,16 +4,17 @@ TAG=${1:-r01}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/sweep_$TAG.jsonl; : > $OUT
 run() { python bench.py "$@" 2>/dev/null | tail -1 >> $OUT; }
-run --steps 12 --warmup 3                                         # headline: 2^22 table, 2 in flight (+cpu baseline)
-run --steps 12 --warmup 3 --no-cpu-baseline --pipeline 3
-run --steps 10 --warmup 3 --no-cpu-baseline --pipeline 1
-run --steps 10 --warmup 3 --no-cpu-baseline --pipeline 1 --precompute 0
-run --steps 10 --warmup 3 --no-cpu-baseline --dist witness
-run --steps 20 --warmup 3 --no-cpu-baseline --log-n 20 --pipeline 3
-run --steps 20 --warmup 3 --no-cpu-baseline --log-n 20 --pipeline 1
-run --steps 20 --warmup 3 --no-cpu-baseline --log-n 20 --pipeline 1 --precompute 0
-run --steps 20 --warmup 3 --no-cpu-baseline --log-n 20 --pipeline 1 --precompute 0 --dist witness
-run --steps 10 --warmup 2 --no-cpu-baseline --log-n 22 --verify
+run --steps 12 --warmup 3                                         # headline: 2^22 table, 3 in flight (+ live PMC traffic, plain leg, cpu baseline)
+run --steps 12 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --pipeline 2
+run --steps 10 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --pipeline 1
+run --steps 10 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --pipeline 1 --precompute 0
+run --steps 10 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --dist witness
+run --steps 20 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --log-n 20 --pipeline 3
+run --steps 20 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --log-n 20 --pipeline 1
+run --steps 20 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --log-n 20 --pipeline 1 --precompute 0
+run --steps 20 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --log-n 20 --pipeline 1 --precompute 0 --dist witness
+run --steps 10 --warmup 2 --no-cpu-baseline --pmc off --no-plain-leg --log-n 22 --verify
+run --gpus 2 --backend gloo --verify --log-n 20 --steps 5 --warmup 1 --no-cpu-baseline   # two ranks sharing this box's one GPU: functional line only
 run --workload fold_step --steps 10 --warmup 2
 run --workload fold_step --steps 5 --warmup 2 --rc 900 --no-cpu-baseline
 run --workload poseidon_tree --steps 3 --warmup 1

@@ -489,7 +489,7 @@ struct MsmTuning {
     int persistent, waves, r128, prio, sort_prio, tail_prio;
     MsmTuning() {
         auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
-        persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);
+        persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // 0 = never, 1 = by size, 2 = always
         waves = geti("LURK_MSM_ACC_WAVES", 1);
         r128 = geti("LURK_MSM_ACC_R128", 0);
         prio = geti("LURK_MSM_PRIO", 1);
@@ -883,12 +883,15 @@ struct MsmCtx : MsmCtxBase {
         }
         if (s_acc) {
             const MsmTuning& tn = msm_tuning();
+            // the persistent form pays off when the accumulation is long enough to hide another commitment's short kernels
+            // under it (>= 2^25 sorted entries: 2^22 points and up with the table); below that the plain launch is faster
+            const bool persistent = tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 25) : tn.persistent != 0;
             LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4, s));
             LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
             LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, wk.planned, 0));
             {
                 ProfScope ps("msm_accumulate", s_acc);
-                if (tn.persistent)
+                if (persistent)
                     msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
                                                         wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
                                                         wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(), tn.waves, tn.r128 != 0,
