@@ -105,6 +105,9 @@ int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_s
                                 size_t nscalars, int is_mont, void* stream);
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out_jacobian96);
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx);
+/* Points the context at other device-resident bases (borrowed, plain key) and keeps its workspaces: a key that changes every
+ * round (the folded key of the inner-product argument) without re-allocation. */
+int lurk_hip_msm_ctx_rebind_dev(lurk_hip_msm_ctx* ctx, const void* d_bases_affine64, size_t npoints);
 /* Workspaces (sort buffers, task partials, buckets: ~1 GiB per slot at 2^22 points) are allocated on a slot's first use; a
  * prover that wants no allocation inside its first steps reserves them up front for the largest commitment it will make. */
 int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots);
@@ -290,6 +293,33 @@ int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* ctx, const void* r32_mont);
 int lurk_hip_fold_ctx_running_dev(lurk_hip_fold_ctx* ctx, void** d_z, void** d_e, void** stream);
 /* copies of the running pair for the host (either may be NULL); synchronises the context's stream */
 int lurk_hip_fold_ctx_read(lurk_hip_fold_ctx* ctx, void* z_host, void* e_host);
+
+/* ---- sum-check rounds (the data-parallel half of CompressedSNARK::prove) -----------------------
+ * CompressedSNARK::prove (/root/reference/src/proof/nova.rs:341-356, supernova.rs:293-302) -> arecibo RelaxedR1CSSNARK::prove ->
+ * SumcheckProof::prove_cubic_with_additive_term (outer: eq(tau) (Az Bz - (u Cz + E))) and prove_quad (inner: poly_ABC z).
+ * The tables (Montgomery, len = 2^k elements each, device memory) stay in HBM, the transcript stays on the host.  One call is
+ * one round: if bind_r32_mont != NULL every table's top variable is first bound to it in place (P[i] += r (P[len/2 + i] - P[i]),
+ * the table is len / 2 long afterwards); then, if evals_out != NULL, the evaluations of the next round polynomial over the
+ * current tables are summed and written to HOST memory (the call synchronises the stream for them):
+ *   degree 3: d_polys = {A, B, C, D}, evals_out = [e(0), e(2), e(3)] of sum_i A (B C - D)     (3 x 32 B)
+ *   degree 2: d_polys = {A, B},       evals_out = [e(0), e(2)]       of sum_i A B             (2 x 32 B)
+ * A prover calls it with (NULL, evals) for the first round, (r_j, evals) in between and (r_last, NULL) at the end, after which
+ * P[0] of every table is its evaluation at the challenge point. */
+int lurk_hip_sumcheck_round_dev(int field_id, int degree, void* const* d_polys, size_t len, const void* bind_r32_mont,
+                                void* evals_out, void* stream);
+/* EqPolynomial::evals: d_out[b] = prod_j (b_j ? r_j : 1 - r_j), r_0 <-> the most significant bit of b; r: ell x 32 B Montgomery, host */
+int lurk_hip_eq_evals_dev(int field_id, const void* r32_mont, int ell, void* d_out, void* stream);
+
+/* ---- inner-product argument rounds (the opening half of CompressedSNARK::prove) ------------------
+ * EE1 / EE2 = ipa_pc::EvaluationEngine on the Pasta cycle (/root/reference/src/proof/nova.rs:57-62).  Per round of the published
+ * argument, with the vectors a, b and the (folded) key resident in HBM: the two cross inner products, the two commitments
+ * L, R (lurk_hip_msm_ctx_create_dev / run_dev over the halves of the device key), then with the transcript's challenge r the
+ * folds a' = r a_L + r^-1 a_R, b' = r^-1 b_L + r b_R (fold_halves, in place: the vector is len / 2 long afterwards) and
+ * ck' = [r^-1] ck_L + [r] ck_R (points_fold_halves: len / 2 affine points out; may not alias the input). */
+int lurk_hip_inner_product_dev(int field_id, const void* d_a, const void* d_b, size_t n, void* out32_mont, void* stream);
+int lurk_hip_fold_halves_dev(int field_id, void* d_v, size_t len, const void* s_lo32_mont, const void* s_hi32_mont, void* stream);
+int lurk_hip_points_fold_halves_dev(int curve, const void* d_points_affine64, size_t len, const void* s_lo32_mont,
+                                    const void* s_hi32_mont, void* d_out_affine64, void* stream);
 
 /* ---- synthetic inputs (bench / tests) -------------------------------------
  * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */

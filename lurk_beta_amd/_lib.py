@@ -39,6 +39,7 @@ SIGNATURES = {
     "lurk_hip_msm_ctx_submit_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lurk_hip_msm_ctx_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lurk_hip_msm_ctx_destroy": (c_int, [c_void_p]),
+    "lurk_hip_msm_ctx_rebind_dev": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lurk_hip_msm_ctx_reserve": (c_int, [c_void_p, c_size_t, c_int]),
     "lurk_hip_msm_ctx_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "lurk_hip_msm_ctx_save": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
@@ -82,6 +83,11 @@ SIGNATURES = {
     "lurk_hip_fold_step_finish": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_running_dev": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
     "lurk_hip_fold_ctx_read": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_sumcheck_round_dev": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), c_size_t, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_eq_evals_dev": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "lurk_hip_inner_product_dev": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_fold_halves_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_points_fold_halves_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
 }

@@ -1,0 +1,172 @@
+// ipa.hip - the vector and key folds of the inner-product argument that opens CompressedSNARK's polynomial commitments on the
+// Pasta cycle.
+//
+// Reference: EE1 / EE2 = nova::provider::ipa_pc::EvaluationEngine for Pallas / Vesta (/root/reference/src/proof/nova.rs:57-62),
+// run by CompressedSNARK::prove (nova.rs:341-356).  One round of the published argument (arecibo ipa_pc.rs, un-vendored; restated
+// in oracle/pyref.py, parity unpinned), n = current length:
+//     c_L = <a_L, b_R>, c_R = <a_R, b_L>                        -> lurk_hip_inner_product_dev
+//     L = commit(ck_R || ck_c, a_L || c_L), R = commit(ck_L || ck_c, a_R || c_R)   -> the MSM entry points over device bases
+//     r = transcript(L, R)                                                           (host)
+//     a' = r a_L + r^-1 a_R,  b' = r^-1 b_L + r b_R               -> lurk_hip_fold_halves_dev
+//     ck' = [r^-1] ck_L + [r] ck_R                                -> lurk_hip_points_fold_halves_dev
+// The key fold is the expensive part (n/2 double scalar multiplications with full-size scalars per round): one lane per output
+// point runs a joint double-and-add over the two scalars (Shamir: L, R and L + R as affine addends), so every lane of the
+// launch takes the same branch at every bit - the scalars are launch-wide - and finishes with its own inversion.
+#include <memory>
+
+#include "common.hpp"
+#include "curve.cuh"
+
+namespace lurk {
+
+constexpr int IPA_BLOCK = 256;
+
+template <class F>
+__global__ __launch_bounds__(IPA_BLOCK) void inner_product_kernel(const Fe<F>* __restrict__ a, const Fe<F>* __restrict__ b, size_t n,
+                                                                    Fe<F>* __restrict__ partial) {
+    __shared__ uint4 raw[IPA_BLOCK * 2];
+    Fe<F>* sh = reinterpret_cast<Fe<F>*>(raw);
+    Fe<F> acc = fe_zero<F>();
+    for (size_t i = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * IPA_BLOCK) acc = fe_add<F>(acc, fe_mul<F>(a[i], b[i]));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = IPA_BLOCK / 2; s >= 1; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] = fe_add<F>(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+// v[i] <- s_lo v[i] + s_hi v[h + i], i < h
+template <class F>
+__global__ __launch_bounds__(IPA_BLOCK) void fold_halves_kernel(Fe<F>* v, size_t h, Fe<F> s_lo, Fe<F> s_hi) {
+    for (size_t i = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x; i < h; i += (size_t)gridDim.x * IPA_BLOCK)
+        v[i] = fe_add<F>(fe_mul<F>(s_lo, v[i]), fe_mul<F>(s_hi, v[h + i]));
+}
+
+struct Scalar256 {
+    uint32_t w[8];  // canonical
+};
+
+// out[i] = [k_lo] P[i] + [k_hi] P[h + i]
+template <class P>
+__global__ __launch_bounds__(IPA_BLOCK) void points_fold_halves_kernel(const Affine<P>* __restrict__ pts, size_t h, Scalar256 k_lo, Scalar256 k_hi, int top_bit,
+                                                                         Affine<P>* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x;
+    if (i >= h) return;
+    const Affine<P> L = pts[i], R = pts[h + i];
+    Xyzz<P> t = xyzz_from_affine<P>(L);
+    xyzz_add<P>(t, xyzz_from_affine<P>(R));
+    const Affine<P> T = xyzz_to_affine<P>(t);  // L + R (the identity stays (0, 0): madd skips it)
+    Xyzz<P> acc = xyzz_identity<P>();
+    for (int bit = top_bit; bit >= 0; bit--) {
+        acc = xyzz_dbl<P>(acc);
+        const uint32_t bl = (k_lo.w[bit >> 5] >> (bit & 31)) & 1u, bh = (k_hi.w[bit >> 5] >> (bit & 31)) & 1u;  // launch-wide: no divergence
+        if (bl & bh) xyzz_madd<P>(acc, T, false);
+        else if (bl) xyzz_madd<P>(acc, L, false);
+        else if (bh) xyzz_madd<P>(acc, R, false);
+    }
+    out[i] = xyzz_to_affine<P>(acc);
+}
+
+template <class F>
+static Scalar256 canonical_scalar(const void* s32_mont) {
+    Fe<F> s;
+    memcpy(s.l, s32_mont, 32);
+    s = fe_from_mont<F>(s);
+    Scalar256 k;
+    for (int i = 0; i < 8; i++) k.w[i] = s.l[i];
+    return k;
+}
+static int top_bit_of(const Scalar256& a, const Scalar256& b) {
+    for (int bit = 255; bit >= 0; bit--)
+        if (((a.w[bit >> 5] | b.w[bit >> 5]) >> (bit & 31)) & 1u) return bit;
+    return -1;
+}
+
+template <class F>
+static void inner_product(const void* d_a, const void* d_b, size_t n, void* out32, hipStream_t s) {
+    unsigned blocks = n ? div_up(n, IPA_BLOCK) : 1, cap = (unsigned)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    Fe<F>* partial = nullptr;
+    LURK_HIP_CHECK(hipMallocAsync((void**)&partial, (size_t)blocks * 32, s));
+    {
+        ProfScope ps("ipa_inner_product", s);
+        hipLaunchKernelGGL((inner_product_kernel<F>), dim3(blocks), dim3(IPA_BLOCK), 0, s, (const Fe<F>*)d_a, (const Fe<F>*)d_b, n, partial);
+    }
+    hipError_t e = hipGetLastError();
+    std::vector<uint64_t> host((size_t)blocks * 4);
+    if (e == hipSuccess) e = hipMemcpyAsync(host.data(), partial, host.size() * 8, hipMemcpyDeviceToHost, s);
+    (void)hipFreeAsync(partial, s);
+    LURK_HIP_CHECK(e);
+    LURK_HIP_CHECK(hipStreamSynchronize(s));
+    Fe<F> acc = fe_zero<F>();
+    for (unsigned b = 0; b < blocks; b++) {
+        Fe<F> x;
+        memcpy(x.l, host.data() + (size_t)b * 4, 32);
+        acc = fe_add<F>(acc, x);
+    }
+    memcpy(out32, acc.l, 32);
+}
+
+template <class F>
+static void fold_halves(void* d_v, size_t len, const void* lo32, const void* hi32, hipStream_t s) {
+    const size_t h = len / 2;
+    Fe<F> a, b;
+    memcpy(a.l, lo32, 32);
+    memcpy(b.l, hi32, 32);
+    unsigned blocks = div_up(h, IPA_BLOCK), cap = (unsigned)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    ProfScope ps("ipa_fold_halves", s);
+    hipLaunchKernelGGL((fold_halves_kernel<F>), dim3(blocks), dim3(IPA_BLOCK), 0, s, (Fe<F>*)d_v, h, a, b);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+
+template <class P, class SF>
+static void points_fold_halves(const void* d_pts, size_t len, const void* lo32, const void* hi32, void* d_out, hipStream_t s) {
+    const size_t h = len / 2;
+    const Scalar256 kl = canonical_scalar<SF>(lo32), kh = canonical_scalar<SF>(hi32);
+    ProfScope ps("ipa_points_fold", s);
+    hipLaunchKernelGGL((points_fold_halves_kernel<P>), dim3(div_up(h, IPA_BLOCK)), dim3(IPA_BLOCK), 0, s, (const Affine<P>*)d_pts, h, kl, kh, top_bit_of(kl, kh),
+                       (Affine<P>*)d_out);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace lurk
+
+using namespace lurk;
+
+extern "C" {
+
+int lurk_hip_inner_product_dev(int field_id, const void* d_a, const void* d_b, size_t n, void* out32_mont, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(out32_mont && (n == 0 || (d_a && d_b)), "null argument");
+        if (field_id == 0) inner_product<PallasFp>(d_a, d_b, n, out32_mont, (hipStream_t)stream);
+        else if (field_id == 1) inner_product<PallasFq>(d_a, d_b, n, out32_mont, (hipStream_t)stream);
+        else inner_product<Bn254Fr>(d_a, d_b, n, out32_mont, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_fold_halves_dev(int field_id, void* d_v, size_t len, const void* s_lo32_mont, const void* s_hi32_mont, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(len >= 2 && len % 2 == 0, "length must be even and >= 2");
+        LURK_REQUIRE(d_v && s_lo32_mont && s_hi32_mont, "null argument");
+        if (field_id == 0) fold_halves<PallasFp>(d_v, len, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
+        else if (field_id == 1) fold_halves<PallasFq>(d_v, len, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
+        else fold_halves<Bn254Fr>(d_v, len, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_points_fold_halves_dev(int curve, const void* d_points_affine64, size_t len, const void* s_lo32_mont, const void* s_hi32_mont,
+                                    void* d_out_affine64, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
+        LURK_REQUIRE(len >= 2 && len % 2 == 0, "length must be even and >= 2");
+        LURK_REQUIRE(d_points_affine64 && d_out_affine64 && s_lo32_mont && s_hi32_mont, "null argument");
+        if (curve == LURK_CURVE_PALLAS) points_fold_halves<PallasFp, PallasFq>(d_points_affine64, len, s_lo32_mont, s_hi32_mont, d_out_affine64, (hipStream_t)stream);
+        else points_fold_halves<PallasFq, PallasFp>(d_points_affine64, len, s_lo32_mont, s_hi32_mont, d_out_affine64, (hipStream_t)stream);
+    });
+}
+}

@@ -677,6 +677,7 @@ struct MsmCtxBase {
     // asynchronous: enqueue on the slot's own stream (after `after`, the stream that produced the scalars)
     virtual void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after) = 0;
     virtual void wait(int slot, void* out_jac96_host) = 0;
+    virtual void rebind(const void* d_bases, size_t n) = 0;  // plain key over other (borrowed) device bases, workspaces kept
     virtual void reserve(size_t n, int slots) = 0;  // allocate the workspaces of slots 0..slots-1 for n scalars now
     virtual const void* device_table() const = 0;  // npoints (x windows when precomputed) 64-byte records
     // adopt a table that is already complete in device memory (loaded from a key file)
@@ -777,6 +778,18 @@ struct MsmCtx : MsmCtxBase {
         }
     }
 
+    void rebind(const void* d_bases, size_t n) override {
+        LURK_REQUIRE((size_t)msm_num_windows(MSM_C_PLAIN) * n < ((size_t)1 << 31), "too many points");
+        for (auto& wk : work) {
+            std::lock_guard<std::mutex> lk(wk.mu);
+            LURK_REQUIRE(!wk.pending, "a slot has a commitment in flight");
+        }
+        own_bases.release();
+        table = (const Affine<P>*)d_bases;
+        npoints = n;
+        precomputed = false;
+        c = MSM_C_PLAIN;
+    }
     void reserve(size_t n, int slots) override {
         LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
         LURK_REQUIRE(slots >= 1 && slots <= MSM_SLOTS, "slot count out of range");
@@ -881,25 +894,21 @@ struct MsmCtx : MsmCtxBase {
             hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
                                wk.group_task_base.template as<uint32_t>(), sh.NG, lh + MSM_S + 1, wk.task_order.template as<uint32_t>());
         }
-        if (s_acc) {
-            const MsmTuning& tn = msm_tuning();
-            // the persistent form pays off when the accumulation is long enough to hide another commitment's short kernels
-            // under it (>= 2^25 sorted entries: 2^22 points and up with the table); below that the plain launch is faster
-            const bool persistent = tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 25) : tn.persistent != 0;
+        const MsmTuning& tn = msm_tuning();
+        // the persistent form (own low-priority stream) pays off when the accumulation is long enough to hide another
+        // commitment's short kernels under it (>= 2^25 sorted entries: 2^22 points and up with the table); below that the plain
+        // launch on the slot's own stream is faster (measured: 2^20, 3 in flight, 760 vs 660 Mscalar-mul/s)
+        const bool persistent = s_acc && (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 25) : tn.persistent != 0);
+        if (persistent) {
             LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4, s));
             LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
             LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, wk.planned, 0));
             {
                 ProfScope ps("msm_accumulate", s_acc);
-                if (persistent)
-                    msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
-                                                        wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
-                                                        wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(), tn.waves, tn.r128 != 0,
-                                                        s_acc);
-                else
-                    msm_launch_accumulate<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
-                                             wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
-                                             wk.partials.template as<Xyzz<P>>(), nt, s_acc);
+                msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
+                                                    wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
+                                                    wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(), tn.waves, tn.r128 != 0,
+                                                    s_acc);
             }
             LURK_HIP_CHECK(hipEventRecord(wk.accumulated, s_acc));
             LURK_HIP_CHECK(hipStreamWaitEvent(s, wk.accumulated, 0));
@@ -1299,6 +1308,13 @@ int lurk_hip_msm_ctx_load(lurk_hip_msm_ctx** ctx, const char* path, int flags) {
         }
         if (map) munmap(map, sizeof(h) + total);
         *ctx = new lurk_hip_msm_ctx{std::move(c)};
+    });
+}
+int lurk_hip_msm_ctx_rebind_dev(lurk_hip_msm_ctx* ctx, const void* d_bases, size_t npoints) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && (npoints == 0 || d_bases), "null argument");
+        DeviceGuard dg(ctx->impl->device);
+        ctx->impl->rebind(d_bases, npoints);
     });
 }
 int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots) {

@@ -1,0 +1,212 @@
+// sumcheck.hip - the data-parallel half of Spartan's sum-check, for CompressedSNARK::prove.
+//
+// Reference call sites: CompressedSNARK::prove as lurk-beta reaches it (/root/reference/src/proof/nova.rs:341-356,
+// /root/reference/src/proof/supernova.rs:293-302) -> arecibo spartan::snark::RelaxedR1CSSNARK::prove -> SumcheckProof::
+// prove_cubic_with_additive_term (outer: eq(tau) * (Az * Bz - (u Cz + E))) and prove_quad (inner: poly_ABC * z), arecibo being the
+// un-vendored `nova` dependency (/root/reference/Cargo.toml:128): the published Spartan prover, restated in oracle/pyref.py
+// (parity unpinned: no proof bytes exist upstream).  Per round the prover needs
+//     e0 = sum_i comb(P[i]),  e2 = sum_i comb(2 P[h+i] - P[i]),  e3 = sum_i comb(3 P[h+i] - 2 P[i])        (h = len / 2)
+// then, with the verifier's challenge r, binds the top variable of every table: P[i] <- P[i] + r (P[h+i] - P[i]).
+// The transcript (Keccak) stays on the host; the tables (2^20 .. 2^24 field elements each) stay in HBM.  One kernel per round
+// does BOTH the bind with the previous challenge and the evaluation sums of the next round, so a round reads each table once
+// (4 x 32 B per element) and writes half of it back: HBM-bound, 160 B per element-row of the cubic round.
+#include <memory>
+
+#include "common.hpp"
+#include "field.cuh"
+
+namespace lurk {
+
+constexpr int SC_BLOCK = 256;
+
+template <class F>
+__device__ __forceinline__ Fe<F> sc_bind(const Fe<F>& lo, const Fe<F>& hi, const Fe<F>& r) {
+    return fe_add<F>(lo, fe_mul<F>(r, fe_sub<F>(hi, lo)));
+}
+template <class F>
+__device__ __forceinline__ Fe<F> sc_comb_cubic(const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, const Fe<F>& d) {
+    return fe_mul<F>(a, fe_sub<F>(fe_mul<F>(b, c), d));  // comb_func_outer: a * (b * c - d)
+}
+
+// workgroup tree sum of NV values per thread; thread 0 writes the block's partial sums
+template <class F, int NV>
+__device__ __forceinline__ void sc_block_sum(Fe<F>* v, Fe<F>* __restrict__ partial) {
+    __shared__ uint4 raw[SC_BLOCK * NV * 2];
+    Fe<F>* sh = reinterpret_cast<Fe<F>*>(raw);
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < NV; k++) sh[k * SC_BLOCK + t] = v[k];
+    __syncthreads();
+    for (int s = SC_BLOCK / 2; s >= 1; s >>= 1) {
+        if (t < s) {
+#pragma unroll
+            for (int k = 0; k < NV; k++) sh[k * SC_BLOCK + t] = fe_add<F>(sh[k * SC_BLOCK + t], sh[k * SC_BLOCK + t + s]);
+        }
+        __syncthreads();
+    }
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) partial[(size_t)blockIdx.x * NV + k] = sh[k * SC_BLOCK];
+    }
+}
+
+// NP tables of `len` elements (len = 2 m).  BIND: first P[i] <- bind(P[i], P[m+i], r) for i < m (in place), then the
+// evaluation sums over the bound tables (length m, halves of q = m / 2); !BIND: sums over the tables as they are (h = m).
+// Cubic (NP = 4): e0, e2, e3 with comb = a (b c - d); quadratic (NP = 2): e0, e2 with comb = a b.
+template <class F, int NP, bool BIND>
+__global__ __launch_bounds__(SC_BLOCK) void sumcheck_round_kernel(Fe<F>* p0, Fe<F>* p1, Fe<F>* p2, Fe<F>* p3, size_t len, Fe<F> r,
+                                                                    Fe<F>* __restrict__ partial) {
+    constexpr int NV = NP == 4 ? 3 : 2;
+    Fe<F>* P[4] = {p0, p1, p2, p3};
+    Fe<F> acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) acc[k] = fe_zero<F>();
+    const size_t m = len / 2, h = BIND ? m / 2 : m;  // pairs (i, i + h) of the tables the sums run over
+    for (size_t i = (size_t)blockIdx.x * SC_BLOCK + threadIdx.x; i < (h ? h : 1); i += (size_t)gridDim.x * SC_BLOCK) {
+        Fe<F> lo[NP], hi[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            if (BIND) {
+                if (h == 0) {  // len == 2: the last bind, nothing left to sum
+                    P[k][0] = sc_bind<F>(P[k][0], P[k][1], r);
+                    continue;
+                }
+                lo[k] = sc_bind<F>(P[k][i], P[k][m + i], r);
+                hi[k] = sc_bind<F>(P[k][h + i], P[k][m + h + i], r);
+                P[k][i] = lo[k];
+                P[k][h + i] = hi[k];
+            } else {
+                lo[k] = P[k][i];
+                hi[k] = P[k][h + i];
+            }
+        }
+        if (BIND && h == 0) break;
+        Fe<F> b2[NP], b3[NP];
+#pragma unroll
+        for (int k = 0; k < NP; k++) {
+            const Fe<F> d = fe_sub<F>(hi[k], lo[k]);
+            b2[k] = fe_add<F>(hi[k], d);  // 2 hi - lo
+            if (NP == 4) b3[k] = fe_add<F>(b2[k], d);  // 3 hi - 2 lo
+        }
+        if (NP == 4) {
+            acc[0] = fe_add<F>(acc[0], sc_comb_cubic<F>(lo[0], lo[1], lo[2], lo[3]));
+            acc[1] = fe_add<F>(acc[1], sc_comb_cubic<F>(b2[0], b2[1], b2[2], b2[3]));
+            acc[2] = fe_add<F>(acc[2], sc_comb_cubic<F>(b3[0], b3[1], b3[2], b3[3]));
+        } else {
+            acc[0] = fe_add<F>(acc[0], fe_mul<F>(lo[0], lo[1]));
+            acc[1] = fe_add<F>(acc[1], fe_mul<F>(b2[0], b2[1]));
+        }
+    }
+    sc_block_sum<F, NV>(acc, partial);
+}
+
+// EqPolynomial::evals: out[b] = prod_j (b_j ? r_j : 1 - r_j), r_0 the most significant bit of b
+template <class F>
+__global__ __launch_bounds__(SC_BLOCK) void eq_evals_kernel(const Fe<F>* __restrict__ r, int ell, Fe<F>* __restrict__ out) {
+    extern __shared__ uint4 raw[];
+    Fe<F>* rr = reinterpret_cast<Fe<F>*>(raw);  // [ell] r_j, [ell] 1 - r_j
+    for (int j = threadIdx.x; j < ell; j += SC_BLOCK) {
+        rr[j] = r[j];
+        rr[ell + j] = fe_sub<F>(fe_one<F>(), r[j]);
+    }
+    __syncthreads();
+    const size_t n = (size_t)1 << ell;
+    for (size_t b = (size_t)blockIdx.x * SC_BLOCK + threadIdx.x; b < n; b += (size_t)gridDim.x * SC_BLOCK) {
+        Fe<F> acc = fe_one<F>();
+        for (int j = 0; j < ell; j++) acc = fe_mul<F>(acc, ((b >> (ell - 1 - j)) & 1) ? rr[j] : rr[ell + j]);
+        out[b] = acc;
+    }
+}
+
+template <class F>
+static void sum_partials(const std::vector<uint64_t>& host, unsigned blocks, int nv, void* out) {
+    for (int k = 0; k < nv; k++) {
+        Fe<F> acc = fe_zero<F>();
+        for (unsigned b = 0; b < blocks; b++) {
+            Fe<F> x;
+            memcpy(x.l, host.data() + ((size_t)b * nv + k) * 4, 32);
+            acc = fe_add<F>(acc, x);
+        }
+        memcpy((char*)out + k * 32, acc.l, 32);
+    }
+}
+
+template <class F>
+static void sumcheck_round(int np, void* const* d_polys, size_t len, const void* r32_mont, void* evals_out, hipStream_t s) {
+    LURK_REQUIRE(len >= 2 && (len & (len - 1)) == 0, "table length must be a power of two >= 2");
+    const bool bind = r32_mont != nullptr;
+    const size_t work = bind ? len / 4 : len / 2;
+    unsigned blocks = work ? div_up(work, SC_BLOCK) : 1;
+    const unsigned cap = (unsigned)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    const int nv = np == 4 ? 3 : 2;
+    Fe<F> r = fe_zero<F>();
+    if (bind) memcpy(r.l, r32_mont, 32);
+    Fe<F>* partial = nullptr;
+    LURK_HIP_CHECK(hipMallocAsync((void**)&partial, (size_t)blocks * nv * 32, s));
+    Fe<F>* p[4] = {(Fe<F>*)d_polys[0], (Fe<F>*)d_polys[1], np == 4 ? (Fe<F>*)d_polys[2] : nullptr, np == 4 ? (Fe<F>*)d_polys[3] : nullptr};
+    {
+        ProfScope ps("sumcheck_round", s);
+        if (np == 4 && bind) hipLaunchKernelGGL((sumcheck_round_kernel<F, 4, true>), dim3(blocks), dim3(SC_BLOCK), 0, s, p[0], p[1], p[2], p[3], len, r, partial);
+        else if (np == 4) hipLaunchKernelGGL((sumcheck_round_kernel<F, 4, false>), dim3(blocks), dim3(SC_BLOCK), 0, s, p[0], p[1], p[2], p[3], len, r, partial);
+        else if (bind) hipLaunchKernelGGL((sumcheck_round_kernel<F, 2, true>), dim3(blocks), dim3(SC_BLOCK), 0, s, p[0], p[1], p[2], p[3], len, r, partial);
+        else hipLaunchKernelGGL((sumcheck_round_kernel<F, 2, false>), dim3(blocks), dim3(SC_BLOCK), 0, s, p[0], p[1], p[2], p[3], len, r, partial);
+    }
+    hipError_t launch_err = hipGetLastError();
+    std::vector<uint64_t> host((size_t)blocks * nv * 4);
+    hipError_t copy_err = launch_err == hipSuccess && evals_out
+                              ? hipMemcpyAsync(host.data(), partial, host.size() * 8, hipMemcpyDeviceToHost, s)
+                              : hipSuccess;
+    (void)hipFreeAsync(partial, s);
+    LURK_HIP_CHECK(launch_err);
+    LURK_HIP_CHECK(copy_err);
+    if (evals_out) {  // the round polynomial goes into the host transcript: this is the round's one synchronisation
+        LURK_HIP_CHECK(hipStreamSynchronize(s));
+        sum_partials<F>(host, blocks, nv, evals_out);
+    }
+}
+
+}  // namespace lurk
+
+using namespace lurk;
+
+extern "C" {
+
+int lurk_hip_sumcheck_round_dev(int field_id, int degree, void* const* d_polys, size_t len, const void* bind_r32_mont, void* evals_out,
+                                void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(degree == 2 || degree == 3, "degree must be 2 (a b) or 3 (a (b c - d))");
+        LURK_REQUIRE(d_polys, "null table list");
+        const int np = degree == 3 ? 4 : 2;
+        for (int k = 0; k < np; k++) LURK_REQUIRE(d_polys[k], "null table");
+        LURK_REQUIRE(evals_out || bind_r32_mont, "nothing to do");
+        LURK_REQUIRE(evals_out == nullptr || bind_r32_mont == nullptr || len >= 4, "after the last bind (len = 2) there is nothing to sum: pass evals_out = NULL");
+        if (field_id == 0) sumcheck_round<PallasFp>(np, d_polys, len, bind_r32_mont, evals_out, (hipStream_t)stream);
+        else if (field_id == 1) sumcheck_round<PallasFq>(np, d_polys, len, bind_r32_mont, evals_out, (hipStream_t)stream);
+        else sumcheck_round<Bn254Fr>(np, d_polys, len, bind_r32_mont, evals_out, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_eq_evals_dev(int field_id, const void* r32_mont, int ell, void* d_out, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(ell >= 0 && ell <= 30 && d_out && (ell == 0 || r32_mont), "bad argument");
+        hipStream_t s = (hipStream_t)stream;
+        void* d_r = nullptr;
+        LURK_HIP_CHECK(hipMallocAsync(&d_r, (size_t)(ell ? ell : 1) * 32, s));
+        if (ell) LURK_HIP_CHECK(hipMemcpyAsync(d_r, r32_mont, (size_t)ell * 32, hipMemcpyHostToDevice, s));
+        const size_t n = (size_t)1 << ell;
+        unsigned blocks = div_up(n, SC_BLOCK), cap = (unsigned)num_cus() * 16;
+        if (blocks > cap) blocks = cap;
+        const size_t lds = (size_t)(2 * ell + 1) * 32;
+        ProfScope ps("eq_evals", s);
+        if (field_id == 0) hipLaunchKernelGGL((eq_evals_kernel<PallasFp>), dim3(blocks), dim3(SC_BLOCK), lds, s, (const Fe<PallasFp>*)d_r, ell, (Fe<PallasFp>*)d_out);
+        else if (field_id == 1) hipLaunchKernelGGL((eq_evals_kernel<PallasFq>), dim3(blocks), dim3(SC_BLOCK), lds, s, (const Fe<PallasFq>*)d_r, ell, (Fe<PallasFq>*)d_out);
+        else hipLaunchKernelGGL((eq_evals_kernel<Bn254Fr>), dim3(blocks), dim3(SC_BLOCK), lds, s, (const Fe<Bn254Fr>*)d_r, ell, (Fe<Bn254Fr>*)d_out);
+        hipError_t e = hipGetLastError();
+        (void)hipFreeAsync(d_r, s);
+        LURK_HIP_CHECK(e);
+    });
+}
+}

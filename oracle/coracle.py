@@ -67,6 +67,15 @@ def from_mont(field: int, a: np.ndarray) -> np.ndarray:
     return out
 
 
+def mul_canonical(field: int, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Element-wise product of canonical field elements."""
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_mul_canonical(field, _p(a), _p(b), _p(out), ctypes.c_size_t(a.size // 4))
+    return out
+
+
 def dot(field: int, a: np.ndarray, b: np.ndarray) -> int:
     a = np.ascontiguousarray(a, dtype=np.uint64)
     b = np.ascontiguousarray(b, dtype=np.uint64)

@@ -476,3 +476,123 @@ def cross_term(p, az1, bz1, cz1, az2, bz2, cz2, u1, u2):
 
 def axpy(p, a, b, r):
     return [(x + r * y) % p for x, y in zip(a, b)]
+
+
+# --------------------------------------------------------------------------------------------
+# Spartan sum-check.  PARITY UNPINNED: restates the published prover of arecibo's
+# spartan::sumcheck (SumcheckProof::prove_cubic_with_additive_term / prove_quad, UniPoly::from_evals,
+# MultilinearPolynomial::bind_poly_var_top, EqPolynomial::evals) as CompressedSNARK::prove reaches it
+# (/root/reference/src/proof/nova.rs:341-356); arecibo is un-vendored (/root/reference/Cargo.toml:128) and no proof
+# bytes exist upstream.  The challenges are an argument (the Keccak transcript is host-side plumbing, not arithmetic).
+# --------------------------------------------------------------------------------------------
+def unipoly_from_evals(p: int, evals: list[int]) -> list[int]:
+    """Coefficients (low first) of the polynomial with the given values at 0, 1, 2[, 3] (UniPoly::from_evals)."""
+    inv2, inv6 = pow(2, p - 2, p), pow(6, p - 2, p)
+    if len(evals) == 3:
+        e0, e1, e2 = evals
+        c = e0
+        a = (e2 - 2 * e1 + e0) * inv2 % p
+        b = (e1 - c - a) % p
+        return [c, b, a]
+    e0, e1, e2, e3 = evals
+    d = e0
+    a = (e3 - 3 * e2 + 3 * e1 - e0) * inv6 % p
+    b = (e2 - 2 * e1 + e0) * inv2 % p
+    b = (b - 3 * a) % p  # second difference at 0 = 2b + 6a
+    c = (e1 - d - a - b) % p
+    return [d, c, b, a]
+
+
+def unipoly_eval(p: int, coeffs: list[int], x: int) -> int:
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * x + c) % p
+    return acc
+
+
+def bind_top(p: int, table: list[int], r: int) -> list[int]:
+    h = len(table) // 2
+    return [(table[i] + r * (table[h + i] - table[i])) % p for i in range(h)]
+
+
+def eq_evals(p: int, r: list[int]) -> list[int]:
+    """EqPolynomial::evals: index bit for r[0] is the most significant."""
+    ev = [1]
+    for rj in reversed(r):
+        right = [x * rj % p for x in ev]
+        ev = [(x - y) % p for x, y in zip(ev, right)] + right
+    return ev
+
+
+def sumcheck_prove(p: int, claim: int, tables: list[list[int]], challenges: list[int]):
+    """degree 3 with 4 tables (comb = a (b c - d)) or degree 2 with 2 tables (comb = a b).  Returns
+    (round polynomials as coefficient lists, final evaluations P_k(r))."""
+    cubic = len(tables) == 4
+    comb = (lambda a, b, c, d: a * (b * c - d) % p) if cubic else (lambda a, b: a * b % p)
+    tables = [list(t) for t in tables]
+    polys = []
+    for r in challenges:
+        h = len(tables[0]) // 2
+        e0 = e2 = e3 = 0
+        for i in range(h):
+            lo = [t[i] for t in tables]
+            hi = [t[h + i] for t in tables]
+            b2 = [(2 * y - x) % p for x, y in zip(lo, hi)]
+            e0 += comb(*lo)
+            e2 += comb(*b2)
+            if cubic:
+                e3 += comb(*[(3 * y - 2 * x) % p for x, y in zip(lo, hi)])
+        e0, e2, e3 = e0 % p, e2 % p, e3 % p
+        evals = [e0, (claim - e0) % p, e2] + ([e3] if cubic else [])
+        poly = unipoly_from_evals(p, evals)
+        polys.append(poly)
+        claim = unipoly_eval(p, poly, r)
+        tables = [bind_top(p, t, r) for t in tables]
+    return polys, [t[0] for t in tables], claim
+
+
+# --------------------------------------------------------------------------------------------
+# Inner-product argument (SURVEY.md section 8 f3).  PARITY UNPINNED: restates the published argument of arecibo's
+# provider::ipa_pc (InnerProductArgument::prove / verify) that opens CompressedSNARK's commitments on the Pasta cycle
+# (/root/reference/src/proof/nova.rs:57-62, 341-356).  Points are affine tuples or None; challenges are arguments.
+# --------------------------------------------------------------------------------------------
+def ipa_prove(curve: str, ck: list, ck_c, a: list[int], b: list[int], r0: int, challenges: list[int]):
+    """Returns (L_vec, R_vec, a_hat, final folded key point).  ck_c is scaled by r0 first (the transcript's first squeeze)."""
+    q = CURVES[curve]["order"]
+    ck_c = ec_mul(curve, r0, ck_c)
+    ck, a, b = list(ck), [x % q for x in a], [x % q for x in b]
+    Ls, Rs = [], []
+    for r in challenges:
+        h = len(a) // 2
+        c_L = sum(x * y for x, y in zip(a[:h], b[h:])) % q
+        c_R = sum(x * y for x, y in zip(a[h:], b[:h])) % q
+        Ls.append(ec_add(curve, msm_naive(curve, a[:h], ck[h:]), ec_mul(curve, c_L, ck_c)))
+        Rs.append(ec_add(curve, msm_naive(curve, a[h:], ck[:h]), ec_mul(curve, c_R, ck_c)))
+        ri = pow(r, q - 2, q)
+        a = [(x * r + ri * y) % q for x, y in zip(a[:h], a[h:])]
+        b = [(x * ri + r * y) % q for x, y in zip(b[:h], b[h:])]
+        ck = [ec_add(curve, ec_mul(curve, ri, l), ec_mul(curve, r, rr)) for l, rr in zip(ck[:h], ck[h:])]
+    return Ls, Rs, a[0], ck[0]
+
+
+def ipa_verify(curve: str, ck: list, ck_c, comm_a, b: list[int], c: int, r0: int, challenges: list[int], Ls: list, Rs: list, a_hat: int) -> bool:
+    """P + sum_j (r_j^2 L_j + r_j^-2 R_j) == [a_hat] ck_hat + [a_hat b_hat] ck_c', ck_hat = <s, ck>, b_hat = <s, b> with the usual s vector."""
+    q = CURVES[curve]["order"]
+    n = len(b)
+    ck_c = ec_mul(curve, r0, ck_c)
+    P = ec_add(curve, comm_a, ec_mul(curve, c, ck_c))
+    for r, L, Rr in zip(challenges, Ls, Rs):
+        ri = pow(r, q - 2, q)
+        P = ec_add(curve, P, ec_add(curve, ec_mul(curve, r * r % q, L), ec_mul(curve, ri * ri % q, Rr)))
+    k = len(challenges)
+    s = []
+    for i in range(n):
+        acc = 1
+        for j, r in enumerate(challenges):
+            bit = (i >> (k - 1 - j)) & 1  # round j folds the current top half with weight r, the bottom half with r^-1
+            acc = acc * (r if bit else pow(r, q - 2, q)) % q
+        s.append(acc)
+    ck_hat = msm_naive(curve, s, ck)
+    b_hat = sum(x * y for x, y in zip(s, b)) % q
+    rhs = ec_add(curve, ec_mul(curve, a_hat, ck_hat), ec_mul(curve, a_hat * b_hat % q, ck_c))
+    return P == rhs

@@ -1,0 +1,82 @@
+"""f3 (opening half): the rounds of the inner-product argument on the device against the oracle's restatement of the published
+argument (oracle/pyref.py: ipa_prove / ipa_verify), on both curves; the device-assisted proof must also pass the oracle's
+VERIFIER (the size-independent property).  Parity unpinned upstream."""
+import numpy as np
+import pytest
+
+from oracle import coracle as C
+from oracle import pyref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    import torch
+
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def _aff(curve_id, jac):
+    from lurk_beta_amd import point_to_affine
+
+    xy = point_to_affine(curve_id, jac)
+    return None if xy == (0, 0) else xy
+
+
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+@pytest.mark.parametrize("log_n", [1, 4, 7])
+def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n):
+    from lurk_beta_amd import ipa, msm
+
+    sf = 1 if c == 0 else 0
+    q = R.CURVES[cn]["order"]
+    n = 1 << log_n
+    B = C.synth_bases(c, n + 1)
+    bf = 0 if c == 0 else 1  # base field id
+    ck_pts = [tuple(C.limbs_to_ints(C.from_mont(bf, B[i].reshape(2, 4)))) for i in range(n + 1)]
+    ck, ck_c = ck_pts[:n], ck_pts[n]
+    a = C.limbs_to_ints(C.synth_scalars(sf, 160, 1, n))
+    b = C.limbs_to_ints(C.synth_scalars(sf, 161, 0, n))
+    r0 = R.uniform_fe(162, 0, q)
+    chal = [R.uniform_fe(163, j, q) for j in range(log_n)]
+    want_L, want_R, want_a, want_ck = R.ipa_prove(cn, ck, ck_c, a, b, r0, chal)
+    ck_c_jac = np.concatenate([B[n], C.to_mont(bf, C.ints_to_limbs([1])).reshape(4)])
+    got_L, got_R, got_a, got_ck = ipa.prove(c, q, _dev(B[:n]), ck_c_jac, _dev(C.to_mont(sf, C.ints_to_limbs(a))), _dev(C.to_mont(sf, C.ints_to_limbs(b))),
+                                            r0, lambda j, L, Rr: chal[j])
+    assert [_aff(c, x) for x in got_L] == want_L and [_aff(c, x) for x in got_R] == want_R
+    assert got_a == want_a
+    assert tuple(C.limbs_to_ints(C.from_mont(bf, got_ck.reshape(2, 4)))) == want_ck
+    comm_a = R.msm_naive(cn, a, ck)
+    cc = sum(x * y for x, y in zip(a, b)) % q
+    assert R.ipa_verify(cn, ck, ck_c, comm_a, b, cc, r0, chal, [_aff(c, x) for x in got_L], [_aff(c, x) for x in got_R], got_a)
+    assert not R.ipa_verify(cn, ck, ck_c, comm_a, b, (cc + 1) % q, r0, chal, want_L, want_R, want_a)
+
+
+def test_fold_kernels_edge_cases(hip):
+    """Identity points, equal halves (L = R: the joint ladder's L + R is a doubling), opposite halves (L + R = identity), zero and
+    one scalars."""
+    import torch
+
+    from lurk_beta_amd import _lib
+
+    lib = _lib.load()
+    c, cn, bf, sf = 0, "pallas", 0, 1
+    q = R.CURVES[cn]["order"]
+    B = C.synth_bases(c, 8)
+    pts = [tuple(C.limbs_to_ints(C.from_mont(bf, B[i].reshape(2, 4)))) for i in range(8)]
+    half = [pts[0], None, pts[2], pts[3]] + [pts[0], pts[1], R.ec_neg(cn, pts[2]), None]
+    arr = np.zeros((8, 8), dtype=np.uint64)
+    for i, P in enumerate(half):
+        if P is not None:
+            arr[i] = C.to_mont(bf, C.ints_to_limbs(list(P))).reshape(8)
+    R256 = (1 << 256) % q
+    for lo, hi in ((R.uniform_fe(170, 0, q), R.uniform_fe(170, 1, q)), (1, 1), (0, 5), (7, 0), (q - 1, 1)):
+        out = torch.zeros((4, 8), dtype=torch.int64, device="cuda")
+        d_arr, lo_m, hi_m = _dev(arr), C.ints_to_limbs([lo * R256 % q]), C.ints_to_limbs([hi * R256 % q])
+        _lib.check(lib.lurk_hip_points_fold_halves_dev(c, _lib.ptr(d_arr), 8, _lib.ptr(lo_m), _lib.ptr(hi_m), _lib.ptr(out), None))
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint64)
+        for i in range(4):
+            want = R.ec_add(cn, R.ec_mul(cn, lo, half[i]) if half[i] else None, R.ec_mul(cn, hi, half[4 + i]) if half[4 + i] else None)
+            g = tuple(C.limbs_to_ints(C.from_mont(bf, got[i].reshape(2, 4))))
+            assert (None if g == (0, 0) else g) == want, (lo, hi, i)
