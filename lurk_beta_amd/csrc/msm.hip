@@ -677,6 +677,8 @@ struct MsmCtxBase {
     // asynchronous: enqueue on the slot's own stream (after `after`, the stream that produced the scalars)
     virtual void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after) = 0;
     virtual void wait(int slot, void* out_jac96_host) = 0;
+    // pasta-msm's calling convention: everything in host memory, nothing resident (buffers and workspaces are kept for the next call)
+    virtual void run_oneshot(const void* bases, const void* scalars, size_t n, int is_mont, void* out_jac96_host) = 0;
     virtual void rebind(const void* d_bases, size_t n) = 0;  // plain key over other (borrowed) device bases, workspaces kept
     virtual void reserve(size_t n, int slots) = 0;  // allocate the workspaces of slots 0..slots-1 for n scalars now
     virtual const void* device_table() const = 0;  // npoints (x windows when precomputed) 64-byte records
@@ -778,6 +780,33 @@ struct MsmCtx : MsmCtxBase {
         }
     }
 
+    DevBuf oneshot_scalars;
+    void run_oneshot(const void* bases, const void* scalars, size_t n, int is_mont, void* out) override {
+        if (n == 0) {
+            put_identity(out);
+            return;
+        }
+        LURK_REQUIRE((size_t)msm_num_windows(MSM_C_PLAIN) * n < ((size_t)1 << 31), "too many points");
+        Work& wk = work[0];
+        std::lock_guard<std::mutex> lk(wk.mu);
+        LURK_REQUIRE(!wk.pending, "slot 0 has a submitted commitment that was not waited for");
+        own_bases.ensure(n * sizeof(Affine<P>));
+        oneshot_scalars.ensure(n * 32);
+        table = own_bases.as<Affine<P>>();
+        npoints = n;
+        precomputed = false;
+        c = MSM_C_PLAIN;
+        ensure_streams(wk);
+        hipStream_t s = wk.stream;
+        // scalars first (the sort needs only them); the 64 B/point of bases follow behind the sort, right before the accumulation
+        LURK_HIP_CHECK(hipMemcpyAsync(oneshot_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
+        const std::function<void()> upload_bases = [&] {
+            LURK_HIP_CHECK(hipMemcpyAsync(own_bases.p, bases, n * sizeof(Affine<P>), hipMemcpyHostToDevice, s));
+        };
+        enqueue(wk, oneshot_scalars.p, n, is_mont, s, nullptr, &upload_bases);
+        LURK_HIP_CHECK(hipStreamSynchronize(s));
+        host_tail(wk, n, out);
+    }
     void rebind(const void* d_bases, size_t n) override {
         LURK_REQUIRE((size_t)msm_num_windows(MSM_C_PLAIN) * n < ((size_t)1 << 31), "too many points");
         for (auto& wk : work) {
@@ -853,7 +882,8 @@ struct MsmCtx : MsmCtxBase {
 
     // every kernel of one commitment + the D2H of its <= 20 result points, on stream s
     // s_acc: stream of the accumulate kernel (nullptr: same stream, classic launch)
-    void enqueue(Work& wk, const void* d_scalars, size_t n, int is_mont, hipStream_t s, hipStream_t s_acc = nullptr) {
+    void enqueue(Work& wk, const void* d_scalars, size_t n, int is_mont, hipStream_t s, hipStream_t s_acc = nullptr,
+                 const std::function<void()>* before_accumulate = nullptr) {
         const MsmShape sh = shape(n);
         ensure_workspace(wk, sh);
         const size_t chunk = (n + MSM_NB1 - 1) / MSM_NB1;
@@ -898,6 +928,7 @@ struct MsmCtx : MsmCtxBase {
         // the persistent form (own low-priority stream) pays off when the accumulation is long enough to hide another
         // commitment's short kernels under it (>= 2^25 sorted entries: 2^22 points and up with the table); below that the plain
         // launch on the slot's own stream is faster (measured: 2^20, 3 in flight, 760 vs 660 Mscalar-mul/s)
+        if (before_accumulate) (*before_accumulate)();  // the one-shot entry point uploads the bases here, behind the sort
         const bool persistent = s_acc && (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 25) : tn.persistent != 0);
         if (persistent) {
             LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4, s));
@@ -1081,14 +1112,19 @@ static int msm_oneshot(int curve, void* out, const void* bases, size_t n, const 
     return guarded([&] {
         LURK_REQUIRE(out, "null output");
         LURK_REQUIRE(n == 0 || (bases && scalars), "null buffer");
-        std::unique_ptr<MsmCtxBase> c(new_ctx(curve));
-        DevBuf db(n * 64), ds(n * 32);
-        if (n) {
-            LURK_HIP_CHECK(hipMemcpy(db.p, bases, n * 64, hipMemcpyHostToDevice));
-            LURK_HIP_CHECK(hipMemcpy(ds.p, scalars, n * 32, hipMemcpyHostToDevice));
+        // one cached context per (device, curve): its device buffers and workspaces survive between calls, so an unmodified caller
+        // of the pasta-msm symbols pays PCIe (96 B per point) but no allocation.  Calls on one (device, curve) serialise.
+        static std::mutex mu;
+        static std::map<std::pair<int, int>, std::unique_ptr<MsmCtxBase>> cache;
+        MsmCtxBase* c;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto key = std::make_pair(current_device(), curve);
+            auto it = cache.find(key);
+            if (it == cache.end()) it = cache.emplace(key, std::unique_ptr<MsmCtxBase>(new_ctx(curve))).first;
+            c = it->second.get();
         }
-        ctx_set_bases(c.get(), db.p, n, false, 0, nullptr);
-        c->run(ds.p, n, is_mont, nullptr, out);
+        c->run_oneshot(bases, scalars, n, is_mont, out);
     });
 }
 
