@@ -112,6 +112,19 @@ int lurk_hip_msm_ctx_rebind_dev(lurk_hip_msm_ctx* ctx, const void* d_bases_affin
  * prover that wants no allocation inside its first steps reserves them up front for the largest commitment it will make. */
 int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots);
 int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoints, int* window_bits, int* precomputed);
+/* Commitment-key generation: arecibo's CommitmentEngine::setup(label, n) = DlogGroup::from_label as
+ * PublicParams::setup reaches it (/root/reference/src/proof/nova.rs:196-216): SHAKE256(label) squeezed 32 bytes per point (host:
+ * the XOF is sequential), point i = pasta_curves hash_to_curve("from_uniform_bytes") of its bytes - BLAKE2b-512 expand_message_xmd,
+ * simplified SWU on the 3-isogenous curve, the degree-3 isogeny - one point per lane on the device, affine Montgomery out.
+ * from_label_dev writes npoints x 64 B to device memory (synchronises `stream`); ctx_from_label builds the resident context in
+ * place, no host copy of the key ever exists; hash_to_curve_dev is the per-point map on caller-supplied 32-byte strings. */
+int lurk_hip_shake256(const void* in, size_t in_len, void* out, size_t out_len); /* host-only helper (the XOF above) */
+int lurk_hip_ck_hash_to_curve_dev(int curve, const char* domain_prefix, const void* d_uniform32, size_t n, void* d_out_affine64,
+                                  void* stream);
+int lurk_hip_ck_from_label_dev(int curve, const void* label, size_t label_len, size_t npoints, void* d_out_affine64,
+                               void* stream);
+int lurk_hip_msm_ctx_from_label(lurk_hip_msm_ctx** ctx, int curve, const void* label, size_t label_len, size_t npoints,
+                                int flags);
 /* Key files.  The reference caches its public parameters - mostly the commitment key - on disk and
  * maps them back (/root/reference/src/public_parameters/mod.rs:33-56, disk_cache.rs:69-77).  save writes the resident key as it
  * sits in HBM (64-byte header + 64-byte affine Montgomery records; with_table != 0 also the per-window multiples of a

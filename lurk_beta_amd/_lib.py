@@ -41,6 +41,10 @@ SIGNATURES = {
     "lurk_hip_msm_ctx_destroy": (c_int, [c_void_p]),
     "lurk_hip_msm_ctx_rebind_dev": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lurk_hip_msm_ctx_reserve": (c_int, [c_void_p, c_size_t, c_int]),
+    "lurk_hip_shake256": (c_int, [ctypes.c_char_p, c_size_t, c_void_p, c_size_t]),
+    "lurk_hip_ck_hash_to_curve_dev": (c_int, [c_int, ctypes.c_char_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_ck_from_label_dev": (c_int, [c_int, ctypes.c_char_p, c_size_t, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_msm_ctx_from_label": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.c_char_p, c_size_t, c_size_t, c_int]),
     "lurk_hip_msm_ctx_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "lurk_hip_msm_ctx_save": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
     "lurk_hip_msm_ctx_load": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int]),

@@ -26,6 +26,8 @@
 
 namespace lurk {
 
+void keygen_from_label_device(int curve, const void* label, size_t label_len, size_t n, void* d_out, hipStream_t s);  // keygen.hip
+
 constexpr int MSM_P_MIN = 2048;    // coarse partitions of the key space (pass 1 of the sort): 2048 up to n = 2^22, then
 constexpr int MSM_P_MAX = 8192;    // doubled until a partition fits the LDS stage of pass 2 (MsmCtx::shape)
 constexpr int MSM_P_PER_MAX = MSM_P_MAX / 1024;
@@ -1358,6 +1360,18 @@ int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots) 
         LURK_REQUIRE(ctx, "null ctx");
         DeviceGuard dg(ctx->impl->device);
         ctx->impl->reserve(nscalars, slots);
+    });
+}
+int lurk_hip_msm_ctx_from_label(lurk_hip_msm_ctx** ctx, int curve, const void* label, size_t label_len, size_t npoints, int flags) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && (label || label_len == 0), "null argument");
+        *ctx = nullptr;
+        std::unique_ptr<MsmCtxBase> c(new_ctx(curve));
+        DevBuf bases(npoints * 64);
+        keygen_from_label_device(curve, label, label_len, npoints, bases.p, nullptr);
+        if (flags & LURK_MSM_FLAG_PRECOMPUTE) ctx_set_bases(c.get(), bases.p, npoints, false, flags, nullptr);  // the table owns its copy
+        else c->adopt_table(std::move(bases), npoints, false, MSM_C_PLAIN);
+        *ctx = new lurk_hip_msm_ctx{std::move(c)};
     });
 }
 int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoints, int* window_bits, int* precomputed) {

@@ -81,6 +81,19 @@ class CommitmentKey:
         self.curve, self.n = info["curve"], info["npoints"]
         return self
 
+    @classmethod
+    def from_label(cls, curve: int, label: bytes, n: int, precompute: bool = False, window_bits: int = 0) -> "CommitmentKey":
+        """``CommitmentEngine::setup(label, n)`` (arecibo ``from_label``; /root/reference/src/proof/nova.rs:196-216) generated on the
+        device straight into the resident context."""
+        lib = _lib.load()
+        self = cls.__new__(cls)
+        self._ctx = ctypes.c_void_p()
+        flags = (1 if precompute else 0) | ((window_bits & 0xFF) << 8)
+        lab = bytes(label)
+        _lib.check(lib.lurk_hip_msm_ctx_from_label(ctypes.byref(self._ctx), curve, lab, len(lab), n, flags))
+        self.curve, self.n = curve, n
+        return self
+
     def reserve(self, n: int, slots: int = 3) -> None:
         """Allocate the workspaces of slots 0..slots-1 for n-scalar commitments now instead of on first use."""
         _lib.check(_lib.load().lurk_hip_msm_ctx_reserve(self._ctx, n, slots))
@@ -187,3 +200,20 @@ class MultiCommitmentKey:
             self.close()
         except Exception:
             pass
+
+
+def shake256(data: bytes, out_len: int) -> bytes:
+    """The library's host-side SHAKE256 (the XOF behind ``from_label``); no GPU needed."""
+    out = ctypes.create_string_buffer(out_len)
+    _lib.check(_lib.load().lurk_hip_shake256(data, len(data), out, out_len))
+    return out.raw
+
+
+def ck_from_label(curve: int, label: bytes, n: int):
+    """``from_label`` into a fresh device tensor of n affine Montgomery points (n, 8) int64."""
+    import torch
+
+    out = torch.empty((n, 8), dtype=torch.int64, device="cuda")
+    lab = bytes(label)
+    _lib.check(_lib.load().lurk_hip_ck_from_label_dev(curve, lab, len(lab), n, _lib.ptr(out), _lib.ptr(torch.cuda.current_stream().cuda_stream)))
+    return out
