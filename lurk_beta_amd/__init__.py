@@ -15,7 +15,7 @@ from .msm import CommitmentKey, MultiCommitmentKey, msm, point_sum, point_to_aff
 from .ntt import ntt  # noqa: E402
 from .fold import R1CSShape, fold_vec  # noqa: E402
 from .step import FoldingContext, point_mul, public_io  # noqa: E402
-from . import sumcheck  # noqa: E402,F401
+from . import sumcheck, ipa, spartan  # noqa: E402,F401
 from .witness import MultiFrameWitness, slot_witness, slot_witness_size  # noqa: E402
 
 __all__ = [

@@ -1,0 +1,163 @@
+"""Host-side orchestration of a Spartan-style SNARK for a relaxed R1CS instance over the HIP library: the
+structure of arecibo's ``RelaxedR1CSSNARK::prove`` as ``CompressedSNARK::prove`` runs it per curve
+(/root/reference/src/proof/nova.rs:341-356) - outer cubic sum-check, inner quadratic sum-check over (A + r B + r^2 C)(r_x, .) z,
+the two evaluation claims batched to one point, one inner-product-argument opening.  Every vector (z, Az, Bz, Cz, E, the eq tables, the
+key) stays in HBM; the host runs the transcript and moves a few field elements per round.
+
+NOT byte-compatible with arecibo (its Keccak256 transcript and claim rescaling are replaced by the SHA3-based transcript and the
+zero padding documented in oracle/spartan_ref.py, whose prover this one must match element for element and whose verifier must
+accept the result): no proof bytes exist upstream to be compatible with."""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+from . import _lib, ipa, sumcheck
+from .fold import R1CSShape, fold_vec
+from .msm import point_to_affine
+
+
+class Transcript:
+    def __init__(self, label: bytes):
+        self.state = hashlib.sha3_256(b"lurk-hip spartan v1" + label).digest()
+
+    def absorb(self, label: bytes, data: bytes):
+        self.state = hashlib.sha3_256(self.state + label + len(data).to_bytes(8, "little") + data).digest()
+
+    def absorb_scalars(self, label: bytes, xs):
+        self.absorb(label, b"".join(int(x).to_bytes(32, "little") for x in xs))
+
+    def absorb_point(self, label: bytes, xy):
+        self.absorb(label, int(xy[0]).to_bytes(32, "little") + int(xy[1]).to_bytes(32, "little"))
+
+    def squeeze(self, label: bytes, modulus: int) -> int:
+        a = hashlib.sha3_256(self.state + label + b"\x00").digest()
+        b = hashlib.sha3_256(self.state + label + b"\x01").digest()
+        self.state = hashlib.sha3_256(self.state + label + b"\x02").digest()
+        v = int.from_bytes(a + b, "little") % modulus
+        return v if v > 1 else 2
+
+
+def transpose_csr(indptr, indices, data, ncols: int):
+    """CSR (rows x ncols) -> CSR of the transpose (ncols x rows); data: (nnz, 4) u64."""
+    indptr = np.asarray(indptr, dtype=np.int64)
+    indices = np.asarray(indices, dtype=np.int64)
+    data = np.ascontiguousarray(data, dtype=np.uint64).reshape(-1, 4)
+    rows = np.repeat(np.arange(indptr.size - 1, dtype=np.int64), np.diff(indptr))
+    order = np.argsort(indices, kind="stable")
+    t_indptr = np.zeros(ncols + 1, dtype=np.uint64)
+    np.cumsum(np.bincount(indices, minlength=ncols), out=t_indptr[1:])
+    return t_indptr, rows[order].astype(np.uint64), np.ascontiguousarray(data[order])
+
+
+class SpartanProver:
+    """Keeps the shape and its transpose resident.  mats: (A, B, C) as (indptr, indices, data Montgomery) over columns
+    z = [W | u | X | 0 ...] of length 2 num_vars; num_cons and num_vars powers of two."""
+
+    def __init__(self, curve: int, order: int, mats, num_cons: int, num_vars: int, num_io: int):
+        self.curve, self.q, self.num_cons, self.num_vars, self.num_io = curve, order, num_cons, num_vars, num_io
+        self.sf = 1 if curve == 0 else 0
+        assert num_cons & (num_cons - 1) == 0 and num_vars & (num_vars - 1) == 0 and 1 + num_io <= num_vars
+        self.shape = R1CSShape(self.sf, num_cons, num_vars, num_io, *mats)
+        # the transpose acts on eq(r_x) (num_cons entries = its "z") and yields 2 num_vars rows
+        self.shape_t = R1CSShape(self.sf, 2 * num_vars, num_cons - 1, 0, *[transpose_csr(*m, 2 * num_vars) for m in mats])
+        self.R = (1 << 256) % order
+        self.Rinv = pow(self.R, order - 2, order)
+
+    def _mont(self, vals) -> np.ndarray:
+        return sumcheck._limbs([int(v) * self.R % self.q for v in vals])
+
+    def _dev(self, vals):
+        import torch
+
+        return torch.from_numpy(self._mont(vals).view(np.int64)).cuda()
+
+    def _mle(self, d_table, point) -> int:
+        import torch
+
+        lib = _lib.load()
+        if len(point) == 0:
+            return sumcheck._ints(d_table[:1].cpu().numpy().view(np.uint64))[0] * self.Rinv % self.q
+        eq = sumcheck.eq_evals(self.sf, self._mont(point))
+        out = np.zeros(4, dtype=np.uint64)
+        _lib.check(lib.lurk_hip_inner_product_dev(self.sf, _lib.ptr(d_table), _lib.ptr(eq), 1 << len(point), _lib.ptr(out), _lib.ptr(torch.cuda.current_stream().cuda_stream)))
+        return sumcheck._ints(out)[0] * self.Rinv % self.q
+
+    def prove(self, X, u: int, d_W, d_E, d_ck, comm_W_jac, comm_E_jac) -> dict:
+        """d_W (num_vars, 4), d_E (num_cons, 4): Montgomery device tensors (not modified); d_ck: (N + 1, 8) affine Montgomery points,
+        N = max(num_cons, num_vars), the last one the inner-product base; commitments as 96-byte Jacobians."""
+        import torch
+
+        q, sf, nc, nv = self.q, self.sf, self.num_cons, self.num_vars
+        ell_x, ell_y = nc.bit_length() - 1, nv.bit_length()
+        N = max(nc, nv)
+        ell = N.bit_length() - 1
+        curve_name = b"pallas" if self.curve == 0 else b"vesta"
+        tr = Transcript(curve_name)
+        tr.absorb_point(b"comm_W", point_to_affine(self.curve, comm_W_jac))
+        tr.absorb_point(b"comm_E", point_to_affine(self.curve, comm_E_jac))
+        tr.absorb_scalars(b"uX", [u] + list(X))
+        d_z = torch.zeros((2 * nv, 4), dtype=torch.int64, device="cuda")
+        d_z[:nv] = d_W
+        d_z[nv:nv + 1 + len(X)] = self._dev([u] + list(X))
+        d_az, d_bz, d_cz = self.shape.multiply_vec(d_z[: self.shape.num_cols])
+        tau = [tr.squeeze(b"t", q) for _ in range(ell_x)]
+        d_tau = sumcheck.eq_evals(sf, self._mont(tau))
+        d_ucze = fold_vec(sf, d_E, d_cz, self._mont([u]))  # E + u Cz
+
+        def chal(j, poly):
+            tr.absorb_scalars(b"p", poly)
+            return tr.squeeze(b"c", q)
+
+        r_x = []
+        polys_outer, finals, _ = sumcheck.prove(sf, q, 0, [d_tau, d_az.clone(), d_bz.clone(), d_ucze], lambda j, poly: r_x.append(chal(j, poly)) or r_x[-1])
+        claim_Az, claim_Bz = finals[1], finals[2]
+        claim_Cz, eval_E = self._mle(d_cz, r_x), self._mle(d_E, r_x)
+        tr.absorb_scalars(b"claims_outer", [claim_Az, claim_Bz, claim_Cz, eval_E])
+        r = tr.squeeze(b"r", q)
+        claim_inner = (claim_Az + r * claim_Bz + r * r * claim_Cz) % q
+        d_eq_rx = sumcheck.eq_evals(sf, self._mont(r_x))
+        d_ea, d_eb, d_ec = self.shape_t.multiply_vec(d_eq_rx)
+        d_abc = fold_vec(sf, fold_vec(sf, d_ea, d_eb, self._mont([r])), d_ec, self._mont([r * r % q]))
+        r_y = []
+        polys_inner, _, _ = sumcheck.prove(sf, q, claim_inner, [d_abc, d_z.clone()], lambda j, poly: r_y.append(chal(j, poly)) or r_y[-1])
+        eval_W = self._mle(d_W, r_y[1:])
+        tr.absorb_scalars(b"eval_W", [eval_W])
+        # ---- the two evaluation claims -> one point
+        d_p1 = torch.zeros((N, 4), dtype=torch.int64, device="cuda")
+        d_p2 = torch.zeros((N, 4), dtype=torch.int64, device="cuda")
+        d_p1[:nv] = d_W
+        d_p2[:nc] = d_E
+        x1 = [0] * (ell - (ell_y - 1)) + r_y[1:]
+        x2 = [0] * (ell - ell_x) + r_x
+        rho = tr.squeeze(b"rho", q)
+        pairs = [(sumcheck.eq_evals(sf, self._mont(x1)), d_p1.clone()), (sumcheck.eq_evals(sf, self._mont(x2)), d_p2.clone())]
+        polys_batch, r_z, fin, _ = sumcheck.prove_quad_batch(sf, q, [eval_W, eval_E], pairs, [1, rho], lambda poly: chal(0, poly))
+        evals_batch = [fin[0][1], fin[1][1]]
+        tr.absorb_scalars(b"evals_batch", evals_batch)
+        gamma = tr.squeeze(b"gamma", q)
+        d_joint = fold_vec(sf, d_p1, d_p2, self._mont([gamma]))
+        r0 = tr.squeeze(b"ipa_r0", q)
+
+        def ipa_chal(j, L, Rr):
+            tr.absorb_point(b"L", point_to_affine(self.curve, L))
+            tr.absorb_point(b"R", point_to_affine(self.curve, Rr))
+            return tr.squeeze(b"r", q)
+
+        ck_c = d_ck[N].cpu().numpy().view(np.uint64).reshape(8)
+        bf = 0 if self.curve == 0 else 1
+        ck_c_jac = np.concatenate([ck_c, _mont_one(bf)])
+        Ls, Rs, a_hat, _ = ipa.prove(self.curve, q, d_ck[:N].clone(), ck_c_jac, d_joint, sumcheck.eq_evals(sf, self._mont(r_z)), r0, ipa_chal)
+        aff = lambda P: (lambda xy: None if xy == (0, 0) else xy)(point_to_affine(self.curve, P))
+        return dict(polys_outer=polys_outer, claims_outer=[claim_Az, claim_Bz, claim_Cz], eval_E=eval_E, polys_inner=polys_inner, eval_W=eval_W,
+                    polys_batch=polys_batch, evals_batch=evals_batch, ipa_L=[aff(x) for x in Ls], ipa_R=[aff(x) for x in Rs], ipa_a=a_hat)
+
+    def close(self):
+        self.shape.close()
+        self.shape_t.close()
+
+
+def _mont_one(base_field_id: int) -> np.ndarray:
+    p = (0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001, 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001)[base_field_id]
+    return sumcheck._limbs([(1 << 256) % p])[0]

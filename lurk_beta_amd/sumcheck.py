@@ -90,3 +90,47 @@ def prove(field_id: int, modulus: int, claim: int, tables, challenge, stream=Non
     torch.cuda.synchronize()
     finals = [_ints(t[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p for t in tables]
     return polys, finals, claim
+
+
+def prove_quad_batch(field_id: int, modulus: int, claims, pairs, coeffs, challenge, stream=None):
+    """sum_i coeff_i * sum_x A_i(x) B_i(x) with ONE challenge per round shared by every pair (the evaluation-claim batching of
+    arecibo's snark.rs).  pairs: [(A_i, B_i)] device tensors of one common length (consumed); challenge(poly) -> r.
+    Returns (round polynomials, challenges, [(A_i(r), B_i(r))], final claim)."""
+    import torch
+
+    lib = _lib.load()
+    p = modulus
+    R = (1 << 256) % p
+    Rinv = pow(R, p - 2, p)
+    inv2 = pow(2, p - 2, p)
+    n = pairs[0][0].shape[0]
+    s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    ptrs = [(ctypes.c_void_p * 2)(_lib.ptr(a), _lib.ptr(b)) for a, b in pairs]
+    claim = sum(c * e for c, e in zip(coeffs, claims)) % p
+    polys, rs, length, r_prev = [], [], n, None
+    for _ in range(n.bit_length() - 1):
+        e0 = e2 = 0
+        rm = None if r_prev is None else _limbs([r_prev * R % p])
+        for c, pp in zip(coeffs, ptrs):
+            ev = np.zeros((2, 4), dtype=np.uint64)
+            _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 2, pp, length, None if rm is None else _lib.ptr(rm), _lib.ptr(ev), _lib.ptr(s)))
+            a0, a2 = [x * Rinv % p for x in _ints(ev)]
+            e0, e2 = (e0 + c * a0) % p, (e2 + c * a2) % p
+        if r_prev is not None:
+            length //= 2
+        e1 = (claim - e0) % p
+        a2c = (e2 - 2 * e1 + e0) * inv2 % p
+        poly = [e0, (e1 - e0 - a2c) % p, a2c]
+        r_prev = int(challenge(poly)) % p
+        polys.append(poly)
+        rs.append(r_prev)
+        acc = 0
+        for co in reversed(poly):
+            acc = (acc * r_prev + co) % p
+        claim = acc
+    rm = _limbs([r_prev * R % p])
+    for pp in ptrs:
+        _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 2, pp, length, _lib.ptr(rm), None, _lib.ptr(s)))
+    torch.cuda.synchronize()
+    finals = [(_ints(a[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p, _ints(b[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p) for a, b in pairs]
+    return polys, rs, finals, claim
