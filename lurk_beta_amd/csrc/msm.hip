@@ -64,12 +64,28 @@ __device__ __forceinline__ void msm_set_wave_prio(int cls) {
 // ---- 1. digits ---------------------------------------------------------------------------
 // Both sweeps of sort pass 1 read the scalars themselves (32 B each) and recode them on the fly:
 // cheaper than materialising W digits per scalar (4 W bytes written once and read twice).
+// (Montgomery scalars are brought to canonical form once, by msm_canon_kernel, not inside the two sweeps: besides halving that
+// work it keeps the sort kernels at <= 56 VGPRs, so a 1024-thread sort workgroup of the next commitment fits on a SIMD beside
+// two accumulate waves - with the conversion inlined msm_scatter1 needed 63 and had to wait for an accumulation to end.)
 template <class SF>  // scalar field
-__device__ __forceinline__ Fe<SF> msm_scalar_from_words(const uint4& lo, const uint4& hi, int is_mont) {
+__device__ __forceinline__ Fe<SF> msm_scalar_from_words(const uint4& lo, const uint4& hi, int /*is_mont: always canonical here*/) {
     Fe<SF> s;
     s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
     s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
-    return is_mont ? fe_from_mont<SF>(s) : s;
+    return s;
+}
+template <class SF>
+__global__ __launch_bounds__(256) void msm_canon_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+    msm_set_wave_prio(0);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const uint4 lo = in[2 * i], hi = in[2 * i + 1];
+        Fe<SF> s;
+        s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
+        s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
+        s = fe_from_mont<SF>(s);
+        out[2 * i] = make_uint4(s.l[0], s.l[1], s.l[2], s.l[3]);
+        out[2 * i + 1] = make_uint4(s.l[4], s.l[5], s.l[6], s.l[7]);
+    }
 }
 template <class SF>
 __device__ __forceinline__ Fe<SF> msm_load_scalar(const uint4* __restrict__ scalars, size_t i, int is_mont) {
@@ -488,7 +504,7 @@ void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* t
 // three commitments in flight share every SIMD (three dependent mad chains keep the VALU issuing) and the short kernels of
 // the others always find registers and wave slots beside them.
 struct MsmTuning {
-    int persistent, waves, r128, prio, sort_prio, tail_prio;
+    int persistent, waves, r128, prio, sort_prio, tail_prio, max_acc;
     MsmTuning() {
         auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
         persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // 0 = never, 1 = by size, 2 = always
@@ -497,6 +513,8 @@ struct MsmTuning {
         prio = geti("LURK_MSM_PRIO", 1);
         sort_prio = geti("LURK_MSM_SORT_PRIO", 3);
         tail_prio = geti("LURK_MSM_TAIL_PRIO", 3);
+        max_acc = geti("LURK_MSM_MAX_ACC", 2);
+        if (max_acc > 2) max_acc = 0;  // 0 = unlimited (3 slots)
         if (waves < 1) waves = 1;
         if (waves > 8) waves = 8;
     }
@@ -696,7 +714,7 @@ struct MsmCtx : MsmCtxBase {
     struct Work {
         std::mutex mu;
         DevBuf inter, sorted, block_hist, part_cnt, part_start, cnt, bucket_start, task_start, group_tasks, group_task_base, task_info,
-            task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, ws;
+            task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, ws, canon;
         Xyzz<P>* host_pts = nullptr;  // pinned: window sums or bit planes for the host tail
         size_t ws_n = 0;
         hipStream_t stream = nullptr;      // slot stream: sort, plan, finalize, reduce (high priority)
@@ -715,6 +733,9 @@ struct MsmCtx : MsmCtxBase {
         }
     };
     Work work[MSM_SLOTS];
+    std::mutex acc_ring_mu;  // the last MSM_SLOTS persistent accumulations, in submission order
+    Work* acc_ring[MSM_SLOTS] = {nullptr, nullptr, nullptr};
+    int acc_ring_pos = 0, acc_ring_count = 0;
 
     MsmShape shape(size_t n) const {
         MsmShape sh;
@@ -893,6 +914,15 @@ struct MsmCtx : MsmCtxBase {
         allow_dynamic_lds((const void*)msm_scatter1_kernel<SF>, (int)MSM_LDS_BYTES);
         allow_dynamic_lds((const void*)msm_part2_kernel, (int)MSM_LDS_BYTES);
         LURK_REQUIRE(msm_scatter1_lds(sh.P, sh.W, sh.tile) <= MSM_LDS_BYTES, "pass-1 tile does not fit the LDS");
+        if (is_mont) {  // one conversion pass; both sweeps of sort pass 1 then read canonical scalars
+            wk.canon.ensure(n * 32);
+            ProfScope ps("msm_sort", s);
+            unsigned blocks = div_up(n, 256), cap = (unsigned)num_cus() * 8;
+            if (blocks > cap) blocks = cap;
+            hipLaunchKernelGGL((msm_canon_kernel<SF>), dim3(blocks), dim3(256), 0, s, (const uint4*)d_scalars, wk.canon.template as<uint4>(), n);
+            d_scalars = wk.canon.p;
+            is_mont = 0;
+        }
         {
             ProfScope ps("msm_sort", s);
             hipLaunchKernelGGL((msm_hist1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), (size_t)sh.P * 4, s, (const uint4*)d_scalars,
@@ -927,15 +957,29 @@ struct MsmCtx : MsmCtxBase {
                                wk.group_task_base.template as<uint32_t>(), sh.NG, lh + MSM_S + 1, wk.task_order.template as<uint32_t>());
         }
         const MsmTuning& tn = msm_tuning();
-        // the persistent form (own low-priority stream) pays off when the accumulation is long enough to hide another
-        // commitment's short kernels under it (>= 2^25 sorted entries: 2^22 points and up with the table); below that the plain
-        // launch on the slot's own stream is faster (measured: 2^20, 3 in flight, 760 vs 660 Mscalar-mul/s)
-        if (before_accumulate) (*before_accumulate)();  // the one-shot entry point uploads the bases here, behind the sort
-        const bool persistent = s_acc && (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 25) : tn.persistent != 0);
+        // commitments in flight take the persistent form on the slot's low-priority accumulate stream (tiny ones excepted: their
+        // accumulation is over before a second kernel could share the chip); synchronous calls keep the plain launch
+        const bool persistent = s_acc && (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 22) : tn.persistent != 0);
         if (persistent) {
             LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4, s));
             LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
             LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, wk.planned, 0));
+            if (tn.max_acc >= 1) {
+                // at most max_acc accumulations resident at once: this one also waits for the one submitted max_acc submissions ago.
+                // Two one-wave-per-SIMD accumulations saturate the VALU and leave every SIMD the registers a 1024-thread sort
+                // workgroup of the NEXT commitment needs; a third would take them (measured: the sort then waits for an
+                // accumulation to end and the remaining one runs alone at half speed).
+                std::lock_guard<std::mutex> lk(acc_ring_mu);
+                Work* old = acc_ring[acc_ring_pos % MSM_SLOTS];
+                if (acc_ring_count >= tn.max_acc) {
+                    Work* gate = acc_ring[(acc_ring_pos + MSM_SLOTS - tn.max_acc) % MSM_SLOTS];
+                    if (gate && gate != &wk && gate->accumulated) LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, gate->accumulated, 0));
+                }
+                (void)old;
+                acc_ring[acc_ring_pos % MSM_SLOTS] = &wk;
+                acc_ring_pos++;
+                if (acc_ring_count < MSM_SLOTS) acc_ring_count++;
+            }
             {
                 ProfScope ps("msm_accumulate", s_acc);
                 msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
