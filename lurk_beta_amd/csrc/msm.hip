@@ -956,6 +956,7 @@ struct MsmCtx : MsmCtxBase {
             hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
                                wk.group_task_base.template as<uint32_t>(), sh.NG, lh + MSM_S + 1, wk.task_order.template as<uint32_t>());
         }
+        if (before_accumulate) (*before_accumulate)();  // the one-shot entry point uploads the bases here, behind the sort
         const MsmTuning& tn = msm_tuning();
         // commitments in flight take the persistent form on the slot's low-priority accumulate stream (tiny ones excepted: their
         // accumulation is over before a second kernel could share the chip); synchronous calls keep the plain launch
