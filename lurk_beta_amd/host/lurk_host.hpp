@@ -250,6 +250,26 @@ class R1CSShape {
     lurk_hip_r1cs* h_ = nullptr;
 };
 
+// compute_witness_size (/root/reference/src/lem/multiframe.rs:503-516): elements a slot contributes to the witness vector
+inline size_t slot_witness_size(int field_id, int slot_type) {
+    size_t n = 0;
+    check(lurk_hip_slot_witness_size(field_id, slot_type, &n));
+    return n;
+}
+// allocate_slot's aux block for n slots of one type (circuit.rs:242-315), host buffers: n x size Montgomery elements
+inline std::vector<Fe> slot_witness(int field_id, int slot_type, const std::vector<Fe>& preimages, bool preimages_mont) {
+    const size_t per = slot_type == LURK_SLOT_BIT_DECOMP ? 1 : (size_t)slot_type, n = preimages.size() / per;
+    std::vector<Fe> out(n * slot_witness_size(field_id, slot_type));
+    check(lurk_hip_slot_witness(field_id, slot_type, preimages.data(), n, preimages_mont ? 1 : 0, out.data()));
+    return out;
+}
+// StoreCore::hydrate_z_cache (/root/reference/src/lem/store_core.rs:256-269) over a topologically ordered node array
+inline std::vector<Fe> store_hydrate(int field_id, const std::vector<lurk_hip_store_node>& nodes, const std::vector<Fe>& values, size_t* levels = nullptr) {
+    std::vector<Fe> digests(nodes.size());
+    check(lurk_hip_store_hydrate(field_id, nodes.data(), nodes.size(), values.data(), values.size(), digests.data(), levels));
+    return digests;
+}
+
 // Store::to_scalar_vector (/root/reference/src/lem/store.rs:883-895): the public IO of a step, [tag, hash] per pointer
 inline std::vector<Fe> to_scalar_vector(const std::vector<std::pair<Fe, Fe>>& z_ptrs) {
     std::vector<Fe> out;

