@@ -3,10 +3,11 @@
 
 A "step" is one commitment  C = sum_i s_i * ck_i  over Pallas: scalars and the commitment key are
 already resident in HBM when the timed region starts (the PCIe-inclusive rate is noted in
-DESIGN.md, never here).  By default two commitments are in flight (`--pipeline 2`: the commit(W) / commit(T) pair
-of a folding step, two of a context's three async slots): every step is still one complete MSM and all K results
+DESIGN.md, never here).  By default three commitments are in flight (`--pipeline 3`, a context's three async slots:
+the sort of the third runs under the two resident accumulations; 8 of 8 paired runs at K = 20 were faster and steadier
+than two in flight, 958-971 against 900-959 Mscalar-mul/s): every step is still one complete MSM and all K results
 are produced inside the timed region, which starts and ends with an empty pipeline (so a small K pays the fill and
-drain: K = 10 / 20 / 40 measure 4.52 / 4.34 / 4.25 ms per step); `--pipeline 1` is the fully synchronous form, and
+drain: K = 20 / 40 measure about 4.35 / 4.25 ms per step); `--pipeline 1` is the fully synchronous form, and
 the default line also carries `sync_ms_per_commit`, the plain-key synchronous sub-record and the one-shot
 host-pointer sub-record.  The resident key
 carries the precomputed per-window table by default (`--precompute 0` = plain 64 B/point key).  N = 1: n = 2^log_n points on one GPU (default 2^22, the size the metric
@@ -42,7 +43,7 @@ def main():
     ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--precompute", type=int, default=1,
                     help="1 = resident key with the per-window precomputed table (13 x 64 B per point, 20-bit windows); 0 = plain key")
-    ap.add_argument("--pipeline", type=int, default=2,
+    ap.add_argument("--pipeline", type=int, default=3,
                     help="commitments in flight (1 = synchronous; 2..3 = async slots: the tail of one overlaps the accumulation of the next)")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
     ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt", "fold_step", "compress"], default="msm",

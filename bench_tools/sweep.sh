@@ -4,8 +4,8 @@ TAG=${1:-r01}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/sweep_$TAG.jsonl; : > $OUT
 run() { python bench.py "$@" 2>/dev/null | tail -1 >> $OUT; }
-run --steps 20 --warmup 3                                         # headline: 2^22 table, 2 in flight (+ live PMC traffic, plain leg, one-shot leg, cpu baseline)
-run --steps 20 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --pipeline 3
+run --steps 20 --warmup 3                                         # headline: 2^22 table, 3 in flight (+ live PMC traffic, plain leg, one-shot leg, cpu baseline)
+run --steps 20 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --pipeline 2
 run --steps 10 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --pipeline 1
 run --steps 10 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --pipeline 1 --precompute 0
 run --steps 10 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg --dist witness

@@ -121,7 +121,10 @@ LURK_HD __attribute__((noinline)) Xyzz29<P> xyzz29_double_affine(F29<P> qx, F29<
 }
 
 // acc += (+/-) q.  q is the 64-byte table record (Montgomery 2^256 limbs); acc_id tracks the identity.
-template <class P>
+// ACC_AFFINE: the caller knows zz = zzz = 1 (the accumulator holds exactly one base so far), which saves the four
+// products with zz / zzz: 4 M + 2 S instead of 8 M + 2 S.  Every task's first real addition is of this kind, and the
+// loop position is the same in all lanes of a wave, so the specialisation costs no divergence.
+template <class P, bool ACC_AFFINE = false>
 LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool negate) {
     if (affine_is_identity<P>(q)) return;
     const F29<P> qx = f29_from_mont256<P>(q.x);  // 32 x~ < 2^259, tight
@@ -139,8 +142,8 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
     F29_ASSERT_LIMBS(acc.y, 29, "acc.y"); F29_ASSERT_TOP(acc.y, 27, "acc.y");
     F29_ASSERT_LIMBS(acc.zz, 29, "acc.zz"); F29_ASSERT_TOP(acc.zz, 27, "acc.zz");
     F29_ASSERT_LIMBS(acc.zzz, 29, "acc.zzz"); F29_ASSERT_TOP(acc.zzz, 27, "acc.zzz");
-    const F29<P> u2 = f29_mul<P>(qx, acc.zz);    // < 2^257.2
-    const F29<P> s2 = f29_mul<P>(qy, acc.zzz);
+    const F29<P> u2 = ACC_AFFINE ? qx : f29_mul<P>(qx, acc.zz);    // < 2^257.2  (affine: < 2^259)
+    const F29<P> s2 = ACC_AFFINE ? qy : f29_mul<P>(qy, acc.zzz);
     const F29<P> p = f29_carry<P>(f29_sub<P>(u2, acc.x));  // U2 - X1 + 64p  < 2^260.3
     // r = S2 - Y1 for +q; for -q the true r is -(S2 + Y1): keep r' = S2 + Y1 and flip the sign of (Q - X3) below
     F29<P> r;
@@ -183,8 +186,13 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
 #endif
     acc.x = x3;
     acc.y = y3;
-    acc.zz = f29_mul<P>(acc.zz, pp);             // < 2^257.8
-    acc.zzz = f29_mul<P>(acc.zzz, ppp);          // < 2^257.2
+    if (ACC_AFFINE) {
+        acc.zz = f29_reduce<P>(pp);              // < 2^255.1 (the loop invariant wants < 2^259)
+        acc.zzz = f29_reduce<P>(ppp);
+    } else {
+        acc.zz = f29_mul<P>(acc.zz, pp);         // < 2^257.8
+        acc.zzz = f29_mul<P>(acc.zzz, ppp);      // < 2^257.2
+    }
 }
 
 // One accumulation task on the radix-2^29 layer; returns an ordinary XYZZ point.
@@ -195,7 +203,18 @@ LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, ui
     bool acc_id = true;
     // (gathering the next base ahead of the current addition was measured: no gain, the other waves of the SIMD
     // already cover the load)
-    for (uint32_t j = first; j < last; j++) {
+    uint32_t j = first;
+    if (j < last) {  // first base: a copy (zz = zzz = 1)
+        const uint32_t e = sorted[j++];
+        xyzz29_madd<P>(acc, acc_id, table[e & 0x7fffffffu], (e & 0x80000000u) != 0);
+    }
+    if (j < last) {  // second base: affine + affine (unless the first was the identity record)
+        const uint32_t e = sorted[j++];
+        const Affine<P> q = table[e & 0x7fffffffu];
+        if (!acc_id) xyzz29_madd<P, true>(acc, acc_id, q, (e & 0x80000000u) != 0);
+        else xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);
+    }
+    for (; j < last; j++) {
         const uint32_t e = sorted[j];
         const Affine<P> q = table[e & 0x7fffffffu];
         xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);

@@ -504,7 +504,7 @@ void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* t
 // three commitments in flight share every SIMD (three dependent mad chains keep the VALU issuing) and the short kernels of
 // the others always find registers and wave slots beside them.
 struct MsmTuning {
-    int persistent, waves, r128, prio, sort_prio, tail_prio, max_acc;
+    int persistent, waves, r128, prio, sort_prio, tail_prio, max_acc, placement_log;
     MsmTuning() {
         auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
         persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // 0 = never, 1 = by size, 2 = always
@@ -514,6 +514,7 @@ struct MsmTuning {
         sort_prio = geti("LURK_MSM_SORT_PRIO", 3);
         tail_prio = geti("LURK_MSM_TAIL_PRIO", 3);
         max_acc = geti("LURK_MSM_MAX_ACC", 2);
+        placement_log = geti("LURK_MSM_PLACEMENT_LOG", 0);
         if (max_acc > 2) max_acc = 0;  // 0 = unlimited (3 slots)
         if (waves < 1) waves = 1;
         if (waves > 8) waves = 8;
@@ -720,7 +721,8 @@ struct MsmCtx : MsmCtxBase {
         hipStream_t stream = nullptr;      // slot stream: sort, plan, finalize, reduce (high priority)
         hipStream_t acc_stream = nullptr;  // the accumulate kernel alone (low priority)
         hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
-        DevBuf cursor;                     // task cursor of the persistent accumulate kernel
+        DevBuf cursor;                     // task cursor of the persistent accumulate kernel (+ its per-CU placement counters)
+        bool placement_valid = false;
         bool pending = false;
         size_t pending_n = 0;
         ~Work() {
@@ -895,7 +897,7 @@ struct MsmCtx : MsmCtxBase {
         wk.buckets.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
         wk.big_list.ensure((size_t)sh.NB * 4);
         wk.big_count.ensure(16);
-        wk.cursor.ensure(16);
+        wk.cursor.ensure(4 * (MSM_PLACEMENT_BASE + 512));
         wk.planes_a.ensure((size_t)sh.NB * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
         wk.planes_b.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
         wk.ws.ensure(32 * sizeof(Xyzz<P>));
@@ -962,7 +964,8 @@ struct MsmCtx : MsmCtxBase {
         // accumulation is over before a second kernel could share the chip); synchronous calls keep the plain launch
         const bool persistent = s_acc && (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 22) : tn.persistent != 0);
         if (persistent) {
-            LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4, s));
+            LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4 * (MSM_PLACEMENT_BASE + 512), s));
+            wk.placement_valid = true;
             LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
             LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, wk.planned, 0));
             if (tn.max_acc >= 1) {
@@ -1097,7 +1100,22 @@ struct MsmCtx : MsmCtxBase {
             return;
         }
         LURK_HIP_CHECK(hipStreamSynchronize(wk.stream));
+        if (wk.placement_valid && msm_tuning().placement_log) log_placement(wk);
         host_tail(wk, wk.pending_n, out);
+    }
+    // LURK_MSM_PLACEMENT_LOG=1: how the dispatcher spread the persistent accumulate's workgroups (one per CU wanted)
+    void log_placement(Work& wk) {
+        std::vector<uint32_t> h(MSM_PLACEMENT_BASE + 512);
+        LURK_HIP_CHECK(hipMemcpy(h.data(), wk.cursor.p, h.size() * 4, hipMemcpyDeviceToHost));
+        int hist[8] = {0}, used = 0;
+        for (int i = 0; i < 512; i++) {
+            uint32_t c = h[MSM_PLACEMENT_BASE + i];
+            if (c) used++;
+            hist[c > 7 ? 7 : c]++;
+        }
+        fprintf(stderr, "[lurk_hip] accumulate placement: %d CUs used; CUs with 1/2/3/4+ workgroups: %d/%d/%d/%d\n", used, hist[1], hist[2], hist[3],
+                hist[4] + hist[5] + hist[6] + hist[7]);
+        wk.placement_valid = false;
     }
 };
 

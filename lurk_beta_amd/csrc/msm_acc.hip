@@ -40,6 +40,13 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uin
     msm_accumulate_task<P>(i, sorted, table, task_info, order, partials);
 }
 
+// (XCC, SE, CU) of the running wave as one index < 512 (HW_ID: CU_ID [11:8], SE_ID [14:13]; XCC_ID [3:0])
+__device__ __forceinline__ uint32_t msm_cu_index() {
+    const uint32_t hw = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11));
+    return (xcc & 7u) * 64u + ((hw >> 13) & 3u) * 16u + ((hw >> 8) & 15u);
+}
+
 // Persistent form for commitments in flight: a fixed number of waves per SIMD (the launch grid), each wave pulls the next
 // 64 tasks of the longest-first order from a global cursor.  The kernel then never holds more than its share of every
 // SIMD's registers and wave slots, so the latency / HBM-bound kernels of the NEXT commitment (sort, plan, bucket
@@ -47,6 +54,7 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uin
 #define LURK_ACC_PERSISTENT_BODY                                                                                       \
     const uint32_t ntasks = group_task_base[NG];                                                                       \
     const uint32_t lane = threadIdx.x & 63u;                                                                           \
+    if (threadIdx.x == 0) atomicAdd(&cursor[MSM_PLACEMENT_BASE + msm_cu_index()], 1u); /* diagnostic: workgroups per CU */ \
     for (;;) {                                                                                                         \
         uint32_t base = 0;                                                                                             \
         if (lane == 0) base = atomicAdd(cursor, 64u);                                                                  \

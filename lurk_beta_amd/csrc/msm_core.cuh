@@ -30,6 +30,7 @@ constexpr int MSM_C_PLAIN = 16;                // window bits of the plain mode
 constexpr int MSM_MAX_W = 16;                  // windows: ceil(256 / c), c >= 16
 constexpr int MSM_GRP = 1 << 15;               // keys per scan group
 constexpr uint32_t MSM_SIGN = 0x80000000u;
+constexpr int MSM_PLACEMENT_BASE = 16;         // word offset of the per-CU workgroup counters behind the persistent kernel's task cursor
 
 LURK_HD int msm_num_windows(int c) { return (256 + c - 1) / c; }
 

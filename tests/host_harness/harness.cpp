@@ -171,7 +171,8 @@ extern "C" int hh_poseidon_params(int field, int arity, int* rf, int* rp, uint32
 
 // mode 0: acc = sum (+/-) P_i with xyzz_madd; mode 1: pairwise xyzz_add of xyzz_from_affine;
 // mode 2: sum k_i * P_i with xyzz_mul_small (k_i = signs[i] as small integer); mode 3: as mode 0 on the
-// radix-2^29 layer (xyzz29_madd, bound assertions enabled).  Output: affine Montgomery.
+// radix-2^29 layer (xyzz29_madd, bound assertions enabled; the second base goes through the affine-accumulator
+// specialisation exactly as in msm_task_accumulate29); mode 4: radix-2^29, general addition only.  Output: affine Montgomery.
 template <class P>
 static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, size_t n, uint32_t* out) {
     Xyzz<P> acc = xyzz_identity<P>();
@@ -181,7 +182,8 @@ static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, si
     for (size_t i = 0; i < n; i++) {
         Affine<P> a;
         for (int k = 0; k < 8; k++) { a.x.l[k] = bases[i * 16 + k]; a.y.l[k] = bases[i * 16 + 8 + k]; }
-        if (mode == 3) xyzz29_madd<P>(acc29, acc29_id, a, signs[i] != 0);
+        if (mode == 3 && i == 1 && !acc29_id) xyzz29_madd<P, true>(acc29, acc29_id, a, signs[i] != 0);  // the kernel's schedule
+        else if (mode == 3 || mode == 4) xyzz29_madd<P>(acc29, acc29_id, a, signs[i] != 0);
         else if (mode == 0) xyzz_madd<P>(acc, a, signs[i] != 0);
         else if (mode == 1) {
             Xyzz<P> q = xyzz_from_affine<P>(a);
@@ -192,7 +194,7 @@ static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, si
             xyzz_add<P>(acc, q);
         }
     }
-    if (mode == 3) acc = xyzz29_to_xyzz<P>(acc29, acc29_id);
+    if (mode == 3 || mode == 4) acc = xyzz29_to_xyzz<P>(acc29, acc29_id);
     Affine<P> r = xyzz_to_affine<P>(acc);
     // round-trip through the Jacobian helpers as well
     Jacobian<P> j = jacobian_from_affine<P>(r);

@@ -72,13 +72,13 @@ def test_xyzz_group_law_with_exceptional_cases(cn, c):
     want = None
     for pt, s in zip(pts, signs):
         want = R.ec_add(cn, want, R.ec_neg(cn, pt) if s else pt)
-    for mode in (0, 1, 3):  # 3 = radix-2^29 accumulator (the bucket-accumulation kernel's inner loop)
+    for mode in (0, 1, 3, 4):  # 3 = radix-2^29 accumulator (the bucket-accumulation kernel's inner loop)
         out = np.zeros(8, dtype=np.uint64)
         L.hh_curve_sum(c, mode, vp(B), vp(signs), ctypes.c_size_t(12), vp(out))
         assert C.affine_to_ints(c, out)[0] == want, mode
     # chain that ends on the identity
     B2 = np.concatenate([B[:1], B[:1]])
-    for mode in (0, 3):
+    for mode in (0, 3, 4):
         out = np.zeros(8, dtype=np.uint64)
         L.hh_curve_sum(c, mode, vp(B2), vp(np.array([0, 1], dtype=np.uint32)), ctypes.c_size_t(2), vp(out))
         assert C.affine_to_ints(c, out)[0] == (0, 0)
@@ -86,11 +86,11 @@ def test_xyzz_group_law_with_exceptional_cases(cn, c):
     B3 = np.concatenate([B[:1], B[:1], B[1:4]])
     s3 = np.array([1, 1, 0, 1, 1], dtype=np.uint32)
     outs = []
-    for mode in (0, 3):
+    for mode in (0, 3, 4):
         out = np.zeros(8, dtype=np.uint64)
         L.hh_curve_sum(c, mode, vp(B3), vp(s3), ctypes.c_size_t(5), vp(out))
         outs.append(C.affine_to_ints(c, out)[0])
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
     # small-scalar multiples
     ks = np.array([0, 1, 2, 3, 17, 255, 32768, 65535, 1, 0, 5, 6], dtype=np.uint32)
     want = None
@@ -151,11 +151,11 @@ def test_radix29_accumulator_long_chains(c):
     signs = rng.integers(0, 2, n).astype(np.uint32)
     for lo, hi in [(0, 64), (64, 1000), (1000, 3000)]:
         outs = []
-        for mode in (0, 3):
+        for mode in (0, 3, 4):
             out = np.zeros(8, dtype=np.uint64)
             L.hh_curve_sum(c, mode, vp(B[lo:hi].copy()), vp(signs[lo:hi].copy()), ctypes.c_size_t(hi - lo), vp(out))
             outs.append(C.affine_to_ints(c, out)[0])
-        assert outs[0] == outs[1]
+        assert outs[0] == outs[1] == outs[2]
 
 
 @pytest.mark.parametrize("f", [0, 1])
