@@ -45,6 +45,10 @@ def main():
                     help="1 = resident key with the per-window precomputed table (13 x 64 B per point, 20-bit windows); 0 = plain key")
     ap.add_argument("--pipeline", type=int, default=3,
                     help="commitments in flight (1 = synchronous; 2..3 = async slots: the tail of one overlaps the accumulation of the next)")
+    ap.add_argument("--stage-ahead", type=int, default=0,
+                    help="fold_step: 1 = the next step's witness is traced and its commitment started one step ahead (lurk_hip_fold_step_prefetch); "
+                         "0 = plain begin (default: measured 4.4 ms against 4.05 ms staged whole / 5.1 ms staged with late ranges at rc = 100, DESIGN.md)")
+    ap.add_argument("--late-ranges", type=int, default=1, help="fold_step with --stage-ahead: 1 = 12 000 positions of W2 arrive with begin (the augmented circuit's), 0 = none")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
     ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt", "fold_step", "compress"], default="msm",
                     help="msm = the headline metric; poseidon_tree / ntt = the other hot-path kernels (BASELINE configs[2], N1); "
@@ -353,11 +357,14 @@ def fold_step_workload(args, lib, world, rank):
     d_bases = synth.bases(L.CURVE_PALLAS, n_key)
     pre = {"hash4": synth.scalars(F, 3, 1, 14 * rc * 4, mont=True), "hash8": synth.scalars(F, 4, 1, 6 * rc * 8, mont=True),
            "commitment": synth.scalars(F, 5, 1, rc * 3, mont=True), "bit_decomp": synth.scalars(F, 6, 1, 3 * rc, mont=True)}
-    globals_host = synth.scalars(F, 7, 1, mf.globals_len, mont=True).cpu().numpy().view(np.uint64)
+    globals_pinned = torch.empty((mf.globals_len, 4), dtype=torch.int64).pin_memory()   # (a pageable source would make the async copy wait for the stream)
+    globals_pinned.copy_(synth.scalars(F, 7, 1, mf.globals_len, mont=True).cpu())
+    globals_host = globals_pinned.numpy().view(np.uint64)
     bodies_host = torch.empty((rc, mf.body_len, 4), dtype=torch.int64).pin_memory()
     bodies_host.copy_(synth.scalars(F, 8, 1, rc * mf.body_len, mont=True).reshape(rc, mf.body_len, 4).cpu())
     bodies_np = bodies_host.numpy().view(np.uint64)
-    d_w2 = torch.zeros((n_w, 4), dtype=torch.int64, device="cuda")
+    d_w2s = [torch.zeros((n_w, 4), dtype=torch.int64, device="cuda") for _ in range(2)]
+    d_w2 = d_w2s[0]
     x2 = synth.scalars(F, 9, 0, n_io, mont=True).cpu().numpy().view(np.uint64)
     t_setup = time.perf_counter()
     shape = L.R1CSShape(F, n_t, n_w, n_io, *synth_r1cs_shape(F, q, n_t, n_w, n_io))
@@ -372,17 +379,50 @@ def fold_step_workload(args, lib, world, rank):
     ident = np.zeros(12, dtype=np.uint64)
     ctx.set_running(z1, e1, ident, ident)
 
+    # --stage-ahead 1: the step circuit's range of the NEXT witness is traced and its commitment started before this
+    # step opens (lurk-beta synthesizes witnesses ahead of the folding loop, nova.rs:304-326); the augmented circuit's own
+    # variables depend on the previous fold and arrive with begin: modelled as the first 9 000 and the last 3 000 positions
+    ck.reserve(n_key, 4)
+    lo, hi = (9000, n_w - 3000) if args.stage_ahead and args.late_ranges else (0, n_w)
+    late_host = synth.scalars(F, 10, 1, lo + n_w - hi, mont=True).cpu().numpy().view(np.uint64)
+    patches = [(0, late_host[:lo]), (hi, late_host[lo:])] if lo else []
+    staged_k = [0]
+
+    def stage():
+        buf = d_w2s[staged_k[0] & 1]
+        staged_k[0] += 1
+        mf.assemble(buf, pre, globals_host, bodies_np, mont=True, stream=stream)     # W2 in HBM (slot traces on the device)
+        ctx.prefetch(buf[lo:hi], lo, stream=stream)                                  # commit(step circuit's range) starts now
+
+    phase = {"assemble_and_stage": 0.0, "begin": 0.0, "finish": 0.0}  # host wall time per call site (begin blocks on the commitments)
+
     def step():
-        mf.assemble(d_w2, pre, globals_host, bodies_np, mont=True, stream=stream)   # W2 in HBM (slot traces on the device)
-        cw, ct = ctx.begin(d_w2, x2, stream=stream)                                  # both commitments + the cross term
+        t_a = time.perf_counter()
+        if args.stage_ahead:
+            stage()                                                                   # the next step's, under this step's work
+            t_b = time.perf_counter()
+            cw, ct = ctx.begin_prefetched(x2, patches)                               # late ranges + cross term + commit(T)
+        else:
+            mf.assemble(d_w2, pre, globals_host, bodies_np, mont=True, stream=stream)
+            t_b = time.perf_counter()
+            cw, ct = ctx.begin(d_w2, x2, stream=stream)                              # both commitments + the cross term
+        t_c = time.perf_counter()
         ctx.finish(r_mont)                                                            # the transcript's r would come between
+        t_d = time.perf_counter()
+        phase["assemble_and_stage"] += t_b - t_a
+        phase["begin"] += t_c - t_b
+        phase["finish"] += t_d - t_c
         return cw, ct
 
+    if args.stage_ahead:
+        stage()
     for _ in range(args.warmup):
         step()
     lib.lurk_hip_profile_enable(1)
     lib.lurk_hip_profile_reset()
     torch.cuda.synchronize()
+    for k in phase:
+        phase[k] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -390,6 +430,9 @@ def fold_step_workload(args, lib, world, rank):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lib.lurk_hip_profile_enable(0)
+    if args.stage_ahead:  # drain the instance staged by the last timed step (one was staged before the region: K stagings inside it)
+        ctx.begin_prefetched(x2, patches)
+        ctx.finish(r_mont)
 
     def kernel_ms(name):
         tot, cnt = ctypes.c_double(), ctypes.c_uint64()
@@ -412,13 +455,15 @@ def fold_step_workload(args, lib, world, rank):
             "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
-            "config": {"workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_begin/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
+            "config": {"staged_ahead": bool(args.stage_ahead),
+                       "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
                                    f"slot blocks traced on the device + {rc} x 1311 body aux over PCIe) -> MSM(W2) + cross term over {n_t} rows ({nnz} non-zeros, "
                                    f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) -> fold of [W|u|X] and E",
                        "note": "device work only; transcript / body synthesis / the small secondary-curve fold not modelled",
                        "r1cs_columns": "frame-structured (88 % frame-local, 6 % globals, 4 % previous frame, 2 % u): a builder-chosen model of the step circuit's sparsity, "
                                        "see fold_kernels.r1cs_cross_term_uniform_columns for the structure-free case",
                        "shape_setup_s_once": round(shape_setup_s, 2)},
+            "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase.items()},
             "fold_kernels": {
                 "r1cs_cross_term": {"ms": round(ct_ms, 4), "algorithmic_bytes": ct_bytes, "achieved_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms else None,
                                     "hbm_frac": round(ct_bytes / (ct_ms * 1e-3) / 8e12, 4) if ct_ms else None},

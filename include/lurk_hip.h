@@ -100,9 +100,19 @@ int lurk_hip_msm_ctx_run_dev(lurk_hip_msm_ctx* ctx, void* out_jacobian96, const 
  * consecutive steps - so that the latency-bound tail of one overlaps the throughput-bound bucket
  * accumulation of the next.  submit enqueues (ordered after `stream`, the stream that produced the
  * scalars) and returns; wait blocks for that slot and writes the 96-byte result to host memory. */
-#define LURK_MSM_SLOTS 3
+#define LURK_MSM_SLOTS 4
 int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars32,
                                 size_t nscalars, int is_mont, void* stream);
+/* The same with a scheduling class.  Commitments in flight share the integer VALU; a prover knows which one its next step
+ * waits for.  FOREGROUND: the accumulation is the plain launch (three waves per SIMD, raised wave priority) - the commitment
+ * the host is about to wait for (commit(T) of the open folding step).  BACKGROUND: the persistent one-wave-per-SIMD
+ * accumulation at the lowest priority whatever the size - work staged ahead (commit(W2) of the next step), which fills the
+ * issue slots the foreground commitment leaves during its sort and its bucket reduction.  DEFAULT = submit_dev (by size). */
+#define LURK_MSM_SUBMIT_DEFAULT 0
+#define LURK_MSM_SUBMIT_FOREGROUND 1
+#define LURK_MSM_SUBMIT_BACKGROUND 2
+int lurk_hip_msm_ctx_submit_dev_mode(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars32, size_t nscalars, int is_mont,
+                                     void* stream, int mode);
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out_jacobian96);
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx);
 /* Points the context at other device-resident bases (borrowed, plain key) and keeps its workspaces: a key that changes every
@@ -286,7 +296,7 @@ int lurk_hip_fold_vec(int field_id, const void* a, const void* b, const void* r3
  * supernova.rs:231-244) runs per curve through arecibo's NIFS::prove, with the running pair (z1 = [W1 | u1 | X1], E1)
  * resident in HBM from step to step.  A prover holds one context per curve: Pallas (primary, the Lurk step circuit) and
  * Vesta (secondary).  shape and key are borrowed (same curve / scalar field, created on the same device) and must outlive
- * the context; the context uses the key's async slots 0 and 1.  The challenge r comes from the caller's transcript (a
+ * the context; the context uses the key's async slots (W2: 0 and 2 alternately, T: 1, late ranges: 3).  The challenge r comes from the caller's transcript (a
  * Poseidon sponge over the OTHER field of the cycle, absorbing the two commitments `begin` returns), hence two halves:
  *   begin:  comm_W2 = commit(W2); T = cross term of (z1, [W2 | 1 | X2]); comm_T = commit(T)   - commitments in flight
  *   finish: W <- W1 + r W2, u <- u1 + r, X <- X1 + r X2, E <- E1 + r T                         - stream-ordered, no sync
@@ -301,6 +311,22 @@ int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* ctx, const void* z1, const 
  * stream); x2_mont: num_io x 32 B, host */
 int lurk_hip_fold_step_begin(lurk_hip_fold_ctx* ctx, const void* w2, int w2_on_device, void* w2_stream, const void* x2_mont,
                              void* comm_w2_jacobian96, void* comm_t_jacobian96);
+/* Staging ahead (MI355X-side pipelining of nova.rs:282-326, where the witness of step i+1 is synthesized by a producer thread
+ * while step i folds): the commitment to W2 needs no running instance, so it can run under the previous step's commit(T).
+ *   prefetch(range)  stages positions [offset, offset + count) of the NEXT fresh witness (the rest zero for now) and starts
+ *                    its commitment; at most two instances may be staged;
+ *   begin_prefetched consumes the oldest staged instance: `patches` are the ranges known only now (the augmented circuit's
+ *                    own variables around the step circuit's: they depend on the previous step's fold), host memory,
+ *                    Montgomery; commit is linear, so comm_W2 = commit(staged ranges) + commit(late ranges).
+ * The context uses the key's four async slots (lurk_hip_msm_ctx_reserve(key, n, 4)): W2 commitments alternate between slots 0
+ * and 2, T uses slot 1, the late ranges slot 3.  lurk_hip_fold_step_begin is prefetch(whole W2) + begin_prefetched(no patches). */
+typedef struct lurk_hip_w2_patch {
+    size_t offset, count;   /* positions [offset, offset + count) of W2 */
+    const void* values;     /* count x 32 bytes, host memory */
+} lurk_hip_w2_patch;
+int lurk_hip_fold_step_prefetch(lurk_hip_fold_ctx* ctx, const void* w2_range, size_t offset, size_t count, int on_device, void* stream);
+int lurk_hip_fold_step_begin_prefetched(lurk_hip_fold_ctx* ctx, const lurk_hip_w2_patch* patches, size_t n_patches, const void* x2_mont,
+                                        void* comm_w2_jac96, void* comm_t_jac96);
 int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* ctx, const void* r32_mont);
 /* the running pair where it lives (valid until the next finish) and the stream its updates are ordered on */
 int lurk_hip_fold_ctx_running_dev(lurk_hip_fold_ctx* ctx, void** d_z, void** d_e, void** stream);

@@ -37,6 +37,7 @@ SIGNATURES = {
     "lurk_hip_msm_ctx_run": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "lurk_hip_msm_ctx_run_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_void_p]),
     "lurk_hip_msm_ctx_submit_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_msm_ctx_submit_dev_mode": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p, c_int]),
     "lurk_hip_msm_ctx_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lurk_hip_msm_ctx_destroy": (c_int, [c_void_p]),
     "lurk_hip_msm_ctx_rebind_dev": (c_int, [c_void_p, c_void_p, c_size_t]),
@@ -84,6 +85,8 @@ SIGNATURES = {
     "lurk_hip_fold_ctx_destroy": (c_int, [c_void_p]),
     "lurk_hip_fold_ctx_set_running": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_begin": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_fold_step_prefetch": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
+    "lurk_hip_fold_step_begin_prefetched": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_finish": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_running_dev": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
     "lurk_hip_fold_ctx_read": (c_int, [c_void_p, c_void_p, c_void_p]),

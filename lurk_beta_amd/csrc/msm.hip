@@ -497,6 +497,7 @@ void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const
 template <class P>
 void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
                                       const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, int waves_per_simd, bool r128,
+                                      bool raised,
                                       hipStream_t s);
 
 // Tuning switches of the commitments-in-flight path (read once; the defaults are the measured best):
@@ -504,7 +505,7 @@ void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* t
 // three commitments in flight share every SIMD (three dependent mad chains keep the VALU issuing) and the short kernels of
 // the others always find registers and wave slots beside them.
 struct MsmTuning {
-    int persistent, waves, r128, prio, sort_prio, tail_prio, max_acc, placement_log;
+    int persistent, waves, r128, prio, sort_prio, tail_prio, max_acc, placement_log, bg_behind_sort, fg_waves;
     MsmTuning() {
         auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
         persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // 0 = never, 1 = by size, 2 = always
@@ -515,6 +516,8 @@ struct MsmTuning {
         tail_prio = geti("LURK_MSM_TAIL_PRIO", 3);
         max_acc = geti("LURK_MSM_MAX_ACC", 2);
         placement_log = geti("LURK_MSM_PLACEMENT_LOG", 0);
+        bg_behind_sort = geti("LURK_MSM_BG_BEHIND_SORT", 1);
+        fg_waves = geti("LURK_MSM_FG_WAVES", 2);  // foreground accumulation: persistent with this many waves per SIMD (0 = the plain launch)
         if (max_acc > 2) max_acc = 0;  // 0 = unlimited (3 slots)
         if (waves < 1) waves = 1;
         if (waves > 8) waves = 8;
@@ -684,7 +687,7 @@ __global__ __launch_bounds__(256) void msm_precompute_kernel(const Affine<P>* __
 }
 
 // ---- context -------------------------------------------------------------------------------
-constexpr int MSM_SLOTS = 3;  // commitments in flight per context (independent workspaces + streams)
+constexpr int MSM_SLOTS = 4;  // commitments in flight per context (independent workspaces + streams)
 
 struct MsmCtxBase {
     int curve = 0;
@@ -696,7 +699,7 @@ struct MsmCtxBase {
     // synchronous: enqueue on `s` with slot 0's workspace, wait, host tail
     virtual void run(const void* d_scalars, size_t n, int is_mont, hipStream_t s, void* out_jac96_host) = 0;
     // asynchronous: enqueue on the slot's own stream (after `after`, the stream that produced the scalars)
-    virtual void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after) = 0;
+    virtual void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int mode) = 0;
     virtual void wait(int slot, void* out_jac96_host) = 0;
     // pasta-msm's calling convention: everything in host memory, nothing resident (buffers and workspaces are kept for the next call)
     virtual void run_oneshot(const void* bases, const void* scalars, size_t n, int is_mont, void* out_jac96_host) = 0;
@@ -723,6 +726,9 @@ struct MsmCtx : MsmCtxBase {
         hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
         DevBuf cursor;                     // task cursor of the persistent accumulate kernel (+ its per-CU placement counters)
         bool placement_valid = false;
+        bool force_persistent = false;     // LURK_MSM_SUBMIT_BACKGROUND
+        bool foreground = false;           // LURK_MSM_SUBMIT_FOREGROUND
+        hipStream_t pending_stream = nullptr;  // the stream the pending commitment ends on
         bool pending = false;
         size_t pending_n = 0;
         ~Work() {
@@ -735,8 +741,10 @@ struct MsmCtx : MsmCtxBase {
         }
     };
     Work work[MSM_SLOTS];
+    std::mutex fg_mu;
+    Work* last_fg = nullptr;  // the slot of the latest LURK_MSM_SUBMIT_FOREGROUND commitment
     std::mutex acc_ring_mu;  // the last MSM_SLOTS persistent accumulations, in submission order
-    Work* acc_ring[MSM_SLOTS] = {nullptr, nullptr, nullptr};
+    Work* acc_ring[MSM_SLOTS] = {};
     int acc_ring_pos = 0, acc_ring_count = 0;
 
     MsmShape shape(size_t n) const {
@@ -962,7 +970,8 @@ struct MsmCtx : MsmCtxBase {
         const MsmTuning& tn = msm_tuning();
         // commitments in flight take the persistent form on the slot's low-priority accumulate stream (tiny ones excepted: their
         // accumulation is over before a second kernel could share the chip); synchronous calls keep the plain launch
-        const bool persistent = s_acc && (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 22) : tn.persistent != 0);
+        const bool persistent = s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 22) : tn.persistent != 0));
+        if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));  // sort and plan are enqueued: a background commitment may start behind this point
         if (persistent) {
             LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4 * (MSM_PLACEMENT_BASE + 512), s));
             wk.placement_valid = true;
@@ -988,8 +997,8 @@ struct MsmCtx : MsmCtxBase {
                 ProfScope ps("msm_accumulate", s_acc);
                 msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
                                                     wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
-                                                    wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(), tn.waves, tn.r128 != 0,
-                                                    s_acc);
+                                                    wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(),
+                                                    wk.foreground ? tn.fg_waves : tn.waves, tn.r128 != 0, wk.foreground, s_acc);
             }
             LURK_HIP_CHECK(hipEventRecord(wk.accumulated, s_acc));
             LURK_HIP_CHECK(hipStreamWaitEvent(s, wk.accumulated, 0));
@@ -1056,7 +1065,7 @@ struct MsmCtx : MsmCtxBase {
         host_tail(wk, n, out);
     }
 
-    void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after) override {
+    void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int mode) override {
         LURK_REQUIRE(slot >= 0 && slot < MSM_SLOTS, "slot out of range");
         LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
         Work& wk = work[slot];
@@ -1065,9 +1074,26 @@ struct MsmCtx : MsmCtxBase {
         ensure_streams(wk);
         if (n) {
             // the scalars were produced on the caller's stream: order the slot stream after it
+            // foreground: the accumulation too on the slot's high-priority stream, more waves per SIMD, raised wave priority;
+            // background: persistent one-wave accumulation whatever the size, started behind the foreground commitment's sort.
+            // (Its short kernels stay on the high-priority stream: on the low-priority queue every one of the ~45 dependent
+            // launches of a commitment was dispatched 40 us late - 50-60 us per bit-plane level instead of 13 - even on an idle chip.)
+            const bool bg = mode == LURK_MSM_SUBMIT_BACKGROUND;
+            wk.foreground = mode == LURK_MSM_SUBMIT_FOREGROUND;
+            wk.force_persistent = bg || (wk.foreground && msm_tuning().fg_waves > 0);
+            wk.pending_stream = wk.stream;
             LURK_HIP_CHECK(hipEventRecord(wk.ready, after));
-            LURK_HIP_CHECK(hipStreamWaitEvent(wk.stream, wk.ready, 0));
-            enqueue(wk, d_scalars, n, is_mont, wk.stream, wk.acc_stream);
+            LURK_HIP_CHECK(hipStreamWaitEvent(wk.pending_stream, wk.ready, 0));
+            {
+                // a background commitment starts behind the sort of the foreground commitment in flight: its own sort (LDS atomics,
+                // barriers) then runs under the foreground accumulation (integer VALU) instead of beside the foreground sort
+                std::lock_guard<std::mutex> lk2(fg_mu);
+                if (bg && last_fg && last_fg != &wk && last_fg->planned && msm_tuning().bg_behind_sort)
+                    LURK_HIP_CHECK(hipStreamWaitEvent(wk.pending_stream, last_fg->planned, 0));
+                if (mode == LURK_MSM_SUBMIT_FOREGROUND) last_fg = &wk;
+            }
+            // foreground: everything on the (high-priority) slot stream
+            enqueue(wk, d_scalars, n, is_mont, wk.pending_stream, wk.foreground ? (msm_tuning().fg_waves > 0 ? wk.stream : nullptr) : wk.acc_stream);
         }
         wk.pending = true;
         wk.pending_n = n;
@@ -1099,7 +1125,7 @@ struct MsmCtx : MsmCtxBase {
             put_identity(out);
             return;
         }
-        LURK_HIP_CHECK(hipStreamSynchronize(wk.stream));
+        LURK_HIP_CHECK(hipStreamSynchronize(wk.pending_stream ? wk.pending_stream : wk.stream));
         if (wk.placement_valid && msm_tuning().placement_log) log_placement(wk);
         host_tail(wk, wk.pending_n, out);
     }
@@ -1312,7 +1338,16 @@ int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_s
         LURK_REQUIRE(ctx, "null ctx");
         LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
         DeviceGuard dg(ctx->impl->device);
-        ctx->impl->submit(slot, d_scalars, n, is_mont, (hipStream_t)stream);
+        ctx->impl->submit(slot, d_scalars, n, is_mont, (hipStream_t)stream, LURK_MSM_SUBMIT_DEFAULT);
+    });
+}
+int lurk_hip_msm_ctx_submit_dev_mode(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars, size_t n, int is_mont, void* stream, int mode) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx, "null ctx");
+        LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
+        LURK_REQUIRE(mode >= LURK_MSM_SUBMIT_DEFAULT && mode <= LURK_MSM_SUBMIT_BACKGROUND, "unknown submit mode");
+        DeviceGuard dg(ctx->impl->device);
+        ctx->impl->submit(slot, d_scalars, n, is_mont, (hipStream_t)stream, mode);
     });
 }
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out) {

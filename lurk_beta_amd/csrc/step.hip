@@ -11,6 +11,7 @@
 // async slots, the cross term between them; returns when the two 96-byte commitments are on the host) and `finish(r)`.
 // The running pair (z1 = [W1 | u1 | X1], E1) never leaves HBM; a step's W2 may already be there (lurk_hip_slot_witness_dev).
 // A prover holds two of these contexts: Pallas (primary: the Lurk step circuit) and Vesta (secondary: ~10^4 constraints).
+#include <chrono>
 #include <memory>
 
 #include "common.hpp"
@@ -37,17 +38,151 @@ struct lurk_hip_fold_ctx {
     lurk_hip_r1cs* shape = nullptr;    // borrowed
     lurk_hip_msm_ctx* key = nullptr;   // borrowed
     size_t num_cons = 0, num_vars = 0, num_io = 0, ncols = 0;
-    DevBuf z[2], e[2], z2, t;          // running pair ping-pongs between two buffers (cur = index of the live one)
+    DevBuf z[2], e[2], t;              // running pair ping-pongs between two buffers (cur = index of the live one)
+    DevBuf z2[2], zstaged[2], zpatch;  // fresh instances [W2 | 1 | X2]: the open step's and the one staged ahead; the staged ranges alone
+                                       // (what their commitment reads while late ranges are written into z2); the late ranges alone
     int cur = 0;
     bool begun = false;
-    hipStream_t stream = nullptr;
-    hipEvent_t w2_ready = nullptr;
+    // fresh instances staged ahead of their step (lurk_hip_fold_step_prefetch): buffer b commits on the key's slot 2 b, T on slot 1
+    int staged[2] = {0, 0}, n_staged = 0, next_buf = 0, open_buf = 0;
+    bool folded_valid[2] = {false, false}, submitted[2] = {false, false}, partial[2] = {false, false};
+    char* pin = nullptr;               // pinned staging for what arrives in pageable host memory (u2, X2, late ranges): an async copy
+    size_t pin_cap = 0;                // from pageable memory makes the runtime wait, which held the cross term back by ~0.5 ms
+    hipStream_t stream = nullptr, stage_stream = nullptr;
+    hipEvent_t w2_ready = nullptr, staged_ev[2] = {nullptr, nullptr}, folded_ev[2] = {nullptr, nullptr};
     std::mutex mu;
     ~lurk_hip_fold_ctx() {
+        if (pin) (void)hipHostFree(pin);
         if (stream) (void)hipStreamDestroy(stream);
+        if (stage_stream) (void)hipStreamDestroy(stage_stream);
         if (w2_ready) (void)hipEventDestroy(w2_ready);
+        for (int k = 0; k < 2; k++) {
+            if (staged_ev[k]) (void)hipEventDestroy(staged_ev[k]);
+            if (folded_ev[k]) (void)hipEventDestroy(folded_ev[k]);
+        }
     }
 };
+
+namespace lurk {
+
+static void fold_submit_staged(lurk_hip_fold_ctx* c, int b, int mode) {
+    if (c->submitted[b]) return;
+    ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 2 * b, c->partial[b] ? c->zstaged[b].p : c->z2[b].p, c->num_vars, 1, c->stage_stream,
+                                        mode));  // zero digits cost the sort nothing
+    c->submitted[b] = true;
+}
+
+// Stage positions [offset, offset + count) of the next fresh witness (the rest zero for now) and start its commitment.
+static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size_t count, int on_device, void* w2_stream) {
+    LURK_REQUIRE(c->n_staged < 2, "two fresh instances are already staged: begin a step first");
+    LURK_REQUIRE(offset <= c->num_vars && count <= c->num_vars - offset, "witness range out of bounds");
+    LURK_REQUIRE(count == 0 || w2, "null witness");
+    const int b = c->next_buf;
+    char* z2 = (char*)c->z2[b].p;
+    if (c->folded_valid[b]) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream, c->folded_ev[b], 0));  // the fold two steps back still reads it
+    if (on_device) {  // W2 was produced on the caller's stream (e.g. by lurk_hip_slot_witness_dev): order ours after it
+        LURK_HIP_CHECK(hipEventRecord(c->w2_ready, (hipStream_t)w2_stream));
+        LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream, c->w2_ready, 0));
+    }
+    if (count < c->num_vars) LURK_HIP_CHECK(hipMemsetAsync(z2, 0, c->num_vars * 32, c->stage_stream));
+    if (count)
+        LURK_HIP_CHECK(hipMemcpyAsync(z2 + offset * 32, w2, count * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stage_stream));
+    c->partial[b] = count < c->num_vars;
+    if (c->partial[b]) {  // late ranges will be written into z2 while the commitment of the staged ones is still in flight: it reads a copy
+        if (!c->zstaged[b].p) c->zstaged[b].alloc(c->num_vars * 32);
+        LURK_HIP_CHECK(hipMemcpyAsync(c->zstaged[b].p, z2, c->num_vars * 32, hipMemcpyDeviceToDevice, c->stage_stream));
+    }
+    c->submitted[b] = false;
+    c->staged[c->n_staged++] = b;
+    c->next_buf = b ^ 1;
+    // Between begin and finish nothing the host waits for is in flight: the commitment starts now, in the background class.
+    // Otherwise it is submitted by the begin that comes next, BEHIND that step's commit(T): the device serves its queues
+    // roughly in submission order, and T is what the host waits for.
+    if (c->begun) fold_submit_staged(c, b, LURK_MSM_SUBMIT_BACKGROUND);
+}
+
+// The oldest staged instance becomes this step's: late ranges, u2 = 1, X2, then T and its commitment.
+static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, size_t n_patches, const void* x2_mont, void* comm_w2_jac96,
+                       void* comm_t_jac96) {
+    LURK_REQUIRE(c->n_staged > 0, "no fresh instance is staged");
+    static const bool trace = getenv("LURK_STEP_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double tt[8] = {0};
+    tt[0] = now();
+    const int b = c->staged[0];
+    char* z2 = (char*)c->z2[b].p;
+    size_t patched = 0;
+    for (size_t k = 0; k < n_patches; k++) {
+        LURK_REQUIRE(patches[k].offset <= c->num_vars && patches[k].count <= c->num_vars - patches[k].offset, "patch out of bounds");
+        LURK_REQUIRE(patches[k].count == 0 || patches[k].values, "null patch values");
+        patched += patches[k].count;
+    }
+    LURK_REQUIRE(!patched || c->partial[b], "late ranges for an instance that was staged whole");
+    uint64_t body[12], late[12];
+    c->staged[0] = c->staged[1];
+    c->n_staged--;
+    const bool ahead = c->n_staged > 0 && !c->submitted[c->staged[0]];  // the NEXT step's instance waits to be submitted behind T
+    // u2 = 1 (a fresh instance is strict), X2 and the late ranges go through the pinned staging buffer
+    const size_t need = (1 + c->num_io + patched) * 32;
+    if (need > c->pin_cap) {
+        if (c->pin) LURK_HIP_CHECK(hipHostFree(c->pin));
+        c->pin = nullptr;
+        c->pin_cap = 0;
+        LURK_HIP_CHECK(hipHostMalloc((void**)&c->pin, need + need / 2, hipHostMallocDefault));
+        c->pin_cap = need + need / 2;
+    }
+    if (c->field_id == LURK_FIELD_PALLAS_FQ) mont_one<PallasFq>(c->pin);
+    else mont_one<PallasFp>(c->pin);
+    if (c->num_io) memcpy(c->pin + 32, x2_mont, c->num_io * 32);
+    LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, (1 + c->num_io) * 32, hipMemcpyHostToDevice, c->stage_stream));
+    if (patched) {
+        if (!c->zpatch.p) {
+            c->zpatch.alloc(c->num_vars * 32);
+            LURK_HIP_CHECK(hipMemsetAsync(c->zpatch.p, 0, c->num_vars * 32, c->stage_stream));
+        }
+        char* src = c->pin + (1 + c->num_io) * 32;
+        for (size_t k = 0; k < n_patches; k++) {
+            if (!patches[k].count) continue;
+            memcpy(src, patches[k].values, patches[k].count * 32);
+            LURK_HIP_CHECK(hipMemcpyAsync(z2 + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream));
+            LURK_HIP_CHECK(hipMemcpyAsync((char*)c->zpatch.p + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream));
+            src += patches[k].count * 32;
+        }
+    }
+    LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream));
+    LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
+    fold_submit_staged(c, b, LURK_MSM_SUBMIT_DEFAULT);  // not staged early enough to be in flight already: it is on this step's path
+    tt[1] = now();
+    const int fg = ahead ? LURK_MSM_SUBMIT_FOREGROUND : LURK_MSM_SUBMIT_DEFAULT;
+    ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));          // T ...
+    ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t.p, c->num_cons, 1, c->stream, fg));     // ... commit(T): what the host waits for
+    if (patched) ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream, fg));  // commitment of the late ranges
+    tt[2] = now();
+    if (ahead) fold_submit_staged(c, c->staged[0], LURK_MSM_SUBMIT_BACKGROUND);  // commit(next W2) fills what T leaves
+    tt[3] = now();
+    if (patched) {
+        ok(lurk_hip_msm_ctx_wait(c->key, 2 * b, body));
+        ok(lurk_hip_msm_ctx_wait(c->key, 3, late));
+        uint64_t two[24];
+        memcpy(two, body, 96);
+        memcpy(two + 12, late, 96);
+        ok(lurk_hip_point_sum(c->curve, comm_w2_jac96, two, 2));  // commit is linear: body + late ranges
+        for (size_t k = 0; k < n_patches; k++)
+            if (patches[k].count) LURK_HIP_CHECK(hipMemsetAsync((char*)c->zpatch.p + patches[k].offset * 32, 0, patches[k].count * 32, c->stage_stream));
+    } else {
+        ok(lurk_hip_msm_ctx_wait(c->key, 2 * b, comm_w2_jac96));
+    }
+    tt[4] = now();
+    ok(lurk_hip_msm_ctx_wait(c->key, 1, comm_t_jac96));
+    tt[5] = now();
+    if (trace)
+        fprintf(stderr, "[step] copies %.0f us, cross+T submit %.0f, next-W2 submit %.0f, W2 wait %.0f, T wait %.0f\n", tt[1] - tt[0], tt[2] - tt[1],
+                tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4]);
+    c->open_buf = b;
+    c->begun = true;
+}
+
+}  // namespace lurk
 
 extern "C" {
 
@@ -70,10 +205,15 @@ int lurk_hip_fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* 
             c->z[k].alloc(c->ncols * 32);
             c->e[k].alloc(c->num_cons * 32);
         }
-        c->z2.alloc(c->ncols * 32);
         c->t.alloc(c->num_cons * 32);
         LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
         LURK_HIP_CHECK(hipEventCreateWithFlags(&c->w2_ready, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) {
+            c->z2[k].alloc(c->ncols * 32);
+            LURK_HIP_CHECK(hipEventCreateWithFlags(&c->staged_ev[k], hipEventDisableTiming));
+            LURK_HIP_CHECK(hipEventCreateWithFlags(&c->folded_ev[k], hipEventDisableTiming));
+        }
         // RelaxedR1CSWitness::default / RelaxedR1CSInstance::default: W = 0, E = 0, u = 0, X = 0
         LURK_HIP_CHECK(hipMemsetAsync(c->z[0].p, 0, c->ncols * 32, c->stream));
         LURK_HIP_CHECK(hipMemsetAsync(c->e[0].p, 0, c->num_cons * 32, c->stream));
@@ -112,24 +252,31 @@ int lurk_hip_fold_step_begin(lurk_hip_fold_ctx* c, const void* w2, int w2_on_dev
         DeviceGuard dg(c->device);
         std::lock_guard<std::mutex> lk(c->mu);
         LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
-        char* z2 = (char*)c->z2.p;
-        if (w2_on_device) {  // W2 was produced on the caller's stream (e.g. by lurk_hip_slot_witness_dev): order ours after it
-            LURK_HIP_CHECK(hipEventRecord(c->w2_ready, (hipStream_t)w2_stream));
-            LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->w2_ready, 0));
-        }
-        if (c->num_vars)
-            LURK_HIP_CHECK(hipMemcpyAsync(z2, w2, c->num_vars * 32, w2_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-        uint64_t one[4];
-        if (c->field_id == LURK_FIELD_PALLAS_FQ) mont_one<PallasFq>(one);
-        else mont_one<PallasFp>(one);
-        LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, one, 32, hipMemcpyHostToDevice, c->stream));  // u2 = 1 (a fresh instance is strict)
-        if (c->num_io) LURK_HIP_CHECK(hipMemcpyAsync(z2 + (c->num_vars + 1) * 32, x2_mont, c->num_io * 32, hipMemcpyHostToDevice, c->stream));
-        ok(lurk_hip_msm_ctx_submit_dev(c->key, 0, z2, c->num_vars, 1, c->stream));                            // commit(W2) ...
-        ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));                    // ... T beside it ...
-        ok(lurk_hip_msm_ctx_submit_dev(c->key, 1, c->t.p, c->num_cons, 1, c->stream));                       // ... commit(T)
-        ok(lurk_hip_msm_ctx_wait(c->key, 0, comm_w2_jac96));
-        ok(lurk_hip_msm_ctx_wait(c->key, 1, comm_t_jac96));
-        c->begun = true;
+        LURK_REQUIRE(c->n_staged == 0, "fresh instances are staged: use lurk_hip_fold_step_begin_prefetched");
+        fold_stage(c, w2, 0, c->num_vars, w2_on_device, w2_stream);
+        fold_begin(c, nullptr, 0, x2_mont, comm_w2_jac96, comm_t_jac96);
+    });
+}
+
+int lurk_hip_fold_step_prefetch(lurk_hip_fold_ctx* c, const void* w2_range, size_t offset, size_t count, int on_device, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(c, "null ctx");
+        DeviceGuard dg(c->device);
+        std::lock_guard<std::mutex> lk(c->mu);
+        fold_stage(c, w2_range, offset, count, on_device, stream);
+    });
+}
+
+int lurk_hip_fold_step_begin_prefetched(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, size_t n_patches, const void* x2_mont,
+                                        void* comm_w2_jac96, void* comm_t_jac96) {
+    return guarded([&] {
+        LURK_REQUIRE(c && comm_w2_jac96 && comm_t_jac96, "null argument");
+        LURK_REQUIRE(n_patches == 0 || patches, "null patches");
+        LURK_REQUIRE(c->num_io == 0 || x2_mont, "null public IO");
+        DeviceGuard dg(c->device);
+        std::lock_guard<std::mutex> lk(c->mu);
+        LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
+        fold_begin(c, patches, n_patches, x2_mont, comm_w2_jac96, comm_t_jac96);
     });
 }
 
@@ -141,8 +288,10 @@ int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
         LURK_REQUIRE(c->begun, "no step is open");
         const int nx = c->cur ^ 1;
         // z = [W | u | X]: one pass folds the witness, u <- u1 + r * 1 and X <- X1 + r X2
-        ok(lurk_hip_fold_vec_dev(c->field_id, c->z[c->cur].p, c->z2.p, r32_mont, c->ncols, c->z[nx].p, c->stream));
+        ok(lurk_hip_fold_vec_dev(c->field_id, c->z[c->cur].p, c->z2[c->open_buf].p, r32_mont, c->ncols, c->z[nx].p, c->stream));
         ok(lurk_hip_fold_vec_dev(c->field_id, c->e[c->cur].p, c->t.p, r32_mont, c->num_cons, c->e[nx].p, c->stream));
+        LURK_HIP_CHECK(hipEventRecord(c->folded_ev[c->open_buf], c->stream));
+        c->folded_valid[c->open_buf] = true;
         c->cur = nx;
         c->begun = false;
     });

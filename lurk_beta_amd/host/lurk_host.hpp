@@ -293,6 +293,19 @@ class FoldingContext {
         open_ = c;
         return c;
     }
+    // staging ahead: positions [offset, offset + range.size()) of the next fresh witness, its commitment starts now
+    void prefetch(const std::vector<Fe>& w2_range_mont, size_t offset = 0) {
+        check(lurk_hip_fold_step_prefetch(h_, w2_range_mont.data(), offset, w2_range_mont.size(), 0, nullptr));
+    }
+    // the step of the oldest staged instance; patches = (offset, values) ranges of W2 known only now
+    std::array<Jacobian, 2> begin_prefetched(const std::vector<Fe>& x2_mont, const std::vector<std::pair<size_t, std::vector<Fe>>>& patches = {}) {
+        std::vector<lurk_hip_w2_patch> ps;
+        for (auto& p : patches) ps.push_back(lurk_hip_w2_patch{p.first, p.second.size(), p.second.data()});
+        std::array<Jacobian, 2> c;
+        check(lurk_hip_fold_step_begin_prefetched(h_, ps.data(), ps.size(), x2_mont.data(), &c[0], &c[1]));
+        open_ = c;
+        return c;
+    }
     void finish(const Fe& r_mont) {
         check(lurk_hip_fold_step_finish(h_, &r_mont));
         Jacobian rw, rt, pair[2];

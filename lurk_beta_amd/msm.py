@@ -121,12 +121,13 @@ class CommitmentKey:
         _lib.check(lib.lurk_hip_msm_ctx_run_dev(self._ctx, _lib.ptr(out), _lib.ptr(d_scalars), n, int(is_mont), _lib.ptr(stream)))
         return out
 
-    def submit_device(self, slot: int, d_scalars, n: int, is_mont: bool = False, stream=None) -> None:
-        """Asynchronous commit on `slot` (0..2); pair with ``wait(slot)``."""
+    def submit_device(self, slot: int, d_scalars, n: int, is_mont: bool = False, stream=None, mode: int = 0) -> None:
+        """Asynchronous commit on `slot` (0..2); pair with ``wait(slot)``.  mode: 0 = default, 1 = foreground (the commitment the
+        host waits for next), 2 = background (work staged ahead)."""
         lib = _lib.load()
         self._keep = getattr(self, "_keep", {})
         self._keep[slot] = d_scalars  # the scalars must stay alive until wait()
-        _lib.check(lib.lurk_hip_msm_ctx_submit_dev(self._ctx, slot, _lib.ptr(d_scalars), n, int(is_mont), _lib.ptr(stream)))
+        _lib.check(lib.lurk_hip_msm_ctx_submit_dev_mode(self._ctx, slot, _lib.ptr(d_scalars), n, int(is_mont), _lib.ptr(stream), mode))
 
     def wait(self, slot: int) -> np.ndarray:
         lib = _lib.load()

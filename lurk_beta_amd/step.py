@@ -65,6 +65,35 @@ class FoldingContext:
         self._open = (cw, ct)
         return cw, ct
 
+    def prefetch(self, w2_range, offset: int = 0, stream=None):
+        """Stage positions [offset, offset + len) of the NEXT fresh witness (host array or device tensor, Montgomery; the rest
+        zero until ``begin_prefetched`` supplies it) and start its commitment under whatever the device is doing now."""
+        on_dev = hasattr(w2_range, "data_ptr")
+        if on_dev:
+            count = w2_range.numel() // 4
+        else:
+            w2_range = np.ascontiguousarray(w2_range, dtype=np.uint64)
+            count = w2_range.size // 4
+        _lib.check(_lib.load().lurk_hip_fold_step_prefetch(self._h, _lib.ptr(w2_range), offset, count, int(on_dev), _lib.ptr(stream)))
+
+    def begin_prefetched(self, x2_mont: np.ndarray, patches=()):
+        """Open the step of the oldest staged instance.  patches: [(offset, host (k, 4) u64 array)], the ranges of W2 known only
+        now.  Returns (comm_W2, comm_T)."""
+
+        class Patch(ctypes.Structure):
+            _fields_ = [("offset", ctypes.c_size_t), ("count", ctypes.c_size_t), ("values", ctypes.c_void_p)]
+
+        keep = [np.ascontiguousarray(v, dtype=np.uint64) for _, v in patches]
+        arr = (Patch * max(1, len(keep)))()
+        for k, ((off, _), v) in enumerate(zip(patches, keep)):
+            arr[k] = Patch(int(off), v.size // 4, v.ctypes.data)
+        x2 = np.ascontiguousarray(x2_mont, dtype=np.uint64)
+        cw, ct = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+        _lib.check(_lib.load().lurk_hip_fold_step_begin_prefetched(self._h, ctypes.cast(arr, ctypes.c_void_p), len(keep), _lib.ptr(x2),
+                                                                    _lib.ptr(cw), _lib.ptr(ct)))
+        self._open = (cw, ct)
+        return cw, ct
+
     def finish(self, r_mont: np.ndarray):
         """Folds the witness pair on the device and the running instance's commitments on the host."""
         r = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(4)

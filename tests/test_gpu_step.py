@@ -99,6 +99,80 @@ def test_three_consecutive_steps(hip, curve, m, nfree):
     shape.close()
 
 
+@pytest.mark.parametrize("curve,m,nfree", [(0, 20000, 9000), (1, 3000, 1500)])
+def test_steps_with_instances_staged_ahead(hip, curve, m, nfree):
+    """lurk_hip_fold_step_prefetch / begin_prefetched: the step circuit's range of W2 is staged (and its commitment started) one
+    step ahead, the augmented circuit's ranges around it arrive with begin.  Every step must give what the plain begin gives:
+    comm_W2 = commit(whole W2) by linearity, same T, same folded pair."""
+    import torch
+
+    from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape, point_to_affine
+
+    f = 1 if curve == 0 else 0
+    p = R.modulus(f)
+    nio = 6 if curve == 0 else 2
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=13 + curve)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    bases = C.synth_bases(curve, max(m, nv))
+    key = CommitmentKey(curve, bases, precompute=bool(curve))
+    key.reserve(max(m, nv), 4)
+    ctx = FoldingContext(curve, shape, key)
+    commit = lambda v: C.jac_to_affine(curve, C.msm_pippenger(curve, bases[: len(v)], v))
+    lo, hi = nv // 50, nv - nv // 30  # the staged body is [lo, hi); prefix and suffix arrive late
+    steps = 4
+    fresh = [_fresh(f, A, B, m, nfree, nio, 300 + 10 * k + curve) for k in range(steps)]
+    w2m = [C.to_mont(f, z2[:nv]) for z2, _ in fresh]
+
+    def stage(k):
+        body = np.ascontiguousarray(w2m[k][lo:hi])
+        if k % 2:  # device-resident range on odd steps
+            ctx.prefetch(torch.from_numpy(body.view(np.int64)).cuda(), lo, stream=torch.cuda.current_stream().cuda_stream)
+        else:
+            ctx.prefetch(body, lo)
+
+    z1 = np.zeros((nv + 1 + nio, 4), dtype=np.uint64)
+    e1 = np.zeros((m, 4), dtype=np.uint64)
+    stage(0)
+    for k in range(steps):
+        if k + 1 < steps:
+            stage(k + 1)  # two instances staged: k (about to open) and k + 1
+        if k == 0:
+            with pytest.raises(LurkHipError):
+                ctx.prefetch(w2m[0][lo:hi], lo)  # a third one is refused
+            with pytest.raises(LurkHipError):
+                ctx.begin(w2m[0], C.to_mont(f, fresh[0][1]))  # the plain form is refused while instances are staged
+        z2, x2 = fresh[k]
+        patches = [(0, w2m[k][:lo]), (hi, w2m[k][hi:])] if k != 2 else [(hi, w2m[k][hi:]), (0, w2m[k][:lo]), (5, w2m[k][5:5])]
+        cw, ct = ctx.begin_prefetched(C.to_mont(f, x2), patches)
+        m1 = [C.spmv(f, *M, z1) for M in (A, B, Cm)]
+        m2 = [C.spmv(f, *M, z2) for M in (A, B, Cm)]
+        u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+        t = C.cross_term(f, *m1, *m2, u1, 1)
+        assert point_to_affine(curve, cw) == commit(z2[:nv])
+        assert point_to_affine(curve, ct) == commit(t)
+        r = R.uniform_fe(97, k * 2 + curve, p) >> 128
+        ctx.finish(C.to_mont(f, C.ints_to_limbs([r])))
+        z1, e1 = C.axpy(f, z1, z2, r), C.axpy(f, e1, t, r)
+        gz, ge = ctx.read()
+        assert np.array_equal(C.from_mont(f, gz), z1) and np.array_equal(C.from_mont(f, ge), e1)
+        assert point_to_affine(curve, ctx.comm_W) == commit(z1[:nv])
+        assert point_to_affine(curve, ctx.comm_E) == commit(e1)
+    # nothing staged any more: the plain form works again, and a whole witness staged ahead needs no patches
+    with pytest.raises(LurkHipError):
+        ctx.begin_prefetched(C.to_mont(f, fresh[0][1]))
+    z2, x2 = fresh[1]
+    ctx.prefetch(w2m[1])
+    cw, ct = ctx.begin_prefetched(C.to_mont(f, x2))
+    assert point_to_affine(curve, cw) == commit(z2[:nv])
+    ctx.finish(C.to_mont(f, C.ints_to_limbs([3])))
+    cw2, _ = ctx.begin(w2m[1], C.to_mont(f, x2))
+    assert point_to_affine(curve, cw2) == point_to_affine(curve, cw)
+    ctx.close()
+    key.close()
+    shape.close()
+
+
 def test_shape_and_key_must_match_the_curve(hip):
     from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape
 
