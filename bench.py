@@ -49,6 +49,7 @@ def main():
                     help="fold_step: 1 = the next step's witness is traced and its commitment started one step ahead (lurk_hip_fold_step_prefetch); "
                          "0 = plain begin (default: measured 4.4 ms against 4.05 ms staged whole / 5.1 ms staged with late ranges at rc = 100, DESIGN.md)")
     ap.add_argument("--late-ranges", type=int, default=1, help="fold_step with --stage-ahead: 1 = 12 000 positions of W2 arrive with begin (the augmented circuit's), 0 = none")
+    ap.add_argument("--ipa-resident-key", type=int, default=1, help="compress: 1 = inner-product rounds under the resident key (composed scalars), 0 = fold the key")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
     ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt", "fold_step", "compress"], default="msm",
                     help="msm = the headline metric; poseidon_tree / ntt = the other hot-path kernels (BASELINE configs[2], N1); "
@@ -563,13 +564,14 @@ def compress_workload(args, lib, world, rank):
     d_E = torch.zeros((nc, 4), dtype=torch.int64, device="cuda")
     X = [int(v) for v in _ints_from(d_z[nv + 1:].cpu().numpy().view(np.uint64), R, q)]
     d_ck = synth.bases(L.CURVE_PALLAS, nc + 1)
-    key = L.CommitmentKey(L.CURVE_PALLAS, d_ck, n=nc, device=True)
+    key = L.CommitmentKey(L.CURVE_PALLAS, d_ck, n=nc, device=True, precompute=bool(args.precompute))   # the prover's resident key (table by default)
+    key.reserve(nc, 2)
     cw = key.commit_device(d_W, nv, is_mont=True)
     ce = key.commit_device(d_E, nc, is_mont=True)
     torch.cuda.synchronize()
 
     def step():
-        return prover.prove(X, 1, d_W, d_E, d_ck, cw, ce)
+        return prover.prove(X, 1, d_W, d_E, d_ck, cw, ce, key=key if args.ipa_resident_key else None)
 
     for _ in range(args.warmup):
         step()
@@ -604,7 +606,9 @@ def compress_workload(args, lib, world, rank):
                           "note": "functional stand-in, not byte-compatible with arecibo; transcript and round glue in Python on the host",
                           "shape_setup_s_once": round(setup_s, 2)},
                "kernels_ms_per_proof": {k: kernel_ms(k) for k in ("sumcheck_round", "eq_evals", "r1cs_multiply_vec", "fold_vec", "ipa_inner_product",
-                                                                   "ipa_fold_halves", "ipa_points_fold", "msm_accumulate", "msm_sort", "msm_reduce")}}
+                                                                   "ipa_fold_halves", "ipa_points_fold", "ipa_round_scalars", "ipa_coef_fold", "msm_accumulate", "msm_sort",
+                                                                   "msm_reduce")},
+               "ipa": "rounds under the resident table key (no key fold)" if args.ipa_resident_key else "published form: key folded every round"}
         print(json.dumps(out), flush=True)
     key.close()
     prover.close()

@@ -360,6 +360,19 @@ int lurk_hip_fold_halves_dev(int field_id, void* d_v, size_t len, const void* s_
 int lurk_hip_points_fold_halves_dev(int curve, const void* d_points_affine64, size_t len, const void* s_lo32_mont,
                                     const void* s_hi32_mont, void* d_out_affine64, void* stream);
 
+/* The same rounds WITHOUT folding the key (the form lurk_beta_amd/ipa.py uses when the prover's resident table key is at hand):
+ * the folded key of round k is a fixed linear image of the original one, ck_k[p] = sum_{i = p mod m} coef_k[i] ck[i] (m = the
+ * current length, coef_k[i] = the product of the fold weights position i met so far), so L and R are ordinary commitments under
+ * the ORIGINAL key of the two length-n vectors round_scalars writes (n/2 non-zeros each):
+ *   out_l[i] = a[(i mod m) - m/2] coef[i] if (i mod m) >= m/2 else 0;  out_r[i] = a[(i mod m) + m/2] coef[i] if (i mod m) < m/2 else 0
+ * and after the challenge coef_fold multiplies coef[i] by s_lo / s_hi according to the half (i mod m) lies in (coef starts as
+ * all ones; after the last round it is the verifier's s vector: the final key element is commit(ck, coef)).  Two table-mode
+ * MSMs per round replace m/2 full-size double scalar multiplications whose 255-step ladder is latency-bound for every m. */
+int lurk_hip_ipa_round_scalars_dev(int field_id, const void* d_a, size_t m, const void* d_coef, size_t n, void* d_out_l,
+                                   void* d_out_r, void* stream);
+int lurk_hip_ipa_coef_fold_dev(int field_id, void* d_coef, size_t n, size_t m, const void* s_lo32_mont, const void* s_hi32_mont,
+                               void* stream);
+
 /* ---- synthetic inputs (bench / tests) -------------------------------------
  * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */
 int lurk_hip_synth_scalars_dev(int field_id, uint64_t stream_id, int dist, size_t first, size_t n,

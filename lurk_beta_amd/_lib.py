@@ -94,6 +94,8 @@ SIGNATURES = {
     "lurk_hip_eq_evals_dev": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lurk_hip_inner_product_dev": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_fold_halves_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_ipa_round_scalars_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_ipa_coef_fold_dev": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_points_fold_halves_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),

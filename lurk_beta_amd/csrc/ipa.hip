@@ -44,6 +44,33 @@ __global__ __launch_bounds__(IPA_BLOCK) void fold_halves_kernel(Fe<F>* v, size_t
         v[i] = fe_add<F>(fe_mul<F>(s_lo, v[i]), fe_mul<F>(s_hi, v[h + i]));
 }
 
+// The rounds without a folded key.  The folded key of round k is  ck_k[p] = sum over the originals i = p mod m (m = n / 2^k)
+// of coef_k[i] * ck[i], coef_k[i] = the product of the fold weights i met so far; so
+//     <a_L, ck_k R> = sum_{i : (i mod m) >= m/2} (a[(i mod m) - m/2] * coef_k[i]) * ck[i]
+//     <a_R, ck_k L> = sum_{i : (i mod m) <  m/2} (a[(i mod m) + m/2] * coef_k[i]) * ck[i]
+// are ordinary commitments under the ORIGINAL key - the resident table key the witness commitments use - of two length-n
+// vectors with n/2 non-zeros each (zero digits never enter the MSM's sort).  A round then costs two table-mode MSMs instead of
+// m/2 full-size double scalar multiplications whose 255-step ladder is latency-bound however short the key has become.
+template <class F>
+__global__ __launch_bounds__(IPA_BLOCK) void ipa_round_scalars_kernel(const Fe<F>* __restrict__ a, size_t m, const Fe<F>* __restrict__ coef, size_t n,
+                                                                        Fe<F>* __restrict__ out_l, Fe<F>* __restrict__ out_r) {
+    const size_t h = m >> 1;
+    for (size_t i = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * IPA_BLOCK) {
+        const size_t p = i & (m - 1);
+        const bool hi = p >= h;
+        const Fe<F> v = fe_mul<F>(a[hi ? p - h : p + h], coef[i]);
+        out_l[i] = hi ? v : fe_zero<F>();
+        out_r[i] = hi ? fe_zero<F>() : v;
+    }
+}
+// coef[i] <- coef[i] * (s_lo if (i mod m) < m/2 else s_hi): the key folds as ck' = [s_lo] ck_L + [s_hi] ck_R
+template <class F>
+__global__ __launch_bounds__(IPA_BLOCK) void ipa_coef_fold_kernel(Fe<F>* __restrict__ coef, size_t n, size_t m, Fe<F> s_lo, Fe<F> s_hi) {
+    const size_t h = m >> 1;
+    for (size_t i = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * IPA_BLOCK)
+        coef[i] = fe_mul<F>(coef[i], (i & (m - 1)) >= h ? s_hi : s_lo);
+}
+
 struct Scalar256 {
     uint32_t w[8];  // canonical
 };
@@ -122,6 +149,27 @@ static void fold_halves(void* d_v, size_t len, const void* lo32, const void* hi3
     LURK_HIP_CHECK(hipGetLastError());
 }
 
+template <class F>
+static void ipa_round_scalars(const void* d_a, size_t m, const void* d_coef, size_t n, void* d_l, void* d_r, hipStream_t s) {
+    unsigned blocks = div_up(n, IPA_BLOCK), cap = (unsigned)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    ProfScope ps("ipa_round_scalars", s);
+    hipLaunchKernelGGL((ipa_round_scalars_kernel<F>), dim3(blocks), dim3(IPA_BLOCK), 0, s, (const Fe<F>*)d_a, m, (const Fe<F>*)d_coef, n, (Fe<F>*)d_l,
+                       (Fe<F>*)d_r);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+template <class F>
+static void ipa_coef_fold(void* d_coef, size_t n, size_t m, const void* lo32, const void* hi32, hipStream_t s) {
+    Fe<F> a, b;
+    memcpy(a.l, lo32, 32);
+    memcpy(b.l, hi32, 32);
+    unsigned blocks = div_up(n, IPA_BLOCK), cap = (unsigned)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    ProfScope ps("ipa_coef_fold", s);
+    hipLaunchKernelGGL((ipa_coef_fold_kernel<F>), dim3(blocks), dim3(IPA_BLOCK), 0, s, (Fe<F>*)d_coef, n, m, a, b);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+
 template <class P, class SF>
 static void points_fold_halves(const void* d_pts, size_t len, const void* lo32, const void* hi32, void* d_out, hipStream_t s) {
     const size_t h = len / 2;
@@ -156,6 +204,28 @@ int lurk_hip_fold_halves_dev(int field_id, void* d_v, size_t len, const void* s_
         if (field_id == 0) fold_halves<PallasFp>(d_v, len, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
         else if (field_id == 1) fold_halves<PallasFq>(d_v, len, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
         else fold_halves<Bn254Fr>(d_v, len, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_ipa_round_scalars_dev(int field_id, const void* d_a, size_t m, const void* d_coef, size_t n, void* d_out_l, void* d_out_r, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(m >= 2 && (m & (m - 1)) == 0 && n >= m && n % m == 0, "m must be a power of two >= 2 that divides n");
+        LURK_REQUIRE(d_a && d_coef && d_out_l && d_out_r, "null argument");
+        if (field_id == 0) ipa_round_scalars<PallasFp>(d_a, m, d_coef, n, d_out_l, d_out_r, (hipStream_t)stream);
+        else if (field_id == 1) ipa_round_scalars<PallasFq>(d_a, m, d_coef, n, d_out_l, d_out_r, (hipStream_t)stream);
+        else ipa_round_scalars<Bn254Fr>(d_a, m, d_coef, n, d_out_l, d_out_r, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_ipa_coef_fold_dev(int field_id, void* d_coef, size_t n, size_t m, const void* s_lo32_mont, const void* s_hi32_mont, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(m >= 2 && (m & (m - 1)) == 0 && n >= m && n % m == 0, "m must be a power of two >= 2 that divides n");
+        LURK_REQUIRE(d_coef && s_lo32_mont && s_hi32_mont, "null argument");
+        if (field_id == 0) ipa_coef_fold<PallasFp>(d_coef, n, m, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
+        else if (field_id == 1) ipa_coef_fold<PallasFq>(d_coef, n, m, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
+        else ipa_coef_fold<Bn254Fr>(d_coef, n, m, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
     });
 }
 

@@ -84,8 +84,9 @@ class SpartanProver:
         _lib.check(lib.lurk_hip_inner_product_dev(self.sf, _lib.ptr(d_table), _lib.ptr(eq), 1 << len(point), _lib.ptr(out), _lib.ptr(torch.cuda.current_stream().cuda_stream)))
         return sumcheck._ints(out)[0] * self.Rinv % self.q
 
-    def prove(self, X, u: int, d_W, d_E, d_ck, comm_W_jac, comm_E_jac) -> dict:
-        """d_W (num_vars, 4), d_E (num_cons, 4): Montgomery device tensors (not modified); d_ck: (N + 1, 8) affine Montgomery points,
+    def prove(self, X, u: int, d_W, d_E, d_ck, comm_W_jac, comm_E_jac, key=None) -> dict:
+        """key: the resident ``CommitmentKey`` over d_ck[:N] (the one that committed W and E): the opening argument then runs under it
+        without folding the key (ipa.py).  d_W (num_vars, 4), d_E (num_cons, 4): Montgomery device tensors (not modified); d_ck: (N + 1, 8) affine Montgomery points,
         N = max(num_cons, num_vars), the last one the inner-product base; commitments as 96-byte Jacobians."""
         import torch
 
@@ -148,7 +149,8 @@ class SpartanProver:
         ck_c = d_ck[N].cpu().numpy().view(np.uint64).reshape(8)
         bf = 0 if self.curve == 0 else 1
         ck_c_jac = np.concatenate([ck_c, _mont_one(bf)])
-        Ls, Rs, a_hat, _ = ipa.prove(self.curve, q, d_ck[:N].clone(), ck_c_jac, d_joint, sumcheck.eq_evals(sf, self._mont(r_z)), r0, ipa_chal)
+        Ls, Rs, a_hat, _ = ipa.prove(self.curve, q, None if key is not None else d_ck[:N].clone(), ck_c_jac, d_joint, sumcheck.eq_evals(sf, self._mont(r_z)), r0,
+                                     ipa_chal, key=key)
         aff = lambda P: (lambda xy: None if xy == (0, 0) else xy)(point_to_affine(self.curve, P))
         return dict(polys_outer=polys_outer, claims_outer=[claim_Az, claim_Bz, claim_Cz], eval_E=eval_E, polys_inner=polys_inner, eval_W=eval_W,
                     polys_batch=polys_batch, evals_batch=evals_batch, ipa_L=[aff(x) for x in Ls], ipa_R=[aff(x) for x in Rs], ipa_a=a_hat)

@@ -16,18 +16,13 @@ def _dev(a):
     return torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).cuda()
 
 
-def _aff(curve_id, jac):
-    from lurk_beta_amd import point_to_affine
-
-    xy = point_to_affine(curve_id, jac)
-    return None if xy == (0, 0) else xy
+_ORACLE = {}
 
 
-@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
-@pytest.mark.parametrize("log_n", [1, 4, 7])
-def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n):
-    from lurk_beta_amd import ipa, msm
-
+def _oracle_case(cn, c, log_n):
+    """Inputs and the oracle's proof, computed once per (curve, size): the three forms of the device prover share them."""
+    if (cn, log_n) in _ORACLE:
+        return _ORACLE[(cn, log_n)]
     sf = 1 if c == 0 else 0
     q = R.CURVES[cn]["order"]
     n = 1 << log_n
@@ -39,17 +34,44 @@ def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n):
     b = C.limbs_to_ints(C.synth_scalars(sf, 161, 0, n))
     r0 = R.uniform_fe(162, 0, q)
     chal = [R.uniform_fe(163, j, q) for j in range(log_n)]
-    want_L, want_R, want_a, want_ck = R.ipa_prove(cn, ck, ck_c, a, b, r0, chal)
+    want = R.ipa_prove(cn, ck, ck_c, a, b, r0, chal)
+    comm_a = R.msm_naive(cn, a, ck)
+    _ORACLE[(cn, log_n)] = (B, ck, ck_c, a, b, r0, chal, want, comm_a)
+    return _ORACLE[(cn, log_n)]
+
+
+def _aff(curve_id, jac):
+    from lurk_beta_amd import point_to_affine
+
+    xy = point_to_affine(curve_id, jac)
+    return None if xy == (0, 0) else xy
+
+
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+@pytest.mark.parametrize("log_n", [1, 4, 7])
+@pytest.mark.parametrize("form", ["folded_key", "resident_plain_key", "resident_table_key"])
+def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n, form):
+    from lurk_beta_amd import CommitmentKey, ipa, msm
+
+    sf = 1 if c == 0 else 0
+    bf = 0 if c == 0 else 1
+    q = R.CURVES[cn]["order"]
+    n = 1 << log_n
+    B, ck, ck_c, a, b, r0, chal, (want_L, want_R, want_a, want_ck), comm_a = _oracle_case(cn, c, log_n)
     ck_c_jac = np.concatenate([B[n], C.to_mont(bf, C.ints_to_limbs([1])).reshape(4)])
-    got_L, got_R, got_a, got_ck = ipa.prove(c, q, _dev(B[:n]), ck_c_jac, _dev(C.to_mont(sf, C.ints_to_limbs(a))), _dev(C.to_mont(sf, C.ints_to_limbs(b))),
-                                            r0, lambda j, L, Rr: chal[j])
+    # the resident key may be longer than the argument (Spartan opens under a prefix of the witness key)
+    key = None if form == "folded_key" else CommitmentKey(c, B[: n + 1], precompute=form == "resident_table_key")
+    got_L, got_R, got_a, got_ck = ipa.prove(c, q, None if key else _dev(B[:n]), ck_c_jac, _dev(C.to_mont(sf, C.ints_to_limbs(a))),
+                                            _dev(C.to_mont(sf, C.ints_to_limbs(b))), r0, lambda j, L, Rr: chal[j], key=key)
+    if key:
+        key.close()
     assert [_aff(c, x) for x in got_L] == want_L and [_aff(c, x) for x in got_R] == want_R
     assert got_a == want_a
     assert tuple(C.limbs_to_ints(C.from_mont(bf, got_ck.reshape(2, 4)))) == want_ck
-    comm_a = R.msm_naive(cn, a, ck)
-    cc = sum(x * y for x, y in zip(a, b)) % q
-    assert R.ipa_verify(cn, ck, ck_c, comm_a, b, cc, r0, chal, [_aff(c, x) for x in got_L], [_aff(c, x) for x in got_R], got_a)
-    assert not R.ipa_verify(cn, ck, ck_c, comm_a, b, (cc + 1) % q, r0, chal, want_L, want_R, want_a)
+    if form == "folded_key":  # (the other forms produced the identical proof: one run of the oracle's verifier covers them)
+        cc = sum(x * y for x, y in zip(a, b)) % q
+        assert R.ipa_verify(cn, ck, ck_c, comm_a, b, cc, r0, chal, [_aff(c, x) for x in got_L], [_aff(c, x) for x in got_R], got_a)
+        assert not R.ipa_verify(cn, ck, ck_c, comm_a, b, (cc + 1) % q, r0, chal, want_L, want_R, want_a)
 
 
 def test_fold_kernels_edge_cases(hip):

@@ -41,6 +41,8 @@ def test_device_prover_matches_the_oracle_and_verifies(hip, cn, c, num_cons, num
     ce = k.commit(C.ints_to_limbs(E))
     got = prover.prove(X, u, d_W, d_E, _dev(B), cw, ce)
     assert got == want
+    # the opening argument under the resident key (never folded) gives the identical proof
+    assert prover.prove(X, u, d_W, d_E, _dev(B), cw, ce, key=k) == want
     assert S.verify(cn, mats, num_cons, num_vars, X, ck, ck_c, comm_W, comm_E, u, got)
     assert not S.verify(cn, mats, num_cons, num_vars, [(X[0] + 1) % q] + X[1:], ck, ck_c, comm_W, comm_E, u, got)
     k.close()
