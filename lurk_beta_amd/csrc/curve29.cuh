@@ -15,6 +15,9 @@
 #ifndef LURK_ACC_Y3_ROW
 #define LURK_ACC_Y3_ROW 1
 #endif
+#ifndef LURK_ACC_AFFINE_FIRST
+#define LURK_ACC_AFFINE_FIRST 1
+#endif
 
 namespace lurk {
 
@@ -202,7 +205,9 @@ LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, ui
     acc.x = acc.y = acc.zz = acc.zzz = f29_zero<P>();
     bool acc_id = true;
     // (gathering the next base ahead of the current addition was measured: no gain, the other waves of the SIMD
-    // already cover the load)
+    // already cover the load; so was requesting one dword of it ahead - a one-VGPR "touch" for L2 and the TLB - 3.6 against
+    // 3.5 ms, although confining every gather to a 64 MB window of the 3.25 GiB table does make the kernel 8 % faster)
+#if LURK_ACC_AFFINE_FIRST
     uint32_t j = first;
     if (j < last) {  // first base: a copy (zz = zzz = 1)
         const uint32_t e = sorted[j++];
@@ -211,14 +216,28 @@ LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, ui
     if (j < last) {  // second base: affine + affine (unless the first was the identity record)
         const uint32_t e = sorted[j++];
         const Affine<P> q = table[e & 0x7fffffffu];
+#if LURK_ACC_AFFINE_FIRST
         if (!acc_id) xyzz29_madd<P, true>(acc, acc_id, q, (e & 0x80000000u) != 0);
-        else xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);
+        else
+#endif
+            xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);
     }
     for (; j < last; j++) {
         const uint32_t e = sorted[j];
         const Affine<P> q = table[e & 0x7fffffffu];
         xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);
     }
+#else
+    for (uint32_t j = first; j < last; j++) {
+        const uint32_t e = sorted[j];
+#ifdef LURK_ACC_DEBUG_TABLE_MASK  // timing experiment only (wrong results): every gather lands in a small window of the table
+        const Affine<P> q = table[e & LURK_ACC_DEBUG_TABLE_MASK];
+#else
+        const Affine<P> q = table[e & 0x7fffffffu];
+#endif
+        xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);
+    }
+#endif
     return xyzz29_to_xyzz<P>(acc, acc_id);
 }
 

@@ -16,8 +16,16 @@ namespace lurk {
 
 constexpr int MSM_ACC_BLOCK = 256;
 
+#ifndef LURK_ACC_TASK_NOINLINE
+#define LURK_ACC_TASK_NOINLINE 0
+#endif
+#if LURK_ACC_TASK_NOINLINE
+#define LURK_ACC_TASK_ATTR __attribute__((noinline))
+#else
+#define LURK_ACC_TASK_ATTR __forceinline__
+#endif
 template <class P>
-__device__ __forceinline__ void msm_accumulate_task(uint32_t i, const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
+__device__ LURK_ACC_TASK_ATTR void msm_accumulate_task(uint32_t i, const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
                                                     const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
                                                     Xyzz<P>* __restrict__ partials) {
     uint32_t t = order[i];
@@ -35,7 +43,9 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uin
                                                                          const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
                                                                          const uint32_t* __restrict__ group_task_base, int NG,
                                                                          Xyzz<P>* __restrict__ partials) {
+#if !defined(LURK_ACC_NO_SETPRIO)
     __builtin_amdgcn_s_setprio(1);  // above a persistent (background) accumulation sharing the SIMD, below every short kernel (3)
+#endif
     uint32_t i = blockIdx.x * MSM_ACC_BLOCK + threadIdx.x;
     if (i >= group_task_base[NG]) return;
     msm_accumulate_task<P>(i, sorted, table, task_info, order, partials);
@@ -60,12 +70,15 @@ __device__ __forceinline__ uint32_t msm_cu_index() {
     for (;;) {                                                                                                         \
         uint32_t base = 0;                                                                                             \
         if (lane == 0) base = atomicAdd(cursor, 64u);                                                                  \
-        base = __shfl(base, 0);                                                                                        \
+        base = __builtin_amdgcn_readfirstlane(base); /* wave-uniform: the loop control stays scalar */                 \
         if (base >= ntasks) break;                                                                                     \
         if (base + lane < ntasks) msm_accumulate_task<P>(base + lane, sorted, table, task_info, order, partials);      \
     }
+#ifndef LURK_ACC_PERSISTENT_ATTR
+#define LURK_ACC_PERSISTENT_ATTR
+#endif
 template <class P>
-__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_persistent_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
+__global__ __launch_bounds__(MSM_ACC_BLOCK) LURK_ACC_PERSISTENT_ATTR void msm_accumulate_persistent_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
                                                                                     const uint2* __restrict__ task_info,
                                                                                     const uint32_t* __restrict__ order,
                                                                                     const uint32_t* __restrict__ group_task_base, int NG,
