@@ -208,7 +208,22 @@ int main() {
             EXPECT(key.to_affine(ctx.comm_w) == key.to_affine(key.commit(w, true)));      // comm_W1 + r comm_W2 = commit(W1 + r W2)
             EXPECT(key.to_affine(ctx.comm_e) == key.to_affine(key.commit(e_run, true)));  // comm_E1 + r comm_T  = commit(E1 + r T)
         }
-        // after three folds of satisfied instances the pair is a relaxed witness: E = A z o B z - u C z.  Row 1 of this shape is
+        // a fourth step with the fresh instance staged ahead: position 0 of W2 early, position 1 as a late range
+        {
+            std::vector<Fe> io{rs[0]};
+            ctx.prefetch({fresh[1][0]}, 0);
+            auto comms = ctx.begin_prefetched(io, {{1, {fresh[1][1]}}});
+            std::vector<Fe> z2{fresh[1][0], fresh[1][1], one, io[0]};
+            EXPECT(key.to_affine(comms[0]) == key.to_affine(key.commit(fresh[1], true)));
+            auto t = shape.cross_term(z_run, z2);
+            EXPECT(key.to_affine(comms[1]) == key.to_affine(key.commit(t, true)));
+            ctx.finish(rs[1]);
+            z_run = shape.fold(z_run, z2, rs[1]);
+            e_run = shape.fold(e_run, t, rs[1]);
+            auto got = ctx.read();
+            EXPECT(got.first == z_run && got.second == e_run);
+        }
+        // after four folds of satisfied instances the pair is a relaxed witness: E = A z o B z - u C z.  Row 1 of this shape is
         // linear in z times u, so E_1 = (x + y) u - u (x + y) = 0 whatever was folded.
         EXPECT(e_run[1] == zero);
     }

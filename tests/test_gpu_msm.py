@@ -179,6 +179,34 @@ def test_async_slots(hip, cn, c):
         ck.close()
 
 
+@pytest.mark.parametrize("log_n", [14, 20])
+def test_submit_scheduling_classes_and_four_slots(hip, log_n):
+    """lurk_hip_msm_ctx_submit_dev_mode: the class changes how the accumulation is launched (plain / persistent with one or
+    two waves per SIMD, raised wave priority, start behind the foreground sort), never the result; all four slots in flight."""
+    import torch
+
+    from lurk_beta_amd import CommitmentKey, LurkHipError, point_to_affine, synth
+
+    c, n = 0, 1 << log_n
+    d_bases = synth.bases(c, n)
+    scal = [synth.scalars(_sf(c), 40 + j, j % 2, n, mont=True) for j in range(4)]
+    torch.cuda.synchronize()
+    s = torch.cuda.current_stream().cuda_stream
+    for pre in (False, True):
+        ck = CommitmentKey(c, d_bases, n=n, device=True, precompute=pre)
+        ck.reserve(n, 4)
+        want = [point_to_affine(c, ck.commit_device(sc, n, is_mont=True)) for sc in scal]
+        for modes in ((1, 2, 2, 0), (2, 1, 0, 1), (2, 2, 2, 2), (1, 1, 1, 1)):  # 1 = foreground, 2 = background
+            for slot in range(4):
+                ck.submit_device(slot, scal[slot], n, is_mont=True, stream=s, mode=modes[slot])
+            assert [point_to_affine(c, ck.wait(slot)) for slot in range(4)] == want, modes
+        with pytest.raises(LurkHipError):
+            ck.submit_device(0, scal[0], n, is_mont=True, stream=s, mode=3)  # unknown class
+        with pytest.raises(LurkHipError):
+            ck.submit_device(4, scal[0], n, is_mont=True, stream=s)  # only four slots
+        ck.close()
+
+
 def test_point_sum(hip):
     from lurk_beta_amd import msm, point_sum, point_to_affine
 
