@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--stage-ahead", type=int, default=0,
                     help="fold_step: 1 = the next step's witness is traced and its commitment started one step ahead (lurk_hip_fold_step_prefetch); "
                          "0 = plain begin (default: measured 4.4 ms against 4.05 ms staged whole / 5.1 ms staged with late ranges at rc = 100, DESIGN.md)")
+    ap.add_argument("--witness-ahead", type=int, default=1,
+                    help="fold_step: 1 = the witness of step k+1 is traced while step k folds (the reference's producer thread); 0 = traced at the start of its own step")
     ap.add_argument("--late-ranges", type=int, default=1, help="fold_step with --stage-ahead: 1 = 12 000 positions of W2 arrive with begin (the augmented circuit's), 0 = none")
     ap.add_argument("--ipa-resident-key", type=int, default=1, help="compress: 1 = inner-product rounds under the resident key (composed scalars), 0 = fold the key")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
@@ -403,6 +405,14 @@ def fold_step_workload(args, lib, world, rank):
             stage()                                                                   # the next step's, under this step's work
             t_b = time.perf_counter()
             cw, ct = ctx.begin_prefetched(x2, patches)                               # late ranges + cross term + commit(T)
+        elif args.witness_ahead:
+            # the witness of step k+1 is produced while step k folds (lurk-beta's producer thread, nova.rs:304-326): its trace
+            # kernels are enqueued before this step's commitments and run beside them; this step's W2 was produced a step ago
+            k = staged_k[0]
+            staged_k[0] += 1
+            mf.assemble(d_w2s[(k + 1) & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[(k + 1) & 1].cuda_stream)
+            t_b = time.perf_counter()
+            cw, ct = ctx.begin(d_w2s[k & 1], x2, stream=wstreams[k & 1].cuda_stream)  # both commitments + the cross term
         else:
             mf.assemble(d_w2, pre, globals_host, bodies_np, mont=True, stream=stream)
             t_b = time.perf_counter()
@@ -417,6 +427,10 @@ def fold_step_workload(args, lib, world, rank):
 
     if args.stage_ahead:
         stage()
+    elif args.witness_ahead:
+        wstreams = [torch.cuda.Stream(), torch.cuda.Stream()]  # witness k is produced on stream k & 1, into buffer k & 1
+        mf.assemble(d_w2s[0], pre, globals_host, bodies_np, mont=True, stream=wstreams[0].cuda_stream)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     lib.lurk_hip_profile_enable(1)
@@ -456,7 +470,7 @@ def fold_step_workload(args, lib, world, rank):
             "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
-            "config": {"staged_ahead": bool(args.stage_ahead),
+            "config": {"staged_ahead": bool(args.stage_ahead), "witness_ahead": bool(args.witness_ahead and not args.stage_ahead),
                        "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
                                    f"slot blocks traced on the device + {rc} x 1311 body aux over PCIe) -> MSM(W2) + cross term over {n_t} rows ({nnz} non-zeros, "
                                    f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) -> fold of [W|u|X] and E",
