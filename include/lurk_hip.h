@@ -71,6 +71,13 @@ int lurk_hip_msm_pallas(void* out_jacobian96, const void* bases_affine64, size_t
                         const void* scalars32, int is_mont);
 int lurk_hip_msm_vesta(void* out_jacobian96, const void* bases_affine64, size_t npoints,
                        const void* scalars32, int is_mont);
+/* The two symbols above under the names and the signature pasta-msm's src/lib.rs binds (pasta-msm 0.1.x, arecibo's
+ * dependency; un-vendored: /root/reference/Cargo.toml:128 pulls it in through nova): a pasta-msm whose build script links
+ * liblurk_hip.so instead of compiling its own C objects needs no source change.  They return nothing, as the originals; a
+ * failure (no device, allocation) prints lurk_hip_last_error() and aborts the process. */
+#include <stdbool.h>
+void mult_pippenger_pallas(void* out_jacobian96, const void* points_affine64, size_t npoints, const void* scalars32, bool is_mont);
+void mult_pippenger_vesta(void* out_jacobian96, const void* points_affine64, size_t npoints, const void* scalars32, bool is_mont);
 
 /* Resident-bases context: the commitment key `ck` is constant for the whole proof
  * (/root/reference/src/proof/nova.rs:196-216), so it is uploaded once and kept in HBM.

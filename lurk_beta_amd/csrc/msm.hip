@@ -1295,6 +1295,21 @@ int lurk_hip_msm_vesta(void* out, const void* bases, size_t n, const void* scala
     return msm_oneshot(LURK_CURVE_VESTA, out, bases, n, scalars, is_mont);
 }
 
+// pasta-msm's own C symbols: they return nothing (its CPU Pippenger cannot fail), so a failure here ends the process with the
+// library's message - never a silent wrong commitment, never a CPU fallback
+static void pasta_msm_symbol(int curve, void* out, const void* points, size_t npoints, const void* scalars, bool is_mont) {
+    if (msm_oneshot(curve, out, points, npoints, scalars, is_mont ? 1 : 0) != 0) {
+        fprintf(stderr, "liblurk_hip: mult_pippenger_%s failed: %s\n", curve == LURK_CURVE_PALLAS ? "pallas" : "vesta", lurk_hip_last_error());
+        abort();
+    }
+}
+void mult_pippenger_pallas(void* out, const void* points, size_t npoints, const void* scalars, bool is_mont) {
+    pasta_msm_symbol(LURK_CURVE_PALLAS, out, points, npoints, scalars, is_mont);
+}
+void mult_pippenger_vesta(void* out, const void* points, size_t npoints, const void* scalars, bool is_mont) {
+    pasta_msm_symbol(LURK_CURVE_VESTA, out, points, npoints, scalars, is_mont);
+}
+
 int lurk_hip_msm_ctx_create(lurk_hip_msm_ctx** ctx, int curve, const void* bases, size_t n, int flags) {
     return guarded([&] {
         LURK_REQUIRE(ctx, "null ctx pointer");

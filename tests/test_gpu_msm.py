@@ -207,6 +207,24 @@ def test_submit_scheduling_classes_and_four_slots(hip, log_n):
         ck.close()
 
 
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+def test_pasta_msm_symbol_names(hip, cn, c):
+    """mult_pippenger_{pallas,vesta}: the names and the signature pasta-msm's Rust side binds (void return, bool is_mont)."""
+    import ctypes
+
+    from lurk_beta_amd import _lib, point_to_affine
+
+    n = 3000
+    B = C.synth_bases(c, n)
+    S = C.synth_scalars(_sf(c), 77, 0, n)
+    want = C.jac_to_affine(c, C.msm_pippenger(c, B, S))
+    fn = getattr(_lib.load(), f"mult_pippenger_{cn}")
+    for is_mont, scal in ((False, S), (True, C.to_mont(_sf(c), S))):
+        out = np.zeros(12, dtype=np.uint64)
+        fn(_lib.ptr(out), _lib.ptr(B), n, _lib.ptr(np.ascontiguousarray(scal)), ctypes.c_bool(is_mont))
+        assert point_to_affine(c, out) == want
+
+
 def test_point_sum(hip):
     from lurk_beta_amd import msm, point_sum, point_to_affine
 
