@@ -75,6 +75,13 @@ int lurk_hip_msm_vesta(void* out_jacobian96, const void* bases_affine64, size_t 
  * dependency; un-vendored: /root/reference/Cargo.toml:128 pulls it in through nova): a pasta-msm whose build script links
  * liblurk_hip.so instead of compiling its own C objects needs no source change.  They return nothing, as the originals; a
  * failure (no device, allocation) prints lurk_hip_last_error() and aborts the process. */
+/* Opt-in key cache of the four one-shot symbols (default off; LURK_MSM_ONESHOT_KEY_CACHE=1 in the environment does the same):
+ * arecibo commits under ONE immutable key at ONE address for a whole proof, yet the pasta-msm signature makes it hand the
+ * bases over on every call (64 of the 96 bytes per point that cross PCIe).  With the cache on, the bases of the previous call
+ * stay in HBM; a call with the same `points` pointer, npoints <= the cached length and bit-identical points at 4 096 sampled
+ * positions reuses them (2^22: 14.0 ms -> 8.9 ms per call, of which 2.7 ms are the scalars' own upload).  A buffer rewritten in place at unsampled positions only would be missed:
+ * do not enable it for callers that edit a key in place. */
+int lurk_hip_msm_oneshot_key_cache(int enable);
 #include <stdbool.h>
 void mult_pippenger_pallas(void* out_jacobian96, const void* points_affine64, size_t npoints, const void* scalars32, bool is_mont);
 void mult_pippenger_vesta(void* out_jacobian96, const void* points_affine64, size_t npoints, const void* scalars32, bool is_mont);

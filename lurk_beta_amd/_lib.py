@@ -32,6 +32,7 @@ SIGNATURES = {
     "lurk_hip_profile_get": (c_int, [ctypes.c_char_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_u64)]),
     "lurk_hip_msm_pallas": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
     "lurk_hip_msm_vesta": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_int]),
+    "lurk_hip_msm_oneshot_key_cache": (c_int, [c_int]),
     "mult_pippenger_pallas": (None, [c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_bool]),   # pasta-msm's own symbol names
     "mult_pippenger_vesta": (None, [c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_bool]),
     "lurk_hip_msm_ctx_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int]),

@@ -19,6 +19,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <memory>
 
 #include "common.hpp"
@@ -710,6 +711,17 @@ struct MsmCtxBase {
     virtual void adopt_table(DevBuf&& buf, size_t n, bool precomputed_, int c_) = 0;
 };
 
+static std::atomic<int> g_oneshot_key_cache{-1};  // -1: take LURK_MSM_ONESHOT_KEY_CACHE from the environment (default off)
+static bool oneshot_key_cache_enabled() {
+    int v = g_oneshot_key_cache.load();
+    if (v < 0) {
+        const char* e = getenv("LURK_MSM_ONESHOT_KEY_CACHE");
+        v = e && atoi(e) != 0 ? 1 : 0;
+        g_oneshot_key_cache.store(v);
+    }
+    return v != 0;
+}
+
 template <class P, class SF>
 struct MsmCtx : MsmCtxBase {
     DevBuf own_bases;                // bases (or the whole table when precomputed)
@@ -814,6 +826,32 @@ struct MsmCtx : MsmCtxBase {
     }
 
     DevBuf oneshot_scalars;
+    // Opt-in key cache of the one-shot entry points (lurk_hip_msm_oneshot_key_cache): the bases of the previous call stay in HBM
+    // with ONESHOT_SAMPLES of them kept on the host; a call whose `bases` pointer and (prefix) length match and whose points at the
+    // sampled positions are bit-identical skips the 64 B/point upload.  A commitment key is immutable and lives at one address
+    // for a whole proof, which is the only caller this is for; a buffer rewritten at unsampled positions only would be missed.
+    static constexpr size_t ONESHOT_SAMPLES = 4096;
+    const void* oneshot_host = nullptr;
+    size_t oneshot_n = 0;
+    std::vector<char> oneshot_samples;
+    static size_t oneshot_sample_pos(size_t k, size_t n) { return (size_t)(((unsigned __int128)k * n) / ONESHOT_SAMPLES); }
+    bool oneshot_key_matches(const void* bases, size_t n) const {
+        if (!oneshot_host || bases != oneshot_host || n > oneshot_n || oneshot_samples.empty()) return false;
+        const size_t cnt = oneshot_n < ONESHOT_SAMPLES ? oneshot_n : ONESHOT_SAMPLES;
+        for (size_t k = 0; k < cnt; k++) {
+            const size_t i = oneshot_n < ONESHOT_SAMPLES ? k : oneshot_sample_pos(k, oneshot_n);
+            if (i >= n) break;
+            if (memcmp((const char*)bases + i * 64, oneshot_samples.data() + k * 64, 64) != 0) return false;
+        }
+        return true;
+    }
+    void oneshot_key_remember(const void* bases, size_t n) {
+        const size_t cnt = n < ONESHOT_SAMPLES ? n : ONESHOT_SAMPLES;
+        oneshot_samples.resize(cnt * 64);
+        for (size_t k = 0; k < cnt; k++) memcpy(oneshot_samples.data() + k * 64, (const char*)bases + (n < ONESHOT_SAMPLES ? k : oneshot_sample_pos(k, n)) * 64, 64);
+        oneshot_host = bases;
+        oneshot_n = n;
+    }
     void run_oneshot(const void* bases, const void* scalars, size_t n, int is_mont, void* out) override {
         if (n == 0) {
             put_identity(out);
@@ -823,7 +861,11 @@ struct MsmCtx : MsmCtxBase {
         Work& wk = work[0];
         std::lock_guard<std::mutex> lk(wk.mu);
         LURK_REQUIRE(!wk.pending, "slot 0 has a submitted commitment that was not waited for");
-        own_bases.ensure(n * sizeof(Affine<P>));
+        const bool cached = oneshot_key_cache_enabled() && oneshot_key_matches(bases, n);
+        if (!cached) {
+            oneshot_host = nullptr;  // the device copy is about to be overwritten
+            own_bases.ensure(n * sizeof(Affine<P>));
+        }
         oneshot_scalars.ensure(n * 32);
         table = own_bases.as<Affine<P>>();
         npoints = n;
@@ -834,10 +876,11 @@ struct MsmCtx : MsmCtxBase {
         // scalars first (the sort needs only them); the 64 B/point of bases follow behind the sort, right before the accumulation
         LURK_HIP_CHECK(hipMemcpyAsync(oneshot_scalars.p, scalars, n * 32, hipMemcpyHostToDevice, s));
         const std::function<void()> upload_bases = [&] {
-            LURK_HIP_CHECK(hipMemcpyAsync(own_bases.p, bases, n * sizeof(Affine<P>), hipMemcpyHostToDevice, s));
+            if (!cached) LURK_HIP_CHECK(hipMemcpyAsync(own_bases.p, bases, n * sizeof(Affine<P>), hipMemcpyHostToDevice, s));
         };
         enqueue(wk, oneshot_scalars.p, n, is_mont, s, nullptr, &upload_bases);
         LURK_HIP_CHECK(hipStreamSynchronize(s));
+        if (!cached && oneshot_key_cache_enabled()) oneshot_key_remember(bases, n);
         host_tail(wk, n, out);
     }
     void rebind(const void* d_bases, size_t n) override {
@@ -1308,6 +1351,10 @@ void mult_pippenger_pallas(void* out, const void* points, size_t npoints, const 
 }
 void mult_pippenger_vesta(void* out, const void* points, size_t npoints, const void* scalars, bool is_mont) {
     pasta_msm_symbol(LURK_CURVE_VESTA, out, points, npoints, scalars, is_mont);
+}
+
+int lurk_hip_msm_oneshot_key_cache(int enable) {
+    return guarded([&] { g_oneshot_key_cache.store(enable ? 1 : 0); });
 }
 
 int lurk_hip_msm_ctx_create(lurk_hip_msm_ctx** ctx, int curve, const void* bases, size_t n, int flags) {

@@ -225,6 +225,33 @@ def test_pasta_msm_symbol_names(hip, cn, c):
         assert point_to_affine(c, out) == want
 
 
+def test_oneshot_key_cache(hip):
+    """lurk_hip_msm_oneshot_key_cache: same pointer + same sampled points -> the device copy is reused (also for a prefix);
+    new contents at the same address -> detected, uploaded again."""
+    from lurk_beta_amd import _lib, msm, point_to_affine
+
+    lib = _lib.load()
+    c, n = 0, 20000
+    B = np.ascontiguousarray(C.synth_bases(c, n))
+    S1, S2 = C.synth_scalars(1, 90, 0, n), C.synth_scalars(1, 91, 1, n)
+    want = lambda bases, sc: C.jac_to_affine(c, C.msm_pippenger(c, bases, sc))
+    _lib.check(lib.lurk_hip_msm_oneshot_key_cache(1))
+    try:
+        assert point_to_affine(c, msm(c, B, S1)) == want(B, S1)           # uploads and remembers
+        assert point_to_affine(c, msm(c, B, S2)) == want(B, S2)           # hit
+        assert point_to_affine(c, msm(c, B[:7000], S1[:7000])) == want(B[:7000], S1[:7000])  # prefix of the cached key: hit
+        B2 = C.synth_bases(c, 2 * n)[n:]
+        B[:] = B2                                                         # same address, other key
+        assert point_to_affine(c, msm(c, B, S1)) == want(B2, S1)          # miss detected by the samples
+        assert point_to_affine(c, msm(c, B, S2)) == want(B2, S2)
+        B3 = np.ascontiguousarray(C.synth_bases(c, n + 1000))             # another buffer, longer
+        S3 = C.synth_scalars(1, 92, 0, n + 1000)
+        assert point_to_affine(c, msm(c, B3, S3)) == want(B3, S3)
+    finally:
+        _lib.check(lib.lurk_hip_msm_oneshot_key_cache(0))
+    assert point_to_affine(c, msm(c, B, S1)) == want(B, S1)               # cache off again: plain path
+
+
 def test_point_sum(hip):
     from lurk_beta_amd import msm, point_sum, point_to_affine
 
