@@ -518,7 +518,7 @@ struct MsmTuning {
         max_acc = geti("LURK_MSM_MAX_ACC", 2);
         placement_log = geti("LURK_MSM_PLACEMENT_LOG", 0);
         bg_behind_sort = geti("LURK_MSM_BG_BEHIND_SORT", 1);
-        fg_waves = geti("LURK_MSM_FG_WAVES", 2);  // foreground accumulation: persistent with this many waves per SIMD (0 = the plain launch)
+        fg_waves = geti("LURK_MSM_FG_WAVES", 0);  // foreground accumulation: 0 = the plain launch (measured best), k = persistent with k waves per SIMD
         if (max_acc > 2) max_acc = 0;  // 0 = unlimited (3 slots)
         if (waves < 1) waves = 1;
         if (waves > 8) waves = 8;

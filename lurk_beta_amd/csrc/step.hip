@@ -153,9 +153,12 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
     // a W2 that is not in flight yet (the plain begin) is on this step's path: its commitment first, the cross term beside its sort
     // (measured against cross term -> commit(T) -> commit(W2): 4.10 vs 4.19 ms at rc = 100, 24.5 vs 24.1 at rc = 900)
-    fold_submit_staged(c, b, LURK_MSM_SUBMIT_DEFAULT);
+    // (both commitments of a step in the FOREGROUND class - the plain accumulate launch: with only two commitments in flight and the
+    // host waiting for both, it beats the persistent form the DEFAULT class picks at these sizes: 4.01 vs 4.24 ms at rc = 100,
+    // 23.4 vs 24.4 ms at rc = 900)
+    fold_submit_staged(c, b, LURK_MSM_SUBMIT_FOREGROUND);
     tt[1] = now();
-    const int fg = ahead ? LURK_MSM_SUBMIT_FOREGROUND : LURK_MSM_SUBMIT_DEFAULT;
+    const int fg = LURK_MSM_SUBMIT_FOREGROUND;
     ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));          // T ...
     ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t.p, c->num_cons, 1, c->stream, fg));     // ... commit(T): what the host waits for
     if (patched) ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream, fg));  // commitment of the late ranges
