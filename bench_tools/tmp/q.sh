@@ -1,8 +1,6 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-python -m pytest tests/test_gpu_step.py tests/test_gpu_msm.py -x -q 2>&1 | tail -2
-run() { python bench.py --workload fold_step --steps 12 --warmup 3 --no-cpu-baseline "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$E $*', d['value'], d['ms_per_step'], d['host_ms_per_step'])"; }
-E=fg; run; run
-run --stage-ahead 1 --late-ranges 0
-run --stage-ahead 1 --late-ranges 1
-run --witness-ahead 0
-run --rc 900 --steps 5 --warmup 2
+python -m pytest tests/test_gpu_msm.py tests/test_gpu_ipa.py -x -q 2>&1 | tail -2
+B="--no-cpu-baseline --pmc off --no-plain-leg"
+for a in "--log-n 13 --precompute 0" "--log-n 13 --precompute 1" "--log-n 20 --precompute 0" "--log-n 22 --precompute 0" "--log-n 22 --precompute 1"; do
+python bench.py --steps 20 --warmup 5 --pipeline 1 $a $B 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$a', d['value'], d['ms_per_step'], d.get('kernel_ms_per_commit_sync'), d.get('sync_ms_per_commit'))"
+done

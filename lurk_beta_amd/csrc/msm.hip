@@ -617,35 +617,6 @@ __global__ __launch_bounds__(256) void msm_planes_kernel(const Xyzz<P>* __restri
 // (A two-launch form - one workgroup running ten levels on 1024 buckets behind barriers, then one workgroup per key space for
 // the rest - was measured at 0.69 ms against 0.45 ms for the per-level launches: a level is one addition deep, and an addition
 // is fastest when its wave has a SIMD to itself, which only the chip-wide launches give.)
-// plain mode (c = 16): block g, 16 lanes: W_g = S + sum_k 2^k P_k by a tree-shaped Horner
-// (15 doublings + 5 additions deep)
-template <class P>
-__global__ __launch_bounds__(64) void msm_horner16_kernel(const Xyzz<P>* __restrict__ planes, Xyzz<P>* __restrict__ ws) {
-    msm_set_wave_prio(1);
-    __shared__ uint4 lds_raw[16 * sizeof(Xyzz<P>) / 16];
-    Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
-    const int g = blockIdx.x, t = threadIdx.x;
-    const Xyzz<P>* v = planes + (size_t)g * 16;  // [S, P_0 .. P_14]
-    if (t < 16) sh[t] = t < 15 ? v[1 + t] : xyzz_identity<P>();
-    __syncthreads();
-    for (int lvl = 0; lvl < 4; lvl++) {  // q_j = q_2j + 2^(2^lvl) * q_2j+1
-        Xyzz<P> r;
-        bool active = t < (8 >> lvl);
-        if (active) {
-            r = xyzz_dbl_n<P>(sh[2 * t + 1], 1 << lvl);
-            xyzz_add<P>(r, sh[2 * t]);
-        }
-        __syncthreads();
-        if (active) sh[t] = r;
-        __syncthreads();
-    }
-    if (t == 0) {
-        Xyzz<P> r = sh[0];
-        xyzz_add<P>(r, v[0]);
-        ws[g] = r;
-    }
-}
-
 // ---- precomputed table: T[w*n + i] = 2^(c w) * P_i ----------------------------------------------
 // One inversion per POINT, not per table entry: the W-1 multiples are carried in XYZZ form, their (X, Y) parked in the table,
 // ZZ, ZZZ and the running product of the ZZZ parked in a scratch buffer, then one field inversion and Montgomery's trick walk
@@ -730,7 +701,7 @@ struct MsmCtx : MsmCtxBase {
     struct Work {
         std::mutex mu;
         DevBuf inter, sorted, block_hist, part_cnt, part_start, cnt, bucket_start, task_start, group_tasks, group_task_base, task_info,
-            task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, ws, canon;
+            task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, canon;
         Xyzz<P>* host_pts = nullptr;  // pinned: window sums or bit planes for the host tail
         size_t ws_n = 0;
         hipStream_t stream = nullptr;      // slot stream: sort, plan, finalize, reduce (high priority)
@@ -951,8 +922,7 @@ struct MsmCtx : MsmCtxBase {
         wk.cursor.ensure(4 * (MSM_PLACEMENT_BASE + 512));
         wk.planes_a.ensure((size_t)sh.NB * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
         wk.planes_b.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
-        wk.ws.ensure(32 * sizeof(Xyzz<P>));
-        if (!wk.host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&wk.host_pts, 32 * sizeof(Xyzz<P>)));
+        if (!wk.host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&wk.host_pts, (size_t)MSM_MAX_W * 20 * sizeof(Xyzz<P>)));
         wk.ws_n = sh.n;
     }
 
@@ -1072,12 +1042,9 @@ struct MsmCtx : MsmCtxBase {
                 in = bufs[k & 1];
             }
             // `in` = [G][c] points: S, P_0 .. P_{c-2}
-            if (sh.G > 1) {
-                hipLaunchKernelGGL((msm_horner16_kernel<P>), dim3(sh.G), dim3(64), 0, s, in, wk.ws.template as<Xyzz<P>>());
-                LURK_HIP_CHECK(hipMemcpyAsync(wk.host_pts, wk.ws.p, (size_t)sh.G * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
-            } else {
-                LURK_HIP_CHECK(hipMemcpyAsync(wk.host_pts, in, (size_t)sh.c * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
-            }
+            // the G x c plane sums go to the host as they are: its Horner over them (G c doublings and as many additions, ~0.13 ms)
+            // is cheaper than the 20-deep dependent chain a device kernel needs for the same 256 points (0.18 ms)
+            LURK_HIP_CHECK(hipMemcpyAsync(wk.host_pts, in, (size_t)sh.G * sh.c * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
         }
         LURK_HIP_CHECK(hipGetLastError());
     }
@@ -1088,8 +1055,7 @@ struct MsmCtx : MsmCtxBase {
     static void put_identity(void* out) { put_point(out, jacobian_from_affine<P>(Affine<P>{fe_zero<P>(), fe_zero<P>()})); }
     void host_tail(Work& wk, size_t n, void* out) {
         const MsmShape sh = shape(n);
-        Xyzz<P> total = sh.G > 1 ? msm_combine_windows<P>(wk.host_pts, sh.G, sh.c)  // sum_w 2^(c w) W_w
-                                 : msm_planes_horner<P>(wk.host_pts, sh.c);         // one key space: c-1 doublings
+        const Xyzz<P> total = msm_planes_horner_windows<P>(wk.host_pts, sh.G, sh.c);  // sum_g 2^(c g) (S_g + sum_k 2^k P_gk)
         put_point(out, jacobian_from_affine<P>(xyzz_to_affine<P>(total)));
     }
 

@@ -84,25 +84,18 @@ LURK_HD Xyzz<P> xyzz_dbl_n(Xyzz<P> p, int n) {
     return p;
 }
 
-// Host tail: sum_g 2^(c g) * ws[g], Horner from the top window.
+// Host Horner over the plane sums of G key spaces, v[g] = [S_g, P_g0 .. P_g(c-2)]: sum_g 2^(c g) (S_g + sum_k 2^k P_gk)
 template <class P>
-LURK_HD Xyzz<P> msm_combine_windows(const Xyzz<P>* ws, int g, int c) {
+LURK_HD Xyzz<P> msm_planes_horner_windows(const Xyzz<P>* v, int G, int c) {
     Xyzz<P> acc = xyzz_identity<P>();
-    for (int w = g - 1; w >= 0; w--) {
-        acc = xyzz_dbl_n<P>(acc, c);
-        xyzz_add<P>(acc, ws[w]);
+    for (int g = G - 1; g >= 0; g--) {
+        const Xyzz<P>* vg = v + (size_t)g * c;
+        for (int k = c - 1; k >= 0; k--) {
+            acc = xyzz_dbl<P>(acc);
+            if (k <= c - 2) xyzz_add<P>(acc, vg[1 + k]);
+        }
+        xyzz_add<P>(acc, vg[0]);
     }
-    return acc;
-}
-// Host Horner over the bit planes of one key space: v = [S, P_0 .. P_{c-2}] -> S + sum_k 2^k P_k
-template <class P>
-LURK_HD Xyzz<P> msm_planes_horner(const Xyzz<P>* v, int c) {
-    Xyzz<P> acc = xyzz_identity<P>();
-    for (int k = c - 2; k >= 0; k--) {
-        acc = xyzz_dbl<P>(acc);
-        xyzz_add<P>(acc, v[1 + k]);
-    }
-    xyzz_add<P>(acc, v[0]);
     return acc;
 }
 
