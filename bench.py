@@ -50,6 +50,7 @@ def main():
                          "0 = plain begin (default: measured 4.4 ms against 4.05 ms staged whole / 5.1 ms staged with late ranges at rc = 100, DESIGN.md)")
     ap.add_argument("--witness-ahead", type=int, default=1,
                     help="fold_step: 1 = the witness of step k+1 is traced while step k folds (the reference's producer thread); 0 = traced at the start of its own step")
+    ap.add_argument("--secondary", type=int, default=1, help="fold_step: 1 = also time the secondary-curve (Vesta, ~10^4 constraints) half of a step")
     ap.add_argument("--late-ranges", type=int, default=1, help="fold_step with --stage-ahead: 1 = 12 000 positions of W2 arrive with begin (the augmented circuit's), 0 = none")
     ap.add_argument("--ipa-resident-key", type=int, default=1, help="compress: 1 = inner-product rounds under the resident key (composed scalars), 0 = fold the key")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
@@ -233,7 +234,7 @@ def main():
                             f"{'precomputed-table' if args.precompute else 'plain'} resident commitment key",
                 "points_per_gpu": n,
                 "total_points": total_points,
-                "window_bits": args.window_bits or (20 if args.precompute else 16),
+                "window_bits": args.window_bits or ((16 if args.log_n <= 18 else 20) if args.precompute else 16),
                 "parallelism": f"shard{world}+all_gather(96B)" if world > 1 else "single",
                 "commitments_in_flight": depth,
             },
@@ -249,7 +250,7 @@ def main():
                 "traffic_from_profile": traffic_from_profile,
                 "avg_launch_ms": round(acc_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "mixed_additions_per_launch": (13 if args.precompute and not args.window_bits else msm_windows(args)) * n,
+                "mixed_additions_per_launch": msm_windows(args) * n,
                 "note": "integer-VALU bound (v_mad_u64_u32 issue), not HBM bound: see roofline_valu and DESIGN.md",
             },
             # the honest ceiling for this kernel is VALU issue, not HBM: a mixed addition needs 1224 v_mad_u64_u32
@@ -489,6 +490,41 @@ def fold_step_workload(args, lib, world, rank):
                                        "bit_decomp_ms_per_launch": round(bd_ms, 4), "bytes_written_per_step": mf.slots_len * rc * 32.0},
             },
         }
+        # the secondary-curve half of the step (Vesta, scalars in Fp): arecibo's augmented circuit on the other curve of the cycle is
+        # ~10^4 constraints; its NIFS::prove runs BEFORE the primary's in prove_step and the two depend on each other through the
+        # circuits, so a whole step is the sum.  W2 comes from host memory here (that circuit is synthesized on the CPU).
+        if args.secondary:
+            P_MOD = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+            nc2, nv2, nio2 = 10_000, 10_000, 2
+            shape2 = L.R1CSShape(L.FIELD_PALLAS_FP, nc2, nv2, nio2, *synth_r1cs_shape(L.FIELD_PALLAS_FP, P_MOD, nc2, nv2, nio2, seed=11, uniform_columns=True))
+            ck2 = L.CommitmentKey(L.CURVE_VESTA, synth.bases(L.CURVE_VESTA, max(nc2, nv2)), n=max(nc2, nv2), device=True, precompute=bool(args.precompute))
+            ck2.reserve(max(nc2, nv2), 3)
+            ctx2 = L.FoldingContext(L.CURVE_VESTA, shape2, ck2)
+            ctx2.set_running(synth.scalars(L.FIELD_PALLAS_FP, 31, 1, nv2 + 1 + nio2, mont=True).cpu().numpy().view(np.uint64),
+                             synth.scalars(L.FIELD_PALLAS_FP, 32, 0, nc2, mont=True).cpu().numpy().view(np.uint64), ident, ident)
+            w2_sec = torch.empty((nv2, 4), dtype=torch.int64).pin_memory()
+            w2_sec.copy_(synth.scalars(L.FIELD_PALLAS_FP, 33, 1, nv2, mont=True).cpu())
+            w2_sec_np = w2_sec.numpy().view(np.uint64)
+            x2_sec = synth.scalars(L.FIELD_PALLAS_FP, 34, 0, nio2, mont=True).cpu().numpy().view(np.uint64)
+            for _ in range(3):
+                ctx2.begin(w2_sec_np, x2_sec)
+                ctx2.finish(r_mont)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            reps2 = max(args.steps, 10)
+            for _ in range(reps2):
+                ctx2.begin(w2_sec_np, x2_sec)
+                ctx2.finish(r_mont)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t2) / reps2 * 1e3
+            res["secondary_curve_step"] = {"ms_per_step": round(ms2, 4), "curve": "vesta", "constraints": nc2, "variables": nv2,
+                                           "note": "arecibo's augmented circuit on the secondary curve is ~10^4 constraints [SURVEY 8: MEM]; two latency-bound "
+                                                   "commitments of 10^4 points + cross term + folds, W2 from host memory"}
+            res["both_curves_ms_per_step"] = round(ms + ms2, 4)
+            res["both_curves_iterations_per_s"] = round(rc / ((ms + ms2) * 1e-3), 1)
+            ctx2.close()
+            ck2.close()
+            shape2.close()
         # the same cross term over a structure-free shape (uniformly random columns): the other end of the sparsity range
         lib.lurk_hip_profile_enable(1)
         lib.lurk_hip_profile_reset()
@@ -787,7 +823,7 @@ def valu_roofline(acc_ms, mixed_adds):
 
 
 def msm_windows(args):
-    c = args.window_bits or (20 if args.precompute else 16)
+    c = args.window_bits or ((16 if args.log_n <= 18 else 20) if args.precompute else 16)  # the library's own choice (msm.hip: set_bases_device)
     return -(-256 // c)
 
 

@@ -91,7 +91,7 @@ void mult_pippenger_vesta(void* out_jacobian96, const void* points_affine64, siz
  * Mirrors the msm-context API of the argumentcomputer pasta-msm fork (init(points) -> ctx,
  * with(ctx, scalars) -> point).  flags: bit0 = build the per-window precomputed table
  * (2^(c*k) * P_i for every window k; costs windows x 64 B x npoints of HBM; every window then shares
- * one bucket set, so the window grows to c = 18 or 20 bits: 15 n / 13 n mixed additions instead of
+ * one bucket set, so the window grows to c = 20 bits from 2^19 points on: 13 n mixed additions instead of
  * 16 n); bits 8..15 = window-bit override for the table mode (16..20, 0 = automatic). */
 typedef struct lurk_hip_msm_ctx lurk_hip_msm_ctx;
 #define LURK_MSM_FLAG_PRECOMPUTE 1

@@ -404,7 +404,9 @@ def test_key_files_round_trip(hip, tmp_path, cn, c):
     ck.save(with_table, with_table=True)
     import os
 
-    assert os.path.getsize(bases_only) == 64 + 64 * n and os.path.getsize(with_table) == 64 + 13 * 64 * n
+    windows = -(-256 // ck.info()["window_bits"])
+    assert ck.info()["window_bits"] == 16  # a key this small keeps 16-bit windows with its table (20 bits from 2^19 points on)
+    assert os.path.getsize(bases_only) == 64 + 64 * n and os.path.getsize(with_table) == 64 + windows * 64 * n
     for path in (bases_only, with_table):
         for pre in (False, True):
             k2 = CommitmentKey.load(path, precompute=pre)
