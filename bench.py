@@ -374,7 +374,8 @@ def fold_step_workload(args, lib, world, rank):
     shape = L.R1CSShape(F, n_t, n_w, n_io, *synth_r1cs_shape(F, q, n_t, n_w, n_io))
     shape_setup_s = time.perf_counter() - t_setup
     info = shape.info()
-    r_mont = np.array([0x1234567890ABCDEF, 0x0FEDCBA098765432, 0x1111111122222222, 0x0333333344444444], dtype=np.uint64)  # stands in for the transcript's challenge
+    r_chal = 0x0FEDCBA0987654321234567890ABCDEF  # stands in for the transcript's challenge: 128 bits, as arecibo squeezes (NUM_CHALLENGE_BITS)
+    r_mont = np.array([((r_chal << 256) % q) >> (64 * w) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
     torch.cuda.synchronize()
     ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     ctx = L.FoldingContext(L.CURVE_PALLAS, shape, ck)
@@ -506,15 +507,16 @@ def fold_step_workload(args, lib, world, rank):
             w2_sec.copy_(synth.scalars(L.FIELD_PALLAS_FP, 33, 1, nv2, mont=True).cpu())
             w2_sec_np = w2_sec.numpy().view(np.uint64)
             x2_sec = synth.scalars(L.FIELD_PALLAS_FP, 34, 0, nio2, mont=True).cpu().numpy().view(np.uint64)
+            r_mont2 = np.array([((r_chal << 256) % P_MOD) >> (64 * w) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
             for _ in range(3):
                 ctx2.begin(w2_sec_np, x2_sec)
-                ctx2.finish(r_mont)
+                ctx2.finish(r_mont2)
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             reps2 = max(args.steps, 10)
             for _ in range(reps2):
                 ctx2.begin(w2_sec_np, x2_sec)
-                ctx2.finish(r_mont)
+                ctx2.finish(r_mont2)
             torch.cuda.synchronize()
             ms2 = (time.perf_counter() - t2) / reps2 * 1e3
             res["secondary_curve_step"] = {"ms_per_step": round(ms2, 4), "curve": "vesta", "constraints": nc2, "variables": nv2,

@@ -1202,7 +1202,9 @@ static void point_mul_host(const void* pt, const void* scalar32, int is_mont, vo
     memcpy(&j, pt, sizeof(j));
     const Xyzz<P> base = xyzz_from_jacobian<P>(j);
     Xyzz<P> acc = xyzz_identity<P>();
-    for (int i = 255; i >= 0; i--) {
+    int top = 255;  // Nova's folding challenges are 128 bits (NUM_CHALLENGE_BITS): start at the highest set bit
+    while (top >= 0 && !((k.l[top >> 5] >> (top & 31)) & 1u)) top--;
+    for (int i = top; i >= 0; i--) {
         acc = xyzz_dbl<P>(acc);
         if ((k.l[i >> 5] >> (i & 31)) & 1u) xyzz_add<P>(acc, base);
     }
