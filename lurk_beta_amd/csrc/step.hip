@@ -152,7 +152,8 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
     // a W2 that is not in flight yet (the plain begin) is on this step's path: its commitment first, the cross term beside its sort
-    // (measured against cross term -> commit(T) -> commit(W2): 4.10 vs 4.19 ms at rc = 100, 24.5 vs 24.1 at rc = 900)
+    // (measured against cross term -> commit(T) -> commit(W2): 4.10 vs 4.19 ms at rc = 100, 24.5 vs 24.1 at rc = 900; and against
+    // cross term -> commit(W2) -> commit(T): no difference)
     // (both commitments of a step in the FOREGROUND class - the plain accumulate launch: with only two commitments in flight and the
     // host waiting for both, it beats the persistent form the DEFAULT class picks at these sizes: 4.01 vs 4.24 ms at rc = 100,
     // 23.4 vs 24.4 ms at rc = 900)
