@@ -143,12 +143,15 @@ class Profiler {
 
 // scopes may be open on several host threads / devices at once (the multi-device MSM): the opening event travels
 // with the scope
+// set while the calling thread records launches into a hipGraph (msm.hip): timing events do not belong in the recording
+inline thread_local bool tl_capturing = false;
+
 struct ProfScope {
     hipStream_t s;
     const char* name;
     hipEvent_t a = nullptr;
     ProfScope(const char* nm, hipStream_t st) : s(st), name(nm) {
-        if (Profiler::get().enabled()) a = Profiler::get().begin(s);
+        if (Profiler::get().enabled() && !tl_capturing) a = Profiler::get().begin(s);
     }
     ~ProfScope() {
         if (a) Profiler::get().end(name, a, s);

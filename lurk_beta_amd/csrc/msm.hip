@@ -506,7 +506,7 @@ void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* t
 // three commitments in flight share every SIMD (three dependent mad chains keep the VALU issuing) and the short kernels of
 // the others always find registers and wave slots beside them.
 struct MsmTuning {
-    int persistent, waves, r128, prio, sort_prio, tail_prio, max_acc, placement_log, bg_behind_sort, fg_waves;
+    int persistent, waves, r128, prio, sort_prio, tail_prio, max_acc, placement_log, bg_behind_sort, fg_waves, graph;
     MsmTuning() {
         auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
         persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // 0 = never, 1 = by size, 2 = always
@@ -518,6 +518,7 @@ struct MsmTuning {
         max_acc = geti("LURK_MSM_MAX_ACC", 2);
         placement_log = geti("LURK_MSM_PLACEMENT_LOG", 0);
         bg_behind_sort = geti("LURK_MSM_BG_BEHIND_SORT", 1);
+        graph = geti("LURK_MSM_GRAPH", 0);  // 1 = foreground commitments are recorded once per (slot, scalars, n) and replayed as a hipGraph
         fg_waves = geti("LURK_MSM_FG_WAVES", 0);  // foreground accumulation: 0 = the plain launch (measured best), k = persistent with k waves per SIMD
         if (max_acc > 2) max_acc = 0;  // 0 = unlimited (3 slots)
         if (waves < 1) waves = 1;
@@ -709,12 +710,18 @@ struct MsmCtx : MsmCtxBase {
         hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
         DevBuf cursor;                     // task cursor of the persistent accumulate kernel (+ its per-CU placement counters)
         bool placement_valid = false;
+        hipGraphExec_t graph_exec = nullptr;  // the recorded commitment (LURK_MSM_GRAPH) and what it was recorded for
+        const void* graph_scalars = nullptr;
+        const void* graph_table = nullptr;
+        size_t graph_n = 0;
+        int graph_mont = -1, graph_c = 0;
         bool force_persistent = false;     // LURK_MSM_SUBMIT_BACKGROUND
         bool foreground = false;           // LURK_MSM_SUBMIT_FOREGROUND
         hipStream_t pending_stream = nullptr;  // the stream the pending commitment ends on
         bool pending = false;
         size_t pending_n = 0;
         ~Work() {
+            if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
             if (host_pts) (void)hipHostFree(host_pts);
             if (stream) (void)hipStreamDestroy(stream);
             if (acc_stream) (void)hipStreamDestroy(acc_stream);
@@ -903,6 +910,10 @@ struct MsmCtx : MsmCtxBase {
 
     void ensure_workspace(Work& wk, const MsmShape& sh) {
         if (sh.n <= wk.ws_n && wk.ws_n != 0) return;
+        if (wk.graph_exec) {  // the buffers are about to move: a recorded commitment holds their old addresses
+            (void)hipGraphExecDestroy(wk.graph_exec);
+            wk.graph_exec = nullptr;
+        }
         const size_t entries = (size_t)sh.W * sh.n, nt = ntask_max(sh);
         wk.inter.ensure(entries * 8);
         wk.sorted.ensure(entries * 4);
@@ -986,7 +997,7 @@ struct MsmCtx : MsmCtxBase {
         // commitments in flight take the persistent form on the slot's low-priority accumulate stream (tiny ones excepted: their
         // accumulation is over before a second kernel could share the chip); synchronous calls keep the plain launch
         const bool persistent = s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 22) : tn.persistent != 0));
-        if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));  // sort and plan are enqueued: a background commitment may start behind this point
+        if (wk.planned && !tl_capturing) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));  // sort and plan are enqueued: a background commitment may start behind this point
         if (persistent) {
             LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4 * (MSM_PLACEMENT_BASE + 512), s));
             wk.placement_valid = true;
@@ -1104,7 +1115,45 @@ struct MsmCtx : MsmCtxBase {
                 if (mode == LURK_MSM_SUBMIT_FOREGROUND) last_fg = &wk;
             }
             // foreground: everything on the (high-priority) slot stream
-            enqueue(wk, d_scalars, n, is_mont, wk.pending_stream, wk.foreground ? (msm_tuning().fg_waves > 0 ? wk.stream : nullptr) : wk.acc_stream);
+            hipStream_t acc_s = wk.foreground ? (msm_tuning().fg_waves > 0 ? wk.stream : nullptr) : wk.acc_stream;
+            if (msm_tuning().graph && wk.foreground && acc_s == nullptr) {
+                // A foreground commitment is ~45 dependent launches on ONE stream with nothing but device pointers in their arguments:
+                // recorded once per (scalars, n) and replayed, it costs the host one call instead of 45 (the small commitments of the
+                // secondary curve are launch-bound on both sides).
+                if (!wk.graph_exec || wk.graph_scalars != d_scalars || wk.graph_n != n || wk.graph_mont != is_mont || wk.graph_table != (const void*)table ||
+                    wk.graph_c != c) {
+                    if (wk.graph_exec) LURK_HIP_CHECK(hipGraphExecDestroy(wk.graph_exec));
+                    wk.graph_exec = nullptr;
+                    ensure_workspace(wk, shape(n));   // nothing may allocate inside the recording
+                    if (is_mont) wk.canon.ensure(n * 32);
+                    allow_dynamic_lds((const void*)msm_scatter1_kernel<SF>, (int)MSM_LDS_BYTES);
+                    allow_dynamic_lds((const void*)msm_part2_kernel, (int)MSM_LDS_BYTES);
+                    hipGraph_t g = nullptr;
+                    LURK_HIP_CHECK(hipStreamBeginCapture(wk.stream, hipStreamCaptureModeThreadLocal));
+                    tl_capturing = true;
+                    try {
+                        enqueue(wk, d_scalars, n, is_mont, wk.stream, nullptr);
+                    } catch (...) {
+                        tl_capturing = false;
+                        (void)hipStreamEndCapture(wk.stream, &g);
+                        if (g) (void)hipGraphDestroy(g);
+                        throw;
+                    }
+                    tl_capturing = false;
+                    LURK_HIP_CHECK(hipStreamEndCapture(wk.stream, &g));
+                    hipError_t e = hipGraphInstantiate(&wk.graph_exec, g, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(g);
+                    LURK_HIP_CHECK(e);
+                    wk.graph_scalars = d_scalars;
+                    wk.graph_n = n;
+                    wk.graph_mont = is_mont;
+                    wk.graph_table = (const void*)table;
+                    wk.graph_c = c;
+                }
+                LURK_HIP_CHECK(hipGraphLaunch(wk.graph_exec, wk.stream));
+            } else {
+                enqueue(wk, d_scalars, n, is_mont, wk.pending_stream, acc_s);
+            }
         }
         wk.pending = true;
         wk.pending_n = n;

@@ -252,6 +252,40 @@ def test_oneshot_key_cache(hip):
     assert point_to_affine(c, msm(c, B, S1)) == want(B, S1)               # cache off again: plain path
 
 
+def test_foreground_commitments_replayed_as_hipgraph(hip):
+    """LURK_MSM_GRAPH=1 (read once per process, hence a child): a foreground commitment is recorded into a hipGraph on first use
+    and replayed; new scalars in the SAME buffer give new results, another buffer / length records again."""
+    import os
+    import subprocess
+    import sys
+
+    child = r"""
+import numpy as np, torch
+from lurk_beta_amd import CommitmentKey, point_to_affine, synth
+c, n = 0, 1 << 14
+d_bases = synth.bases(c, n)
+bufs = [torch.empty((n, 4), dtype=torch.int64, device="cuda") for _ in range(2)]
+s = torch.cuda.current_stream().cuda_stream
+for pre in (False, True):
+    ck = CommitmentKey(c, d_bases, n=n, device=True, precompute=pre)
+    for j in range(6):
+        sc = synth.scalars(1, 60 + j, j % 2, n, mont=True)
+        m = n if j < 4 else n // 2
+        buf = bufs[j % 2]
+        buf.copy_(sc)
+        torch.cuda.synchronize()
+        want = point_to_affine(c, ck.commit_device(buf, m, is_mont=True))
+        ck.submit_device(1, buf, m, is_mont=True, stream=s, mode=1)
+        assert point_to_affine(c, ck.wait(1)) == want, (pre, j)
+    ck.close()
+print("GRAPH_OK")
+"""
+    env = dict(os.environ, LURK_MSM_GRAPH="1")
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=300, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "GRAPH_OK" in r.stdout, r.stderr[-800:]
+
+
 def test_point_sum(hip):
     from lurk_beta_amd import msm, point_sum, point_to_affine
 
