@@ -122,7 +122,7 @@ class CommitmentKey:
         return out
 
     def submit_device(self, slot: int, d_scalars, n: int, is_mont: bool = False, stream=None, mode: int = 0) -> None:
-        """Asynchronous commit on `slot` (0..2); pair with ``wait(slot)``.  mode: 0 = default, 1 = foreground (the commitment the
+        """Asynchronous commit on `slot` (0..3); pair with ``wait(slot)``.  mode: 0 = default, 1 = foreground (the commitment the
         host waits for next), 2 = background (work staged ahead)."""
         lib = _lib.load()
         self._keep = getattr(self, "_keep", {})
