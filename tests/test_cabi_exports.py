@@ -62,3 +62,18 @@ def test_compute_entry_points_fail_loudly_without_a_device():
         msm(0, np.zeros((1, 8), dtype=np.uint64), np.zeros((1, 4), dtype=np.uint64))
     with pytest.raises(LurkHipError):
         ntt(1, np.zeros((8, 4), dtype=np.uint64))
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/lurk_hip.h must stay a C header (a cgo / bindgen / cffi consumer compiles it as C): strict C99 and C++14, no warnings."""
+    import shutil
+    import subprocess
+
+    inc = os.path.join(ROOT, "include")
+    for cc, std, ext in (("gcc", "-std=c99", "c"), ("g++", "-std=c++14", "cpp")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"{cc} not available")
+        src = tmp_path / f"h.{ext}"
+        src.write_text('#include "lurk_hip.h"\nint main(void) { return 0; }\n')
+        r = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + inc, "-fsyntax-only", str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
