@@ -49,8 +49,8 @@ def _prove_resident_key(curve: int, q: int, key, ck_c: np.ndarray, d_a, d_b, cha
         h = m // 2
         cl, cr = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
         _lib.check(lib.lurk_hip_ipa_round_scalars_dev(sf, _lib.ptr(d_a), m, _lib.ptr(d_coef), n0, _lib.ptr(d_l), _lib.ptr(d_r), _lib.ptr(s)))
-        key.submit_device(0, d_l, n0, is_mont=True, stream=s)   # both commitments in flight under the inner products
-        key.submit_device(1, d_r, n0, is_mont=True, stream=s)
+        key.submit_device(0, d_l, n0, is_mont=True, stream=s, mode=1)   # both commitments in flight under the inner products; the host
+        key.submit_device(1, d_r, n0, is_mont=True, stream=s, mode=1)   # waits for both: the foreground class (plain accumulate launch)
         _lib.check(lib.lurk_hip_inner_product_dev(sf, _lib.ptr(d_a), _lib.ptr(d_b[h:]), h, _lib.ptr(cl), _lib.ptr(s)))
         _lib.check(lib.lurk_hip_inner_product_dev(sf, _lib.ptr(d_a[h:]), _lib.ptr(d_b), h, _lib.ptr(cr), _lib.ptr(s)))
         L = point_sum(curve, np.stack([key.wait(0), point_mul(curve, ck_c, cl)]))
