@@ -77,3 +77,22 @@ def test_header_is_plain_c_and_cxx(tmp_path):
         src.write_text('#include "lurk_hip.h"\nint main(void) { return 0; }\n')
         r = subprocess.run([cc, std, "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + inc, "-fsyntax-only", str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_inline_asm_operands_avoid_the_clobbered_scratch_registers(tmp_path):
+    """The generated multipliers use fixed scratch registers (declared as clobbers); compile the accumulate kernel to ISA and check
+    that no asm operand was allocated to one of them (bench_tools/check_asm_operands.py)."""
+    import shutil
+    import subprocess
+    import sys
+
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "lurk_beta_amd", "csrc")
+    r = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-variable", "-c", "msm_acc.hip",
+                        "-save-temps=obj", "-o", str(tmp_path / "msm_acc.o")], cwd=csrc, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-800:]
+    isa = [f for f in os.listdir(tmp_path) if f.endswith("gfx950.s")]
+    assert isa
+    chk = subprocess.run([sys.executable, os.path.join(ROOT, "bench_tools", "check_asm_operands.py"), str(tmp_path / isa[0])], capture_output=True, text=True)
+    assert chk.returncode == 0, chk.stdout[-800:]
