@@ -181,6 +181,9 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
     dot29_init<P>(row);
     dot29_mac<P>(row, r, f29_carry<P>(d));
     dot29_mac<P>(row, f29_carry<P>(f29_sub<P>(f29_zero<P>(), acc.y)), ppp);
+    // (the f29_reduce is not optional: in the affine-accumulator form r and p reach 2^260.6, the row 2^521.4, so Y3 can exceed
+    // 64p = 2^260 and the next addition's 64p - Y1 would go negative - seen on the GPU and reproduced on the host with points
+    // 640..642 of the synthetic key; in the general form Y3 stays below 2^259.96, but dropping the reduce there measured no gain)
     F29<P> y3 = f29_reduce<P>(dot29_finish<P>(row));
 #else
     const F29<P> t1 = f29_mul<P>(r, d);          // r tight (< 2^260.3), d loose (< 2^260.1): < 2^259.5
