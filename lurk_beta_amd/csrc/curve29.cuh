@@ -151,7 +151,10 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
     // r = S2 - Y1 for +q; for -q the true r is -(S2 + Y1): keep r' = S2 + Y1 and flip the sign of (Q - X3) below
     F29<P> r;
 #pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = s2.l[i] + (negate ? acc.y.l[i] : f29_bias<P>(i) - acc.y.l[i]);
+    for (int i = 0; i < 9; i++) {
+        F29_ASSERT(f29_bias<P>(i) >= acc.y.l[i], "madd: Y1 limb above the bias");
+        r.l[i] = s2.l[i] + (negate ? acc.y.l[i] : f29_bias<P>(i) - acc.y.l[i]);
+    }
     r = f29_carry<P>(r);
     if (p.l[0] < 128u && f29_is_multiple_of_p<P>(p)) {
         if (r.l[0] < 128u && f29_is_multiple_of_p<P>(r)) {  // r (or r' = -r) == 0: equal points
@@ -172,8 +175,10 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
     // D = Q - X3 (or X3 - Q when r' = -r)
     F29<P> d;
 #pragma unroll
-    for (int i = 0; i < 9; i++)
+    for (int i = 0; i < 9; i++) {
+        F29_ASSERT(f29_bias<P>(i) >= qq.l[i] && f29_bias<P>(i) >= x3.l[i], "madd: Q / X3 limb above the bias");
         d.l[i] = negate ? x3.l[i] + (f29_bias<P>(i) - qq.l[i]) : qq.l[i] + (f29_bias<P>(i) - x3.l[i]);
+    }
 #if LURK_ACC_Y3_ROW
     // Y3 = R D - Y1 PPP as ONE lazy row: R * D + (64p - Y1) * PPP, a single Montgomery reduction
     // (operands tight: 18 products of < 2^58 per column); value < 2^259.7 + p

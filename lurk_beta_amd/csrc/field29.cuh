@@ -21,6 +21,7 @@
 #if defined(LURK_F29_CHECK) && !defined(__HIP_DEVICE_COMPILE__)
 #include <cstdio>
 #include <cstdlib>
+#define F29_CHECKS_ACTIVE 1
 #define F29_ASSERT_LIMBS(v, bits, what)                                                        \
     do {                                                                                       \
         for (int _i = 0; _i < 9; _i++)                                                         \
@@ -38,6 +39,7 @@
 #define F29_ASSERT_LIMBS(v, bits, what) ((void)0)
 #define F29_ASSERT_TOP(v, bits, what) ((void)0)
 #define F29_ASSERT(cond, what) ((void)0)
+#define F29_CHECKS_ACTIVE 0
 #endif
 
 
@@ -119,7 +121,10 @@ template <class P>
 LURK_HD F29<P> f29_sub(const F29<P>& a, const F29<P>& b) {
     F29<P> r;
 #pragma unroll
-    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + (f29_bias<P>(i) - b.l[i]);
+    for (int i = 0; i < 9; i++) {
+        F29_ASSERT(f29_bias<P>(i) >= b.l[i], "f29_sub: subtrahend limb above the bias (value >= 64p or limbs not tight)");
+        r.l[i] = a.l[i] + (f29_bias<P>(i) - b.l[i]);
+    }
     return r;
 }
 template <class P>

@@ -1,6 +1,9 @@
 // Host-side harness: compiles the library's host/device headers (field.cuh, curve.cuh, ...) with
 // plain g++ so their arithmetic can be checked against the oracle without a GPU.  TEST ONLY: the
 // product never runs these on the CPU; the kernels in lurk_beta_amd/csrc/*.hip are the product.
+// every limb / accumulator bound the radix-2^29 layer relies on is asserted at run time in this host build: the switch has to
+// precede the FIRST inclusion of field29.cuh (poseidon29.cuh pulls it in)
+#define LURK_F29_CHECK 1
 #include <stddef.h>
 #include "../../lurk_beta_amd/csrc/field.cuh"
 using namespace lurk;
@@ -166,7 +169,6 @@ extern "C" int hh_poseidon_params(int field, int arity, int* rf, int* rp, uint32
 }
 
 // ---------------------------------------------------------------------------------------------
-#define LURK_F29_CHECK 1
 #include "../../lurk_beta_amd/csrc/curve29.cuh"
 
 // mode 0: acc = sum (+/-) P_i with xyzz_madd; mode 1: pairwise xyzz_add of xyzz_from_affine;
@@ -201,6 +203,9 @@ static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, si
     r = xyzz_to_affine<P>(xyzz_from_jacobian<P>(j));
     for (int k = 0; k < 8; k++) { out[k] = r.x.l[k]; out[8 + k] = r.y.l[k]; }
 }
+// 1 when the bound assertions of field29.cuh / curve29.cuh are compiled in (they silently were not while another header pulled
+// field29.cuh in ahead of the switch)
+extern "C" int hh_f29_checks_active() { return F29_CHECKS_ACTIVE; }
 extern "C" void hh_curve_sum(int curve, int mode, const uint32_t* bases, const uint32_t* signs, size_t n, uint32_t* out) {
     if (curve == 0) curve_sum<PallasFp>(mode, bases, signs, n, out);
     else curve_sum<PallasFq>(mode, bases, signs, n, out);

@@ -177,3 +177,37 @@ def test_radix29_partial_reduction(f):
         assert vout % p == vin % p
         assert all(x <= M for x in r_out[:8]) and r_out[8] < (1 << 23) + 1
         assert vout < (1 << 255) + (1 << 254)
+
+
+def test_bound_assertions_are_compiled_in_and_the_known_hard_window_passes():
+    """The harness exists to run the radix-2^29 code with every limb / accumulator bound asserted: make sure the switch reaches
+    the headers.  Points 640..703 of the synthetic Pallas key are the chain on which an accumulator without the Y3 reduction went
+    wrong (affine-accumulator first addition: Y3 above 64p): the shipped schedule must agree with the plain one on it."""
+    L = H.lib()
+    L.hh_f29_checks_active.restype = ctypes.c_int
+    assert L.hh_f29_checks_active() == 1
+    B = C.synth_bases(0, 704)[640:].copy()
+    for signs in (np.zeros(64, dtype=np.uint32), np.ones(64, dtype=np.uint32), (np.arange(64) % 2).astype(np.uint32)):
+        outs = []
+        for mode in (0, 3, 4):
+            out = np.zeros(8, dtype=np.uint64)
+            L.hh_curve_sum(0, mode, vp(B), vp(signs), ctypes.c_size_t(64), vp(out))
+            outs.append(C.affine_to_ints(0, out)[0])
+        assert outs[0] == outs[1] == outs[2]
+
+
+@pytest.mark.parametrize("c", [0, 1])
+def test_accumulator_stress_under_bound_assertions(c):
+    """40 000 points in task-sized chains (64 additions, the affine-accumulator first step each time, random signs) through the
+    kernel's schedule (mode 3) and the general-addition-only one (mode 4), every lazy bound asserted: no abort, same sums."""
+    L = H.lib()
+    n = 40000
+    B = C.synth_bases(c, n)
+    rng = np.random.default_rng(77 + c)
+    for w in range(0, n - 64, 64):
+        Bc = np.ascontiguousarray(B[w:w + 64])
+        signs = rng.integers(0, 2, 64).astype(np.uint32)
+        o3, o4 = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+        L.hh_curve_sum(c, 3, vp(Bc), vp(signs), ctypes.c_size_t(64), vp(o3))
+        L.hh_curve_sum(c, 4, vp(Bc), vp(signs), ctypes.c_size_t(64), vp(o4))
+        assert np.array_equal(o3, o4), w
