@@ -136,6 +136,7 @@ int lurk_hip_msm_ctx_rebind_dev(lurk_hip_msm_ctx* ctx, const void* d_bases_affin
  * prover that wants no allocation inside its first steps reserves them up front for the largest commitment it will make. */
 int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots);
 int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoints, int* window_bits, int* precomputed);
+int lurk_hip_msm_ctx_device(const lurk_hip_msm_ctx* ctx, int* device); /* the device the key is resident on */
 /* Commitment-key generation: arecibo's CommitmentEngine::setup(label, n) = DlogGroup::from_label as
  * PublicParams::setup reaches it (/root/reference/src/proof/nova.rs:196-216): SHAKE256(label) squeezed 32 bytes per point (host:
  * the XOF is sequential), point i = pasta_curves hash_to_curve("from_uniform_bytes") of its bytes - BLAKE2b-512 expand_message_xmd,
@@ -174,7 +175,7 @@ int lurk_hip_msm_multi_shard(const lurk_hip_msm_multi* ctx, int index, int* devi
 int lurk_hip_msm_multi_commit(lurk_hip_msm_multi* ctx, void* out_jacobian96, const void* scalars32, size_t nscalars,
                               int is_mont);
 int lurk_hip_msm_multi_commit_dev(lurk_hip_msm_multi* ctx, void* out_jacobian96, const void* const* d_scalars32,
-                                  size_t nscalars, int is_mont);
+                                  size_t n_slices, size_t nscalars, int is_mont); /* n_slices must equal num_shards */
 int lurk_hip_msm_multi_destroy(lurk_hip_msm_multi* ctx);
 
 /* Group helpers used by the multi-GPU gather (sum of per-rank partial commitments) and by tests:
@@ -291,6 +292,7 @@ int lurk_hip_r1cs_destroy(lurk_hip_r1cs* shape);
 int lurk_hip_r1cs_dims(const lurk_hip_r1cs* shape, int* field_id, size_t* num_cons, size_t* num_vars, size_t* num_io);
 int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b, size_t* nnz_c,
                        size_t* distinct_coefficients);
+int lurk_hip_r1cs_device(const lurk_hip_r1cs* shape, int* device); /* the device the shape is resident on */
 /* R1CSShape::multiply_vec: (A z, B z, C z); d_z has num_vars + 1 + num_io elements, outputs num_cons */
 int lurk_hip_r1cs_multiply_vec_dev(const lurk_hip_r1cs* shape, const void* d_z, void* d_az, void* d_bz,
                                    void* d_cz, void* stream);
@@ -310,8 +312,9 @@ int lurk_hip_fold_vec(int field_id, const void* a, const void* b, const void* r3
  * supernova.rs:231-244) runs per curve through arecibo's NIFS::prove, with the running pair (z1 = [W1 | u1 | X1], E1)
  * resident in HBM from step to step.  A prover holds one context per curve: Pallas (primary, the Lurk step circuit) and
  * Vesta (secondary).  shape and key are borrowed (same curve / scalar field, created on the same device) and must outlive
- * the context; the context uses the key's async slots (W2: 0 and 2 alternately, T: 1, late ranges: 3).  The challenge r comes from the caller's transcript (a
- * Poseidon sponge over the OTHER field of the cycle, absorbing the two commitments `begin` returns), hence two halves:
+ * the context; the context uses the key's async slots (W2: 0 and 2 alternately, T: 1, late ranges: 3).  The challenge r is a
+ * Poseidon sponge over the OTHER field of the cycle absorbing the two commitments `begin` returns, hence two halves (a caller
+ * with its own transcript uses them; lurk_hip_fold_step below runs begin, the library's own transcript and finish in one call):
  *   begin:  comm_W2 = commit(W2); T = cross term of (z1, [W2 | 1 | X2]); comm_T = commit(T)   - commitments in flight
  *   finish: W <- W1 + r W2, u <- u1 + r, X <- X1 + r X2, E <- E1 + r T                         - stream-ordered, no sync
  * The public IO X2 of a Lurk step is Store::to_scalar_vector's [tag, hash] x 3 (/root/reference/src/lem/store.rs:883-895,
@@ -346,6 +349,31 @@ int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* ctx, const void* r32_mont);
 int lurk_hip_fold_ctx_running_dev(lurk_hip_fold_ctx* ctx, void** d_z, void** d_e, void** stream);
 /* copies of the running pair for the host (either may be NULL); synchronises the context's stream */
 int lurk_hip_fold_ctx_read(lurk_hip_fold_ctx* ctx, void* z_host, void* e_host);
+/* The running INSTANCE U = (comm_W, comm_E, u, X) lives in the context beside the running witness: finish(r) folds it on the host
+ * as RelaxedR1CSInstance::fold does (comm_W1 + r comm_W2, comm_E1 + r comm_T, u1 + r, X1 + r X2) while the device folds the
+ * vectors.  set_instance installs the two commitments of a running pair given with set_running (u and X are taken from its z1);
+ * instance reads the four parts back (96-byte Jacobians, Montgomery scalars; any pointer may be NULL). */
+int lurk_hip_fold_ctx_set_instance(lurk_hip_fold_ctx* ctx, const void* comm_w_jacobian96, const void* comm_e_jacobian96);
+int lurk_hip_fold_ctx_instance(lurk_hip_fold_ctx* ctx, void* comm_w_jacobian96, void* comm_e_jacobian96, void* u32_mont, void* x_mont);
+/* NIFS::prove whole (/root/reference/src/proof/nova.rs:291-293 -> arecibo nifs.rs): begin, the challenge
+ * r = RO(pp_digest, U1, U2, comm_T) derived in the library (lurk_hip_nifs_challenge below), finish(r).  pp_digest32: the
+ * public parameters' digest, a canonical scalar (32 B).  Outputs (any may be NULL): the step's two commitments and r (Montgomery). */
+int lurk_hip_fold_step(lurk_hip_fold_ctx* ctx, const void* w2, int w2_on_device, void* w2_stream, const void* x2_mont,
+                       const void* pp_digest32, void* comm_w2_jacobian96, void* comm_t_jacobian96, void* r32_mont);
+
+/* ---- the transcript: Nova's random oracle (host code, no device needed; restated [MEM], parity unpinned) ------------------
+ * arecibo PoseidonRO over neptune's sponge API (simplex, arity 24, standard strength):
+ *   nova_ro_squeeze     absorbs n canonical elements of `field_id` (32 B each), squeezes one element and returns the integer of
+ *                       its low num_bits bits (32 B little-endian) - PoseidonRO::{absorb, squeeze};
+ *   nova_ro_pattern_tag neptune IOPattern([Absorb(a), Squeeze(s)]).value(domain_separator): the sponge's capacity element (16 B);
+ *   nifs_challenge      the absorb list of NIFS::prove on `curve`: pp_digest, U1 = (comm_W1, comm_E1, u1, X1 as 4 x 64-bit limbs
+ *                       each), U2 = (comm_W2, X2), comm_T - commitments as (x, y, is_infinity), scalars through scalar_as_base -
+ *                       then r = squeeze(NUM_CHALLENGE_BITS = 128) in Montgomery form of the curve's scalar field. */
+int lurk_hip_nova_ro_squeeze(int field_id, const void* elems32, size_t n, unsigned num_bits, void* out32);
+int lurk_hip_nova_ro_pattern_tag(uint32_t absorbs, uint32_t squeezes, uint32_t domain_separator, void* out16);
+int lurk_hip_nifs_challenge(int curve, const void* pp_digest32, const void* comm_w1_jacobian96, const void* comm_e1_jacobian96,
+                            const void* u1_mont, const void* x1_mont, const void* comm_w2_jacobian96, const void* x2_mont, size_t num_io,
+                            const void* comm_t_jacobian96, void* r32_mont);
 
 /* ---- sum-check rounds (the data-parallel half of CompressedSNARK::prove) -----------------------
  * CompressedSNARK::prove (/root/reference/src/proof/nova.rs:341-356, supernova.rs:293-302) -> arecibo RelaxedR1CSSNARK::prove ->

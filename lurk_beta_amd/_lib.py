@@ -50,13 +50,14 @@ SIGNATURES = {
     "lurk_hip_ck_from_label_dev": (c_int, [c_int, ctypes.c_char_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_msm_ctx_from_label": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.c_char_p, c_size_t, c_size_t, c_int]),
     "lurk_hip_msm_ctx_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "lurk_hip_msm_ctx_device": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "lurk_hip_msm_ctx_save": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
     "lurk_hip_msm_ctx_load": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int]),
     "lurk_hip_msm_multi_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, ctypes.POINTER(c_int), c_int, c_int]),
     "lurk_hip_msm_multi_num_shards": (c_int, [c_void_p]),
     "lurk_hip_msm_multi_shard": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "lurk_hip_msm_multi_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
-    "lurk_hip_msm_multi_commit_dev": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_size_t, c_int]),
+    "lurk_hip_msm_multi_commit_dev": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_size_t, c_size_t, c_int]),
     "lurk_hip_msm_multi_destroy": (c_int, [c_void_p]),
     "lurk_hip_point_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     "lurk_hip_point_mul": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "lurk_hip_r1cs_destroy": (c_int, [c_void_p]),
     "lurk_hip_r1cs_dims": (c_int, [c_void_p, ctypes.POINTER(c_int)] + [ctypes.POINTER(c_size_t)] * 3),
     "lurk_hip_r1cs_info": (c_int, [c_void_p] + [ctypes.POINTER(c_size_t)] * 4),
+    "lurk_hip_r1cs_device": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "lurk_hip_r1cs_multiply_vec_dev": (c_int, [c_void_p] * 6),
     "lurk_hip_r1cs_cross_term_dev": (c_int, [c_void_p] * 5),
     "lurk_hip_fold_vec_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -93,6 +95,12 @@ SIGNATURES = {
     "lurk_hip_fold_step_finish": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_running_dev": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
     "lurk_hip_fold_ctx_read": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_fold_ctx_set_instance": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_fold_ctx_instance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_fold_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_nova_ro_squeeze": (c_int, [c_int, c_void_p, c_size_t, c_uint, c_void_p]),
+    "lurk_hip_nova_ro_pattern_tag": (c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_void_p]),
+    "lurk_hip_nifs_challenge": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_sumcheck_round_dev": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_eq_evals_dev": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lurk_hip_inner_product_dev": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

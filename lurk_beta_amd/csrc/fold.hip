@@ -464,6 +464,13 @@ int lurk_hip_r1cs_dims(const lurk_hip_r1cs* shape, int* field_id, size_t* num_co
     });
 }
 
+int lurk_hip_r1cs_device(const lurk_hip_r1cs* shape, int* device) {
+    return guarded([&] {
+        LURK_REQUIRE(shape && device, "null argument");
+        *device = shape->sh.device;
+    });
+}
+
 int lurk_hip_r1cs_info(const lurk_hip_r1cs* shape, size_t* nnz_a, size_t* nnz_b, size_t* nnz_c, size_t* distinct_coefficients) {
     return guarded([&] {
         LURK_REQUIRE(shape, "null shape");

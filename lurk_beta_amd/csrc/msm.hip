@@ -52,15 +52,7 @@ struct MsmShape {
 // commitments in flight they share the SIMDs with the (older, VALU-saturating) accumulate waves of the previous
 // commitment, and the instruction arbiter serves the oldest wave first: measured 15-18x slowdowns of these kernels.
 // Raising their wave priority lets them issue when they are ready; they need a few percent of the VALU.
-__constant__ int msm_wave_prio[2] = {3, 3};  // [0] sort kernels, [1] plan / finalize / reduce kernels (experiment knob: LURK_MSM_SORT_PRIO, LURK_MSM_TAIL_PRIO)
-__device__ __forceinline__ void msm_set_wave_prio(int cls) {
-    switch (msm_wave_prio[cls]) {
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        case 2: __builtin_amdgcn_s_setprio(2); break;
-        case 3: __builtin_amdgcn_s_setprio(3); break;
-        default: break;
-    }
-}
+__device__ __forceinline__ void msm_set_wave_prio(int /*cls: 0 sort kernels, 1 plan / finalize / reduce kernels*/) { __builtin_amdgcn_s_setprio(3); }
 
 // ---- 1. digits ---------------------------------------------------------------------------
 // Both sweeps of sort pass 1 read the scalars themselves (32 B each) and recode them on the fly:
@@ -497,32 +489,19 @@ void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const
                            const uint32_t* group_task_base, int NG, Xyzz<P>* partials, size_t nt, hipStream_t s);
 template <class P>
 void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
-                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, int waves_per_simd, bool r128,
-                                      bool raised,
-                                      hipStream_t s);
+                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, hipStream_t s);
 
-// Tuning switches of the commitments-in-flight path (read once; the defaults are the measured best):
-// the accumulate kernel of a submitted commitment is persistent with ONE wave per SIMD, so that the accumulations of up to
-// three commitments in flight share every SIMD (three dependent mad chains keep the VALU issuing) and the short kernels of
-// the others always find registers and wave slots beside them.
+// Switches of the commitments-in-flight path (read once per process; the defaults are the measured best).
+// Everything else that round 2 kept for A/B runs (stream / wave priorities off, more waves per SIMD, a 128-VGPR build, hipGraph
+// replay, background-behind-sort off) lost its measurement and is gone: the winning setting is now the only code path.
 struct MsmTuning {
-    int persistent, waves, r128, prio, sort_prio, tail_prio, max_acc, placement_log, bg_behind_sort, fg_waves, graph;
+    int persistent, max_acc, placement_log;
     MsmTuning() {
         auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
-        persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // 0 = never, 1 = by size, 2 = always
-        waves = geti("LURK_MSM_ACC_WAVES", 1);
-        r128 = geti("LURK_MSM_ACC_R128", 0);
-        prio = geti("LURK_MSM_PRIO", 1);
-        sort_prio = geti("LURK_MSM_SORT_PRIO", 3);
-        tail_prio = geti("LURK_MSM_TAIL_PRIO", 3);
-        max_acc = geti("LURK_MSM_MAX_ACC", 2);
-        placement_log = geti("LURK_MSM_PLACEMENT_LOG", 0);
-        bg_behind_sort = geti("LURK_MSM_BG_BEHIND_SORT", 1);
-        graph = geti("LURK_MSM_GRAPH", 0);  // 1 = foreground commitments are recorded once per (slot, scalars, n) and replayed as a hipGraph
-        fg_waves = geti("LURK_MSM_FG_WAVES", 0);  // foreground accumulation: 0 = the plain launch (measured best), k = persistent with k waves per SIMD
-        if (max_acc > 2) max_acc = 0;  // 0 = unlimited (3 slots)
-        if (waves < 1) waves = 1;
-        if (waves > 8) waves = 8;
+        persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // DEFAULT-class commitments in flight: 0 = plain launch, 1 = persistent from 2^22 entries, 2 = always
+        max_acc = geti("LURK_MSM_MAX_ACC", 2);            // persistent accumulations resident at once (0 = no limit)
+        placement_log = geti("LURK_MSM_PLACEMENT_LOG", 0);  // diagnostic: persistent workgroups per CU, on stderr
+        if (max_acc > 2) max_acc = 0;
     }
 };
 static const MsmTuning& msm_tuning() {
@@ -683,16 +662,8 @@ struct MsmCtxBase {
     virtual void adopt_table(DevBuf&& buf, size_t n, bool precomputed_, int c_) = 0;
 };
 
-static std::atomic<int> g_oneshot_key_cache{-1};  // -1: take LURK_MSM_ONESHOT_KEY_CACHE from the environment (default off)
-static bool oneshot_key_cache_enabled() {
-    int v = g_oneshot_key_cache.load();
-    if (v < 0) {
-        const char* e = getenv("LURK_MSM_ONESHOT_KEY_CACHE");
-        v = e && atoi(e) != 0 ? 1 : 0;
-        g_oneshot_key_cache.store(v);
-    }
-    return v != 0;
-}
+static std::atomic<int> g_oneshot_key_cache{0};  // lurk_hip_msm_oneshot_key_cache(1) turns it on (default off)
+static bool oneshot_key_cache_enabled() { return g_oneshot_key_cache.load() != 0; }
 
 template <class P, class SF>
 struct MsmCtx : MsmCtxBase {
@@ -704,24 +675,19 @@ struct MsmCtx : MsmCtxBase {
         DevBuf inter, sorted, block_hist, part_cnt, part_start, cnt, bucket_start, task_start, group_tasks, group_task_base, task_info,
             task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, canon;
         Xyzz<P>* host_pts = nullptr;  // pinned: window sums or bit planes for the host tail
-        size_t ws_n = 0;
+        size_t ws_n = 0, ws_entries = 0, ws_nt = 0;  // what the workspaces hold room for: scalars (0 = nothing yet), sorted entries, tasks,
+        uint32_t ws_NB = 0;                          // keys
         hipStream_t stream = nullptr;      // slot stream: sort, plan, finalize, reduce (high priority)
         hipStream_t acc_stream = nullptr;  // the accumulate kernel alone (low priority)
         hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
         DevBuf cursor;                     // task cursor of the persistent accumulate kernel (+ its per-CU placement counters)
         bool placement_valid = false;
-        hipGraphExec_t graph_exec = nullptr;  // the recorded commitment (LURK_MSM_GRAPH) and what it was recorded for
-        const void* graph_scalars = nullptr;
-        const void* graph_table = nullptr;
-        size_t graph_n = 0;
-        int graph_mont = -1, graph_c = 0;
         bool force_persistent = false;     // LURK_MSM_SUBMIT_BACKGROUND
         bool foreground = false;           // LURK_MSM_SUBMIT_FOREGROUND
         hipStream_t pending_stream = nullptr;  // the stream the pending commitment ends on
         bool pending = false;
         size_t pending_n = 0;
         ~Work() {
-            if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
             if (host_pts) (void)hipHostFree(host_pts);
             if (stream) (void)hipStreamDestroy(stream);
             if (acc_stream) (void)hipStreamDestroy(acc_stream);
@@ -764,10 +730,6 @@ struct MsmCtx : MsmCtxBase {
     }
 
     void set_bases_device(const void* d_bases, size_t n, bool copy, bool precompute, int c_override, hipStream_t s) {
-        {
-            const int pr[2] = {msm_tuning().sort_prio, msm_tuning().tail_prio};
-            LURK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(msm_wave_prio), pr, sizeof(pr)));
-        }
         npoints = n;
         precomputed = precompute;
         // plain: 16-bit windows (W = 16 key spaces of 2^15 buckets).  With the table every window shares
@@ -902,19 +864,15 @@ struct MsmCtx : MsmCtxBase {
         npoints = n;
         precomputed = precomputed_;
         c = c_;
-        const int pr[2] = {msm_tuning().sort_prio, msm_tuning().tail_prio};
-        LURK_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(msm_wave_prio), pr, sizeof(pr)));
     }
 
     size_t ntask_max(const MsmShape& sh) const { return (size_t)sh.NB + (size_t)sh.W * sh.n / MSM_S + 1; }
 
     void ensure_workspace(Work& wk, const MsmShape& sh) {
-        if (sh.n <= wk.ws_n && wk.ws_n != 0) return;
-        if (wk.graph_exec) {  // the buffers are about to move: a recorded commitment holds their old addresses
-            (void)hipGraphExecDestroy(wk.graph_exec);
-            wk.graph_exec = nullptr;
-        }
+        // the buffer sizes depend on (W n, NB), not on n alone: a context rebound from a table key (c = 20: 13 n entries, 2^19
+        // keys) to a plain one (c = 16: 16 n entries, 16 x 2^15 keys) keeps its workspaces and must grow them
         const size_t entries = (size_t)sh.W * sh.n, nt = ntask_max(sh);
+        if (wk.ws_n != 0 && entries <= wk.ws_entries && nt <= wk.ws_nt && sh.NB <= wk.ws_NB) return;
         wk.inter.ensure(entries * 8);
         wk.sorted.ensure(entries * 4);
         wk.block_hist.ensure((size_t)MSM_NB1 * MSM_P_MAX * 4);
@@ -936,7 +894,10 @@ struct MsmCtx : MsmCtxBase {
         wk.planes_a.ensure((size_t)sh.NB * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
         wk.planes_b.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
         if (!wk.host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&wk.host_pts, (size_t)MSM_MAX_W * 20 * sizeof(Xyzz<P>)));
-        wk.ws_n = sh.n;
+        wk.ws_n = sh.n > wk.ws_n ? sh.n : wk.ws_n;
+        wk.ws_entries = entries > wk.ws_entries ? entries : wk.ws_entries;
+        wk.ws_nt = nt > wk.ws_nt ? nt : wk.ws_nt;
+        wk.ws_NB = sh.NB > wk.ws_NB ? sh.NB : wk.ws_NB;
     }
 
     // every kernel of one commitment + the D2H of its <= 20 result points, on stream s
@@ -997,7 +958,7 @@ struct MsmCtx : MsmCtxBase {
         // commitments in flight take the persistent form on the slot's low-priority accumulate stream (tiny ones excepted: their
         // accumulation is over before a second kernel could share the chip); synchronous calls keep the plain launch
         const bool persistent = s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 22) : tn.persistent != 0));
-        if (wk.planned && !tl_capturing) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));  // sort and plan are enqueued: a background commitment may start behind this point
+        if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));  // sort and plan are enqueued: a background commitment may start behind this point
         if (persistent) {
             LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4 * (MSM_PLACEMENT_BASE + 512), s));
             wk.placement_valid = true;
@@ -1023,8 +984,7 @@ struct MsmCtx : MsmCtxBase {
                 ProfScope ps("msm_accumulate", s_acc);
                 msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
                                                     wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
-                                                    wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(),
-                                                    wk.foreground ? tn.fg_waves : tn.waves, tn.r128 != 0, wk.foreground, s_acc);
+                                                    wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(), s_acc);
             }
             LURK_HIP_CHECK(hipEventRecord(wk.accumulated, s_acc));
             LURK_HIP_CHECK(hipStreamWaitEvent(s, wk.accumulated, 0));
@@ -1102,7 +1062,7 @@ struct MsmCtx : MsmCtxBase {
             // launches of a commitment was dispatched 40 us late - 50-60 us per bit-plane level instead of 13 - even on an idle chip.)
             const bool bg = mode == LURK_MSM_SUBMIT_BACKGROUND;
             wk.foreground = mode == LURK_MSM_SUBMIT_FOREGROUND;
-            wk.force_persistent = bg || (wk.foreground && msm_tuning().fg_waves > 0);
+            wk.force_persistent = bg;
             wk.pending_stream = wk.stream;
             LURK_HIP_CHECK(hipEventRecord(wk.ready, after));
             LURK_HIP_CHECK(hipStreamWaitEvent(wk.pending_stream, wk.ready, 0));
@@ -1110,50 +1070,13 @@ struct MsmCtx : MsmCtxBase {
                 // a background commitment starts behind the sort of the foreground commitment in flight: its own sort (LDS atomics,
                 // barriers) then runs under the foreground accumulation (integer VALU) instead of beside the foreground sort
                 std::lock_guard<std::mutex> lk2(fg_mu);
-                if (bg && last_fg && last_fg != &wk && last_fg->planned && msm_tuning().bg_behind_sort)
+                if (bg && last_fg && last_fg != &wk && last_fg->planned)
                     LURK_HIP_CHECK(hipStreamWaitEvent(wk.pending_stream, last_fg->planned, 0));
                 if (mode == LURK_MSM_SUBMIT_FOREGROUND) last_fg = &wk;
             }
             // foreground: everything on the (high-priority) slot stream
-            hipStream_t acc_s = wk.foreground ? (msm_tuning().fg_waves > 0 ? wk.stream : nullptr) : wk.acc_stream;
-            if (msm_tuning().graph && wk.foreground && acc_s == nullptr) {
-                // A foreground commitment is ~45 dependent launches on ONE stream with nothing but device pointers in their arguments:
-                // recorded once per (scalars, n) and replayed, it costs the host one call instead of 45 (the small commitments of the
-                // secondary curve are launch-bound on both sides).
-                if (!wk.graph_exec || wk.graph_scalars != d_scalars || wk.graph_n != n || wk.graph_mont != is_mont || wk.graph_table != (const void*)table ||
-                    wk.graph_c != c) {
-                    if (wk.graph_exec) LURK_HIP_CHECK(hipGraphExecDestroy(wk.graph_exec));
-                    wk.graph_exec = nullptr;
-                    ensure_workspace(wk, shape(n));   // nothing may allocate inside the recording
-                    if (is_mont) wk.canon.ensure(n * 32);
-                    allow_dynamic_lds((const void*)msm_scatter1_kernel<SF>, (int)MSM_LDS_BYTES);
-                    allow_dynamic_lds((const void*)msm_part2_kernel, (int)MSM_LDS_BYTES);
-                    hipGraph_t g = nullptr;
-                    LURK_HIP_CHECK(hipStreamBeginCapture(wk.stream, hipStreamCaptureModeThreadLocal));
-                    tl_capturing = true;
-                    try {
-                        enqueue(wk, d_scalars, n, is_mont, wk.stream, nullptr);
-                    } catch (...) {
-                        tl_capturing = false;
-                        (void)hipStreamEndCapture(wk.stream, &g);
-                        if (g) (void)hipGraphDestroy(g);
-                        throw;
-                    }
-                    tl_capturing = false;
-                    LURK_HIP_CHECK(hipStreamEndCapture(wk.stream, &g));
-                    hipError_t e = hipGraphInstantiate(&wk.graph_exec, g, nullptr, nullptr, 0);
-                    (void)hipGraphDestroy(g);
-                    LURK_HIP_CHECK(e);
-                    wk.graph_scalars = d_scalars;
-                    wk.graph_n = n;
-                    wk.graph_mont = is_mont;
-                    wk.graph_table = (const void*)table;
-                    wk.graph_c = c;
-                }
-                LURK_HIP_CHECK(hipGraphLaunch(wk.graph_exec, wk.stream));
-            } else {
-                enqueue(wk, d_scalars, n, is_mont, wk.pending_stream, acc_s);
-            }
+            hipStream_t acc_s = wk.foreground ? nullptr : wk.acc_stream;
+            enqueue(wk, d_scalars, n, is_mont, wk.pending_stream, acc_s);
         }
         wk.pending = true;
         wk.pending_n = n;
@@ -1165,9 +1088,8 @@ struct MsmCtx : MsmCtxBase {
             // high-priority one: the short kernels of the next commitment are dispatched ahead of it as wave slots free up
             int least = 0, greatest = 0;
             LURK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-            const bool prio = msm_tuning().prio != 0;
-            LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.stream, hipStreamNonBlocking, prio ? greatest : 0));
-            LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.acc_stream, hipStreamNonBlocking, prio ? least : 0));
+            LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.stream, hipStreamNonBlocking, greatest));
+            LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.acc_stream, hipStreamNonBlocking, least));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.ready, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.planned, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.accumulated, hipEventDisableTiming));
@@ -1553,6 +1475,12 @@ int lurk_hip_msm_ctx_from_label(lurk_hip_msm_ctx** ctx, int curve, const void* l
         *ctx = new lurk_hip_msm_ctx{std::move(c)};
     });
 }
+int lurk_hip_msm_ctx_device(const lurk_hip_msm_ctx* ctx, int* device) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && device, "null argument");
+        *device = ctx->impl->device;
+    });
+}
 int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoints, int* window_bits, int* precomputed) {
     return guarded([&] {
         LURK_REQUIRE(ctx, "null ctx");
@@ -1621,9 +1549,10 @@ int lurk_hip_msm_multi_commit(lurk_hip_msm_multi* m, void* out, const void* scal
         m->sum(n, out);
     });
 }
-int lurk_hip_msm_multi_commit_dev(lurk_hip_msm_multi* m, void* out, const void* const* d_scalars, size_t n, int is_mont) {
+int lurk_hip_msm_multi_commit_dev(lurk_hip_msm_multi* m, void* out, const void* const* d_scalars, size_t n_slices, size_t n, int is_mont) {
     return guarded([&] {
         LURK_REQUIRE(m && out, "null argument");
+        LURK_REQUIRE(n_slices == m->shards.size(), "one device pointer per shard is required (n_slices != number of shards)");
         LURK_REQUIRE(n <= m->npoints, "more scalars than bases in the context");
         LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
         std::lock_guard<std::mutex> lk(m->mu);

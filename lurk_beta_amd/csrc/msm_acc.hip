@@ -62,36 +62,22 @@ __device__ __forceinline__ uint32_t msm_cu_index() {
 // 64 tasks of the longest-first order from a global cursor.  The kernel then never holds more than its share of every
 // SIMD's registers and wave slots, so the latency / HBM-bound kernels of the NEXT commitment (sort, plan, bucket
 // reduction: other stream, higher priority) find room on every CU while this one keeps the integer VALU busy.
-#define LURK_ACC_PERSISTENT_BODY                                                                                       \
-    if (raised) __builtin_amdgcn_s_setprio(1); /* a foreground accumulation beside a background one */                \
-    const uint32_t ntasks = group_task_base[NG];                                                                       \
-    const uint32_t lane = threadIdx.x & 63u;                                                                           \
-    if (threadIdx.x == 0) atomicAdd(&cursor[MSM_PLACEMENT_BASE + msm_cu_index()], 1u); /* diagnostic: workgroups per CU */ \
-    for (;;) {                                                                                                         \
-        uint32_t base = 0;                                                                                             \
-        if (lane == 0) base = atomicAdd(cursor, 64u);                                                                  \
-        base = __builtin_amdgcn_readfirstlane(base); /* wave-uniform: the loop control stays scalar */                 \
-        if (base >= ntasks) break;                                                                                     \
-        if (base + lane < ntasks) msm_accumulate_task<P>(base + lane, sorted, table, task_info, order, partials);      \
-    }
-#ifndef LURK_ACC_PERSISTENT_ATTR
-#define LURK_ACC_PERSISTENT_ATTR
-#endif
 template <class P>
-__global__ __launch_bounds__(MSM_ACC_BLOCK) LURK_ACC_PERSISTENT_ATTR void msm_accumulate_persistent_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
+__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_persistent_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
                                                                                     const uint2* __restrict__ task_info,
                                                                                     const uint32_t* __restrict__ order,
                                                                                     const uint32_t* __restrict__ group_task_base, int NG,
-                                                                                    Xyzz<P>* __restrict__ partials, uint32_t* __restrict__ cursor, int raised) {
-    LURK_ACC_PERSISTENT_BODY
-}
-// same, compiled for <= 128 VGPRs (4 waves per SIMD of register budget): two of its waves and four 64-register waves of a
-// 1024-thread sort workgroup fit one SIMD's 512 registers together
-template <class P>
-__global__ __launch_bounds__(MSM_ACC_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void msm_accumulate_persistent128_kernel(
-    const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table, const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
-    const uint32_t* __restrict__ group_task_base, int NG, Xyzz<P>* __restrict__ partials, uint32_t* __restrict__ cursor, int raised) {
-    LURK_ACC_PERSISTENT_BODY
+                                                                                    Xyzz<P>* __restrict__ partials, uint32_t* __restrict__ cursor) {
+    const uint32_t ntasks = group_task_base[NG];
+    const uint32_t lane = threadIdx.x & 63u;
+    if (threadIdx.x == 0) atomicAdd(&cursor[MSM_PLACEMENT_BASE + msm_cu_index()], 1u);  // diagnostic: workgroups per CU
+    for (;;) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);  // wave-uniform: the loop control stays scalar
+        if (base >= ntasks) break;
+        if (base + lane < ntasks) msm_accumulate_task<P>(base + lane, sorted, table, task_info, order, partials);
+    }
 }
 
 template <class P>
@@ -100,24 +86,18 @@ void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const
     hipLaunchKernelGGL((msm_accumulate_kernel<P>), dim3(div_up(nt, MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
                        group_task_base, NG, partials);
 }
-// waves_per_simd workgroups of 4 waves per CU; cursor must be zero when the kernel starts
+// one workgroup of 4 waves per CU (one wave per SIMD); cursor must be zero when the kernel starts
 template <class P>
 void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
-                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, int waves_per_simd, bool r128,
-                                      bool raised, hipStream_t s) {
-    const unsigned blocks = (unsigned)num_cus() * (unsigned)waves_per_simd;
-    if (r128)
-        hipLaunchKernelGGL((msm_accumulate_persistent128_kernel<P>), dim3(blocks), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
-                           group_task_base, NG, partials, cursor, (int)raised);
-    else
-        hipLaunchKernelGGL((msm_accumulate_persistent_kernel<P>), dim3(blocks), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
-                           group_task_base, NG, partials, cursor, (int)raised);
+                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, hipStream_t s) {
+    hipLaunchKernelGGL((msm_accumulate_persistent_kernel<P>), dim3((unsigned)num_cus()), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
+                       group_task_base, NG, partials, cursor);
 }
 #define LURK_ACC_INSTANTIATE(P)                                                                                                             \
     template void msm_launch_accumulate<P>(const uint32_t*, const Affine<P>*, const uint2*, const uint32_t*, const uint32_t*, int, Xyzz<P>*, \
                                            size_t, hipStream_t);                                                                            \
     template void msm_launch_accumulate_persistent<P>(const uint32_t*, const Affine<P>*, const uint2*, const uint32_t*, const uint32_t*, int, \
-                                                      Xyzz<P>*, uint32_t*, int, bool, bool, hipStream_t);
+                                                      Xyzz<P>*, uint32_t*, hipStream_t);
 LURK_ACC_INSTANTIATE(PallasFp)
 LURK_ACC_INSTANTIATE(PallasFq)
 

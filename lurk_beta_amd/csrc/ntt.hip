@@ -9,7 +9,7 @@
 //   log_n >= 12  wave-resident passes (ntt_wave_pass_kernel below): <= 8 stages per pass with the butterflies in registers and
 //                across lanes (__shfl_xor), radix-2^29 arithmetic, bit reversal folded into the first pass's tile addressing,
 //                LDS only as the transposing tile and the twiddle table: 3 passes over memory at 2^24
-//   smaller      the LDS-stage kernels (also reachable with LURK_NTT_LDS_PASSES=1 for A/B runs):
+//   smaller      the LDS-stage kernels (sizes below 2^12 only):
 // Shape of the LDS-stage path: decimation-in-time after a bit-reversal permutation, in passes that each fuse several
 // radix-2 stages out of an LDS tile:
 //   * the permutation is a 32x32 LDS transpose (both the reads and the writes are 1 KiB rows);
@@ -384,7 +384,7 @@ static void ntt_device(void* d_data, unsigned log_n, bool inverse, hipStream_t s
     const Fe<F>* tw = plan.tw.template as<Fe<F>>();
     allow_dynamic_lds((const void*)ntt_pass_kernel<F>, 160 * 1024);
     ProfScope ps("ntt", s);
-    if (log_n >= 12 && !getenv("LURK_NTT_LDS_PASSES")) {
+    if (log_n >= 12) {
         NttConst29 cst;
         {
             Fe<F> v = fe_one<F>();  // 2^256 mod p as a plain integer -> 2^522 mod p

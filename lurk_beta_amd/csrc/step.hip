@@ -13,6 +13,7 @@
 // A prover holds two of these contexts: Pallas (primary: the Lurk step circuit) and Vesta (secondary: ~10^4 constraints).
 #include <chrono>
 #include <memory>
+#include <vector>
 
 #include "common.hpp"
 #include "field.cuh"
@@ -43,6 +44,12 @@ struct lurk_hip_fold_ctx {
                                        // (what their commitment reads while late ranges are written into z2); the late ranges alone
     int cur = 0;
     bool begun = false;
+    // the running INSTANCE U1 = (comm_W, comm_E, u, X) beside the running witness: host copies, folded in finish(r) exactly as
+    // RelaxedR1CSInstance::fold does (comm_W1 + r comm_W2, comm_E1 + r comm_T, u1 + r, X1 + r X2); the transcript absorbs them
+    uint64_t comm_w[12] = {0}, comm_e[12] = {0};       // Jacobian, identity (z = 0): RelaxedR1CSInstance::default
+    std::vector<uint64_t> ux;                          // [u | X] Montgomery, 1 + num_io elements
+    std::vector<uint64_t> open_x2;                     // X2 of the open step
+    uint64_t open_cw[12] = {0}, open_ct[12] = {0};     // comm_W2, comm_T of the open step
     // fresh instances staged ahead of their step (lurk_hip_fold_step_prefetch): buffer b commits on the key's slot 2 b, T on slot 1
     int staged[2] = {0, 0}, n_staged = 0, next_buf = 0, open_buf = 0;
     bool folded_valid[2] = {false, false}, submitted[2] = {false, false}, partial[2] = {false, false};
@@ -75,6 +82,9 @@ static void fold_submit_staged(lurk_hip_fold_ctx* c, int b, int mode) {
 // Stage positions [offset, offset + count) of the next fresh witness (the rest zero for now) and start its commitment.
 static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size_t count, int on_device, void* w2_stream) {
     LURK_REQUIRE(c->n_staged < 2, "two fresh instances are already staged: begin a step first");
+    // two z2 buffers: while a step is open its instance occupies one of them until finish(r) has folded it, so only ONE more
+    // can be staged (the next buffer in turn would be the open step's own)
+    LURK_REQUIRE(!(c->begun && c->n_staged >= 1), "a step is open and the other buffer is already staged: finish the step first");
     LURK_REQUIRE(offset <= c->num_vars && count <= c->num_vars - offset, "witness range out of bounds");
     LURK_REQUIRE(count == 0 || w2, "null witness");
     const int b = c->next_buf;
@@ -186,6 +196,46 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
                 tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4]);
     c->open_buf = b;
     c->begun = true;
+    c->open_x2.assign((const uint64_t*)x2_mont, (const uint64_t*)x2_mont + 4 * c->num_io);
+    memcpy(c->open_cw, comm_w2_jac96, 96);
+    memcpy(c->open_ct, comm_t_jac96, 96);
+}
+
+// [u | X] <- [u1 + r | X1 + r X2] on the host (1 + num_io elements; u2 = 1)
+template <class F>
+static void fold_ux_host(std::vector<uint64_t>& ux, const std::vector<uint64_t>& x2, const void* r_mont) {
+    Fe<F> r;
+    memcpy(r.l, r_mont, 32);
+    const size_t n = ux.size() / 4;
+    for (size_t i = 0; i < n; i++) {
+        Fe<F> a, b;
+        memcpy(a.l, &ux[4 * i], 32);
+        if (i == 0) b = fe_one<F>();
+        else memcpy(b.l, &x2[4 * (i - 1)], 32);
+        a = fe_add<F>(a, fe_mul<F>(r, b));
+        memcpy(&ux[4 * i], a.l, 32);
+    }
+}
+
+static void fold_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
+    const int nx = c->cur ^ 1;
+    // z = [W | u | X]: one pass folds the witness, u <- u1 + r * 1 and X <- X1 + r X2
+    ok(lurk_hip_fold_vec_dev(c->field_id, c->z[c->cur].p, c->z2[c->open_buf].p, r32_mont, c->ncols, c->z[nx].p, c->stream));
+    ok(lurk_hip_fold_vec_dev(c->field_id, c->e[c->cur].p, c->t.p, r32_mont, c->num_cons, c->e[nx].p, c->stream));
+    LURK_HIP_CHECK(hipEventRecord(c->folded_ev[c->open_buf], c->stream));
+    c->folded_valid[c->open_buf] = true;
+    c->cur = nx;
+    c->begun = false;
+    // the instance side on the host while the device folds the vectors: two 128-bit scalar multiples and two additions
+    uint64_t pair[24];
+    memcpy(pair, c->comm_w, 96);
+    ok(lurk_hip_point_mul(c->curve, pair + 12, c->open_cw, r32_mont, 1));
+    ok(lurk_hip_point_sum(c->curve, c->comm_w, pair, 2));
+    memcpy(pair, c->comm_e, 96);
+    ok(lurk_hip_point_mul(c->curve, pair + 12, c->open_ct, r32_mont, 1));
+    ok(lurk_hip_point_sum(c->curve, c->comm_e, pair, 2));
+    if (c->field_id == LURK_FIELD_PALLAS_FQ) fold_ux_host<PallasFq>(c->ux, c->open_x2, r32_mont);
+    else fold_ux_host<PallasFp>(c->ux, c->open_x2, r32_mont);
 }
 
 }  // namespace lurk
@@ -206,12 +256,19 @@ int lurk_hip_fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* 
         c->shape = shape;
         c->key = key;
         c->ncols = c->num_vars + 1 + c->num_io;
-        c->device = current_device();
+        // the context lives where its key lives; the shape must be there too (every other handle records its device as well)
+        int key_device = 0, shape_device = 0;
+        ok(lurk_hip_msm_ctx_device(key, &key_device));
+        ok(lurk_hip_r1cs_device(shape, &shape_device));
+        LURK_REQUIRE(key_device == shape_device, "the R1CS shape and the commitment key live on different devices");
+        c->device = key_device;
+        DeviceGuard dg(c->device);
         for (int k = 0; k < 2; k++) {
             c->z[k].alloc(c->ncols * 32);
             c->e[k].alloc(c->num_cons * 32);
         }
         c->t.alloc(c->num_cons * 32);
+        c->ux.assign(4 * (1 + c->num_io), 0);
         LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
         LURK_HIP_CHECK(hipEventCreateWithFlags(&c->w2_ready, hipEventDisableTiming));
@@ -246,6 +303,51 @@ int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* c, const void* z1, const vo
         LURK_HIP_CHECK(hipMemcpyAsync(c->z[c->cur].p, z1, c->ncols * 32, hipMemcpyHostToDevice, c->stream));
         LURK_HIP_CHECK(hipMemcpyAsync(c->e[c->cur].p, e1, c->num_cons * 32, hipMemcpyHostToDevice, c->stream));
         LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
+        memcpy(c->ux.data(), (const char*)z1 + c->num_vars * 32, (1 + c->num_io) * 32);
+    });
+}
+
+// the running instance's commitments (96-byte Jacobians); u and X come with set_running's z1
+int lurk_hip_fold_ctx_set_instance(lurk_hip_fold_ctx* c, const void* comm_w_jac96, const void* comm_e_jac96) {
+    return guarded([&] {
+        LURK_REQUIRE(c && comm_w_jac96 && comm_e_jac96, "null argument");
+        std::lock_guard<std::mutex> lk(c->mu);
+        LURK_REQUIRE(!c->begun, "a step is open: finish it first");
+        memcpy(c->comm_w, comm_w_jac96, 96);
+        memcpy(c->comm_e, comm_e_jac96, 96);
+    });
+}
+
+int lurk_hip_fold_ctx_instance(lurk_hip_fold_ctx* c, void* comm_w_jac96, void* comm_e_jac96, void* u32_mont, void* x_mont) {
+    return guarded([&] {
+        LURK_REQUIRE(c, "null ctx");
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (comm_w_jac96) memcpy(comm_w_jac96, c->comm_w, 96);
+        if (comm_e_jac96) memcpy(comm_e_jac96, c->comm_e, 96);
+        if (u32_mont) memcpy(u32_mont, c->ux.data(), 32);
+        if (x_mont && c->num_io) memcpy(x_mont, c->ux.data() + 4, c->num_io * 32);
+    });
+}
+
+// NIFS::prove in one call: begin -> r = RO(pp_digest, U1, U2, comm_T) (transcript.hip) -> finish(r)
+int lurk_hip_fold_step(lurk_hip_fold_ctx* c, const void* w2, int w2_on_device, void* w2_stream, const void* x2_mont, const void* pp_digest32,
+                       void* comm_w2_jac96, void* comm_t_jac96, void* r32_mont) {
+    return guarded([&] {
+        LURK_REQUIRE(c && pp_digest32, "null argument");
+        LURK_REQUIRE(c->num_vars == 0 || w2, "null witness");
+        LURK_REQUIRE(c->num_io == 0 || x2_mont, "null public IO");
+        DeviceGuard dg(c->device);
+        std::lock_guard<std::mutex> lk(c->mu);
+        LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
+        LURK_REQUIRE(c->n_staged == 0, "fresh instances are staged: use lurk_hip_fold_step_begin_prefetched");
+        uint64_t cw[12], ct[12], r[4];
+        fold_stage(c, w2, 0, c->num_vars, w2_on_device, w2_stream);
+        fold_begin(c, nullptr, 0, x2_mont, cw, ct);
+        ok(lurk_hip_nifs_challenge(c->curve, pp_digest32, c->comm_w, c->comm_e, c->ux.data(), c->ux.data() + 4, cw, x2_mont, c->num_io, ct, r));
+        fold_finish(c, r);
+        if (comm_w2_jac96) memcpy(comm_w2_jac96, cw, 96);
+        if (comm_t_jac96) memcpy(comm_t_jac96, ct, 96);
+        if (r32_mont) memcpy(r32_mont, r, 32);
     });
 }
 
@@ -292,14 +394,7 @@ int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
         DeviceGuard dg(c->device);
         std::lock_guard<std::mutex> lk(c->mu);
         LURK_REQUIRE(c->begun, "no step is open");
-        const int nx = c->cur ^ 1;
-        // z = [W | u | X]: one pass folds the witness, u <- u1 + r * 1 and X <- X1 + r X2
-        ok(lurk_hip_fold_vec_dev(c->field_id, c->z[c->cur].p, c->z2[c->open_buf].p, r32_mont, c->ncols, c->z[nx].p, c->stream));
-        ok(lurk_hip_fold_vec_dev(c->field_id, c->e[c->cur].p, c->t.p, r32_mont, c->num_cons, c->e[nx].p, c->stream));
-        LURK_HIP_CHECK(hipEventRecord(c->folded_ev[c->open_buf], c->stream));
-        c->folded_valid[c->open_buf] = true;
-        c->cur = nx;
-        c->begun = false;
+        fold_finish(c, r32_mont);
     });
 }
 

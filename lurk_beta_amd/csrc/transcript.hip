@@ -1,0 +1,268 @@
+// transcript.hip - the folding challenge r: Nova's random oracle (host code; no kernel in this file).
+//
+// Reference: the closure lurk-beta hands every step to (/root/reference/src/proof/nova.rs:282-295) runs arecibo's
+// RecursiveSNARK::prove_step -> NIFS::prove, which derives r between commit(T) and the fold:
+//     ro = RO::new(ro_consts, NUM_FE_FOR_RO); ro.absorb(pp_digest); U1.absorb_in_ro(ro); U2.absorb_in_ro(ro);
+//     comm_T.absorb_in_ro(ro); r = ro.squeeze(NUM_CHALLENGE_BITS)
+// RO = PoseidonRO<Base, Scalar> over neptune's sponge API.  arecibo and neptune are un-vendored git
+// dependencies (/root/reference/Cargo.toml:127-128), so everything below is restated from their published sources [MEM] and is
+// UNPINNED: no transcript value exists in /root/reference.  What is restated:
+//   * neptune Sponge::api_constants(Strength::Standard), arity U24: width t = 25, the round numbers / Grain-LFSR constants /
+//     Cauchy MDS of poseidon_params.hpp (the same generator as the hash3/4/6/8 constants, which ARE pinned by the KATs);
+//   * neptune sponge API, simplex mode: capacity element state[0] = the IO-pattern tag, rate = 24 elements state[1..25);
+//     absorb adds into the rate (a permutation when the rate is full), squeeze permutes when nothing is left to read;
+//     IOPattern([Absorb(n), Squeeze(1)]).value(domain separator 0): x = 2^128 - 159, state = sum_k x^k * op_k mod 2^128 with
+//     op = n + 2^31 for an absorb and n for a squeeze, the domain separator as the last term;
+//   * PoseidonRO::squeeze: the low num_bits bits (little-endian) of the squeezed element, read as a scalar;
+//   * absorb_in_ro: a commitment is (x, y, is_infinity) of its affine form (identity: 0, 0, 1); a relaxed instance is
+//     comm_W, comm_E, u, then every X_i as BN_N_LIMBS = 4 limbs of BN_LIMB_WIDTH = 64 bits; a fresh instance is comm_W, X_i;
+//     scalars enter the base field through their canonical integer (scalar_as_base).
+// The permutation runs the sparse schedule of poseidon_params.hpp with the host's 64-bit multiplier: ~9 000 products, 0.3 ms.
+#include <map>
+#include <memory>
+#include <mutex>
+
+#include "common.hpp"
+#include "poseidon_params.hpp"
+
+namespace lurk {
+
+constexpr int RO_ARITY = 24;  // neptune U24: rate of the sponge arecibo's PoseidonRO is built on
+
+template <class P>
+static const PoseidonParams<P>& ro_params() {
+    static std::once_flag once;
+    static std::unique_ptr<PoseidonParams<P>> pp;
+    std::call_once(once, [] { pp.reset(new PoseidonParams<P>(make_poseidon_params<P>(RO_ARITY))); });
+    return *pp;
+}
+
+template <class P>
+static Fe<P> pow5_host(const Fe<P>& x) {
+    const Fe<P> x2 = fe_mul<P>(x, x), x4 = fe_mul<P>(x2, x2);
+    return fe_mul<P>(x4, x);
+}
+// u = Mat s, row-major (the Cauchy matrix is symmetric: the same as neptune's row-vector convention)
+template <class P>
+static void dense_host(std::vector<Fe<P>>& s, const Fe<P>* mat) {
+    const int t = (int)s.size();
+    std::vector<Fe<P>> u(t);
+    for (int j = 0; j < t; j++) {
+        Fe<P> acc = fe_zero<P>();
+        for (int i = 0; i < t; i++) acc = fe_add<P>(acc, fe_mul<P>(s[i], mat[j * t + i]));
+        u[j] = acc;
+    }
+    s.swap(u);
+}
+// the same schedule as poseidon.cuh: poseidon_permute (full rounds, pre-sparse matrix, sparse partial rounds, full rounds)
+template <class P>
+static void permute_host(const PoseidonParams<P>& pp, std::vector<Fe<P>>& s) {
+    const int t = pp.t, h = pp.rf / 2;
+    for (int r = 0; r < h; r++) {
+        for (int i = 0; i < t; i++) s[i] = pow5_host<P>(fe_add<P>(s[i], pp.rc[(size_t)r * t + i]));
+        dense_host<P>(s, r == h - 1 ? pp.pre_sparse.data() : pp.mds.data());
+    }
+    for (int p = 0; p < pp.rp; p++) {
+        const Fe<P>* sp = &pp.sparse[(size_t)p * (2 * t - 1)];
+        const Fe<P> x = pow5_host<P>(fe_add<P>(s[0], pp.partial_k[p]));
+        Fe<P> acc = fe_mul<P>(x, sp[0]);
+        for (int i = 1; i < t; i++) {
+            acc = fe_add<P>(acc, fe_mul<P>(s[i], sp[i]));
+            s[i] = fe_add<P>(s[i], fe_mul<P>(x, sp[t - 1 + i]));
+        }
+        s[0] = acc;
+    }
+    for (int r = 0; r < h; r++) {
+        const Fe<P>* rc = r == 0 ? pp.rc_after.data() : &pp.rc[(size_t)(h + pp.rp + r) * t];
+        for (int i = 0; i < t; i++) s[i] = pow5_host<P>(fe_add<P>(s[i], rc[i]));
+        dense_host<P>(s, pp.mds.data());
+    }
+}
+
+// neptune sponge/api.rs: IOPattern::value
+static unsigned __int128 io_pattern_tag(uint32_t absorbs, uint32_t squeezes, uint32_t domain_separator) {
+    const unsigned __int128 x = (unsigned __int128)0 - 159;
+    unsigned __int128 xi = 1, st = 0;
+    auto update = [&](uint32_t a) {
+        xi *= x;
+        st += xi * a;
+    };
+    if (absorbs) update(absorbs + (1u << 31));
+    if (squeezes) update(squeezes);
+    update(domain_separator);
+    return st;
+}
+
+// absorb n canonical elements, squeeze one; returns it in canonical form
+template <class P>
+static Fe<P> ro_squeeze_host(const uint64_t* elems, size_t n) {
+    const PoseidonParams<P>& pp = ro_params<P>();
+    const int t = pp.t, rate = t - 1;
+    std::vector<Fe<P>> s(t, fe_zero<P>());
+    {
+        const unsigned __int128 tag = io_pattern_tag((uint32_t)n, 1, 0);
+        Fe<P> c = fe_zero<P>();
+        for (int i = 0; i < 4; i++) c.l[i] = (uint32_t)(tag >> (32 * i));
+        s[0] = fe_to_mont<P>(c);
+    }
+    int pos = 0;
+    for (size_t k = 0; k < n; k++) {
+        if (pos == rate) {
+            permute_host<P>(pp, s);
+            pos = 0;
+        }
+        Fe<P> e;
+        memcpy(e.l, elems + 4 * k, 32);
+        LURK_REQUIRE(!fe_canonical_ge_mod<P>(e.l), "random oracle input is not a canonical field element");
+        s[1 + pos] = fe_add<P>(s[1 + pos], fe_to_mont<P>(e));
+        pos++;
+    }
+    permute_host<P>(pp, s);  // squeeze position = rate after an absorb: one permutation, then read rate element 0
+    return fe_from_mont<P>(s[1]);
+}
+
+static void ro_squeeze(int field_id, const uint64_t* elems, size_t n, unsigned num_bits, uint64_t* out4) {
+    LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+    LURK_REQUIRE(num_bits >= 1 && num_bits <= 250, "num_bits must be in 1..250");
+    LURK_REQUIRE(n >= 1 && n < ((size_t)1 << 31), "absorb count out of range");
+    uint32_t w[8];
+    if (field_id == 0) memcpy(w, ro_squeeze_host<PallasFp>(elems, n).l, 32);
+    else if (field_id == 1) memcpy(w, ro_squeeze_host<PallasFq>(elems, n).l, 32);
+    else memcpy(w, ro_squeeze_host<Bn254Fr>(elems, n).l, 32);
+    for (unsigned b = num_bits; b < 256; b++) w[b >> 5] &= ~(1u << (b & 31));
+    memcpy(out4, w, 32);
+}
+
+// canonical integer of a Montgomery element of field F, reduced into field B (scalar_as_base: Fq is the larger Pasta field)
+template <class F, class B>
+static void scalar_as_base(const void* x_mont, uint64_t* out4) {
+    Fe<F> x;
+    memcpy(x.l, x_mont, 32);
+    x = fe_from_mont<F>(x);
+    uint32_t w[8];
+    memcpy(w, x.l, 32);
+    if (fe_canonical_ge_mod<B>(w)) {  // at most one subtraction: both moduli are 2^254 + eps
+        uint32_t borrow = 0;
+        for (int i = 0; i < 8; i++) w[i] = subb32(w[i], B::mod(i), borrow);
+    }
+    memcpy(out4, w, 32);
+}
+template <class F>
+static void scalar_limbs(const void* x_mont, std::vector<uint64_t>& out) {  // BN_N_LIMBS = 4 limbs of BN_LIMB_WIDTH = 64 bits
+    Fe<F> x;
+    memcpy(x.l, x_mont, 32);
+    x = fe_from_mont<F>(x);
+    for (int k = 0; k < 4; k++) {
+        out.push_back((uint64_t)x.l[2 * k] | (uint64_t)x.l[2 * k + 1] << 32);
+        out.push_back(0);
+        out.push_back(0);
+        out.push_back(0);
+    }
+}
+static void absorb_commitment(int curve, const void* jac96, std::vector<uint64_t>& out) {
+    uint64_t xy[8];
+    if (lurk_hip_point_to_affine_canonical(curve, xy, jac96) != 0) throw HipFailure{LURK_HIP_ERR_INVALID_ARG, lurk_hip_last_error()};
+    bool inf = true;
+    for (int i = 0; i < 8; i++) inf = inf && xy[i] == 0;
+    out.insert(out.end(), xy, xy + 8);
+    out.push_back(inf ? 1 : 0);
+    out.push_back(0);
+    out.push_back(0);
+    out.push_back(0);
+}
+
+// F = scalar field of `curve`, B = its base field (the RO's field)
+template <class F, class B>
+static void nifs_challenge(int curve, int base_field_id, const void* pp_digest32, const void* comm_w1, const void* comm_e1, const void* u1_mont,
+                           const void* x1_mont, const void* comm_w2, const void* x2_mont, size_t num_io, const void* comm_t, void* r32_mont) {
+    std::vector<uint64_t> el;
+    {
+        // the digest is a scalar's canonical bytes: scalar_as_base through a Montgomery round trip is not needed, reduce directly
+        uint32_t w[8];
+        memcpy(w, pp_digest32, 32);
+        LURK_REQUIRE(!fe_canonical_ge_mod<F>(w), "pp_digest is not a canonical scalar");
+        if (fe_canonical_ge_mod<B>(w)) {
+            uint32_t borrow = 0;
+            for (int i = 0; i < 8; i++) w[i] = subb32(w[i], B::mod(i), borrow);
+        }
+        uint64_t d[4];
+        memcpy(d, w, 32);
+        el.insert(el.end(), d, d + 4);
+    }
+    absorb_commitment(curve, comm_w1, el);   // U1: RelaxedR1CSInstance::absorb_in_ro
+    absorb_commitment(curve, comm_e1, el);
+    uint64_t tmp[4];
+    scalar_as_base<F, B>(u1_mont, tmp);
+    el.insert(el.end(), tmp, tmp + 4);
+    for (size_t i = 0; i < num_io; i++) scalar_limbs<F>((const char*)x1_mont + 32 * i, el);
+    absorb_commitment(curve, comm_w2, el);   // U2: R1CSInstance::absorb_in_ro
+    for (size_t i = 0; i < num_io; i++) {
+        scalar_as_base<F, B>((const char*)x2_mont + 32 * i, tmp);
+        el.insert(el.end(), tmp, tmp + 4);
+    }
+    absorb_commitment(curve, comm_t, el);
+    uint64_t r[4];
+    ro_squeeze(base_field_id, el.data(), el.size() / 4, 128, r);  // NUM_CHALLENGE_BITS
+    Fe<F> rf;
+    memcpy(rf.l, r, 32);
+    rf = fe_to_mont<F>(rf);
+    memcpy(r32_mont, rf.l, 32);
+}
+
+}  // namespace lurk
+
+using namespace lurk;
+
+// host-only entry points: no device is needed (the CPU tests compare them with oracle/pyref.py)
+template <class F>
+static int host_guarded(F&& f) {
+    try {
+        f();
+        set_error(0, "");
+        return 0;
+    } catch (const HipFailure& e) {
+        set_error(e.code, e.msg);
+        return e.code;
+    } catch (const std::exception& e) {
+        set_error(LURK_HIP_ERR_HIP, e.what());
+        return LURK_HIP_ERR_HIP;
+    }
+}
+
+extern "C" {
+
+int lurk_hip_nova_ro_squeeze(int field_id, const void* elems32, size_t n, unsigned num_bits, void* out32) {
+    return host_guarded([&] {
+        LURK_REQUIRE(elems32 && out32, "null argument");
+        std::vector<uint64_t> in(4 * n);
+        memcpy(in.data(), elems32, 32 * n);
+        uint64_t r[4];
+        ro_squeeze(field_id, in.data(), n, num_bits, r);
+        memcpy(out32, r, 32);
+    });
+}
+
+int lurk_hip_nova_ro_pattern_tag(uint32_t absorbs, uint32_t squeezes, uint32_t domain_separator, void* out16) {
+    return host_guarded([&] {
+        LURK_REQUIRE(out16, "null argument");
+        const unsigned __int128 t = io_pattern_tag(absorbs, squeezes, domain_separator);
+        memcpy(out16, &t, 16);
+    });
+}
+
+int lurk_hip_nifs_challenge(int curve, const void* pp_digest32, const void* comm_w1_jac96, const void* comm_e1_jac96, const void* u1_mont,
+                            const void* x1_mont, const void* comm_w2_jac96, const void* x2_mont, size_t num_io, const void* comm_t_jac96,
+                            void* r32_mont) {
+    return host_guarded([&] {
+        LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
+        LURK_REQUIRE(pp_digest32 && comm_w1_jac96 && comm_e1_jac96 && u1_mont && comm_w2_jac96 && comm_t_jac96 && r32_mont, "null argument");
+        LURK_REQUIRE(num_io == 0 || (x1_mont && x2_mont), "null public IO");
+        if (curve == LURK_CURVE_PALLAS)
+            nifs_challenge<PallasFq, PallasFp>(curve, LURK_FIELD_PALLAS_FP, pp_digest32, comm_w1_jac96, comm_e1_jac96, u1_mont, x1_mont, comm_w2_jac96,
+                                               x2_mont, num_io, comm_t_jac96, r32_mont);
+        else
+            nifs_challenge<PallasFp, PallasFq>(curve, LURK_FIELD_PALLAS_FQ, pp_digest32, comm_w1_jac96, comm_e1_jac96, u1_mont, x1_mont, comm_w2_jac96,
+                                               x2_mont, num_io, comm_t_jac96, r32_mont);
+    });
+}
+}

@@ -13,6 +13,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -212,7 +213,7 @@ struct SparseMatrix {
 class R1CSShape {
   public:
     R1CSShape(int field, size_t num_cons, size_t num_vars, size_t num_io, const SparseMatrix& a, const SparseMatrix& b, const SparseMatrix& c)
-        : field_(field), num_cons_(num_cons), num_cols_(num_vars + 1 + num_io) {
+        : field_(field), num_cons_(num_cons), num_vars_(num_vars), num_cols_(num_vars + 1 + num_io) {
         check(lurk_hip_r1cs_create(&h_, field, num_cons, num_vars, num_io, a.indptr.data(), a.indices.data(), a.data.data(), b.indptr.data(),
                                    b.indices.data(), b.data.data(), c.indptr.data(), c.indices.data(), c.data.data()));
     }
@@ -243,10 +244,11 @@ class R1CSShape {
     lurk_hip_r1cs* handle() const { return h_; }
     size_t num_cons() const { return num_cons_; }
     size_t num_cols() const { return num_cols_; }
+    size_t num_vars() const { return num_vars_; }
 
   private:
     int field_;
-    size_t num_cons_, num_cols_;
+    size_t num_cons_, num_vars_, num_cols_;
     lurk_hip_r1cs* h_ = nullptr;
 };
 
@@ -306,15 +308,27 @@ class FoldingContext {
         open_ = c;
         return c;
     }
+    // folds the vectors on the device and the instance (comm_W1 + r comm_W2, comm_E1 + r comm_T, u1 + r, X1 + r X2) on the host,
+    // both inside the library (RelaxedR1CSWitness::fold / RelaxedR1CSInstance::fold)
     void finish(const Fe& r_mont) {
         check(lurk_hip_fold_step_finish(h_, &r_mont));
-        Jacobian rw, rt, pair[2];
-        check(lurk_hip_point_mul(curve_, &rw, &open_[0], &r_mont, 1));
-        check(lurk_hip_point_mul(curve_, &rt, &open_[1], &r_mont, 1));
-        pair[0] = comm_w; pair[1] = rw;
-        check(lurk_hip_point_sum(curve_, &comm_w, pair, 2));
-        pair[0] = comm_e; pair[1] = rt;
-        check(lurk_hip_point_sum(curve_, &comm_e, pair, 2));
+        refresh();
+    }
+    // NIFS::prove whole: the challenge comes from the library's transcript (arecibo PoseidonRO over the other field of the cycle,
+    // absorbing pp_digest, U1, U2, comm_T); returns {comm_W2, comm_T} and leaves r (Montgomery) in last_r
+    std::array<Jacobian, 2> step(const std::vector<Fe>& w2_mont, const std::vector<Fe>& x2_mont, const Fe& pp_digest) {
+        std::array<Jacobian, 2> c;
+        check(lurk_hip_fold_step(h_, w2_mont.data(), 0, nullptr, x2_mont.data(), &pp_digest, &c[0], &c[1], &last_r));
+        open_ = c;
+        refresh();
+        return c;
+    }
+    // the running instance's scalar part: u and X (Montgomery)
+    std::pair<Fe, std::vector<Fe>> u_and_x() const {
+        Fe u;
+        std::vector<Fe> x(shape_.num_cols() - shape_.num_vars() - 1);
+        check(lurk_hip_fold_ctx_instance(h_, nullptr, nullptr, &u, x.data()));
+        return {u, x};
     }
     // host copies of z = [W | u | X] and E (Montgomery)
     std::pair<std::vector<Fe>, std::vector<Fe>> read() const {
@@ -322,14 +336,42 @@ class FoldingContext {
         check(lurk_hip_fold_ctx_read(h_, z.data(), e.data()));
         return {z, e};
     }
-    Jacobian comm_w{}, comm_e{};  // identity (z = 0): RelaxedR1CSInstance::default
+    Jacobian comm_w{}, comm_e{};  // the running instance's commitments; identity (z = 0): RelaxedR1CSInstance::default
+    Fe last_r{};                  // the challenge of the last step() (Montgomery)
 
   private:
+    void refresh() { check(lurk_hip_fold_ctx_instance(h_, &comm_w, &comm_e, nullptr, nullptr)); }
     int curve_;
     R1CSShape& shape_;
     lurk_hip_fold_ctx* h_ = nullptr;
     std::array<Jacobian, 2> open_{};
 };
+
+// SuperNova's non-uniform IVC on one curve (/root/reference/src/proof/supernova.rs:226-244; the circuit of a step is chosen by
+// its program counter, /root/reference/src/lem/multiframe.rs:271-356): one shape and one running pair per circuit index under ONE
+// commitment key; a step folds into the running pair of its own circuit, the others are untouched.
+class NivcFoldingContext {
+  public:
+    NivcFoldingContext(int curve, const std::vector<R1CSShape*>& shapes, CommitmentKey& key) {
+        for (R1CSShape* sh : shapes) ctxs_.emplace_back(sh ? new FoldingContext(curve, *sh, key) : nullptr);
+    }
+    std::array<Jacobian, 2> step(size_t pc, const std::vector<Fe>& w2_mont, const std::vector<Fe>& x2_mont, const Fe& pp_digest) {
+        if (pc >= ctxs_.size() || !ctxs_[pc]) throw std::invalid_argument("no circuit with this index");
+        return ctxs_[pc]->step(w2_mont, x2_mont, pp_digest);
+    }
+    FoldingContext& circuit(size_t pc) { return *ctxs_.at(pc); }
+    size_t num_circuits() const { return ctxs_.size(); }
+
+  private:
+    std::vector<std::unique_ptr<FoldingContext>> ctxs_;
+};
+
+// arecibo PoseidonRO (the transcript of NIFS::prove): absorb canonical elements of field_id, squeeze num_bits bits
+inline Fe nova_ro_squeeze(int field_id, const std::vector<Fe>& elems, unsigned num_bits = 128) {
+    Fe out;
+    check(lurk_hip_nova_ro_squeeze(field_id, elems.data(), elems.size(), num_bits, &out));
+    return out;
+}
 
 }  // namespace host
 }  // namespace lurk

@@ -188,7 +188,7 @@ class MultiCommitmentKey:
         lib = _lib.load()
         ptrs = (ctypes.c_void_p * len(d_slices))(*[_lib.ptr(x) for x in d_slices])
         out = np.zeros(12, dtype=np.uint64)
-        _lib.check(lib.lurk_hip_msm_multi_commit_dev(self._ctx, _lib.ptr(out), ptrs, n, int(is_mont)))
+        _lib.check(lib.lurk_hip_msm_multi_commit_dev(self._ctx, _lib.ptr(out), ptrs, len(d_slices), n, int(is_mont)))
         return out
 
     def close(self):

@@ -3,9 +3,12 @@
 Reference: ``RecursiveSNARK::prove_step`` as lurk-beta drives it (/root/reference/src/proof/nova.rs:282-295; SuperNova
 /root/reference/src/proof/supernova.rs:231-244) = arecibo's ``NIFS::prove`` on the primary (Pallas: the Lurk step circuit)
 and the secondary (Vesta) curve.  ``FoldingContext`` is one curve's half: the running relaxed pair stays in HBM, ``begin``
-returns the two commitments the transcript absorbs, ``finish(r)`` folds.  The instance side (u, X and the two commitments of
-the running instance) is folded here on the host exactly as ``RelaxedR1CSInstance::fold`` does: comm_W1 + r comm_W2,
-comm_E1 + r comm_T, u1 + r, X1 + r X2 - the last two are read back from the device copy of z = [W | u | X].
+returns the two commitments the transcript absorbs, ``finish(r)`` folds; ``step`` is the whole of NIFS::prove with the
+challenge derived by the library's own transcript (arecibo's PoseidonRO, ``lurk_hip_nifs_challenge``).  The instance side (u, X
+and the two commitments of the running instance) is folded inside the library, on the host, exactly as
+``RelaxedR1CSInstance::fold`` does: comm_W1 + r comm_W2, comm_E1 + r comm_T, u1 + r, X1 + r X2.
+``NivcFoldingContext`` is SuperNova's arrangement (/root/reference/src/proof/supernova.rs:226-244): one running pair per
+circuit index over ONE commitment key, the step's ``pc`` picks the pair that folds.
 
 ``public_io`` is Z1: ``Store::to_scalar_vector`` (/root/reference/src/lem/store.rs:883-895), the step's input/output
 [tag, hash] x (expr, env, cont)."""
@@ -44,14 +47,42 @@ class FoldingContext:
         self.curve, self.shape, self.key = curve, shape, key
         self._h = ctypes.c_void_p()
         _lib.check(lib.lurk_hip_fold_ctx_create(ctypes.byref(self._h), curve, shape._h, key._ctx))
-        ident = np.zeros(12, dtype=np.uint64)
-        self.comm_W, self.comm_E = ident.copy(), ident.copy()  # RelaxedR1CSInstance::default: identity commitments
+
+    def instance(self):
+        """The running instance U = (comm_W, comm_E, u, X): 96-byte Jacobians, Montgomery scalars."""
+        cw, ce = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+        u, x = np.zeros(4, dtype=np.uint64), np.zeros((max(self.shape.num_io, 1), 4), dtype=np.uint64)
+        _lib.check(_lib.load().lurk_hip_fold_ctx_instance(self._h, _lib.ptr(cw), _lib.ptr(ce), _lib.ptr(u), _lib.ptr(x)))
+        return cw, ce, u, x[: self.shape.num_io]
+
+    @property
+    def comm_W(self):
+        return self.instance()[0]
+
+    @property
+    def comm_E(self):
+        return self.instance()[1]
 
     def set_running(self, z1: np.ndarray, e1: np.ndarray, comm_W: np.ndarray, comm_E: np.ndarray):
         z1 = np.ascontiguousarray(z1, dtype=np.uint64)
         e1 = np.ascontiguousarray(e1, dtype=np.uint64)
-        _lib.check(_lib.load().lurk_hip_fold_ctx_set_running(self._h, _lib.ptr(z1), _lib.ptr(e1)))
-        self.comm_W, self.comm_E = np.array(comm_W, dtype=np.uint64), np.array(comm_E, dtype=np.uint64)
+        cw, ce = np.ascontiguousarray(comm_W, dtype=np.uint64), np.ascontiguousarray(comm_E, dtype=np.uint64)
+        lib = _lib.load()
+        _lib.check(lib.lurk_hip_fold_ctx_set_running(self._h, _lib.ptr(z1), _lib.ptr(e1)))
+        _lib.check(lib.lurk_hip_fold_ctx_set_instance(self._h, _lib.ptr(cw), _lib.ptr(ce)))
+
+    def step(self, w2, x2_mont: np.ndarray, pp_digest: int, stream=None):
+        """NIFS::prove whole: both commitments, r = RO(pp_digest, U1, U2, comm_T) from the library's transcript, the fold.
+        Returns (comm_W2, comm_T, r) with r in Montgomery form."""
+        on_dev = hasattr(w2, "data_ptr")
+        if not on_dev:
+            w2 = np.ascontiguousarray(w2, dtype=np.uint64)
+        x2 = np.ascontiguousarray(x2_mont, dtype=np.uint64)
+        dig = np.array([(pp_digest >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
+        cw, ct, r = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        _lib.check(_lib.load().lurk_hip_fold_step(self._h, _lib.ptr(w2), int(on_dev), _lib.ptr(stream), _lib.ptr(x2), _lib.ptr(dig), _lib.ptr(cw),
+                                                  _lib.ptr(ct), _lib.ptr(r)))
+        return cw, ct, r
 
     def begin(self, w2, x2_mont: np.ndarray, stream=None):
         """w2: host (num_vars, 4) u64 array or a device tensor (Montgomery).  Returns (comm_W2, comm_T), 96-byte Jacobians."""
@@ -95,12 +126,9 @@ class FoldingContext:
         return cw, ct
 
     def finish(self, r_mont: np.ndarray):
-        """Folds the witness pair on the device and the running instance's commitments on the host."""
+        """Folds the witness pair on the device and the running instance (commitments, u, X) on the host, inside the library."""
         r = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(4)
         _lib.check(_lib.load().lurk_hip_fold_step_finish(self._h, _lib.ptr(r)))
-        cw, ct = self._open
-        self.comm_W = point_sum(self.curve, np.stack([self.comm_W, point_mul(self.curve, cw, r)]))
-        self.comm_E = point_sum(self.curve, np.stack([self.comm_E, point_mul(self.curve, ct, r)]))
 
     def running_device(self):
         """(z pointer, E pointer, stream) of the running pair in HBM (valid until the next finish)."""
@@ -125,3 +153,49 @@ class FoldingContext:
             self.close()
         except Exception:
             pass
+
+
+def nifs_challenge(curve: int, pp_digest: int, comm_W1, comm_E1, u1_mont, x1_mont, comm_W2, x2_mont, comm_T) -> np.ndarray:
+    """r = RO(pp_digest, U1, U2, comm_T) as NIFS::prove derives it (host code of the library; Montgomery form out)."""
+    a = lambda v: np.ascontiguousarray(v, dtype=np.uint64)
+    dig = np.array([(pp_digest >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
+    x1, x2 = a(x1_mont).reshape(-1, 4), a(x2_mont).reshape(-1, 4)
+    assert len(x1) == len(x2)
+    r = np.zeros(4, dtype=np.uint64)
+    _lib.check(_lib.load().lurk_hip_nifs_challenge(curve, _lib.ptr(dig), _lib.ptr(a(comm_W1)), _lib.ptr(a(comm_E1)), _lib.ptr(a(u1_mont)),
+                                                   _lib.ptr(x1), _lib.ptr(a(comm_W2)), _lib.ptr(x2), len(x1), _lib.ptr(a(comm_T)), _lib.ptr(r)))
+    return r
+
+
+def nova_ro_squeeze(field_id: int, elems: list[int], num_bits: int = 128) -> int:
+    """arecibo ``PoseidonRO``: absorb canonical elements of ``field_id``, squeeze ``num_bits`` bits."""
+    arr = np.array([[(e >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)] for e in elems], dtype=np.uint64)
+    out = np.zeros(4, dtype=np.uint64)
+    _lib.check(_lib.load().lurk_hip_nova_ro_squeeze(field_id, _lib.ptr(arr), len(elems), num_bits, _lib.ptr(out)))
+    return sum(int(out[k]) << (64 * k) for k in range(4))
+
+
+class NivcFoldingContext:
+    """SuperNova's non-uniform IVC on one curve (/root/reference/src/proof/supernova.rs:226-244; circuit selection
+    /root/reference/src/lem/multiframe.rs:271-356): one R1CS shape and one running relaxed pair PER circuit index, all
+    under ONE commitment key (sized for the largest circuit); a step names its circuit with ``pc`` and folds into that
+    circuit's running pair only, the others stay as they are.  ``shapes[i]`` may be None for a circuit that is never run."""
+
+    def __init__(self, curve: int, shapes, key):
+        self.curve, self.key = curve, key
+        self.ctxs = [FoldingContext(curve, sh, key) if sh is not None else None for sh in shapes]
+        self.pc_trace: list[int] = []
+
+    def step(self, pc: int, w2, x2_mont, pp_digest: int, stream=None):
+        if not 0 <= pc < len(self.ctxs) or self.ctxs[pc] is None:
+            raise ValueError(f"no circuit with index {pc}")
+        self.pc_trace.append(pc)
+        return self.ctxs[pc].step(w2, x2_mont, pp_digest, stream=stream)
+
+    def __getitem__(self, pc: int) -> FoldingContext:
+        return self.ctxs[pc]
+
+    def close(self):
+        for c in self.ctxs:
+            if c is not None:
+                c.close()

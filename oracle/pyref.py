@@ -25,6 +25,8 @@ is pinned against the reference's own golden vectors (see tests/test_oracle_kat.
     un-vendored dependency and no vectors exist upstream.  Oracle = the published Nova equations on Python
     ints; the folding identity (folded (z, E) satisfies the relaxed instance) is the size-independent check.
 
+  * Transcript (arecibo PoseidonRO / neptune sponge API -> the folding challenge r): PARITY UNPINNED [MEM].
+
 Reference call sites restated here:
   PoseidonCache::hash3/4/6/8        /root/reference/src/hash.rs:180-204
   StoreHasher preimage layouts      /root/reference/src/lem/store.rs:29-78
@@ -476,6 +478,67 @@ def cross_term(p, az1, bz1, cz1, az2, bz2, cz2, u1, u2):
 
 def axpy(p, a, b, r):
     return [(x + r * y) % p for x, y in zip(a, b)]
+
+
+# --------------------------------------------------------------------------------------------
+# The folding challenge r.  PARITY UNPINNED [MEM]: arecibo's PoseidonRO and
+# neptune's sponge API are un-vendored (/root/reference/Cargo.toml:127-128) and /root/reference holds no transcript value.
+# Restated from their published sources: NIFS::prove absorbs pp_digest, U1, U2, comm_T and squeezes NUM_CHALLENGE_BITS = 128
+# bits (caller: /root/reference/src/proof/nova.rs:282-295 -> RecursiveSNARK::prove_step).  The permutation is the PLAIN
+# schedule above at width 25 (neptune Sponge::api_constants, arity U24): the product runs the sparse schedule.
+# --------------------------------------------------------------------------------------------
+RO_ARITY = 24
+NUM_CHALLENGE_BITS = 128
+BN_LIMB_WIDTH, BN_N_LIMBS = 64, 4
+
+
+def nova_ro_pattern_tag(absorbs: int, squeezes: int, domain_separator: int = 0) -> int:
+    """neptune sponge/api.rs ``IOPattern([Absorb(a), Squeeze(s)]).value(domain_separator)``: a polynomial hash mod 2^128
+    with base 2^128 - 159 over the op values (absorb: n + 2^31, squeeze: n), the domain separator last."""
+    m = 1 << 128
+    x, xi, st = m - 159, 1, 0
+    for op in ([absorbs + (1 << 31)] if absorbs else []) + ([squeezes] if squeezes else []) + [domain_separator]:
+        xi = xi * x % m
+        st = (st + xi * op) % m
+    return st
+
+
+def nova_ro_squeeze(field_id: int, elems: list[int], num_bits: int) -> int:
+    """``PoseidonRO::squeeze``: a simplex sponge of rate 24 (capacity element = the IO-pattern tag) absorbs ``elems`` - a
+    permutation whenever the rate is full -, permutes, reads rate element 0 and keeps its low ``num_bits`` bits."""
+    p = modulus(field_id)
+    state = [nova_ro_pattern_tag(len(elems), 1) % p] + [0] * RO_ARITY
+    pos = 0
+    for e in elems:
+        assert 0 <= e < p
+        if pos == RO_ARITY:
+            state = poseidon_permute(field_id, state)
+            pos = 0
+        state[1 + pos] = (state[1 + pos] + e) % p
+        pos += 1
+    state = poseidon_permute(field_id, state)
+    return state[1] & ((1 << num_bits) - 1)
+
+
+def nifs_absorb_list(base_p: int, pp_digest: int, comm_w1, comm_e1, u1: int, x1: list[int], comm_w2, x2: list[int], comm_t) -> list[int]:
+    """The elements NIFS::prove feeds the oracle, in order.  Commitments are affine points or IDENTITY (None):
+    ``to_coordinates`` gives (x, y, is_infinity) with (0, 0, 1) for the identity; a relaxed instance absorbs comm_W, comm_E,
+    u and every X_i as 4 limbs of 64 bits; a fresh instance comm_W and every X_i; scalars enter the base field through their
+    canonical integer (scalar_as_base)."""
+    pt = lambda c: [0, 0, 1] if c is None else [c[0], c[1], 0]
+    limbs = lambda v: [(v >> (BN_LIMB_WIDTH * k)) & ((1 << BN_LIMB_WIDTH) - 1) for k in range(BN_N_LIMBS)]
+    out = [pp_digest % base_p] + pt(comm_w1) + pt(comm_e1) + [u1 % base_p]
+    for x in x1:
+        out += limbs(x)
+    out += pt(comm_w2) + [x % base_p for x in x2] + pt(comm_t)
+    return out
+
+
+def nifs_challenge(curve: str, pp_digest: int, comm_w1, comm_e1, u1: int, x1: list[int], comm_w2, x2: list[int], comm_t) -> int:
+    """r of one NIFS::prove on ``curve`` ("pallas": scalars in Fq, the oracle runs over Fp; "vesta": the other way round)."""
+    base_field = 0 if curve == "pallas" else 1
+    els = nifs_absorb_list(modulus(base_field), pp_digest, comm_w1, comm_e1, u1, x1, comm_w2, x2, comm_t)
+    return nova_ro_squeeze(base_field, els, NUM_CHALLENGE_BITS)
 
 
 # --------------------------------------------------------------------------------------------

@@ -183,3 +183,194 @@ def test_shape_and_key_must_match_the_curve(hip):
         FoldingContext(0, shape, key)  # Pallas needs a shape over Fq
     key.close()
     shape.close()
+
+
+def _aff_or_none(curve, jac):
+    from lurk_beta_amd import point_to_affine
+
+    a = point_to_affine(curve, jac)
+    return None if a == (0, 0) else a
+
+
+@pytest.mark.parametrize("curve,m,nfree", [(0, 6000, 2500), (1, 2000, 900)])
+def test_steps_with_the_library_transcript(hip, curve, m, nfree):
+    """lurk_hip_fold_step: NIFS::prove whole - nobody hands the context a challenge.  After every step r must be what the ORACLE's
+    restatement of the transcript derives from the oracle's own instance (pp_digest, U1, U2, comm_T), and the folded pair,
+    instance and commitments must be the oracle's.  Reference: /root/reference/src/proof/nova.rs:282-295 (RO row, judge-added)."""
+    from lurk_beta_amd import CommitmentKey, FoldingContext, R1CSShape, point_to_affine
+
+    f = 1 if curve == 0 else 0
+    name = "pallas" if curve == 0 else "vesta"
+    p = R.modulus(f)
+    nio = 2  # the augmented circuit's public IO: two hashes (NUM_FE_FOR_RO = 24)
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=23 + curve)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    bases = C.synth_bases(curve, max(m, nv))
+    key = CommitmentKey(curve, bases, precompute=bool(curve))
+    ctx = FoldingContext(curve, shape, key)
+    commit = lambda v: C.jac_to_affine(curve, C.msm_pippenger(curve, bases[: len(v)], v))
+    pt = lambda a: None if a == (0, 0) else a
+    pp_digest = R.uniform_fe(98, curve, p)
+    z1 = np.zeros((nv + 1 + nio, 4), dtype=np.uint64)
+    e1 = np.zeros((m, 4), dtype=np.uint64)
+    cw1 = ce1 = None  # oracle-side instance: the default relaxed instance has identity commitments
+    for step in range(3):
+        z2, x2 = _fresh(f, A, B, m, nfree, nio, 400 + 10 * step + curve)
+        cw, ct, r_mont = ctx.step(C.to_mont(f, z2[:nv]), C.to_mont(f, x2), pp_digest)
+        m1 = [C.spmv(f, *M, z1) for M in (A, B, Cm)]
+        m2 = [C.spmv(f, *M, z2) for M in (A, B, Cm)]
+        u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+        t = C.cross_term(f, *m1, *m2, u1, 1)
+        cw2_o, ct_o = commit(z2[:nv]), commit(t)
+        assert point_to_affine(curve, cw) == cw2_o and point_to_affine(curve, ct) == ct_o
+        r = R.nifs_challenge(name, pp_digest, cw1, ce1, u1, C.limbs_to_ints(z1[nv + 1:]), pt(cw2_o), C.limbs_to_ints(x2), pt(ct_o))
+        assert C.limbs_to_ints(C.from_mont(f, r_mont.reshape(1, 4)))[0] == r
+        z1, e1 = C.axpy(f, z1, z2, r), C.axpy(f, e1, t, r)
+        gz, ge = ctx.read()
+        assert np.array_equal(C.from_mont(f, gz), z1) and np.array_equal(C.from_mont(f, ge), e1)
+        gcw, gce, gu, gx = ctx.instance()
+        cw1, ce1 = pt(commit(z1[:nv])), pt(commit(e1))
+        assert _aff_or_none(curve, gcw) == cw1 and _aff_or_none(curve, gce) == ce1
+        assert np.array_equal(C.from_mont(f, np.concatenate([gu.reshape(1, 4), gx])), z1[nv:])
+        u = C.limbs_to_ints(z1[nv:nv + 1])[0]
+        az, bz, cz = [C.spmv(f, *M, z1) for M in (A, B, Cm)]
+        assert not C.relaxed_residual(f, az, bz, cz, u, e1).any()
+    ctx.close()
+    key.close()
+    shape.close()
+
+
+def test_nivc_two_shapes_one_key(hip):
+    """SuperNova / NIVC (/root/reference/src/proof/supernova.rs:226-244, circuit selection multiframe.rs:271-356): two R1CS shapes of
+    different sizes (the Lurk step circuit and a coprocessor's) under ONE commitment key, pc alternating 0, 1, 1, 0, 1 - every running
+    instance is checked after every step: the one that folded moved to the oracle's value, the other one did not move at all."""
+    from lurk_beta_amd import CommitmentKey, NivcFoldingContext, R1CSShape, point_to_affine
+
+    curve, f, name = 0, 1, "pallas"
+    p = R.modulus(f)
+    nio = 2
+    dims = [(9000, 4000), (2500, 1000)]  # (rows, free variables) of circuit 0 and circuit 1
+    mats, shapes, nvs = [], [], []
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    for k, (m, nfree) in enumerate(dims):
+        A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=31 + k)
+        mats.append((A, B, Cm))
+        nvs.append(nv)
+        shapes.append(R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm)))
+    nkey = max(max(m, nv) for (m, _), nv in zip(dims, nvs))
+    bases = C.synth_bases(curve, nkey)
+    key = CommitmentKey(curve, bases, precompute=True)
+    nivc = NivcFoldingContext(curve, shapes, key)
+    commit = lambda v: C.jac_to_affine(curve, C.msm_pippenger(curve, bases[: len(v)], v))
+    pt = lambda a: None if a == (0, 0) else a
+    pp_digest = R.uniform_fe(99, 0, p)
+    run = [dict(z=np.zeros((nvs[k] + 1 + nio, 4), dtype=np.uint64), e=np.zeros((dims[k][0], 4), dtype=np.uint64), cw=None, ce=None) for k in range(2)]
+    for step, pc in enumerate([0, 1, 1, 0, 1]):
+        (m, nfree), nv, (A, B, Cm), st = dims[pc], nvs[pc], mats[pc], run[pc]
+        z2, x2 = _fresh(f, A, B, m, nfree, nio, 500 + 10 * step)
+        cw, ct, r_mont = nivc.step(pc, C.to_mont(f, z2[:nv]), C.to_mont(f, x2), pp_digest)
+        u1 = C.limbs_to_ints(st["z"][nv:nv + 1])[0]
+        t = C.cross_term(f, *[C.spmv(f, *M, st["z"]) for M in (A, B, Cm)], *[C.spmv(f, *M, z2) for M in (A, B, Cm)], u1, 1)
+        cw2_o, ct_o = commit(z2[:nv]), commit(t)
+        assert point_to_affine(curve, cw) == cw2_o and point_to_affine(curve, ct) == ct_o
+        r = R.nifs_challenge(name, pp_digest, st["cw"], st["ce"], u1, C.limbs_to_ints(st["z"][nv + 1:]), pt(cw2_o), C.limbs_to_ints(x2), pt(ct_o))
+        assert C.limbs_to_ints(C.from_mont(f, r_mont.reshape(1, 4)))[0] == r
+        st["z"], st["e"] = C.axpy(f, st["z"], z2, r), C.axpy(f, st["e"], t, r)
+        st["cw"], st["ce"] = pt(commit(st["z"][:nv])), pt(commit(st["e"]))
+        for k in range(2):  # BOTH running instances, every step
+            gz, ge = nivc[k].read()
+            assert np.array_equal(C.from_mont(f, gz), run[k]["z"]) and np.array_equal(C.from_mont(f, ge), run[k]["e"]), (step, k)
+            gcw, gce, _, _ = nivc[k].instance()
+            assert _aff_or_none(curve, gcw) == run[k]["cw"] and _aff_or_none(curve, gce) == run[k]["ce"], (step, k)
+            A_, B_, C_ = mats[k]
+            u = C.limbs_to_ints(run[k]["z"][nvs[k]:nvs[k] + 1])[0]
+            az, bz, cz = [C.spmv(f, *M, run[k]["z"]) for M in (A_, B_, C_)]
+            assert not C.relaxed_residual(f, az, bz, cz, u, run[k]["e"]).any()
+    assert nivc.pc_trace == [0, 1, 1, 0, 1]
+    with pytest.raises(ValueError):
+        nivc.step(2, None, None, 0)
+    nivc.close()
+    key.close()
+    for s in shapes:
+        s.close()
+
+
+def test_staging_into_the_open_steps_buffer_is_refused(hip):
+    """prefetch(A), prefetch(B), begin_prefetched() [A open], prefetch(C): C would land in the buffer that still holds A's witness
+    until finish(r) folds it (two z2 buffers).  The call must fail and the fold must still be A's."""
+    from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape
+
+    curve, f, m, nfree, nio = 1, 0, 1500, 700, 2
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=41)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    key = CommitmentKey(curve, C.synth_bases(curve, max(m, nv)), precompute=True)
+    key.reserve(max(m, nv), 4)
+    ctx = FoldingContext(curve, shape, key)
+    fresh = [_fresh(f, A, B, m, nfree, nio, 600 + 10 * k) for k in range(3)]
+    w = [C.to_mont(f, z[:nv]) for z, _ in fresh]
+    ctx.prefetch(w[0])
+    ctx.prefetch(w[1])
+    ctx.begin_prefetched(C.to_mont(f, fresh[0][1]))
+    with pytest.raises(LurkHipError, match="finish the step first"):
+        ctx.prefetch(w[2])
+    r = 12345
+    ctx.finish(C.to_mont(f, C.ints_to_limbs([r])))
+    gz, _ = ctx.read()
+    assert np.array_equal(C.from_mont(f, gz), C.axpy(f, np.zeros_like(fresh[0][0]), fresh[0][0], r))  # A's witness, untouched
+    ctx.prefetch(w[2])  # allowed again: A's buffer is free once its fold is enqueued
+    ctx.begin_prefetched(C.to_mont(f, fresh[1][1]))
+    ctx.finish(C.to_mont(f, C.ints_to_limbs([1])))
+    ctx.begin_prefetched(C.to_mont(f, fresh[2][1]))
+    ctx.finish(C.to_mont(f, C.ints_to_limbs([1])))
+    gz, _ = ctx.read()
+    want = C.axpy(f, C.axpy(f, C.axpy(f, np.zeros_like(fresh[0][0]), fresh[0][0], r), fresh[1][0], 1), fresh[2][0], 1)
+    assert np.array_equal(C.from_mont(f, gz), want)
+    ctx.close()
+    key.close()
+    shape.close()
+
+
+def test_step_at_the_rc100_size(hip):
+    """One folding step at BASELINE config 1's size (rc = 100 on Pallas: 895 164 witness elements, 1 097 300 constraints - the
+    sizes bench.py's fold_step workload runs) through lurk_hip_fold_step, every output against the oracle: both commitments
+    (oracle/msm_fast.c), the challenge (the oracle's transcript), T and the folded (z, E) element by element (oracle/oracle.c)."""
+    from lurk_beta_amd import CommitmentKey, FoldingContext, R1CSShape, point_to_affine
+
+    curve, f, name = 0, 1, "pallas"
+    p = R.modulus(f)
+    rc = 100
+    nv, m, nio = 64 + rc * 8951, rc * 10973, 2
+    A, B, Cm, z2 = C.synth_r1cs(f, m, nv, nio, seed=5)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    bases = C.synth_bases(curve, max(m, nv))
+    key = CommitmentKey(curve, bases, precompute=True)
+    ctx = FoldingContext(curve, shape, key)
+    commit = lambda v: C.jac_to_affine(curve, C.msm_fast(curve, bases[: len(v)], v))
+    pt = lambda a: None if a == (0, 0) else a
+    # a running pair with history: witness-like z1 (u1 random), uniform E1, and their true commitments
+    z1 = C.synth_scalars(f, 1, 1, nv + 1 + nio)
+    e1 = C.synth_scalars(f, 2, 0, m)
+    cw1_j, ce1_j = C.msm_fast(curve, bases[:nv], z1[:nv]), C.msm_fast(curve, bases[:m], e1)
+    ctx.set_running(C.to_mont(f, z1), C.to_mont(f, e1), cw1_j, ce1_j)
+    pp_digest = R.uniform_fe(98, 7, p)
+    x2 = z2[nv + 1:]
+    cw, ct, r_mont = ctx.step(C.to_mont(f, z2[:nv]), C.to_mont(f, x2), pp_digest)
+    u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+    t = C.cross_term(f, *[C.spmv(f, *M, z1) for M in (A, B, Cm)], *[C.spmv(f, *M, z2) for M in (A, B, Cm)], u1, 1)
+    cw2_o, ct_o = commit(z2[:nv]), commit(t)
+    assert point_to_affine(curve, cw) == cw2_o
+    assert point_to_affine(curve, ct) == ct_o
+    r = R.nifs_challenge(name, pp_digest, pt(C.jac_to_affine(curve, cw1_j)), pt(C.jac_to_affine(curve, ce1_j)), u1, C.limbs_to_ints(z1[nv + 1:]),
+                         pt(cw2_o), C.limbs_to_ints(x2), pt(ct_o))
+    assert C.limbs_to_ints(C.from_mont(f, r_mont.reshape(1, 4)))[0] == r
+    zf, ef = C.axpy(f, z1, z2, r), C.axpy(f, e1, t, r)
+    gz, ge = ctx.read()
+    assert np.array_equal(C.from_mont(f, gz), zf) and np.array_equal(C.from_mont(f, ge), ef)
+    gcw, gce, _, _ = ctx.instance()
+    assert point_to_affine(curve, gcw) == commit(zf[:nv]) and point_to_affine(curve, gce) == commit(ef)
+    ctx.close()
+    key.close()
+    shape.close()
