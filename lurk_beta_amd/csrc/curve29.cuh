@@ -206,6 +206,73 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
     }
 }
 
+// Doubling of a general XYZZ29 point: only reached when two equal partial sums meet in a reduction tree - rare, so it goes
+// through the 32-bit-limb group law (out of line; arguments and result by value, see xyzz29_double_affine).
+template <class P>
+LURK_HD __attribute__((noinline)) Xyzz29<P> xyzz29_double_general(Xyzz29<P> a) {
+    const Xyzz<P> d = xyzz_dbl<P>(xyzz29_to_xyzz<P>(a, false));
+    Xyzz29<P> r;
+    bool id;
+    xyzz29_from_xyzz<P>(d, r, id);  // a doubled point of a prime-order curve is never the identity
+    return r;
+}
+
+// acc += q, both on the radix-2^29 layer (add-2008-s: 12 M + 2 S), identities tracked by the flags.  The nodes of the reduction
+// trees of the small-commitment path (msm_small.hip).  Bounds as in xyzz29_madd: both inputs R-bounded (tight limbs, value < 2^259),
+// the result R-bounded again; p and r are carried differences (< 2^260.3), X3 and Y3 leave through f29_reduce.
+template <class P>
+LURK_HD void xyzz29_add(Xyzz29<P>& acc, bool& acc_id, const Xyzz29<P>& q, bool q_id) {
+    if (q_id) return;
+    if (acc_id) {
+        acc = q;
+        acc_id = false;
+        return;
+    }
+    F29_ASSERT_LIMBS(acc.x, 29, "add acc.x"); F29_ASSERT_TOP(acc.x, 27, "add acc.x");
+    F29_ASSERT_LIMBS(acc.y, 29, "add acc.y"); F29_ASSERT_TOP(acc.y, 27, "add acc.y");
+    F29_ASSERT_LIMBS(acc.zz, 29, "add acc.zz"); F29_ASSERT_TOP(acc.zz, 27, "add acc.zz");
+    F29_ASSERT_LIMBS(acc.zzz, 29, "add acc.zzz"); F29_ASSERT_TOP(acc.zzz, 27, "add acc.zzz");
+    F29_ASSERT_LIMBS(q.x, 29, "add q.x"); F29_ASSERT_TOP(q.x, 27, "add q.x");
+    F29_ASSERT_LIMBS(q.y, 29, "add q.y"); F29_ASSERT_TOP(q.y, 27, "add q.y");
+    F29_ASSERT_LIMBS(q.zz, 29, "add q.zz"); F29_ASSERT_TOP(q.zz, 27, "add q.zz");
+    F29_ASSERT_LIMBS(q.zzz, 29, "add q.zzz"); F29_ASSERT_TOP(q.zzz, 27, "add q.zzz");
+    const F29<P> u1 = f29_mul<P>(acc.x, q.zz);     // < 2^257.2, tight
+    const F29<P> u2 = f29_mul<P>(q.x, acc.zz);
+    const F29<P> s1 = f29_mul<P>(acc.y, q.zzz);
+    const F29<P> s2 = f29_mul<P>(q.y, acc.zzz);
+    const F29<P> p = f29_carry<P>(f29_sub<P>(u2, u1));  // U2 - U1 + 64p < 2^260.3
+    const F29<P> r = f29_carry<P>(f29_sub<P>(s2, s1));
+    if (p.l[0] < 128u && f29_is_multiple_of_p<P>(p)) {
+        if (r.l[0] < 128u && f29_is_multiple_of_p<P>(r)) acc = xyzz29_double_general<P>(acc);  // equal points
+        else acc_id = true;                                                                     // opposite points
+        return;
+    }
+    const F29<P> pp = f29_sqr<P>(p);               // < 2^259.7
+    const F29<P> ppp = f29_mul<P>(p, pp);          // < 2^259.1
+    const F29<P> qq = f29_mul<P>(u1, pp);          // < 2^256
+    const F29<P> r2 = f29_sqr<P>(r);               // < 2^259.7
+    F29<P> x3 = f29_sub<P>(f29_sub<P>(r2, ppp), f29_dbl<P>(qq));
+    x3 = f29_reduce<P>(f29_carry<P>(x3));          // < 2^255.1, tight
+    F29<P> d;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        F29_ASSERT(f29_bias<P>(i) >= x3.l[i], "add: X3 limb above the bias");
+        d.l[i] = qq.l[i] + (f29_bias<P>(i) - x3.l[i]);
+    }
+    // Y3 = R (Q - X3) - S1 PPP as one lazy row (see xyzz29_madd): value < 2^259.9 + p before the reduce
+    Dot29<P> row;
+    dot29_init<P>(row);
+    dot29_mac<P>(row, r, f29_carry<P>(d));
+    dot29_mac<P>(row, f29_carry<P>(f29_sub<P>(f29_zero<P>(), s1)), ppp);
+    const F29<P> y3 = f29_reduce<P>(dot29_finish<P>(row));
+    const F29<P> zz12 = f29_mul<P>(acc.zz, q.zz);  // < 2^257.2
+    const F29<P> zzz12 = f29_mul<P>(acc.zzz, q.zzz);
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = f29_mul<P>(zz12, pp);                 // < 2^256
+    acc.zzz = f29_mul<P>(zzz12, ppp);
+}
+
 // One accumulation task on the radix-2^29 layer; returns an ordinary XYZZ point.
 template <class P>
 LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, uint32_t last, const Affine<P>* table) {

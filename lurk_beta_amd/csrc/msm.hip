@@ -491,6 +491,19 @@ template <class P>
 void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
                                       const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, hipStream_t s);
 
+// ---- 4b. the small-commitment path (msm_small.hip): a resident key of <= 2^16 points keeps every multiple of every window base ----
+constexpr size_t MSM_SMALL_MAX_POINTS = (size_t)1 << 16;
+int msm_small_window_bits(size_t n);
+size_t msm_small_table_entries(size_t n, int c);
+unsigned msm_small_groups(size_t n, int c);
+unsigned msm_small_out_points(unsigned groups);
+template <class P>
+void msm_small_build_table(const Affine<P>* wbases, size_t n, int c, Affine<P>* table, hipStream_t s);
+template <class P, class SF>
+void msm_small_launch(const void* d_scalars, size_t n, int is_mont, const Affine<P>* table, int c, void* group_pts, uint32_t* counter, Xyzz<P>* out,
+                      hipStream_t s);
+size_t msm_small_group_bytes();
+
 // Switches of the commitments-in-flight path (read once per process; the defaults are the measured best).
 // Everything else that round 2 kept for A/B runs (stream / wave priorities off, more waves per SIMD, a 128-VGPR build, hipGraph
 // replay, background-behind-sort off) lost its measurement and is gone: the winning setting is now the only code path.
@@ -646,6 +659,7 @@ struct MsmCtxBase {
     int device = 0;  // the device the context lives on: every entry point runs under a DeviceGuard for it
     size_t npoints = 0;
     bool precomputed = false;
+    bool small = false;  // precomputed in the small-commitment form (msm_small.hip): `c` is its window width, no bucket pipeline
     int c = MSM_C_PLAIN;
     virtual ~MsmCtxBase() {}
     // synchronous: enqueue on `s` with slot 0's workspace, wait, host tail
@@ -669,11 +683,12 @@ template <class P, class SF>
 struct MsmCtx : MsmCtxBase {
     DevBuf own_bases;                // bases (or the whole table when precomputed)
     const Affine<P>* table = nullptr;
+    DevBuf small_table;              // small form: n x W x 2^(c-1) multiples (own_bases then holds the plain bases)
 
     struct Work {
         std::mutex mu;
         DevBuf inter, sorted, block_hist, part_cnt, part_start, cnt, bucket_start, task_start, group_tasks, group_task_base, task_info,
-            task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, canon;
+            task_order, len_hist, partials, buckets, big_list, big_count, planes_a, planes_b, canon, small_counter;
         Xyzz<P>* host_pts = nullptr;  // pinned: window sums or bit planes for the host tail
         size_t ws_n = 0, ws_entries = 0, ws_nt = 0;  // what the workspaces hold room for: scalars (0 = nothing yet), sorted entries, tasks,
         uint32_t ws_NB = 0;                          // keys
@@ -682,6 +697,7 @@ struct MsmCtx : MsmCtxBase {
         hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
         DevBuf cursor;                     // task cursor of the persistent accumulate kernel (+ its per-CU placement counters)
         bool placement_valid = false;
+        bool small_ready = false;          // the small path's buffers exist and its arrival counter is zero
         bool force_persistent = false;     // LURK_MSM_SUBMIT_BACKGROUND
         bool foreground = false;           // LURK_MSM_SUBMIT_FOREGROUND
         hipStream_t pending_stream = nullptr;  // the stream the pending commitment ends on
@@ -732,6 +748,29 @@ struct MsmCtx : MsmCtxBase {
     void set_bases_device(const void* d_bases, size_t n, bool copy, bool precompute, int c_override, hipStream_t s) {
         npoints = n;
         precomputed = precompute;
+        small = false;
+        small_table.release();
+        if (precompute && !c_override && n > 0 && n <= MSM_SMALL_MAX_POINTS) {
+            // small resident key: all multiples of all window bases (msm_small.hip); the plain bases stay too (key files, rebinding)
+            c = msm_small_window_bits(n);
+            const int Ws = msm_num_windows(c);
+            own_bases.alloc(n * sizeof(Affine<P>));
+            LURK_HIP_CHECK(hipMemcpyAsync(own_bases.p, d_bases, n * sizeof(Affine<P>), hipMemcpyDeviceToDevice, s));
+            table = own_bases.as<Affine<P>>();
+            {
+                DevBuf wbases((size_t)Ws * n * sizeof(Affine<P>)), scratch((size_t)(Ws - 1) * 3 * n * sizeof(Fe<P>));
+                {
+                    ProfScope ps("msm_precompute", s);
+                    hipLaunchKernelGGL((msm_precompute_kernel<P>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Affine<P>*)d_bases, n,
+                                       wbases.as<Affine<P>>(), c, Ws, scratch.as<Fe<P>>());
+                    LURK_HIP_CHECK(hipGetLastError());
+                }
+                small_table.alloc(msm_small_table_entries(n, c) * sizeof(Affine<P>));
+                msm_small_build_table<P>(wbases.as<Affine<P>>(), n, c, small_table.as<Affine<P>>(), s);  // synchronises s
+            }
+            small = true;
+            return;
+        }
         // plain: 16-bit windows (W = 16 key spaces of 2^15 buckets).  With the table every window shares
         // one key space, so the window grows to 20 bits (13 windows whose top one still holds 15 bits).
         // (small keys keep 16-bit windows with the table as well: the 2^19 buckets of a 20-bit window cost a fixed 0.4 ms of
@@ -812,6 +851,8 @@ struct MsmCtx : MsmCtxBase {
         table = own_bases.as<Affine<P>>();
         npoints = n;
         precomputed = false;
+        small = false;
+        small_table.release();
         c = MSM_C_PLAIN;
         ensure_streams(wk);
         hipStream_t s = wk.stream;
@@ -832,6 +873,8 @@ struct MsmCtx : MsmCtxBase {
             LURK_REQUIRE(!wk.pending, "a slot has a commitment in flight");
         }
         own_bases.release();
+        small_table.release();
+        small = false;
         table = (const Affine<P>*)d_bases;
         npoints = n;
         precomputed = false;
@@ -841,6 +884,19 @@ struct MsmCtx : MsmCtxBase {
         LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
         LURK_REQUIRE(slots >= 1 && slots <= MSM_SLOTS, "slot count out of range");
         if (n == 0) return;
+        if (small) {
+            DevBuf zeros(32);
+            LURK_HIP_CHECK(hipMemset(zeros.p, 0, 32));
+            for (int k = 0; k < slots; k++) {
+                Work& wk = work[k];
+                std::lock_guard<std::mutex> lk(wk.mu);
+                LURK_REQUIRE(!wk.pending, "slot is busy");
+                ensure_streams(wk);
+                enqueue(wk, zeros.p, 1, 0, wk.stream, nullptr);  // one launch through the slot's queue: pays its setup now
+                LURK_HIP_CHECK(hipStreamSynchronize(wk.stream));
+            }
+            return;
+        }
         const MsmShape sh = shape(n);
         // A slot's first commitment otherwise pays for its two hardware queues and their scratch rings (tens of ms): run one
         // empty commitment (all-zero scalars: no entries, every kernel launched) through each slot's streams now.
@@ -861,9 +917,20 @@ struct MsmCtx : MsmCtxBase {
     void adopt_table(DevBuf&& buf, size_t n, bool precomputed_, int c_) override {
         own_bases = std::move(buf);
         table = own_bases.as<Affine<P>>();
+        small_table.release();
+        small = false;
         npoints = n;
         precomputed = precomputed_;
         c = c_;
+    }
+
+    void ensure_workspace_small(Work& wk) {
+        if (wk.small_ready) return;
+        wk.partials.ensure(msm_small_group_bytes());
+        wk.small_counter.ensure(16);
+        LURK_HIP_CHECK(hipMemset(wk.small_counter.p, 0, 16));  // the small kernel's arrival counter: zero before its first launch, left zero by every launch
+        if (!wk.host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&wk.host_pts, (size_t)MSM_MAX_W * 20 * sizeof(Xyzz<P>)));
+        wk.small_ready = true;
     }
 
     size_t ntask_max(const MsmShape& sh) const { return (size_t)sh.NB + (size_t)sh.W * sh.n / MSM_S + 1; }
@@ -904,6 +971,13 @@ struct MsmCtx : MsmCtxBase {
     // s_acc: stream of the accumulate kernel (nullptr: same stream, classic launch)
     void enqueue(Work& wk, const void* d_scalars, size_t n, int is_mont, hipStream_t s, hipStream_t s_acc = nullptr,
                  const std::function<void()>* before_accumulate = nullptr) {
+        if (small) {  // one launch; <= 16 points land in the slot's pinned buffer
+            ensure_workspace_small(wk);
+            msm_small_launch<P, SF>(d_scalars, n, is_mont, small_table.as<Affine<P>>(), c, wk.partials.p,
+                                    wk.small_counter.template as<uint32_t>(), wk.host_pts, s);
+            if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
+            return;
+        }
         const MsmShape sh = shape(n);
         ensure_workspace(wk, sh);
         const size_t chunk = (n + MSM_NB1 - 1) / MSM_NB1;
@@ -1027,6 +1101,13 @@ struct MsmCtx : MsmCtxBase {
     static void put_point(void* out, const Jacobian<P>& j) { memcpy(out, &j, sizeof(j)); }
     static void put_identity(void* out) { put_point(out, jacobian_from_affine<P>(Affine<P>{fe_zero<P>(), fe_zero<P>()})); }
     void host_tail(Work& wk, size_t n, void* out) {
+        if (small) {
+            const unsigned K = msm_small_out_points(msm_small_groups(n, c));
+            Xyzz<P> total = xyzz_identity<P>();
+            for (unsigned k = 0; k < K; k++) xyzz_add<P>(total, wk.host_pts[k]);
+            put_point(out, jacobian_from_affine<P>(xyzz_to_affine<P>(total)));
+            return;
+        }
         const MsmShape sh = shape(n);
         const Xyzz<P> total = msm_planes_horner_windows<P>(wk.host_pts, sh.G, sh.c);  // sum_g 2^(c g) (S_g + sum_k 2^k P_gk)
         put_point(out, jacobian_from_affine<P>(xyzz_to_affine<P>(total)));
@@ -1390,7 +1471,7 @@ int lurk_hip_msm_ctx_save(const lurk_hip_msm_ctx* ctx, const char* path, int wit
         h.version = 1;
         h.curve = (uint32_t)c.curve;
         h.window_bits = (uint32_t)c.c;
-        h.windows = (with_table && c.precomputed) ? (uint32_t)msm_num_windows(c.c) : 1u;
+        h.windows = (with_table && c.precomputed && !c.small) ? (uint32_t)msm_num_windows(c.c) : 1u;  // the small form's table is rebuilt on load
         h.npoints = c.npoints;
         FILE* f = fopen(path, "wb");
         LURK_REQUIRE(f, std::string("cannot create ") + path);

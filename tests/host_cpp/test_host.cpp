@@ -223,9 +223,69 @@ int main() {
             auto got = ctx.read();
             EXPECT(got.first == z_run && got.second == e_run);
         }
-        // after four folds of satisfied instances the pair is a relaxed witness: E = A z o B z - u C z.  Row 1 of this shape is
+        // three more steps with NO externally supplied challenge (FoldingContext::step: the library's transcript derives r): r must be what
+        // lurk_hip_nifs_challenge gives for the instance as it stood BEFORE the step, and the fold must be the fold with that r
+        for (int step = 0; step < 3; step++) {
+            std::vector<Fe> io{rs[(step + 1) % 3]};
+            const Fe pp_digest(0x1234567 + step);
+            const Jacobian cw1 = ctx.comm_w, ce1 = ctx.comm_e;
+            const auto ux = ctx.u_and_x();
+            auto comms = ctx.step(fresh[step], io, pp_digest);
+            Fe r_expect;
+            check(lurk_hip_nifs_challenge(curve, &pp_digest, &cw1, &ce1, &ux.first, ux.second.data(), &comms[0], io.data(), 1, &comms[1], &r_expect));
+            EXPECT(ctx.last_r == r_expect && !ctx.last_r.is_zero());
+            std::vector<Fe> z2{fresh[step][0], fresh[step][1], one, io[0]};
+            auto t = shape.cross_term(z_run, z2);
+            EXPECT(key.to_affine(comms[1]) == key.to_affine(key.commit(t, true)));
+            z_run = shape.fold(z_run, z2, ctx.last_r);
+            e_run = shape.fold(e_run, t, ctx.last_r);
+            auto got = ctx.read();
+            EXPECT(got.first == z_run && got.second == e_run);
+            std::vector<Fe> w(z_run.begin(), z_run.begin() + 2);
+            EXPECT(key.to_affine(ctx.comm_w) == key.to_affine(key.commit(w, true)));
+            EXPECT(key.to_affine(ctx.comm_e) == key.to_affine(key.commit(e_run, true)));
+            const auto ux2 = ctx.u_and_x();
+            EXPECT(ux2.first == z_run[2] && ux2.second[0] == z_run[3]);  // u and X of the instance = the tail of z
+        }
+        // after these folds of satisfied instances the pair is a relaxed witness: E = A z o B z - u C z.  Row 1 of this shape is
         // linear in z times u, so E_1 = (x + y) u - u (x + y) = 0 whatever was folded.
         EXPECT(e_run[1] == zero);
+    }
+    // the transcript alone against values computed by the oracle (oracle/pyref.py: nova_ro_squeeze(f, [1..24], 128))
+    {
+        std::vector<Fe> els;
+        for (uint64_t i = 1; i <= 24; i++) els.push_back(Fe(i));
+        Fe w0, w1;
+        w0.l = {0xba5bb8a08d750a3eULL, 0x5a3a50cee53b37d7ULL, 0, 0};
+        w1.l = {0x184fe0713deef00dULL, 0xe89046b819218fd3ULL, 0, 0};
+        EXPECT(nova_ro_squeeze(LURK_FIELD_PALLAS_FP, els) == w0);
+        EXPECT(nova_ro_squeeze(LURK_FIELD_PALLAS_FQ, els) == w1);
+    }
+    // NIVC: two circuits (the same tiny shape twice is enough to see the bookkeeping) under one key; a step moves only its own circuit
+    {
+        const int curve = LURK_CURVE_PALLAS;
+        Fe one;
+        one.l = {0x5b2b3e9cfffffffdULL, 0x992c350be3420567ULL, 0xffffffffffffffffULL, 0x3fffffffffffffffULL};
+        SparseMatrix A, B, C;
+        A.indptr = {0, 1, 3}; A.indices = {0, 0, 1}; A.data = {one, one, one};
+        B.indptr = {0, 1, 2}; B.indices = {0, 2};    B.data = {one, one};
+        C.indptr = {0, 1, 3}; C.indices = {1, 0, 1}; C.data = {one, one, one};
+        R1CSShape s0(LURK_FIELD_PALLAS_FQ, 2, 2, 1, A, B, C), s1(LURK_FIELD_PALLAS_FQ, 2, 2, 1, A, B, C);
+        CommitmentKey k1(curve, {G}, false);
+        Jacobian g2 = k1.commit({Fe(2)}, false);
+        CommitmentKey key(curve, {G, Affine{g2.x, g2.y}}, false);
+        NivcFoldingContext nivc(curve, {&s0, &s1}, key);
+        auto add = [&](const Fe& a, const Fe& b) { return s0.fold({a}, {b}, one)[0]; };
+        Fe two = add(one, one), three = add(two, one), four = add(two, two), nine = add(add(four, four), one);
+        const Jacobian id{};
+        nivc.step(1, {three, nine}, {two}, Fe(77));
+        EXPECT(key.to_affine(nivc.circuit(0).comm_w) == key.to_affine(id));      // circuit 0 untouched
+        EXPECT(!(key.to_affine(nivc.circuit(1).comm_w) == key.to_affine(id)));
+        nivc.step(0, {two, four}, {three}, Fe(77));
+        EXPECT(!(key.to_affine(nivc.circuit(0).comm_w) == key.to_affine(id)));
+        bool threw = false;
+        try { nivc.step(2, {two, four}, {three}, Fe(77)); } catch (const std::invalid_argument&) { threw = true; }
+        EXPECT(threw);
     }
     printf("host mirror ok\n");
     return 0;

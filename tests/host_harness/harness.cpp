@@ -5,6 +5,7 @@
 // precede the FIRST inclusion of field29.cuh (poseidon29.cuh pulls it in)
 #define LURK_F29_CHECK 1
 #include <stddef.h>
+#include <vector>
 #include "../../lurk_beta_amd/csrc/field.cuh"
 using namespace lurk;
 
@@ -202,6 +203,43 @@ static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, si
     Jacobian<P> j = jacobian_from_affine<P>(r);
     r = xyzz_to_affine<P>(xyzz_from_jacobian<P>(j));
     for (int k = 0; k < 8; k++) { out[k] = r.x.l[k]; out[8 + k] = r.y.l[k]; }
+}
+// The reduction tree of the small-commitment path (msm_small.hip) on the host with the bound assertions on: the n signed bases are
+// dealt round-robin to `lanes` accumulators (xyzz29_madd), which are then summed by an xor butterfly of xyzz29_add - every "lane"
+// computes its own copy of every level, as the wave does.  Output: affine Montgomery.
+template <class P>
+static void curve_tree(const uint32_t* bases, const uint32_t* signs, size_t n, int lanes, uint32_t* out) {
+    std::vector<Xyzz29<P>> acc(lanes);
+    std::vector<char> id(lanes, 1);
+    for (int l = 0; l < lanes; l++) acc[l].x = acc[l].y = acc[l].zz = acc[l].zzz = f29_zero<P>();
+    for (size_t i = 0; i < n; i++) {
+        Affine<P> a;
+        for (int k = 0; k < 8; k++) { a.x.l[k] = bases[i * 16 + k]; a.y.l[k] = bases[i * 16 + 8 + k]; }
+        bool b = id[i % lanes] != 0;
+        xyzz29_madd<P>(acc[i % lanes], b, a, signs[i] != 0);
+        id[i % lanes] = b;
+    }
+    for (int off = 1; off < lanes; off <<= 1) {
+        std::vector<Xyzz29<P>> nxt = acc;
+        std::vector<char> nid = id;
+        for (int l = 0; l < lanes; l++) {
+            bool b = id[l] != 0;
+            xyzz29_add<P>(nxt[l], b, acc[l ^ off], id[l ^ off] != 0);
+            nid[l] = b;
+        }
+        acc.swap(nxt);
+        id.swap(nid);
+    }
+    Affine<P> r = xyzz_to_affine<P>(xyzz29_to_xyzz<P>(acc[0], id[0] != 0));
+    for (int l = 1; l < lanes; l++) {  // every lane must hold the same total
+        Affine<P> o = xyzz_to_affine<P>(xyzz29_to_xyzz<P>(acc[l], id[l] != 0));
+        if (!fe_eq<P>(o.x, r.x) || !fe_eq<P>(o.y, r.y)) { printf("curve_tree: lane %d disagrees\n", l); abort(); }
+    }
+    for (int k = 0; k < 8; k++) { out[k] = r.x.l[k]; out[8 + k] = r.y.l[k]; }
+}
+extern "C" void hh_curve_tree(int curve, const uint32_t* bases, const uint32_t* signs, size_t n, int lanes, uint32_t* out) {
+    if (curve == 0) curve_tree<PallasFp>(bases, signs, n, lanes, out);
+    else curve_tree<PallasFq>(bases, signs, n, lanes, out);
 }
 // 1 when the bound assertions of field29.cuh / curve29.cuh are compiled in (they silently were not while another header pulled
 // field29.cuh in ahead of the switch)

@@ -211,3 +211,52 @@ def test_accumulator_stress_under_bound_assertions(c):
         L.hh_curve_sum(c, 3, vp(Bc), vp(signs), ctypes.c_size_t(64), vp(o3))
         L.hh_curve_sum(c, 4, vp(Bc), vp(signs), ctypes.c_size_t(64), vp(o4))
         assert np.array_equal(o3, o4), w
+
+
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+def test_radix29_reduction_tree_with_bound_assertions(cn, c):
+    """xyzz29_add (the node of the small-commitment path's reduction trees, msm_small.hip) under the bound assertions: signed bases
+    dealt to 1..64 accumulators and summed by the xor butterfly, against the Python group law; with the exceptional meetings
+    (equal partial sums -> doubling, opposite ones -> identity, identity operands) forced into the tree."""
+    L = H.lib()
+    assert L.hh_f29_checks_active() == 1
+    rng = np.random.default_rng(5 + c)
+    n = 200
+    B = C.synth_bases(c, n)
+    pts = [None if pt == (0, 0) else pt for pt in C.affine_to_ints(c, B)]
+    for lanes in (1, 2, 4, 16, 64):
+        signs = rng.integers(0, 2, n).astype(np.uint32)
+        want = None
+        for pt, s in zip(pts, signs):
+            want = R.ec_add(cn, want, R.ec_neg(cn, pt) if s else pt)
+        out = np.zeros(8, dtype=np.uint64)
+        L.hh_curve_tree(c, vp(B), vp(signs), ctypes.c_size_t(n), lanes, vp(out))
+        assert C.affine_to_ints(c, out)[0] == (want or (0, 0)), lanes
+    # 4 lanes: lanes 0 and 1 hold the same point (doubling at level 1), lanes 2 and 3 opposite points (identity at level 1)
+    B4 = np.concatenate([B[:1], B[:1], B[1:2], B[1:2]])
+    s4 = np.array([0, 0, 0, 1], dtype=np.uint32)
+    out = np.zeros(8, dtype=np.uint64)
+    L.hh_curve_tree(c, vp(B4), vp(s4), ctypes.c_size_t(4), 4, vp(out))
+    assert C.affine_to_ints(c, out)[0] == R.ec_add(cn, pts[0], pts[0])
+    # all four equal: doubling at both levels; 8 lanes with only 3 points: identity operands in the tree
+    B5 = np.concatenate([B[:1]] * 4)
+    out = np.zeros(8, dtype=np.uint64)
+    L.hh_curve_tree(c, vp(B5), vp(np.zeros(4, dtype=np.uint32)), ctypes.c_size_t(4), 4, vp(out))
+    assert C.affine_to_ints(c, out)[0] == R.ec_mul(cn, 4, pts[0])
+    out = np.zeros(8, dtype=np.uint64)
+    L.hh_curve_tree(c, vp(B[:3]), vp(np.zeros(3, dtype=np.uint32)), ctypes.c_size_t(3), 8, vp(out))
+    assert C.affine_to_ints(c, out)[0] == R.ec_add(cn, R.ec_add(cn, pts[0], pts[1]), pts[2])
+    # everything cancels
+    B6 = np.concatenate([B[:8], B[:8]])
+    s6 = np.array([0] * 8 + [1] * 8, dtype=np.uint32)
+    out = np.zeros(8, dtype=np.uint64)
+    L.hh_curve_tree(c, vp(B6), vp(s6), ctypes.c_size_t(16), 8, vp(out))
+    assert C.affine_to_ints(c, out)[0] == (0, 0)
+    # a long stress: 20 000 points through 64 lanes (312 mixed additions per lane, then 6 levels), checked against the 32-bit group law
+    n7 = 20000
+    B7 = C.synth_bases(c, n7)
+    s7 = rng.integers(0, 2, n7).astype(np.uint32)
+    o29, o32 = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    L.hh_curve_tree(c, vp(B7), vp(s7), ctypes.c_size_t(n7), 64, vp(o29))
+    L.hh_curve_sum(c, 0, vp(B7), vp(s7), ctypes.c_size_t(n7), vp(o32))
+    assert np.array_equal(o29, o32)
