@@ -61,7 +61,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to exercise the "
                                                       "N > 1 path on a single-GPU box: every rank then shares GPU 0)")
     ap.add_argument("--verify", action="store_true",
-                    help="check the final commitment of the timed loop against the oracle's discrete-log checksum (rank 0)")
+                    help="rank 0 checks the workload's result against the oracle after the timed loop: msm - the discrete-log checksum; fold_step - one more step, "
+                         "every output vs oracle.c / msm_fast.c / the oracle transcript; compress - the oracle's verifier on the last proof; poseidon_tree - the CPU tree")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=22)
     ap.add_argument("--pmc", choices=["auto", "off"], default="auto",
@@ -371,18 +372,27 @@ def fold_step_workload(args, lib, world, rank):
     d_w2 = d_w2s[0]
     x2 = synth.scalars(F, 9, 0, n_io, mont=True).cpu().numpy().view(np.uint64)
     t_setup = time.perf_counter()
-    shape = L.R1CSShape(F, n_t, n_w, n_io, *synth_r1cs_shape(F, q, n_t, n_w, n_io))
+    host_mats = synth_r1cs_shape(F, q, n_t, n_w, n_io)
+    shape = L.R1CSShape(F, n_t, n_w, n_io, *host_mats)
     shape_setup_s = time.perf_counter() - t_setup
+    if not args.verify:
+        host_mats = None
     info = shape.info()
-    r_chal = 0x0FEDCBA0987654321234567890ABCDEF  # stands in for the transcript's challenge: 128 bits, as arecibo squeezes (NUM_CHALLENGE_BITS)
+    # the challenge of every step is derived by the library's transcript (arecibo's PoseidonRO over pp_digest, U1, U2, comm_T: 128 bits),
+    # on the host between begin and finish, as NIFS::prove does
+    pp_digest = 0x1F3C5A7990B2D4E6F8123456789ABCDEF0FEDCBA9876543210AA55AA55AA55
+    r_chal = 0x0FEDCBA0987654321234567890ABCDEF  # the secondary-curve leg below still feeds a constant of that size
     r_mont = np.array([((r_chal << 256) % q) >> (64 * w) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
+    last_r = [r_mont]
     torch.cuda.synchronize()
     ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     ctx = L.FoldingContext(L.CURVE_PALLAS, shape, ck)
     z1 = synth.scalars(F, 1, 1, n_w + 1 + n_io, mont=True).cpu().numpy().view(np.uint64)   # a running instance with witness-like values
     e1 = synth.scalars(F, 2, 0, n_t, mont=True).cpu().numpy().view(np.uint64)              # a running error vector (uniform, like any folded T)
     ident = np.zeros(12, dtype=np.uint64)
-    ctx.set_running(z1, e1, ident, ident)
+    # the running instance's commitments are the commitments of the running vectors (what RecursiveSNARK::verify re-computes)
+    ctx.set_running(z1, e1, ck.commit_device(torch.from_numpy(z1[:n_w].view(np.int64)).cuda(), n_w, is_mont=True),
+                    ck.commit_device(torch.from_numpy(e1.view(np.int64)).cuda(), n_t, is_mont=True))
 
     # --stage-ahead 1: the step circuit's range of the NEXT witness is traced and its commitment started before this
     # step opens (lurk-beta synthesizes witnesses ahead of the folding loop, nova.rs:304-326); the augmented circuit's own
@@ -399,7 +409,7 @@ def fold_step_workload(args, lib, world, rank):
         mf.assemble(buf, pre, globals_host, bodies_np, mont=True, stream=stream)     # W2 in HBM (slot traces on the device)
         ctx.prefetch(buf[lo:hi], lo, stream=stream)                                  # commit(step circuit's range) starts now
 
-    phase = {"assemble_and_stage": 0.0, "begin": 0.0, "finish": 0.0}  # host wall time per call site (begin blocks on the commitments)
+    phase = {"assemble_and_stage": 0.0, "begin": 0.0, "transcript": 0.0, "finish": 0.0}  # host wall time per call site (begin blocks on the commitments)
 
     def step():
         t_a = time.perf_counter()
@@ -420,11 +430,16 @@ def fold_step_workload(args, lib, world, rank):
             t_b = time.perf_counter()
             cw, ct = ctx.begin(d_w2, x2, stream=stream)                              # both commitments + the cross term
         t_c = time.perf_counter()
-        ctx.finish(r_mont)                                                            # the transcript's r would come between
+        ucw, uce, uu, ux = ctx.instance()
+        r = L.nifs_challenge(L.CURVE_PALLAS, pp_digest, ucw, uce, uu, ux, cw, x2, ct)  # r = RO(pp_digest, U1, U2, comm_T)
+        t_r = time.perf_counter()
+        ctx.finish(r)
+        last_r[0] = r
         t_d = time.perf_counter()
         phase["assemble_and_stage"] += t_b - t_a
         phase["begin"] += t_c - t_b
-        phase["finish"] += t_d - t_c
+        phase["transcript"] += t_r - t_c
+        phase["finish"] += t_d - t_r
         return cw, ct
 
     if args.stage_ahead:
@@ -450,6 +465,10 @@ def fold_step_workload(args, lib, world, rank):
     if args.stage_ahead:  # drain the instance staged by the last timed step (one was staged before the region: K stagings inside it)
         ctx.begin_prefetched(x2, patches)
         ctx.finish(r_mont)
+    verified = None
+    if args.verify and rank == 0:
+        verified = verify_fold_step(L, ctx, host_mats, F, q, n_w, n_t, n_io, d_bases, pp_digest, x2,
+                                    lambda buf: mf.assemble(buf, pre, globals_host, bodies_np, mont=True, stream=stream), d_w2s[0])
 
     def kernel_ms(name):
         tot, cnt = ctypes.c_double(), ctypes.c_uint64()
@@ -476,7 +495,9 @@ def fold_step_workload(args, lib, world, rank):
                        "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
                                    f"slot blocks traced on the device + {rc} x 1311 body aux over PCIe) -> MSM(W2) + cross term over {n_t} rows ({nnz} non-zeros, "
                                    f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) -> fold of [W|u|X] and E",
-                       "note": "device work only; transcript / body synthesis / the small secondary-curve fold not modelled",
+                       "note": "device work + the transcript (r derived per step by the library's PoseidonRO on the host); body synthesis not modelled; "
+                               "the secondary-curve half is the separate secondary_curve_step record",
+                       "verified": verified,
                        "r1cs_columns": "frame-structured (88 % frame-local, 6 % globals, 4 % previous frame, 2 % u): a builder-chosen model of the step circuit's sparsity, "
                                        "see fold_kernels.r1cs_cross_term_uniform_columns for the structure-free case",
                        "shape_setup_s_once": round(shape_setup_s, 2)},
@@ -559,6 +580,53 @@ def fold_step_workload(args, lib, world, rank):
     ctx.close()
     ck.close()
     shape.close()
+
+
+def verify_fold_step(L, ctx, host_mats, F, q, n_w, n_t, n_io, d_bases, pp_digest, x2, assemble, d_w2):
+    """--verify: ONE more step after the timed loop through lurk_hip_fold_step, every output against the oracle at the bench's own size:
+    comm_W2 and comm_T (oracle/msm_fast.c), r (the oracle's transcript over the oracle's instance), T and the folded (z, E) element by
+    element (oracle/oracle.c), the folded instance's commitments.  The checker only: nothing here is timed."""
+    import numpy as np
+    import torch
+
+    from oracle import coracle as C
+    from oracle import pyref as R
+
+    f, curve = 1, 0
+    t0 = time.perf_counter()
+    mats = [(ip, ix, C.from_mont(f, d)) for ip, ix, d in host_mats]
+    bases = d_bases.cpu().numpy().view(np.uint64).reshape(-1, 8)
+    z1m, e1m = ctx.read()
+    z1, e1 = C.from_mont(f, z1m), C.from_mont(f, e1m)
+    cw1, ce1, _, _ = ctx.instance()
+    pt = lambda a: None if a == (0, 0) else a
+    cw1_o = pt(C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_w], z1[:n_w])))   # the running instance's commitments, recomputed
+    ce1_o = pt(C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_t], e1)))
+    ok = {"running_comm_W": pt(L.point_to_affine(curve, cw1)) == cw1_o, "running_comm_E": pt(L.point_to_affine(curve, ce1)) == ce1_o}
+    assemble(d_w2)
+    torch.cuda.synchronize()
+    w2 = C.from_mont(f, d_w2.cpu().numpy().view(np.uint64).reshape(-1, 4))
+    x2c = C.from_mont(f, x2.reshape(-1, 4))
+    cw, ct, r_mont = ctx.step(d_w2, x2, pp_digest, stream=torch.cuda.current_stream().cuda_stream)
+    z2 = np.concatenate([w2, C.ints_to_limbs([1]), x2c])
+    u1 = C.limbs_to_ints(z1[n_w:n_w + 1])[0]
+    t = C.cross_term(f, *[C.spmv(f, *M, z1) for M in mats], *[C.spmv(f, *M, z2) for M in mats], u1, 1)
+    cw2_o, ct_o = C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_w], w2)), C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_t], t))
+    ok["comm_W2"] = L.point_to_affine(curve, cw) == cw2_o
+    ok["comm_T"] = L.point_to_affine(curve, ct) == ct_o
+    r = R.nifs_challenge("pallas", pp_digest, cw1_o, ce1_o, u1, C.limbs_to_ints(z1[n_w + 1:]), pt(cw2_o), C.limbs_to_ints(x2c), pt(ct_o))
+    ok["challenge"] = C.limbs_to_ints(C.from_mont(f, r_mont.reshape(1, 4)))[0] == r
+    zf, ef = C.axpy(f, z1, z2, r), C.axpy(f, e1, t, r)
+    gz, ge = ctx.read()
+    ok["folded_z"] = bool(np.array_equal(C.from_mont(f, gz), zf))
+    ok["folded_E"] = bool(np.array_equal(C.from_mont(f, ge), ef))
+    gcw, gce, _, _ = ctx.instance()
+    ok["folded_comm_W"] = L.point_to_affine(curve, gcw) == C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_w], zf[:n_w]))
+    ok["folded_comm_E"] = L.point_to_affine(curve, gce) == C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_t], ef))
+    if not all(ok.values()):
+        raise SystemExit(f"bench.py --verify: the fold step does not match the oracle: {ok}")
+    return {"ok": True, "checks": sorted(ok), "oracle_s": round(time.perf_counter() - t0, 1),
+            "against": "oracle/oracle.c (spmv, cross term, axpy), oracle/msm_fast.c (6 commitments), oracle/pyref.py (transcript), one extra step after the timed loop"}
 
 
 def compress_workload(args, lib, world, rank):
@@ -649,6 +717,23 @@ def compress_workload(args, lib, world, rank):
         # the verifier's sum-check identity on the proof itself: the outer claim chain starts at 0 (a satisfied instance)
         p0 = proof["polys_outer"][0]
         assert (2 * p0[0] + sum(p0[1:])) % q == 0, "outer sum-check does not start from claim 0: the instance is not satisfied"
+        verified = None
+        if args.verify:
+            # the oracle's VERIFIER (oracle/spartan_fast.py: the protocol of spartan_ref.py with the vector work in C) on the proof of the
+            # last timed step, at the bench's own size; and on the same proof for a different statement, which it must reject
+            from oracle import coracle as C
+            from oracle import spartan_fast as SF
+
+            t_v = time.perf_counter()
+            mats_c = [(ip, ix, C.from_mont(1, d)) for ip, ix, d in (A, B, Cm)]
+            ck_host = d_ck.cpu().numpy().view(np.uint64).reshape(-1, 8)
+            aff = lambda j: (lambda a: None if a == (0, 0) else a)(L.point_to_affine(L.CURVE_PALLAS, j))
+            accepted = SF.verify(0, mats_c, nc, nv, X, ck_host, aff(cw), aff(ce), 1, proof)
+            rejected = not SF.verify(0, mats_c, nc, nv, [(X[0] + 1) % q] + X[1:], ck_host, aff(cw), aff(ce), 1, proof)
+            if not (accepted and rejected):
+                raise SystemExit(f"bench.py --verify: the oracle verifier {'rejects the proof' if not accepted else 'accepts the proof for another statement'}")
+            verified = {"ok": True, "oracle_s": round(time.perf_counter() - t_v, 1),
+                        "against": "oracle/spartan_fast.py verify(): accepts the proof of the last timed step, rejects it for X[0] + 1"}
         out = {"metric": "CompressedSNARK-style proofs/s (primary-curve Spartan prover stand-in, Pallas)", "value": round(1e3 / ms, 3), "unit": "proofs/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
@@ -656,6 +741,7 @@ def compress_workload(args, lib, world, rank):
                                       f"({int(A[0][-1]) + int(B[0][-1]) + rows_p} non-zeros): 3 sum-checks ({log_n} + {log_n + 1} + {log_n} rounds), "
                                       f"transposed sparse mat-vec, inner-product argument over a 2^{log_n}-point key",
                           "note": "functional stand-in, not byte-compatible with arecibo; transcript and round glue in Python on the host",
+                          "verified": verified,
                           "shape_setup_s_once": round(setup_s, 2)},
                "kernels_ms_per_proof": {k: kernel_ms(k) for k in ("sumcheck_round", "eq_evals", "r1cs_multiply_vec", "fold_vec", "ipa_inner_product",
                                                                    "ipa_fold_halves", "ipa_points_fold", "ipa_round_scalars", "ipa_coef_fold", "msm_accumulate", "msm_sort",

@@ -431,21 +431,23 @@ def test_key_files_round_trip(hip, tmp_path, cn, c):
     B[7] = 0  # an identity base survives the batched-inversion table build
     S = C.synth_scalars(sf, 55, 1, n)
     want = C.jac_to_affine(c, C.msm_pippenger(c, B, S))
-    ck = CommitmentKey(c, B, precompute=True)
-    assert point_to_affine(c, ck.commit(S)) == want
+    ck = CommitmentKey(c, B, precompute=True, window_bits=16)  # the window table of the bucket pipeline (a key this small would otherwise
+    assert point_to_affine(c, ck.commit(S)) == want             # take the small-commitment form, whose table is never written: test_gpu_msm_small.py)
     bases_only, with_table = str(tmp_path / "ck.bin"), str(tmp_path / "ck_table.bin")
     ck.save(bases_only)
     ck.save(with_table, with_table=True)
     import os
 
     windows = -(-256 // ck.info()["window_bits"])
-    assert ck.info()["window_bits"] == 16  # a key this small keeps 16-bit windows with its table (20 bits from 2^19 points on)
+    assert ck.info()["window_bits"] == 16
     assert os.path.getsize(bases_only) == 64 + 64 * n and os.path.getsize(with_table) == 64 + windows * 64 * n
     for path in (bases_only, with_table):
         for pre in (False, True):
             k2 = CommitmentKey.load(path, precompute=pre)
             info = k2.info()
             assert (info["curve"], info["npoints"], info["precomputed"]) == (c, n, pre)
+            # the file's own table is adopted as it is (16-bit windows); bases alone, loaded with the flag, take the small form (8-bit)
+            assert info["window_bits"] == (16 if not pre or path == with_table else 8)
             assert point_to_affine(c, k2.commit(S)) == want, (path, pre)
             assert point_to_affine(c, k2.commit(S[:777])) == C.jac_to_affine(c, C.msm_pippenger(c, B[:777], S[:777]))
             k2.close()

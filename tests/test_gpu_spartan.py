@@ -47,3 +47,38 @@ def test_device_prover_matches_the_oracle_and_verifies(hip, cn, c, num_cons, num
     assert not S.verify(cn, mats, num_cons, num_vars, [(X[0] + 1) % q] + X[1:], ck, ck_c, comm_W, comm_E, u, got)
     k.close()
     prover.close()
+
+
+@pytest.mark.parametrize("cn,c,log_n", [("pallas", 0, 14), ("vesta", 1, 14), ("pallas", 0, 16)])
+def test_device_prover_matches_the_fast_oracle_at_2_14_and_2_16(hip, cn, c, log_n):
+    """The same end-to-end parity at 2^14 and 2^16 rows and variables: the device-assisted prover's proof equals the proof of the C-backed
+    oracle prover (oracle/spartan_fast.py: the protocol of spartan_ref.py, checked identical to it on CPU at small sizes) element for
+    element - in all three forms of the opening argument (folded key, resident plain key, resident table key) - and the oracle's
+    verifier accepts it and rejects it for another statement.  Reference: /root/reference/src/proof/nova.rs:341-356."""
+    from lurk_beta_amd import CommitmentKey
+    from lurk_beta_amd.spartan import SpartanProver
+    from oracle import spartan_fast as SF
+
+    sf = 1 - c
+    q = R.CURVES[cn]["order"]
+    nc = nv = 1 << log_n
+    A, Bm, Cm, W, X = SF.synth_product_instance(sf, nc, nv, 2, seed=log_n + c)
+    E = np.zeros((nc, 4), dtype=np.uint64)
+    B = C.synth_bases(c, nc + 1)
+    comm_W = SF._aff(c, SF._commit(c, B, W))
+    want = SF.prove(c, (A, Bm, Cm), nc, nv, X, B, comm_W, None, 1, W, E)
+    assert SF.verify(c, (A, Bm, Cm), nc, nv, X, B, comm_W, None, 1, want)
+    mont = lambda M: (M[0], M[1], C.to_mont(sf, M[2]))
+    prover = SpartanProver(c, q, [mont(A), mont(Bm), mont(Cm)], nc, nv, len(X))
+    d_W, d_E, d_B = _dev(C.to_mont(sf, W)), _dev(E), _dev(B)
+    plain = CommitmentKey(c, B[:nc])
+    table = CommitmentKey(c, B[:nc], precompute=True)
+    cw, ce = plain.commit(W), plain.commit(E)
+    got = prover.prove(X, 1, d_W, d_E, d_B, cw, ce)
+    assert got == want
+    assert prover.prove(X, 1, d_W, d_E, d_B, cw, ce, key=plain) == want
+    assert prover.prove(X, 1, d_W, d_E, d_B, cw, ce, key=table) == want
+    assert not SF.verify(c, (A, Bm, Cm), nc, nv, [(X[0] + 1) % q] + X[1:], B, comm_W, None, 1, got)
+    for k in (plain, table):
+        k.close()
+    prover.close()

@@ -80,3 +80,68 @@ def test_complete_and_sound(curve, num_cons, num_vars, folded):
     comm_E2 = R.msm_naive(curve, E2, ck)
     p2 = S.prove(curve, mats, num_cons, num_vars, X, ck, ck_c, comm_W, comm_E2, u, W, E2)
     assert not S.verify(curve, mats, num_cons, num_vars, X, ck, ck_c, comm_W, comm_E2, u, p2)
+
+
+def _to_arrays(mats, X, W, E):
+    import numpy as np
+
+    from oracle import coracle as C
+
+    m = [(np.array(ip, dtype=np.uint64), np.array(ix, dtype=np.uint64), C.ints_to_limbs(d) if len(d) else np.zeros((0, 4), dtype=np.uint64)) for ip, ix, d in mats]
+    return m, C.ints_to_limbs(W), C.ints_to_limbs(E)
+
+
+@pytest.mark.parametrize("curve_id,curve,num_cons,num_vars,folded",
+                         [(0, "pallas", 4, 8, False), (1, "vesta", 8, 16, True), (0, "pallas", 16, 64, True), (1, "vesta", 16, 32, False)])
+def test_fast_oracle_produces_the_reference_oracles_proof(curve_id, curve, num_cons, num_vars, folded):
+    """oracle/spartan_fast.py (C vector work, msm_fast commitments: the oracle that runs at 2^14 .. 2^20) against
+    oracle/spartan_ref.py (Python integers): the same proof element for element, and each verifier accepts the other's proof."""
+    import numpy as np
+
+    from oracle import coracle as C
+    from oracle import spartan_fast as SF
+
+    q = R.CURVES[curve]["order"]
+    mats, X, u, W, E = product_instance(curve, num_cons, num_vars, 2, 7, folded)
+    N = max(num_cons, num_vars)
+    key = R.synth_bases(curve, N + 1)
+    ck, ck_c = key[:N], key[N]
+    key_arr = C.synth_bases(curve_id, N + 1)
+    assert [None if pt == (0, 0) else pt for pt in C.affine_to_ints(curve_id, key_arr)] == key
+    comm_W, comm_E = R.msm_naive(curve, W, ck), R.msm_naive(curve, E, ck)
+    ref = S.prove(curve, mats, num_cons, num_vars, X, ck, ck_c, comm_W, comm_E, u, W, E)
+    m_arr, W_arr, E_arr = _to_arrays(mats, X, W, E)
+    fast = SF.prove(curve_id, m_arr, num_cons, num_vars, X, key_arr, comm_W, comm_E, u, W_arr, E_arr)
+    assert fast == ref
+    assert SF.verify(curve_id, m_arr, num_cons, num_vars, X, key_arr, comm_W, comm_E, u, ref)
+    assert S.verify(curve, mats, num_cons, num_vars, X, ck, ck_c, comm_W, comm_E, u, fast)
+    assert not SF.verify(curve_id, m_arr, num_cons, num_vars, [(X[0] + 1) % q] + X[1:], key_arr, comm_W, comm_E, u, ref)
+    for field in ("eval_W", "eval_E", "ipa_a"):
+        bad = copy.deepcopy(ref)
+        bad[field] = (bad[field] + 1) % q
+        assert not SF.verify(curve_id, m_arr, num_cons, num_vars, X, key_arr, comm_W, comm_E, u, bad), field
+    bad = copy.deepcopy(ref)
+    bad["ipa_L"][0] = bad["ipa_R"][0]
+    assert not SF.verify(curve_id, m_arr, num_cons, num_vars, X, key_arr, comm_W, comm_E, u, bad)
+    bad = copy.deepcopy(ref)
+    bad["polys_batch"][0][1] = (bad["polys_batch"][0][1] + 1) % q
+    assert not SF.verify(curve_id, m_arr, num_cons, num_vars, X, key_arr, comm_W, comm_E, u, bad)
+
+
+def test_fast_oracle_at_2_12():
+    """The fast oracle alone at a size the Python one cannot reach: complete (its verifier accepts its proof) and sound against a
+    tampered statement; a few seconds."""
+    import numpy as np
+
+    from oracle import coracle as C
+    from oracle import spartan_fast as SF
+
+    curve_id, f, nc, nv, nio = 0, 1, 1 << 12, 1 << 12, 2
+    q = R.modulus(f)
+    A, B, Cm, W, X = SF.synth_product_instance(f, nc, nv, nio, seed=3)
+    key = C.synth_bases(curve_id, nc + 1)
+    E = np.zeros((nc, 4), dtype=np.uint64)
+    comm_W = SF._aff(curve_id, SF._commit(curve_id, key, W))
+    proof = SF.prove(curve_id, (A, B, Cm), nc, nv, X, key, comm_W, None, 1, W, E)
+    assert SF.verify(curve_id, (A, B, Cm), nc, nv, X, key, comm_W, None, 1, proof)
+    assert not SF.verify(curve_id, (A, B, Cm), nc, nv, X, key, comm_W, None, 2, proof)
