@@ -48,8 +48,9 @@ def main():
     ap.add_argument("--stage-ahead", type=int, default=0,
                     help="fold_step: 1 = the next step's witness is traced and its commitment started one step ahead (lurk_hip_fold_step_prefetch); "
                          "0 = plain begin (default: measured 4.4 ms against 4.05 ms staged whole / 5.1 ms staged with late ranges at rc = 100, DESIGN.md)")
-    ap.add_argument("--witness-ahead", type=int, default=1,
-                    help="fold_step: 1 = the witness of step k+1 is traced while step k folds (the reference's producer thread); 0 = traced at the start of its own step")
+    ap.add_argument("--witness-ahead", type=int, default=2,
+                    help="fold_step: the witness of step k+1 is traced while step k is in progress (the reference's producer thread): 2 = enqueued behind begin, so that "
+                         "it runs while the host derives r (default: 3.88 vs 4.27 ms at rc = 100); 1 = enqueued ahead of this step's commitments; 0 = traced at the start of its own step")
     ap.add_argument("--secondary", type=int, default=1, help="fold_step: 1 = also time the secondary-curve (Vesta, ~10^4 constraints) half of a step")
     ap.add_argument("--late-ranges", type=int, default=1, help="fold_step with --stage-ahead: 1 = 12 000 positions of W2 arrive with begin (the augmented circuit's), 0 = none")
     ap.add_argument("--ipa-resident-key", type=int, default=1, help="compress: 1 = inner-product rounds under the resident key (composed scalars), 0 = fold the key")
@@ -418,13 +419,17 @@ def fold_step_workload(args, lib, world, rank):
             t_b = time.perf_counter()
             cw, ct = ctx.begin_prefetched(x2, patches)                               # late ranges + cross term + commit(T)
         elif args.witness_ahead:
-            # the witness of step k+1 is produced while step k folds (lurk-beta's producer thread, nova.rs:304-326): its trace
-            # kernels are enqueued before this step's commitments and run beside them; this step's W2 was produced a step ago
+            # the witness of step k+1 is produced while step k folds (lurk-beta's producer thread, nova.rs:304-326); this step's W2 was
+            # produced a step ago.  --witness-ahead 1: its trace kernels are enqueued BEFORE this step's commitments and run beside
+            # them; 2: AFTER begin has returned, so that they run while the host derives r (the device is idle there)
             k = staged_k[0]
             staged_k[0] += 1
-            mf.assemble(d_w2s[(k + 1) & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[(k + 1) & 1].cuda_stream)
+            if args.witness_ahead == 1:
+                mf.assemble(d_w2s[(k + 1) & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[(k + 1) & 1].cuda_stream)
             t_b = time.perf_counter()
             cw, ct = ctx.begin(d_w2s[k & 1], x2, stream=wstreams[k & 1].cuda_stream)  # both commitments + the cross term
+            if args.witness_ahead == 2:
+                mf.assemble(d_w2s[(k + 1) & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[(k + 1) & 1].cuda_stream)
         else:
             mf.assemble(d_w2, pre, globals_host, bodies_np, mont=True, stream=stream)
             t_b = time.perf_counter()

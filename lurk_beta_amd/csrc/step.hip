@@ -161,16 +161,15 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     }
     LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
-    // a W2 that is not in flight yet (the plain begin) is on this step's path: its commitment first, the cross term beside its sort
-    // (measured against cross term -> commit(T) -> commit(W2): 4.10 vs 4.19 ms at rc = 100, 24.5 vs 24.1 at rc = 900; and against
-    // cross term -> commit(W2) -> commit(T): no difference)
-    // (both commitments of a step in the FOREGROUND class - the plain accumulate launch: with only two commitments in flight and the
-    // host waiting for both, it beats the persistent form the DEFAULT class picks at these sizes: 4.01 vs 4.24 ms at rc = 100,
-    // 23.4 vs 24.4 ms at rc = 900)
-    fold_submit_staged(c, b, LURK_MSM_SUBMIT_FOREGROUND);
-    tt[1] = now();
+    // Order (measured on MI355X at rc = 100, `bench_tools/sweep_step_order.sh` of round 3, ms per step with the next witness traced
+    // behind begin): cross term first, then commit(W2), then commit(T), all in the FOREGROUND class: 3.88 - against commit(W2) first
+    // 3.93; commit(W2) in the BACKGROUND class (persistent one-wave accumulation) 4.11 whichever comes first; commit(T) first and
+    // commit(W2)'s accumulation held back until T's sort is through 4.15.  The cross term gathers from HBM while commit(W2) sorts;
+    // its successor commit(T) is what the host waits for last.
     const int fg = LURK_MSM_SUBMIT_FOREGROUND;
     ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));          // T ...
+    fold_submit_staged(c, b, fg);
+    tt[1] = now();
     ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t.p, c->num_cons, 1, c->stream, fg));     // ... commit(T): what the host waits for
     if (patched) ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream, fg));  // commitment of the late ranges
     tt[2] = now();
