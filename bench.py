@@ -207,17 +207,6 @@ def main():
         traffic, traffic_detail = None, None
         if args.pmc == "auto" and world == 1:
             traffic, traffic_detail = collect_traffic(args)
-        traffic_from_profile = None
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_msm_accumulate.json")
-        if traffic is None and os.path.exists(pmc_path):
-            try:
-                with open(pmc_path) as f:
-                    pmc = json.load(f)
-                if pmc.get("log_n") == args.log_n:
-                    traffic_from_profile = {"hbm_bytes_per_launch": pmc.get("hbm_bytes_per_launch"), "tag": pmc.get("tag"),
-                                            "note": "static file from an earlier lease, NOT measured by this run"}
-            except Exception:
-                traffic_from_profile = None
         out = {
             "metric": "MSM Mscalar-mul/s (Pallas Pedersen commitment, bases+scalars resident in HBM)",
             "value": round(value, 3),
@@ -249,7 +238,6 @@ def main():
                 "frac": round(achieved / 8000.0, 6),
                 "traffic": traffic,
                 "traffic_detail": traffic_detail,
-                "traffic_from_profile": traffic_from_profile,
                 "avg_launch_ms": round(acc_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "mixed_additions_per_launch": msm_windows(args) * n,
@@ -487,6 +475,8 @@ def fold_step_workload(args, lib, world, rank):
         fv_ms, _ = kernel_ms("fold_vec")
         tr_ms, tr_n = kernel_ms("poseidon_trace")
         bd_ms, _ = kernel_ms("bit_decomp_trace")
+        acc_ms, acc_n = kernel_ms("msm_accumulate")       # mean launch over the timed region (HIP events on its launch stream): 2 per step
+        acc_bytes = 96.0 * (n_w + n_t) / 2.0              # algorithmic bytes of the mean launch: 32 B scalar + 64 B base per point
         # algorithmic HBM bytes of the cross-term kernel: 8 B per CSR record + 4 B per row pointer, two 32-byte gathers
         # per record (z1, z2), 32 B of T per row; fold_vec: two reads + one write of 32 B per element
         ct_bytes = nnz * 8.0 + 3 * 4.0 * n_t + 2 * 32.0 * nnz + 32.0 * n_t
@@ -507,6 +497,12 @@ def fold_step_workload(args, lib, world, rank):
                                        "see fold_kernels.r1cs_cross_term_uniform_columns for the structure-free case",
                        "shape_setup_s_once": round(shape_setup_s, 2)},
             "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase.items()},
+            # the step's dominant kernel is the bucket accumulation of its two commitments; the cross term (fold_kernels below) is the HBM-side one
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(acc_bytes / (acc_ms * 1e-3) / 1e9, 3) if acc_ms else None,
+                         "peak": 8000.0, "unit": "GB/s", "frac": round(acc_bytes / (acc_ms * 1e-3) / 8e12, 6) if acc_ms else None, "traffic": None,
+                         "avg_launch_ms": round(acc_ms, 4), "launches_per_step": acc_n // max(args.steps, 1), "algorithmic_bytes_per_launch": acc_bytes,
+                         "note": "96 B per point over the mean of the step's two commitments (W2 and T), launches timed inside the step (they share the device with "
+                                 "the cross term and each other's sort); integer-VALU bound as in the msm workload: see its roofline_valu"},
             "fold_kernels": {
                 "r1cs_cross_term": {"ms": round(ct_ms, 4), "algorithmic_bytes": ct_bytes, "achieved_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms else None,
                                     "hbm_frac": round(ct_bytes / (ct_ms * 1e-3) / 8e12, 4) if ct_ms else None},
@@ -748,6 +744,7 @@ def compress_workload(args, lib, world, rank):
                           "note": "functional stand-in, not byte-compatible with arecibo; transcript and round glue in Python on the host",
                           "verified": verified,
                           "shape_setup_s_once": round(setup_s, 2)},
+               "roofline": compress_roofline(lib, args, nc),
                "kernels_ms_per_proof": {k: kernel_ms(k) for k in ("sumcheck_round", "eq_evals", "r1cs_multiply_vec", "fold_vec", "ipa_inner_product",
                                                                    "ipa_fold_halves", "ipa_points_fold", "ipa_round_scalars", "ipa_coef_fold", "msm_accumulate", "msm_sort",
                                                                    "msm_reduce")},
@@ -755,6 +752,24 @@ def compress_workload(args, lib, world, rank):
         print(json.dumps(out), flush=True)
     key.close()
     prover.close()
+
+
+def compress_roofline(lib, args, n):
+    """The proof's dominant kernel is the bucket accumulation of its 40 + commitments (the opening argument's L and R of every round, under
+    the resident key): mean launch from the HIP-event profile of the timed region, 96 B per point of the key."""
+    from lurk_beta_amd import _lib
+
+    tot, cnt = ctypes.c_double(), ctypes.c_uint64()
+    _lib.check(lib.lurk_hip_profile_get(b"msm_accumulate", ctypes.byref(tot), ctypes.byref(cnt)))
+    if not cnt.value:
+        return None
+    ms = tot.value / cnt.value
+    b = 96.0 * n
+    return {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(b / (ms * 1e-3) / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
+            "frac": round(b / (ms * 1e-3) / 8e12, 6), "traffic": None, "avg_launch_ms": round(ms, 4), "launches_per_proof": cnt.value // max(args.steps, 1),
+            "algorithmic_bytes_per_launch": b,
+            "note": "32 B scalar + 64 B base per point of the 2^k-point key; in the opening argument half of every round's scalars are zero (composed scalars under "
+                    "the resident key), so the launches are shorter than a dense commitment's; integer-VALU bound"}
 
 
 def _ints_from(arr, R, q):
@@ -878,11 +893,28 @@ def collect_traffic(args):
     finally:
         shutil.rmtree(work, ignore_errors=True)
     fetch_kib, write_kib = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
-    total = (2.0 * fetch_kib + write_kib) * 1024.0
+    # MI355X_MICROARCH.md (HBM): FETCH_SIZE reports 1/2 of a wide coalesced streaming read - double it - and is UNCALIBRATED for other
+    # access widths: "calibrate on a known byte count in your own access pattern".  This kernel's reads are 64-byte gathers from a
+    # 3.25 GiB table, so the factor comes from bench_tools/fetch_calib.sh (known bytes / reported bytes for exactly that pattern);
+    # without a calibration file the raw figure is reported, and the doubled one beside it as the upper estimate.
+    factor, factor_src = None, None
+    import glob as _glob
+    for pth in sorted(_glob.glob(os.path.join(ROOT, "profiles", "*fetch_calibration.json")), reverse=True):
+        try:
+            with open(pth) as fh:
+                factor, factor_src = float(json.load(fh)["calib_gather64"]["factor"]), os.path.basename(pth)
+            break
+        except Exception:  # noqa: BLE001
+            continue
+    read_bytes = fetch_kib * 1024.0 * (factor if factor else 1.0)
+    total = read_bytes + write_kib * 1024.0
     return total, {"source": "live: rocprofv3 --pmc over a synchronous re-run of this workload, separate passes",
                    "fetch_size_kib_raw": round(fetch_kib, 1), "write_size_kib": round(write_kib, 1), "launches": vals["FETCH_SIZE"][1],
-                   "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests as 64 B; calibrated for streaming reads only, so an upper "
-                                 "estimate for the 64-B gathers of this kernel), WRITE_SIZE as is"}
+                   "read_bytes_raw": fetch_kib * 1024.0, "read_bytes_x2_streaming_correction": 2.0 * fetch_kib * 1024.0,
+                   "read_bytes_calibrated_gather": read_bytes if factor else None,
+                   "correction": (f"FETCH_SIZE x {factor} - the factor {factor_src} measured for 64-byte gathers from a 3.25 GiB table (known bytes / reported bytes); "
+                                  if factor else "FETCH_SIZE raw (no gather calibration file under profiles/); ") +
+                                 "the guide's x2 is for wide streaming reads only and is listed beside it; WRITE_SIZE as is"}
 
 
 def poseidon_mads_per_hash(arity):

@@ -1,0 +1,30 @@
+# One GPU call that regenerates the round's measurement evidence (run through gpurun; results land in gpurun_out/evidence_<tag>/ and,
+# for the rocprofv3 summaries, in gpurun_out/evidence_<tag>/profiles/ - copy those into profiles/ and commit them).
+# usage: bash bench_tools/round_evidence.sh <tag>        (tag e.g. r03)
+TAG=${1:-r03}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+E=gpurun_out/evidence_$TAG
+rm -rf $E; mkdir -p $E/profiles
+# 1. the default line exactly as the driver runs it
+python bench.py --gpus 1 --steps 20 --warmup 5 > $E/bench_default.json 2> $E/bench_default.err
+# 2. rocprofv3 kernel trace + stats + PMC passes of the same workload, condensed (launch classes, traffic three ways)
+bash bench_tools/profile.sh ${TAG}_msm_n22 > $E/profile_n22.log 2>&1
+python bench_tools/summarize_profile.py gpurun_out/prof_${TAG}_msm_n22 ${TAG}_msm_n22_table 22 > $E/summarize_n22.log 2>&1
+bash bench_tools/profile.sh ${TAG}_msm_n20 --log-n 20 > $E/profile_n20.log 2>&1
+python bench_tools/summarize_profile.py gpurun_out/prof_${TAG}_msm_n20 ${TAG}_msm_n20_table 20 > $E/summarize_n20.log 2>&1
+cp profiles/${TAG}_* $E/profiles/ 2>/dev/null
+rm -rf gpurun_out/prof_${TAG}_msm_n22 gpurun_out/prof_${TAG}_msm_n20
+# 3. the sweep: every workload / operating point DESIGN.md section 5 quotes, one JSON line each
+{
+  for ln in 20 22; do for pl in 1 2 3; do python bench.py --log-n $ln --pipeline $pl --steps 20 --warmup 5 --no-cpu-baseline --pmc off --no-plain-leg; done; done
+  python bench.py --log-n 22 --dist witness --steps 20 --warmup 5 --no-cpu-baseline --pmc off --no-plain-leg
+  python bench.py --log-n 22 --precompute 0 --pipeline 1 --steps 10 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg
+  python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --verify
+  python bench.py --workload fold_step --rc 900 --steps 10 --warmup 3 --verify --no-cpu-baseline
+  python bench.py --workload compress --steps 5 --warmup 2 --verify
+  python bench.py --workload poseidon_tree --steps 5 --warmup 2
+  python bench.py --workload ntt --log-n 24 --steps 10 --warmup 3
+  python bench.py --workload ntt --log-n 20 --steps 10 --warmup 3
+} > $E/sweep.jsonl 2> $E/sweep.err
+python bench_tools/small_commit_probe.py 200 > $E/small_commit_probe.jsonl 2>> $E/sweep.err
+tail -c 600 $E/bench_default.json; echo; wc -l $E/sweep.jsonl

@@ -85,6 +85,15 @@ int lurk_hip_msm_oneshot_key_cache(int enable);
 #include <stdbool.h>
 void mult_pippenger_pallas(void* out_jacobian96, const void* points_affine64, size_t npoints, const void* scalars32, bool is_mont);
 void mult_pippenger_vesta(void* out_jacobian96, const void* points_affine64, size_t npoints, const void* scalars32, bool is_mont);
+/* pasta-msm's GPU symbols (its `cuda` feature over sppark; what arecibo's GPU build binds instead of the two above, SURVEY.md
+ * section 8b [MEM]): same arguments, sppark's RustError returned BY VALUE - code 0 and a NULL message on success; otherwise the
+ * library's error code and a malloc'd message that the caller frees (sppark's Rust side does, in Drop).  No abort, no fallback. */
+typedef struct lurk_hip_rust_error {
+    int code;
+    char* message;
+} lurk_hip_rust_error;
+lurk_hip_rust_error cuda_pippenger_pallas(void* out_jacobian96, const void* points_affine64, size_t npoints, const void* scalars32, bool is_mont);
+lurk_hip_rust_error cuda_pippenger_vesta(void* out_jacobian96, const void* points_affine64, size_t npoints, const void* scalars32, bool is_mont);
 
 /* Resident-bases context: the commitment key `ck` is constant for the whole proof
  * (/root/reference/src/proof/nova.rs:196-216), so it is uploaded once and kept in HBM.
@@ -321,6 +330,11 @@ int lurk_hip_fold_vec(int field_id, const void* a, const void* b, const void* r3
  * Z1) in Montgomery form.  A new context holds the default (all-zero) relaxed pair, as RecursiveSNARK::new starts from. */
 typedef struct lurk_hip_fold_ctx lurk_hip_fold_ctx;
 int lurk_hip_fold_ctx_create(lurk_hip_fold_ctx** ctx, int curve, lurk_hip_r1cs* shape, lurk_hip_msm_ctx* key);
+/* The same context over a key cut across several devices (lurk_hip_msm_multi_create; the north star's "witness-commitment batches
+ * shard across the GPUs of one node"): the cross term and the folds run on the shape's device, each commitment pushes slice i of
+ * its vector peer-to-peer into device i, the slices commit concurrently and the 96-byte partials are summed on the host.  begin /
+ * finish / lurk_hip_fold_step as above; staging ahead (prefetch) is not offered with a multi-device key. */
+int lurk_hip_fold_ctx_create_multi(lurk_hip_fold_ctx** ctx, int curve, lurk_hip_r1cs* shape, lurk_hip_msm_multi* key);
 int lurk_hip_fold_ctx_destroy(lurk_hip_fold_ctx* ctx);
 /* running pair <- host values (Montgomery): z1 (num_vars + 1 + num_io elements), E1 (num_cons elements) */
 int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* ctx, const void* z1, const void* e1);

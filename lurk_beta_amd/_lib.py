@@ -21,6 +21,11 @@ class LurkHipError(RuntimeError):
         self.code = code
 
 
+class RustError(ctypes.Structure):
+    """sppark's RustError as pasta-msm's cuda_pippenger_* return it by value: {code, message (malloc'd, NULL on success)}"""
+    _fields_ = [("code", c_int), ("message", ctypes.c_void_p)]
+
+
 # every symbol include/lurk_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "lurk_hip_device_count": (c_int, []),
@@ -35,6 +40,8 @@ SIGNATURES = {
     "lurk_hip_msm_oneshot_key_cache": (c_int, [c_int]),
     "mult_pippenger_pallas": (None, [c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_bool]),   # pasta-msm's own symbol names
     "mult_pippenger_vesta": (None, [c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_bool]),
+    "cuda_pippenger_pallas": (RustError, [c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_bool]),   # pasta-msm's GPU symbol names
+    "cuda_pippenger_vesta": (RustError, [c_void_p, c_void_p, c_size_t, c_void_p, ctypes.c_bool]),
     "lurk_hip_msm_ctx_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int]),
     "lurk_hip_msm_ctx_create_dev": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lurk_hip_msm_ctx_run": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
@@ -87,6 +94,7 @@ SIGNATURES = {
     "lurk_hip_r1cs_cross_term": (c_int, [c_void_p] * 4),
     "lurk_hip_fold_vec": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lurk_hip_fold_ctx_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "lurk_hip_fold_ctx_create_multi": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_destroy": (c_int, [c_void_p]),
     "lurk_hip_fold_ctx_set_running": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_begin": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1375,6 +1375,22 @@ void mult_pippenger_vesta(void* out, const void* points, size_t npoints, const v
     pasta_msm_symbol(LURK_CURVE_VESTA, out, points, npoints, scalars, is_mont);
 }
 
+// pasta-msm's GPU entry points (its `cuda` feature, sppark's calling convention): the same arguments, a RustError {code, message} returned
+// BY VALUE - message is a malloc'd C string the Rust side frees (sppark's `impl Drop for Error`), NULL on success.  What arecibo's GPU
+// path binds instead of mult_pippenger_* (SURVEY.md section 8b).
+static lurk_hip_rust_error rust_error_from(int rc) {
+    lurk_hip_rust_error e;
+    e.code = rc;
+    e.message = rc == 0 ? nullptr : strdup(lurk_hip_last_error());
+    return e;
+}
+lurk_hip_rust_error cuda_pippenger_pallas(void* out, const void* points, size_t npoints, const void* scalars, bool is_mont) {
+    return rust_error_from(msm_oneshot(LURK_CURVE_PALLAS, out, points, npoints, scalars, is_mont ? 1 : 0));
+}
+lurk_hip_rust_error cuda_pippenger_vesta(void* out, const void* points, size_t npoints, const void* scalars, bool is_mont) {
+    return rust_error_from(msm_oneshot(LURK_CURVE_VESTA, out, points, npoints, scalars, is_mont ? 1 : 0));
+}
+
 int lurk_hip_msm_oneshot_key_cache(int enable) {
     return guarded([&] { g_oneshot_key_cache.store(enable ? 1 : 0); });
 }

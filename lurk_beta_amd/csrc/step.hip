@@ -38,6 +38,9 @@ struct lurk_hip_fold_ctx {
     int curve = 0, field_id = 0, device = 0;
     lurk_hip_r1cs* shape = nullptr;    // borrowed
     lurk_hip_msm_ctx* key = nullptr;   // borrowed
+    lurk_hip_msm_multi* mkey = nullptr;  // borrowed: the key cut across several devices (lurk_hip_fold_ctx_create_multi) instead of `key`
+    struct ShardBuf { int device = 0; size_t first = 0, count = 0; DevBuf buf; };
+    std::vector<std::unique_ptr<ShardBuf>> shard_bufs;  // per slice of mkey: a scalar buffer on the slice's device
     size_t num_cons = 0, num_vars = 0, num_io = 0, ncols = 0;
     DevBuf z[2], e[2], t;              // running pair ping-pongs between two buffers (cur = index of the live one)
     DevBuf z2[2], zstaged[2], zpatch;  // fresh instances [W2 | 1 | X2]: the open step's and the one staged ahead; the staged ranges alone
@@ -200,6 +203,58 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     memcpy(c->open_ct, comm_t_jac96, 96);
 }
 
+// ---- the key cut across several devices ("witness-commitment batches shard across the GPUs") ----------------------
+// The step's vectors live on the context's device (cross term, folds); a commitment pushes slice i of the vector peer-to-peer into
+// slice i's device, the slices commit concurrently (one host thread per device inside lurk_hip_msm_multi) and the 96-byte partial
+// commitments are summed with the host group law.  Nothing else crosses a link.
+static void fold_commit_multi(lurk_hip_fold_ctx* c, const void* d_vec, size_t n, void* out_jac96) {
+    std::vector<const void*> ptrs(c->shard_bufs.size(), nullptr);
+    for (size_t i = 0; i < c->shard_bufs.size(); i++) {
+        auto& sb = *c->shard_bufs[i];
+        ptrs[i] = sb.buf.p;
+        if (sb.first >= n || sb.count == 0) continue;
+        const size_t cnt = (sb.first + sb.count < n ? sb.first + sb.count : n) - sb.first;
+        LURK_HIP_CHECK(hipMemcpyPeerAsync(sb.buf.p, sb.device, (const char*)d_vec + sb.first * 32, c->device, cnt * 32, c->stage_stream));
+    }
+    LURK_HIP_CHECK(hipStreamSynchronize(c->stage_stream));
+    ok(lurk_hip_msm_multi_commit_dev(c->mkey, out_jac96, ptrs.data(), ptrs.size(), n, 1));
+}
+
+static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device, void* w2_stream, const void* x2_mont, void* comm_w2_jac96,
+                             void* comm_t_jac96) {
+    const int b = 0;  // one fresh-instance buffer: nothing is staged ahead with a multi-device key
+    char* z2 = (char*)c->z2[b].p;
+    if (c->folded_valid[b]) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream, c->folded_ev[b], 0));  // the previous fold still reads it
+    if (on_device) {
+        LURK_HIP_CHECK(hipEventRecord(c->w2_ready, (hipStream_t)w2_stream));
+        LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream, c->w2_ready, 0));
+    }
+    if (c->num_vars) LURK_HIP_CHECK(hipMemcpyAsync(z2, w2, c->num_vars * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stage_stream));
+    const size_t need = (1 + c->num_io) * 32;
+    if (need > c->pin_cap) {
+        if (c->pin) LURK_HIP_CHECK(hipHostFree(c->pin));
+        c->pin = nullptr;
+        c->pin_cap = 0;
+        LURK_HIP_CHECK(hipHostMalloc((void**)&c->pin, need * 2, hipHostMallocDefault));
+        c->pin_cap = need * 2;
+    }
+    if (c->field_id == LURK_FIELD_PALLAS_FQ) mont_one<PallasFq>(c->pin);
+    else mont_one<PallasFp>(c->pin);
+    if (c->num_io) memcpy(c->pin + 32, x2_mont, c->num_io * 32);
+    LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, need, hipMemcpyHostToDevice, c->stage_stream));
+    LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream));
+    LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
+    ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));  // beside commit(W2)
+    fold_commit_multi(c, z2, c->num_vars, comm_w2_jac96);
+    LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
+    fold_commit_multi(c, c->t.p, c->num_cons, comm_t_jac96);
+    c->open_buf = b;
+    c->begun = true;
+    c->open_x2.assign((const uint64_t*)x2_mont, (const uint64_t*)x2_mont + 4 * c->num_io);
+    memcpy(c->open_cw, comm_w2_jac96, 96);
+    memcpy(c->open_ct, comm_t_jac96, 96);
+}
+
 // [u | X] <- [u1 + r | X1 + r X2] on the host (1 + num_io elements; u2 = 1)
 template <class F>
 static void fold_ux_host(std::vector<uint64_t>& ux, const std::vector<uint64_t>& x2, const void* r_mont) {
@@ -241,46 +296,74 @@ static void fold_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
 
 extern "C" {
 
+static void fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* shape, lurk_hip_msm_ctx* key, lurk_hip_msm_multi* mkey) {
+    LURK_REQUIRE(out && shape && (key || mkey), "null argument");
+    *out = nullptr;
+    LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
+    auto c = std::make_unique<lurk_hip_fold_ctx>();
+    c->curve = curve;
+    int shape_field = 0;
+    ok(lurk_hip_r1cs_dims(shape, &shape_field, &c->num_cons, &c->num_vars, &c->num_io));
+    c->field_id = curve == LURK_CURVE_PALLAS ? LURK_FIELD_PALLAS_FQ : LURK_FIELD_PALLAS_FP;  // the curve's scalar field
+    LURK_REQUIRE(shape_field == c->field_id, "the shape is not over this curve's scalar field");
+    c->shape = shape;
+    c->key = key;
+    c->mkey = mkey;
+    c->ncols = c->num_vars + 1 + c->num_io;
+    // the context lives where its shape lives; a single-device key must be there too (every other handle records its device as well)
+    int shape_device = 0;
+    ok(lurk_hip_r1cs_device(shape, &shape_device));
+    if (key) {
+        int key_device = 0;
+        ok(lurk_hip_msm_ctx_device(key, &key_device));
+        LURK_REQUIRE(key_device == shape_device, "the R1CS shape and the commitment key live on different devices");
+    }
+    c->device = shape_device;
+    DeviceGuard dg(c->device);
+    if (mkey) {
+        const int ns = lurk_hip_msm_multi_num_shards(mkey);
+        size_t total = 0;
+        for (int i = 0; i < ns; i++) {
+            auto sb = std::make_unique<lurk_hip_fold_ctx::ShardBuf>();
+            ok(lurk_hip_msm_multi_shard(mkey, i, &sb->device, &sb->first, &sb->count));
+            total += sb->count;
+            DeviceGuard sg(sb->device);
+            sb->buf.alloc(sb->count * 32);
+            c->shard_bufs.push_back(std::move(sb));
+        }
+        LURK_REQUIRE(total >= c->num_vars && total >= c->num_cons, "the multi-device key is shorter than the step's vectors");
+    }
+    for (int k = 0; k < 2; k++) {
+        c->z[k].alloc(c->ncols * 32);
+        c->e[k].alloc(c->num_cons * 32);
+    }
+    c->t.alloc(c->num_cons * 32);
+    c->ux.assign(4 * (1 + c->num_io), 0);
+    LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
+    LURK_HIP_CHECK(hipEventCreateWithFlags(&c->w2_ready, hipEventDisableTiming));
+    for (int k = 0; k < 2; k++) {
+        c->z2[k].alloc(c->ncols * 32);
+        LURK_HIP_CHECK(hipEventCreateWithFlags(&c->staged_ev[k], hipEventDisableTiming));
+        LURK_HIP_CHECK(hipEventCreateWithFlags(&c->folded_ev[k], hipEventDisableTiming));
+    }
+    // RelaxedR1CSWitness::default / RelaxedR1CSInstance::default: W = 0, E = 0, u = 0, X = 0
+    LURK_HIP_CHECK(hipMemsetAsync(c->z[0].p, 0, c->ncols * 32, c->stream));
+    LURK_HIP_CHECK(hipMemsetAsync(c->e[0].p, 0, c->num_cons * 32, c->stream));
+    LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
+    *out = c.release();
+}
+
 int lurk_hip_fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* shape, lurk_hip_msm_ctx* key) {
     return guarded([&] {
-        LURK_REQUIRE(out && shape && key, "null argument");
-        *out = nullptr;
-        LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
-        auto c = std::make_unique<lurk_hip_fold_ctx>();
-        c->curve = curve;
-        int shape_field = 0;
-        ok(lurk_hip_r1cs_dims(shape, &shape_field, &c->num_cons, &c->num_vars, &c->num_io));
-        c->field_id = curve == LURK_CURVE_PALLAS ? LURK_FIELD_PALLAS_FQ : LURK_FIELD_PALLAS_FP;  // the curve's scalar field
-        LURK_REQUIRE(shape_field == c->field_id, "the shape is not over this curve's scalar field");
-        c->shape = shape;
-        c->key = key;
-        c->ncols = c->num_vars + 1 + c->num_io;
-        // the context lives where its key lives; the shape must be there too (every other handle records its device as well)
-        int key_device = 0, shape_device = 0;
-        ok(lurk_hip_msm_ctx_device(key, &key_device));
-        ok(lurk_hip_r1cs_device(shape, &shape_device));
-        LURK_REQUIRE(key_device == shape_device, "the R1CS shape and the commitment key live on different devices");
-        c->device = key_device;
-        DeviceGuard dg(c->device);
-        for (int k = 0; k < 2; k++) {
-            c->z[k].alloc(c->ncols * 32);
-            c->e[k].alloc(c->num_cons * 32);
-        }
-        c->t.alloc(c->num_cons * 32);
-        c->ux.assign(4 * (1 + c->num_io), 0);
-        LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
-        LURK_HIP_CHECK(hipEventCreateWithFlags(&c->w2_ready, hipEventDisableTiming));
-        for (int k = 0; k < 2; k++) {
-            c->z2[k].alloc(c->ncols * 32);
-            LURK_HIP_CHECK(hipEventCreateWithFlags(&c->staged_ev[k], hipEventDisableTiming));
-            LURK_HIP_CHECK(hipEventCreateWithFlags(&c->folded_ev[k], hipEventDisableTiming));
-        }
-        // RelaxedR1CSWitness::default / RelaxedR1CSInstance::default: W = 0, E = 0, u = 0, X = 0
-        LURK_HIP_CHECK(hipMemsetAsync(c->z[0].p, 0, c->ncols * 32, c->stream));
-        LURK_HIP_CHECK(hipMemsetAsync(c->e[0].p, 0, c->num_cons * 32, c->stream));
-        LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
-        *out = c.release();
+        LURK_REQUIRE(key, "null key");
+        fold_ctx_create(out, curve, shape, key, nullptr);
+    });
+}
+int lurk_hip_fold_ctx_create_multi(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* shape, lurk_hip_msm_multi* key) {
+    return guarded([&] {
+        LURK_REQUIRE(key, "null key");
+        fold_ctx_create(out, curve, shape, nullptr, key);
     });
 }
 
@@ -340,8 +423,12 @@ int lurk_hip_fold_step(lurk_hip_fold_ctx* c, const void* w2, int w2_on_device, v
         LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
         LURK_REQUIRE(c->n_staged == 0, "fresh instances are staged: use lurk_hip_fold_step_begin_prefetched");
         uint64_t cw[12], ct[12], r[4];
-        fold_stage(c, w2, 0, c->num_vars, w2_on_device, w2_stream);
-        fold_begin(c, nullptr, 0, x2_mont, cw, ct);
+        if (c->mkey) {
+            fold_begin_multi(c, w2, w2_on_device, w2_stream, x2_mont, cw, ct);
+        } else {
+            fold_stage(c, w2, 0, c->num_vars, w2_on_device, w2_stream);
+            fold_begin(c, nullptr, 0, x2_mont, cw, ct);
+        }
         ok(lurk_hip_nifs_challenge(c->curve, pp_digest32, c->comm_w, c->comm_e, c->ux.data(), c->ux.data() + 4, cw, x2_mont, c->num_io, ct, r));
         fold_finish(c, r);
         if (comm_w2_jac96) memcpy(comm_w2_jac96, cw, 96);
@@ -360,6 +447,10 @@ int lurk_hip_fold_step_begin(lurk_hip_fold_ctx* c, const void* w2, int w2_on_dev
         std::lock_guard<std::mutex> lk(c->mu);
         LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
         LURK_REQUIRE(c->n_staged == 0, "fresh instances are staged: use lurk_hip_fold_step_begin_prefetched");
+        if (c->mkey) {
+            fold_begin_multi(c, w2, w2_on_device, w2_stream, x2_mont, comm_w2_jac96, comm_t_jac96);
+            return;
+        }
         fold_stage(c, w2, 0, c->num_vars, w2_on_device, w2_stream);
         fold_begin(c, nullptr, 0, x2_mont, comm_w2_jac96, comm_t_jac96);
     });
@@ -370,6 +461,7 @@ int lurk_hip_fold_step_prefetch(lurk_hip_fold_ctx* c, const void* w2_range, size
         LURK_REQUIRE(c, "null ctx");
         DeviceGuard dg(c->device);
         std::lock_guard<std::mutex> lk(c->mu);
+        LURK_REQUIRE(!c->mkey, "staging ahead is not available with a multi-device key");
         fold_stage(c, w2_range, offset, count, on_device, stream);
     });
 }

@@ -188,6 +188,7 @@ class MultiCommitmentKey {
         return out;
     }
     int num_shards() const { return lurk_hip_msm_multi_num_shards(ctx_); }
+    lurk_hip_msm_multi* handle() const { return ctx_; }
     // (device, first point, point count) of slice i
     std::array<size_t, 3> shard(int i) const {
         int dev = 0;
@@ -286,6 +287,10 @@ class FoldingContext {
   public:
     FoldingContext(int curve, R1CSShape& shape, CommitmentKey& key) : curve_(curve), shape_(shape) {
         check(lurk_hip_fold_ctx_create(&h_, curve, shape.handle(), key.handle()));
+    }
+    // the key cut across several devices: every commitment of the step runs its slices concurrently (no staging ahead in this form)
+    FoldingContext(int curve, R1CSShape& shape, MultiCommitmentKey& key) : curve_(curve), shape_(shape) {
+        check(lurk_hip_fold_ctx_create_multi(&h_, curve, shape.handle(), key.handle()));
     }
     ~FoldingContext() { lurk_hip_fold_ctx_destroy(h_); }
     FoldingContext(const FoldingContext&) = delete;

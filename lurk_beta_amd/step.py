@@ -46,7 +46,12 @@ class FoldingContext:
         lib = _lib.load()
         self.curve, self.shape, self.key = curve, shape, key
         self._h = ctypes.c_void_p()
-        _lib.check(lib.lurk_hip_fold_ctx_create(ctypes.byref(self._h), curve, shape._h, key._ctx))
+        from .msm import MultiCommitmentKey
+
+        if isinstance(key, MultiCommitmentKey):  # the key cut across several devices: slices commit concurrently, partials summed on the host
+            _lib.check(lib.lurk_hip_fold_ctx_create_multi(ctypes.byref(self._h), curve, shape._h, key._ctx))
+        else:
+            _lib.check(lib.lurk_hip_fold_ctx_create(ctypes.byref(self._h), curve, shape._h, key._ctx))
 
     def instance(self):
         """The running instance U = (comm_W, comm_E, u, X): 96-byte Jacobians, Montgomery scalars."""

@@ -286,6 +286,16 @@ int main() {
         bool threw = false;
         try { nivc.step(2, {two, four}, {three}, Fe(77)); } catch (const std::invalid_argument&) { threw = true; }
         EXPECT(threw);
+        // the same step through a key cut across the device list [0, 0]: the same commitments, challenge and folded pair
+        MultiCommitmentKey mkey(curve, {G, Affine{g2.x, g2.y}}, {0, 0}, false);
+        R1CSShape s2(LURK_FIELD_PALLAS_FQ, 2, 2, 1, A, B, C);
+        FoldingContext single(curve, s0, key), multi(curve, s2, mkey);  // (s0's NIVC context above is separate: contexts do not share running pairs)
+        auto c1 = single.step({three, nine}, {two}, Fe(5));
+        auto c2 = multi.step({three, nine}, {two}, Fe(5));
+        EXPECT(key.to_affine(c1[0]) == key.to_affine(c2[0]) && key.to_affine(c1[1]) == key.to_affine(c2[1]));
+        EXPECT(single.last_r == multi.last_r);
+        EXPECT(single.read() == multi.read());
+        EXPECT(key.to_affine(single.comm_w) == key.to_affine(multi.comm_w) && key.to_affine(single.comm_e) == key.to_affine(multi.comm_e));
     }
     printf("host mirror ok\n");
     return 0;

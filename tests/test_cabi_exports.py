@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     src = open(os.path.join(ROOT, "include", "lurk_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b((?:lurk_hip|mult_pippenger)_[a-z0-9_]+)\s*\(", src)))
+    return sorted(set(re.findall(r"\b((?:lurk_hip|mult_pippenger|cuda_pippenger)_[a-z0-9_]+)\s*\(", src)))
 
 
 def test_every_declared_symbol_is_exported_and_bound():

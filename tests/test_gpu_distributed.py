@@ -88,3 +88,58 @@ def test_bench_refuses_a_mismatched_world():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stdout + out.stderr)
+
+
+def _nccl_worker(port, n, q):
+    try:
+        import torch
+        import torch.distributed as dist
+
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        from lurk_beta_amd import point_to_affine
+        from lurk_beta_amd.distributed import ShardedCommitmentKey, _all_gather_rows, gather_partials, sharded_tree8_root
+        from oracle import coracle as C
+
+        B = C.synth_bases(0, n)
+        S = C.synth_scalars(1, 1, 1, n)
+        ck = ShardedCommitmentKey(0, B, precompute=True)
+        part = ck.ck.commit(S)
+        gathered = gather_partials(part)          # the RCCL branch: device tensor in, all_gather, host array out
+        full = ck.commit(S)
+        leaves = C.synth_scalars(1, 2, 0, 8 ** 4)
+        root = sharded_tree8_root(1, leaves)
+        rows = _all_gather_rows(leaves[:8])       # the tree path's gather of subtree roots on the same backend (world 1: itself)
+        q.put(("ok", gathered.shape, bool((gathered[0] == part).all()) and bool((rows == leaves[:8]).all()), point_to_affine(0, full),
+               [int(x) for x in np.asarray(root).reshape(-1)]))
+        ck.close()
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        q.put(("error", repr(e)))
+        raise
+
+
+def test_rccl_gather_branch_world1(hip):
+    """The `nccl` (= RCCL) branch of gather_partials / the sharded tree has to have EXECUTED on the hardware it is written for: one rank,
+    one GPU, world size 1 - the all_gather is a device-to-device copy through RCCL, the code path (device tensors, stream ordering, the
+    host round trip of the 96-byte partial) is the one 8 ranks take."""
+    import torch.multiprocessing as mp
+
+    from oracle import coracle as C
+
+    n = 5000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), n, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert res[0] == "ok", res
+    assert p.exitcode == 0
+    assert res[1] == (1, 12) and res[2]
+    assert res[3] == C.jac_to_affine(0, C.msm_pippenger(0, C.synth_bases(0, n), C.synth_scalars(1, 1, 1, n)))
+    want_root = C.poseidon_tree8(1, C.synth_scalars(1, 2, 0, 8 ** 4))
+    assert res[4] == [int(x) for x in np.asarray(want_root).reshape(-1)]

@@ -225,6 +225,32 @@ def test_pasta_msm_symbol_names(hip, cn, c):
         assert point_to_affine(c, out) == want
 
 
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+def test_pasta_msm_gpu_symbol_names(hip, cn, c):
+    """cuda_pippenger_{pallas,vesta}: pasta-msm's GPU symbols (sppark convention, SURVEY.md section 8b): RustError {code, message} BY VALUE;
+    code 0 / NULL message on success, the library's code and a malloc'd message on failure (freed here as the Rust side would)."""
+    import ctypes
+
+    from lurk_beta_amd import _lib, point_to_affine
+
+    n = 3000
+    B = C.synth_bases(c, n)
+    S = C.synth_scalars(_sf(c), 78, 1, n)
+    want = C.jac_to_affine(c, C.msm_pippenger(c, B, S))
+    fn = getattr(_lib.load(), f"cuda_pippenger_{cn}")
+    for is_mont, scal in ((False, S), (True, C.to_mont(_sf(c), S))):
+        out = np.zeros(12, dtype=np.uint64)
+        err = fn(_lib.ptr(out), _lib.ptr(B), n, _lib.ptr(np.ascontiguousarray(scal)), ctypes.c_bool(is_mont))
+        assert err.code == 0 and not err.message
+        assert point_to_affine(c, out) == want
+    err = fn(None, _lib.ptr(B), n, _lib.ptr(S), ctypes.c_bool(False))  # null output: an error value, not an abort
+    assert err.code != 0 and err.message
+    assert b"null" in ctypes.string_at(err.message)
+    libc = ctypes.CDLL(None)
+    libc.free.argtypes = [ctypes.c_void_p]
+    libc.free(err.message)
+
+
 def test_oneshot_key_cache(hip):
     """lurk_hip_msm_oneshot_key_cache: same pointer + same sampled points -> the device copy is reused (also for a prefix);
     new contents at the same address -> detected, uploaded again."""

@@ -374,3 +374,57 @@ def test_step_at_the_rc100_size(hip):
     ctx.close()
     key.close()
     shape.close()
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_steps_with_a_multi_device_key(hip, devices):
+    """lurk_hip_fold_ctx_create_multi: the step's commitments through a key cut across a device list (every
+    slice on GPU 0 here - one box has one GPU - which exercises the same peer copies, worker threads and partial sums).  Three steps with
+    the library transcript: identical commitments, challenges and folded pairs to the single-key context and to the oracle."""
+    from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, MultiCommitmentKey, R1CSShape, point_to_affine
+
+    curve, f, name, m, nfree, nio = 0, 1, "pallas", 5000, 2200, 2
+    p = R.modulus(f)
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=51)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    bases = C.synth_bases(curve, max(m, nv))
+    mkey = MultiCommitmentKey(curve, bases, devices, precompute=True)
+    skey = CommitmentKey(curve, bases, precompute=True)
+    mctx, sctx = FoldingContext(curve, shape, mkey), FoldingContext(curve, shape, skey)
+    commit = lambda v: C.jac_to_affine(curve, C.msm_pippenger(curve, bases[: len(v)], v))
+    pt = lambda a: None if a == (0, 0) else a
+    pp_digest = R.uniform_fe(98, 3, p)
+    z1 = np.zeros((nv + 1 + nio, 4), dtype=np.uint64)
+    e1 = np.zeros((m, 4), dtype=np.uint64)
+    cw1 = ce1 = None
+    for step in range(3):
+        z2, x2 = _fresh(f, A, B, m, nfree, nio, 700 + 10 * step)
+        w2m, x2m = C.to_mont(f, z2[:nv]), C.to_mont(f, x2)
+        cw, ct, r_m = mctx.step(w2m, x2m, pp_digest)
+        scw, sct, sr = sctx.step(w2m, x2m, pp_digest)
+        assert point_to_affine(curve, cw) == point_to_affine(curve, scw) and point_to_affine(curve, ct) == point_to_affine(curve, sct)
+        assert np.array_equal(r_m, sr)
+        u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+        t = C.cross_term(f, *[C.spmv(f, *M, z1) for M in (A, B, Cm)], *[C.spmv(f, *M, z2) for M in (A, B, Cm)], u1, 1)
+        cw2_o, ct_o = commit(z2[:nv]), commit(t)
+        assert point_to_affine(curve, cw) == cw2_o and point_to_affine(curve, ct) == ct_o
+        r = R.nifs_challenge(name, pp_digest, cw1, ce1, u1, C.limbs_to_ints(z1[nv + 1:]), pt(cw2_o), C.limbs_to_ints(x2), pt(ct_o))
+        assert C.limbs_to_ints(C.from_mont(f, r_m.reshape(1, 4)))[0] == r
+        z1, e1 = C.axpy(f, z1, z2, r), C.axpy(f, e1, t, r)
+        gz, ge = mctx.read()
+        assert np.array_equal(C.from_mont(f, gz), z1) and np.array_equal(C.from_mont(f, ge), e1)
+        cw1, ce1 = pt(commit(z1[:nv])), pt(commit(e1))
+        gcw, gce, _, _ = mctx.instance()
+        assert _aff_or_none(curve, gcw) == cw1 and _aff_or_none(curve, gce) == ce1
+    with pytest.raises(LurkHipError, match="multi-device"):
+        mctx.prefetch(w2m)
+    # the two halves with a caller-supplied challenge work too
+    z2, x2 = _fresh(f, A, B, m, nfree, nio, 790)
+    cw, ct = mctx.begin(C.to_mont(f, z2[:nv]), C.to_mont(f, x2))
+    assert point_to_affine(curve, cw) == commit(z2[:nv])
+    mctx.finish(C.to_mont(f, C.ints_to_limbs([7])))
+    gz, _ = mctx.read()
+    assert np.array_equal(C.from_mont(f, gz), C.axpy(f, z1, z2, 7))
+    for x in (mctx, sctx, mkey, skey, shape):
+        x.close()
