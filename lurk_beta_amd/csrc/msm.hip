@@ -504,6 +504,11 @@ void msm_small_launch(const void* d_scalars, size_t n, int is_mont, const Affine
                       hipStream_t s);
 size_t msm_small_group_bytes();
 
+// ---- 6'. the bucket reduction (msm_reduce.hip): one launch per level of the bit-plane merge tree, radix-2^29 points ----
+size_t msm_reduce_plane_bytes(size_t nb);
+template <class P>
+void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s);
+
 // Switches of the commitments-in-flight path (read once per process; the defaults are the measured best).
 // Everything else that round 2 kept for A/B runs (stream / wave priorities off, more waves per SIMD, a 128-VGPR build, hipGraph
 // replay, background-behind-sort off) lost its measurement and is gone: the winning setting is now the only code path.
@@ -581,35 +586,7 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __re
     }
 }
 
-// ---- 6. bucket reduction -------------------------------------------------------------------
-// sum_b b*B_b with the bucket b stored at index idx = b-1:  sum (idx+1) X_idx = S + sum_k 2^k P_k,
-// S = sum X, P_k = sum of the X whose idx has bit k set.  The (S, P_0..P_{k-1}) vectors of two
-// adjacent segments of 2^k items merge with k+1 independent additions (the new plane k is the upper
-// half's S), so the whole reduction is c-1 levels of depth ONE addition each: these tail kernels are
-// latency bound (~10 us per dependent XYZZ addition) and a running-sum formulation needs >100 of them.
-// level k: in[g][seg][0..k] (segments of 2^k items) -> out[g][seg/2][0..k+1]
-template <class P>
-__global__ __launch_bounds__(256) void msm_planes_kernel(const Xyzz<P>* __restrict__ in, Xyzz<P>* __restrict__ out, int k, int G, uint32_t B) {
-    msm_set_wave_prio(1);
-    const size_t nseg_out = (size_t)B >> (k + 1);
-    const size_t comps_out = (size_t)k + 2, comps_in = (size_t)k + 1;
-    size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= (size_t)G * nseg_out * comps_out) return;
-    size_t c = id % comps_out, seg = (id / comps_out) % nseg_out, g = id / (comps_out * nseg_out);
-    const Xyzz<P>* lo = in + ((g * (nseg_out * 2) + 2 * seg) * comps_in);
-    const Xyzz<P>* hi = lo + comps_in;
-    Xyzz<P> r;
-    if (c <= (size_t)k) {
-        r = lo[c];
-        xyzz_add<P>(r, hi[c]);
-    } else {
-        r = hi[0];
-    }
-    out[id] = r;
-}
-// (A two-launch form - one workgroup running ten levels on 1024 buckets behind barriers, then one workgroup per key space for
-// the rest - was measured at 0.69 ms against 0.45 ms for the per-level launches: a level is one addition deep, and an addition
-// is fastest when its wave has a SIMD to itself, which only the chip-wide launches give.)
+// ---- 6. bucket reduction: msm_reduce.hip ------------------------------------------------------------------------------------
 // ---- precomputed table: T[w*n + i] = 2^(c w) * P_i ----------------------------------------------
 // One inversion per POINT, not per table entry: the W-1 multiples are carried in XYZZ form, their (X, Y) parked in the table,
 // ZZ, ZZZ and the running product of the ZZZ parked in a scratch buffer, then one field inversion and Montgomery's trick walk
@@ -958,8 +935,8 @@ struct MsmCtx : MsmCtxBase {
         wk.big_list.ensure((size_t)sh.NB * 4);
         wk.big_count.ensure(16);
         wk.cursor.ensure(4 * (MSM_PLACEMENT_BASE + 512));
-        wk.planes_a.ensure((size_t)sh.NB * sizeof(Xyzz<P>));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
-        wk.planes_b.ensure((size_t)sh.NB * sizeof(Xyzz<P>));
+        wk.planes_a.ensure(msm_reduce_plane_bytes(sh.NB));  // level k holds (B >> (k+1)) * (k+2) <= B points per space
+        wk.planes_b.ensure(msm_reduce_plane_bytes(sh.NB));
         if (!wk.host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&wk.host_pts, (size_t)MSM_MAX_W * 20 * sizeof(Xyzz<P>)));
         wk.ws_n = sh.n > wk.ws_n ? sh.n : wk.ws_n;
         wk.ws_entries = entries > wk.ws_entries ? entries : wk.ws_entries;
@@ -1080,18 +1057,10 @@ struct MsmCtx : MsmCtxBase {
                                wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>());
         }
         {
+            // the c - 1 levels of the bit-plane merge tree; the last one stores the G x c plane sums into the slot's pinned buffer: the
+            // host's Horner over them (G c doublings and as many additions) is cheaper than a 20-deep dependent chain on one lane
             ProfScope ps("msm_reduce", s);
-            const Xyzz<P>* in = wk.buckets.template as<Xyzz<P>>();
-            Xyzz<P>* bufs[2] = {wk.planes_a.template as<Xyzz<P>>(), wk.planes_b.template as<Xyzz<P>>()};
-            for (int k = 0; k < sh.c - 1; k++) {
-                size_t threads = (size_t)sh.G * ((size_t)sh.B >> (k + 1)) * (k + 2);
-                hipLaunchKernelGGL((msm_planes_kernel<P>), dim3(div_up(threads, 256)), dim3(256), 0, s, in, bufs[k & 1], k, sh.G, sh.B);
-                in = bufs[k & 1];
-            }
-            // `in` = [G][c] points: S, P_0 .. P_{c-2}
-            // the G x c plane sums go to the host as they are: its Horner over them (G c doublings and as many additions, ~0.13 ms)
-            // is cheaper than the 20-deep dependent chain a device kernel needs for the same 256 points (0.18 ms)
-            LURK_HIP_CHECK(hipMemcpyAsync(wk.host_pts, in, (size_t)sh.G * sh.c * sizeof(Xyzz<P>), hipMemcpyDeviceToHost, s));
+            msm_launch_reduce<P>(wk.buckets.template as<Xyzz<P>>(), wk.planes_a.p, wk.planes_b.p, sh.c, sh.G, sh.B, wk.host_pts, s);
         }
         LURK_HIP_CHECK(hipGetLastError());
     }

@@ -1,0 +1,106 @@
+// msm_reduce.hip - the bucket reduction of the Pippenger pipeline (msm.hip, stage 6).
+//
+// sum_b b * B_b with bucket b at index b - 1:  sum (idx + 1) X_idx = S + sum_k 2^k P_k,  S = sum X,  P_k = sum of the X whose idx has
+// bit k set.  The (S, P_0 .. P_{k-1}) vectors of two adjacent segments of 2^k buckets merge with k + 1 independent additions (the new
+// plane k is the upper half's S), so the reduction is c - 1 levels of depth ONE addition: a running-sum formulation needs > 100
+// dependent additions, and on this chip a dependent kernel boundary costs ~1.5 us while a dependent addition costs 5-7 us.
+//
+// One launch per level (c - 1 = 19 at 20-bit windows).  What round 3 changed:
+//   * points travel between levels on the radix-2^29 layer (curve29.cuh: xyzz29_add, the inlined 135-mad multiplier - no call per
+//     product, no conversion between levels): 160-byte records with the identity as a flag; level 0 converts the buckets on the fly,
+//     the last level stores ordinary XYZZ points straight into the slot's pinned host buffer (no copy node behind it);
+//   * measured and dropped: ALL levels in one persistent launch behind grid barriers (512 workgroups, one monotonic counter, agent-
+//     scope release / relaxed poll / acquire): 1.07 ms per reduction against 0.45 for the launches - a counter barrier costs 13 us
+//     at two workgroups per CU (MI355X_MICROARCH.md, price list: barrier-counter) and its release fence writes the L2 back, a kernel
+//     boundary 1.5 us.  The guide's verdict for all-to-all seams - cut the launch there - holds for this one too.
+#include "common.hpp"
+#include "msm_core.cuh"
+#include "curve29.cuh"
+
+namespace lurk {
+
+constexpr int REDUCE_BLOCK = 256;
+
+template <class P>
+struct Plane29 {
+    Xyzz29<P> p;
+    uint32_t id, pad[3];
+};
+
+template <class P>
+__device__ __forceinline__ void plane_load(const Plane29<P>* __restrict__ src, Xyzz29<P>& v, bool& id) {
+    const Plane29<P> r = *src;
+    v = r.p;
+    id = r.id != 0;
+}
+
+// level k: in[g][seg][0..k] (segments of 2^k buckets; level 0 reads the buckets themselves) -> out[g][seg / 2][0..k+1]
+// LAST: the G x c plane sums leave as ordinary XYZZ points (out_host, pinned host memory) instead of plane records
+template <class P, bool FIRST, bool LAST>
+__global__ __launch_bounds__(REDUCE_BLOCK) void msm_planes29_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
+                                                                      Plane29<P>* __restrict__ out, Xyzz<P>* __restrict__ out_host, int k, int G, uint32_t B) {
+    __builtin_amdgcn_s_setprio(3);  // a latency-bound tail kernel: issue ahead of an accumulation sharing the SIMD
+    const size_t nseg_out = (size_t)B >> (k + 1);
+    const size_t comps_out = (size_t)k + 2, comps_in = (size_t)k + 1;
+    const size_t id = (size_t)blockIdx.x * REDUCE_BLOCK + threadIdx.x;
+    if (id >= (size_t)G * nseg_out * comps_out) return;
+    const size_t comp = id % comps_out, seg = (id / comps_out) % nseg_out, g = id / (comps_out * nseg_out);
+    Xyzz29<P> r, h;
+    bool r_id, h_id;
+    if (FIRST) {  // segments of one bucket, one component (S)
+        const Xyzz<P> hi = buckets[g * B + 2 * seg + 1];
+        xyzz29_from_xyzz<P>(hi, h, h_id);
+        if (comp == 0) {
+            const Xyzz<P> lo = buckets[g * B + 2 * seg];
+            xyzz29_from_xyzz<P>(lo, r, r_id);
+            xyzz29_add<P>(r, r_id, h, h_id);
+        } else {
+            r = h;
+            r_id = h_id;
+        }
+    } else {
+        const Plane29<P>* lo = in + ((g * (nseg_out * 2) + 2 * seg) * comps_in);
+        const Plane29<P>* hi = lo + comps_in;
+        if (comp <= (size_t)k) {
+            plane_load<P>(lo + comp, r, r_id);
+            plane_load<P>(hi + comp, h, h_id);
+            xyzz29_add<P>(r, r_id, h, h_id);
+        } else {
+            plane_load<P>(hi, r, r_id);  // the new plane k: the upper half's S
+        }
+    }
+    if (LAST) {
+        out_host[id] = xyzz29_to_xyzz<P>(r, r_id);
+    } else {
+        Plane29<P> o;
+        o.p = r;
+        o.id = r_id;
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        out[id] = o;
+    }
+}
+
+size_t msm_reduce_plane_bytes(size_t nb) { return nb * 160; }
+
+// planes_a / planes_b: msm_reduce_plane_bytes(G * B) each; out_host: G * c XYZZ points of pinned host memory
+template <class P>
+void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s) {
+    static_assert(sizeof(Plane29<P>) == 160, "plane record");
+    Plane29<P>* bufs[2] = {(Plane29<P>*)planes_a, (Plane29<P>*)planes_b};
+    for (int k = 0; k < c - 1; k++) {
+        const size_t threads = (size_t)G * ((size_t)B >> (k + 1)) * (k + 2);
+        const dim3 grid(div_up(threads, REDUCE_BLOCK)), block(REDUCE_BLOCK);
+        const Plane29<P>* in = bufs[(k + 1) & 1];
+        Plane29<P>* out = bufs[k & 1];
+        const bool last = k == c - 2;
+        if (k == 0 && last) hipLaunchKernelGGL((msm_planes29_kernel<P, true, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+        else if (k == 0) hipLaunchKernelGGL((msm_planes29_kernel<P, true, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+        else if (last) hipLaunchKernelGGL((msm_planes29_kernel<P, false, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+        else hipLaunchKernelGGL((msm_planes29_kernel<P, false, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+    }
+    LURK_HIP_CHECK(hipGetLastError());
+}
+template void msm_launch_reduce<PallasFp>(const Xyzz<PallasFp>*, void*, void*, int, int, uint32_t, Xyzz<PallasFp>*, hipStream_t);
+template void msm_launch_reduce<PallasFq>(const Xyzz<PallasFq>*, void*, void*, int, int, uint32_t, Xyzz<PallasFq>*, hipStream_t);
+
+}  // namespace lurk
