@@ -203,7 +203,7 @@ __global__ __launch_bounds__(SMALL_BLOCK) void msm_small_kernel(const uint4* __r
         xyzz29_add<P>(acc, acc_id, o, o_id);
     }
     if ((threadIdx.x & ((1 << SMALL_FINAL_LEVELS) - 1)) == 0 && threadIdx.x < G) out[threadIdx.x >> SMALL_FINAL_LEVELS] = xyzz29_to_xyzz<P>(acc, acc_id);
-    if (threadIdx.x == 0) *counter = 0;  // ready for the next launch on this slot
+    if (threadIdx.x == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch on this slot
     __threadfence_system();
 }
 

@@ -339,6 +339,10 @@ static void fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* s
     }
     c->t.alloc(c->num_cons * 32);
     c->ux.assign(4 * (1 + c->num_io), 0);
+    {   // the transcript's width-25 Poseidon constants are generated on first use (~0.15 s): now, not inside the first step
+        uint64_t one[4] = {1, 0, 0, 0}, out[4];
+        ok(lurk_hip_nova_ro_squeeze(c->field_id == LURK_FIELD_PALLAS_FQ ? LURK_FIELD_PALLAS_FP : LURK_FIELD_PALLAS_FQ, one, 1, 128, out));
+    }
     LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
     LURK_HIP_CHECK(hipEventCreateWithFlags(&c->w2_ready, hipEventDisableTiming));
