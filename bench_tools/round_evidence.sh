@@ -27,4 +27,7 @@ rm -rf gpurun_out/prof_${TAG}_msm_n22 gpurun_out/prof_${TAG}_msm_n20
   python bench.py --workload ntt --log-n 20 --steps 10 --warmup 3
 } > $E/sweep.jsonl 2> $E/sweep.err
 python bench_tools/small_commit_probe.py 200 > $E/small_commit_probe.jsonl 2>> $E/sweep.err
+# 4. store hydration: per-level kernel times (the level time is the Poseidon hash's dependency chain)
+( cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}" && rocprofv3 --kernel-trace --stats --output-format csv -d $E/prof_hydrate -- python -m pytest tests/test_gpu_poseidon.py -q -k "hydrat" > $E/hydrate.log 2>&1 )
+cp $(ls $E/prof_hydrate/*/*_kernel_stats.csv | head -1) $E/profiles/${TAG}_store_hydrate_kernel_stats.csv 2>/dev/null; rm -rf $E/prof_hydrate
 tail -c 600 $E/bench_default.json; echo; wc -l $E/sweep.jsonl

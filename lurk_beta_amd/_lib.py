@@ -9,7 +9,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("LURK_HIP_LIB") or os.path.join(_HERE, "liblurk_hip.so")  # override: A/B builds only
+LIB_PATH = os.path.join(_HERE, "liblurk_hip.so")
 _lib = None
 
 c_void_p, c_size_t, c_int, c_uint, c_u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64
@@ -140,8 +140,6 @@ def load():
             pass
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
-            if os.environ.get("LURK_HIP_PARTIAL") and not hasattr(lib, name):
-                continue  # development only: a partially built library
             fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
             fn.restype = res
             fn.argtypes = args

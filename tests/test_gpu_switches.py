@@ -1,0 +1,58 @@
+"""The library's four environment switches (everything else round 2 kept for A/B runs was pruned): each one is read
+once per process, so each setting runs in its own interpreter; whatever the setting, the commitments must be the oracle's."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+import lurk_beta_amd as L
+from oracle import coracle as C
+n = 1 << 17
+B = C.synth_bases(0, n)
+key = L.CommitmentKey(0, B, precompute=True)          # bucket pipeline, 16-bit windows with the table
+key.reserve(n, 3)
+vecs = [C.synth_scalars(1, 40 + k, k %% 2, n) for k in range(3)]
+dev = [torch.from_numpy(C.to_mont(1, v).view(np.int64)).cuda() for v in vecs]
+torch.cuda.synchronize()
+for rep in range(2):
+    for k in range(3):
+        key.submit_device(k, dev[k], n, is_mont=True)      # DEFAULT class: the persistent accumulation when the switch says so
+    for k in range(3):
+        assert L.point_to_affine(0, key.wait(k)) == C.jac_to_affine(0, C.msm_fast(0, B, vecs[k])), (rep, k)
+# a step through the context (LURK_STEP_TRACE prints its phases)
+A, Bm, Cm, z2 = C.synth_r1cs(1, 3000, 2500, 2, seed=9)
+mont = lambda M: (M[0], M[1], C.to_mont(1, M[2]))
+shape = L.R1CSShape(1, 3000, 2500, 2, mont(A), mont(Bm), mont(Cm))
+k2 = L.CommitmentKey(0, B[:3000], precompute=True, window_bits=16)
+ctx = L.FoldingContext(0, shape, k2)
+cw, ct, r = ctx.step(C.to_mont(1, z2[:2500]), C.to_mont(1, z2[2501:]), 12345)
+assert L.point_to_affine(0, cw) == C.jac_to_affine(0, C.msm_fast(0, B[:2500], z2[:2500]))
+print("child ok")
+'''
+
+
+@pytest.mark.parametrize("env,expect_stderr", [
+    ({}, None),
+    ({"LURK_MSM_ACC_PERSISTENT": "0"}, None),                     # never the persistent accumulation
+    ({"LURK_MSM_ACC_PERSISTENT": "2"}, None),                     # always (the default picks it from 2^22 sorted entries on)
+    ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_MAX_ACC": "0"}, None),   # no limit on resident accumulations
+    ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_PLACEMENT_LOG": "1"}, "accumulate placement"),
+    ({"LURK_STEP_TRACE": "1"}, "[step]"),
+])
+def test_switch_settings_keep_the_results(hip, env, expect_stderr):
+    e = dict(os.environ)
+    e.update(env)
+    p = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "child ok" in p.stdout
+    if expect_stderr:
+        assert expect_stderr in p.stderr, p.stderr[-500:]
