@@ -39,6 +39,8 @@ def gather_factor():
 
 
 def launch_classes(trace_csv, needle):
+    """per kernel NAME containing `needle` (the plain and the persistent accumulation are different kernels): warm-up / solo / overlapped,
+    where `overlapped` = another full-size launch of ANY kernel matching `needle` runs during it"""
     rows = []
     with open(trace_csv) as f:
         for r in csv.DictReader(f):
@@ -47,18 +49,27 @@ def launch_classes(trace_csv, needle):
     if not rows:
         return None
     rows.sort()
-    dur = [e - s for s, e, _ in rows]
-    big = statistics.median(sorted(dur)[len(dur) // 2:])  # median of the upper half: a typical full launch
-    classes = collections.defaultdict(list)
-    for i, (s, e, _) in enumerate(rows):
-        if e - s < 0.1 * big:
-            classes["warm_up"].append(e - s)
-            continue
-        overl = any(j != i and rows[j][0] < e and rows[j][1] > s and rows[j][1] - rows[j][0] >= 0.1 * big for j in range(len(rows)))
-        classes["overlapped" if overl else "solo"].append(e - s)
-    out = {"kernel": rows[0][2], "launches": len(rows)}
-    for k, v in classes.items():
-        out[k] = {"count": len(v), "mean_us": round(sum(v) / len(v) / 1e3, 2), "min_us": round(min(v) / 1e3, 2), "max_us": round(max(v) / 1e3, 2)}
+    out = {"kernels": {}}
+    names = sorted(set(n for _, _, n in rows))
+    big = {}
+    for nm in names:
+        dur = sorted(e - s for s, e, n in rows if n == nm)
+        big[nm] = statistics.median(dur[len(dur) // 2:])  # median of the upper half: a typical full launch of this kernel
+    full = [(s, e, n) for s, e, n in rows if e - s >= 0.1 * big[n]]
+    for nm in names:
+        classes = collections.defaultdict(list)
+        for s, e, n in rows:
+            if n != nm:
+                continue
+            if e - s < 0.1 * big[nm]:
+                classes["warm_up"].append(e - s)
+                continue
+            overl = any((s2, e2, n2) != (s, e, n) and s2 < e and e2 > s for s2, e2, n2 in full)
+            classes["overlapped" if overl else "solo"].append(e - s)
+        ent = {"launches": sum(len(v) for v in classes.values())}
+        for k, v in classes.items():
+            ent[k] = {"count": len(v), "mean_us": round(sum(v) / len(v) / 1e3, 2), "min_us": round(min(v) / 1e3, 2), "max_us": round(max(v) / 1e3, 2)}
+        out["kernels"][nm] = ent
     return out
 
 

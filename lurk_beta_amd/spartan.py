@@ -163,3 +163,122 @@ class SpartanProver:
 def _mont_one(base_field_id: int) -> np.ndarray:
     p = (0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001, 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001)[base_field_id]
     return sumcheck._limbs([(1 << 256) % p])[0]
+
+
+class BatchedSpartanProver:
+    """Several relaxed R1CS instances of different shapes and sizes under ONE commitment key, ONE proof: the structure of arecibo's
+    ``spartan::batched::BatchedRelaxedR1CSSNARK``, which lurk-beta's SuperNova prover compresses with
+    (/root/reference/src/proof/supernova.rs:110, 293-302).  One outer (cubic) and one inner (quadratic) sum-check shared by all instances
+    through random linear combinations, every instance's two evaluation claims batched to one point, one inner-product-argument opening
+    under the resident key.  Not byte-compatible (oracle/spartan_fast.py: prove_batched explains the padding and the transcript); its proof
+    must equal that oracle's element for element.  ``provers``: one ``SpartanProver`` per circuit (shape and transpose resident)."""
+
+    def __init__(self, provers):
+        assert provers and all(p.curve == provers[0].curve for p in provers)
+        self.provers = list(provers)
+        self.curve, self.q, self.sf = provers[0].curve, provers[0].q, provers[0].sf
+
+    def prove(self, instances, d_ck, key=None) -> dict:
+        """instances[i] = dict(X, u, d_W, d_E, comm_W, comm_E) for provers[i] (device tensors Montgomery, commitments 96-byte Jacobians).
+        d_ck: (N + 1, 8) affine Montgomery points, N = the largest num_cons / num_vars; key: the resident CommitmentKey over d_ck[:N]."""
+        import torch
+
+        q, sf, n = self.q, self.sf, len(self.provers)
+        P0 = self.provers[0]
+        mont, dev, pad = P0._mont, P0._dev, lambda t, m: torch.cat([t, torch.zeros((m - t.shape[0], 4), dtype=torch.int64, device="cuda")]) if t.shape[0] < m else t.clone()
+        ell_x = max(p.num_cons for p in self.provers).bit_length() - 1
+        ell_y = max(p.num_vars for p in self.provers).bit_length()
+        N = max(max(p.num_cons, p.num_vars) for p in self.provers)
+        ell = N.bit_length() - 1
+        tr = Transcript((b"pallas" if self.curve == 0 else b"vesta") + b"/batched")
+        tr.absorb_scalars(b"n", [n])
+        aff0 = lambda J: (lambda xy: None if xy == (0, 0) else xy)(point_to_affine(self.curve, J))
+
+        def absorb_pt(label, J):
+            a = aff0(J)
+            tr.absorb(label, bytes(64) if a is None else int(a[0]).to_bytes(32, "little") + int(a[1]).to_bytes(32, "little"))
+
+        for it in instances:
+            absorb_pt(b"comm_W", it["comm_W"])
+            absorb_pt(b"comm_E", it["comm_E"])
+            tr.absorb_scalars(b"uX", [it["u"]] + list(it["X"]))
+        tau = [tr.squeeze(b"t", q) for _ in range(ell_x)]
+        rho_o = tr.squeeze(b"rho_outer", q)
+        d_tau = sumcheck.eq_evals(sf, mont(tau))
+        zs, czs, quads = [], [], []
+        for p, it in zip(self.provers, instances):
+            nv = p.num_vars
+            d_z = torch.zeros((2 * nv, 4), dtype=torch.int64, device="cuda")
+            d_z[:nv] = it["d_W"]
+            d_z[nv:nv + 1 + len(it["X"])] = dev([it["u"]] + list(it["X"]))
+            d_az, d_bz, d_cz = p.shape.multiply_vec(d_z[: p.shape.num_cols])
+            d_ucze = fold_vec(sf, it["d_E"], d_cz, mont([it["u"]]))
+            zs.append(d_z)
+            czs.append(d_cz)
+            quads.append((d_tau.clone(), pad(d_az, 1 << ell_x), pad(d_bz, 1 << ell_x), pad(d_ucze, 1 << ell_x)))
+
+        def chal(poly):
+            tr.absorb_scalars(b"p", poly)
+            return tr.squeeze(b"c", q)
+
+        polys_outer, r_x, fin, _ = sumcheck.prove_cubic_batch(sf, q, quads, [pow(rho_o, i, q) for i in range(n)], chal)
+        d_eq_rx = sumcheck.eq_evals(sf, mont(r_x))
+        claims_outer, evals_E = [], []
+        for p, it, f4, d_cz in zip(self.provers, instances, fin, czs):
+            nc = p.num_cons
+            px = ell_x - (nc.bit_length() - 1)
+            claims_outer.append([f4[1], f4[2], self._ip(d_cz, d_eq_rx[:nc])])
+            evals_E.append(p._mle(it["d_E"], r_x[px:]))
+        tr.absorb_scalars(b"claims_outer", [c for cl in claims_outer for c in cl] + evals_E)
+        r = tr.squeeze(b"r", q)
+        rho_i = tr.squeeze(b"rho_inner", q)
+        pairs, claims_inner = [], []
+        for p, d_z, cl in zip(self.provers, zs, claims_outer):
+            d_ea, d_eb, d_ec = p.shape_t.multiply_vec(d_eq_rx[: p.num_cons].contiguous())
+            d_abc = fold_vec(sf, fold_vec(sf, d_ea, d_eb, mont([r])), d_ec, mont([r * r % q]))
+            pairs.append((pad(d_abc, 1 << ell_y), pad(d_z, 1 << ell_y)))
+            claims_inner.append((cl[0] + r * cl[1] + r * r * cl[2]) % q)
+        polys_inner, r_y, _, _ = sumcheck.prove_quad_batch(sf, q, claims_inner, pairs, [pow(rho_i, i, q) for i in range(n)], chal)
+        evals_W = []
+        for p, it in zip(self.provers, instances):
+            py = ell_y - p.num_vars.bit_length()
+            evals_W.append(p._mle(it["d_W"], r_y[py + 1:]))
+        tr.absorb_scalars(b"evals_W", evals_W)
+        polys, points, claims = [], [], []
+        for p, it, eW, eE in zip(self.provers, instances, evals_W, evals_E):
+            nc, nv = p.num_cons, p.num_vars
+            py, px = ell_y - nv.bit_length(), ell_x - (nc.bit_length() - 1)
+            polys += [pad(it["d_W"], N), pad(it["d_E"], N)]
+            points += [[0] * (ell - (nv.bit_length() - 1)) + r_y[py + 1:], [0] * (ell - (nc.bit_length() - 1)) + r_x[px:]]
+            claims += [eW, eE]
+        rho = tr.squeeze(b"rho", q)
+        bp = [(sumcheck.eq_evals(sf, mont(x)), pl.clone()) for x, pl in zip(points, polys)]
+        polys_batch, r_z, finb, _ = sumcheck.prove_quad_batch(sf, q, claims, bp, [pow(rho, k, q) for k in range(2 * n)], chal)
+        evals_batch = [fb[1] for fb in finb]
+        tr.absorb_scalars(b"evals_batch", evals_batch)
+        gamma = tr.squeeze(b"gamma", q)
+        d_joint = polys[0].clone()
+        for k in range(1, 2 * n):
+            d_joint = fold_vec(sf, d_joint, polys[k], mont([pow(gamma, k, q)]))
+        r0 = tr.squeeze(b"ipa_r0", q)
+
+        def ipa_chal(j, L, Rr):
+            absorb_pt(b"L", L)
+            absorb_pt(b"R", Rr)
+            return tr.squeeze(b"r", q)
+
+        ck_c = d_ck[N].cpu().numpy().view(np.uint64).reshape(8)
+        ck_c_jac = np.concatenate([ck_c, _mont_one(0 if self.curve == 0 else 1)])
+        Ls, Rs, a_hat, _ = ipa.prove(self.curve, q, None if key is not None else d_ck[:N].clone(), ck_c_jac, d_joint, sumcheck.eq_evals(sf, mont(r_z)), r0,
+                                     ipa_chal, key=key)
+        return dict(polys_outer=polys_outer, claims_outer=claims_outer, evals_E=evals_E, polys_inner=polys_inner, evals_W=evals_W, polys_batch=polys_batch,
+                    evals_batch=evals_batch, ipa_L=[aff0(x) for x in Ls], ipa_R=[aff0(x) for x in Rs], ipa_a=a_hat)
+
+    def _ip(self, d_a, d_b) -> int:
+        import torch
+
+        out = np.zeros(4, dtype=np.uint64)
+        d_b = d_b.contiguous()
+        _lib.check(_lib.load().lurk_hip_inner_product_dev(self.sf, _lib.ptr(d_a), _lib.ptr(d_b), d_a.shape[0], _lib.ptr(out),
+                                                          _lib.ptr(torch.cuda.current_stream().cuda_stream)))
+        return sumcheck._ints(out)[0] * self.provers[0].Rinv % self.q

@@ -134,3 +134,49 @@ def prove_quad_batch(field_id: int, modulus: int, claims, pairs, coeffs, challen
     torch.cuda.synchronize()
     finals = [(_ints(a[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p, _ints(b[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p) for a, b in pairs]
     return polys, rs, finals, claim
+
+
+def prove_cubic_batch(field_id: int, modulus: int, quads, coeffs, challenge, stream=None):
+    """sum_i coeff_i * sum_x A_i(x) (B_i(x) C_i(x) - D_i(x)) with ONE challenge per round shared by every instance: the outer sum-check
+    of the batched SNARK (arecibo's spartan::batched; /root/reference/src/proof/supernova.rs:110).  quads: [(A_i, B_i, C_i, D_i)] device
+    tensors of one common length (consumed; a table may be shared by several instances only if it is passed as separate copies).  The
+    claim starts at 0 (every instance satisfied).  Returns (round polynomials, challenges, [final (A, B, C, D)(r) per instance], claim)."""
+    import torch
+
+    lib = _lib.load()
+    p = modulus
+    R = (1 << 256) % p
+    Rinv = pow(R, p - 2, p)
+    inv2, inv6 = pow(2, p - 2, p), pow(6, p - 2, p)
+    n = quads[0][0].shape[0]
+    assert all(t.is_cuda and t.shape[0] == n for q in quads for t in q)
+    s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    ptrs = [(ctypes.c_void_p * 4)(*[_lib.ptr(t) for t in q]) for q in quads]
+    claim, polys, rs, length, r_prev = 0, [], [], n, None
+    for _ in range(n.bit_length() - 1):
+        e0 = e2 = e3 = 0
+        rm = None if r_prev is None else _limbs([r_prev * R % p])
+        for c, pp in zip(coeffs, ptrs):
+            ev = np.zeros((3, 4), dtype=np.uint64)
+            _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 3, pp, length, None if rm is None else _lib.ptr(rm), _lib.ptr(ev), _lib.ptr(s)))
+            a0, a2, a3 = [x * Rinv % p for x in _ints(ev)]
+            e0, e2, e3 = (e0 + c * a0) % p, (e2 + c * a2) % p, (e3 + c * a3) % p
+        if r_prev is not None:
+            length //= 2
+        e1 = (claim - e0) % p
+        a3c = (e3 - 3 * e2 + 3 * e1 - e0) * inv6 % p
+        b = ((e2 - 2 * e1 + e0) * inv2 - 3 * a3c) % p
+        poly = [e0, (e1 - e0 - a3c - b) % p, b, a3c]
+        r_prev = int(challenge(poly)) % p
+        polys.append(poly)
+        rs.append(r_prev)
+        acc = 0
+        for co in reversed(poly):
+            acc = (acc * r_prev + co) % p
+        claim = acc
+    rm = _limbs([r_prev * R % p])
+    for pp in ptrs:
+        _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 3, pp, length, _lib.ptr(rm), None, _lib.ptr(s)))
+    torch.cuda.synchronize()
+    finals = [tuple(_ints(t[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p for t in q) for q in quads]
+    return polys, rs, finals, claim

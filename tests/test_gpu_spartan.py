@@ -82,3 +82,73 @@ def test_device_prover_matches_the_fast_oracle_at_2_14_and_2_16(hip, cn, c, log_
     for k in (plain, table):
         k.close()
     prover.close()
+
+
+@pytest.mark.parametrize("cn,c,dims", [("pallas", 0, [(16, 64, True, 11), (64, 128, False, 12), (8, 16, True, 13)]),
+                                       ("vesta", 1, [(32, 64, True, 21), (8, 32, False, 22)])])
+def test_batched_device_prover_matches_the_oracle(hip, cn, c, dims):
+    """The batched SNARK (several instances of different shapes under one key, one proof: the structure of arecibo's
+    BatchedRelaxedR1CSSNARK, /root/reference/src/proof/supernova.rs:110, 293-302): the device-assisted prover's proof equals the oracle
+    prover's (oracle/spartan_fast.py: prove_batched) element for element - opening argument with the folded key and under the resident
+    key - and the oracle's verifier accepts it and rejects it for another statement."""
+    from lurk_beta_amd import CommitmentKey
+    from lurk_beta_amd.spartan import BatchedSpartanProver, SpartanProver
+    from oracle import spartan_fast as SF
+    from tests.test_oracle_spartan import _to_arrays
+
+    sf = 1 - c
+    q = R.CURVES[cn]["order"]
+    N = max(max(nc, nv) for nc, nv, _, _ in dims)
+    B = C.synth_bases(c, N + 1)
+    key = CommitmentKey(c, B[:N])
+    insts, provers, dev_insts = [], [], []
+    for nc, nv, folded, seed in dims:
+        mats, X, u, W, E = product_instance(cn, nc, nv, 2, seed, folded)
+        m_arr, W_arr, E_arr = _to_arrays(mats, X, W, E)
+        cw, ce = key.commit(W_arr), key.commit(E_arr)
+        aff = lambda J: (lambda a: None if a == (0, 0) else a)(C.jac_to_affine(c, J))
+        insts.append(dict(mats=m_arr, num_cons=nc, num_vars=nv, X=X, u=u, W=W_arr, E=E_arr, comm_W=aff(cw), comm_E=aff(ce)))
+        provers.append(SpartanProver(c, q, [(M[0], M[1], C.to_mont(sf, M[2])) for M in m_arr], nc, nv, len(X)))
+        dev_insts.append(dict(X=X, u=u, d_W=_dev(C.to_mont(sf, W_arr)), d_E=_dev(C.to_mont(sf, E_arr)), comm_W=cw, comm_E=ce))
+    want = SF.prove_batched(c, insts, B)
+    bp = BatchedSpartanProver(provers)
+    got = bp.prove(dev_insts, _dev(B))
+    assert got == want
+    assert bp.prove(dev_insts, _dev(B), key=key) == want
+    pub = [{k: v for k, v in it.items() if k not in ("W", "E")} for it in insts]
+    assert SF.verify_batched(c, pub, B, got)
+    pub[0]["X"] = [(pub[0]["X"][0] + 1) % q] + pub[0]["X"][1:]
+    assert not SF.verify_batched(c, pub, B, got)
+    key.close()
+    for p in provers:
+        p.close()
+
+
+def test_batched_device_prover_at_2_12_and_2_14(hip):
+    """Two circuits of 2^12 and 2^14 rows (the shape of a SuperNova batch: a small coprocessor circuit beside the step circuit) under one
+    resident table key: proof = the oracle's, verifier accepts."""
+    from lurk_beta_amd import CommitmentKey
+    from lurk_beta_amd.spartan import BatchedSpartanProver, SpartanProver
+    from oracle import spartan_fast as SF
+
+    c, sf = 0, 1
+    q = R.CURVES["pallas"]["order"]
+    sizes = [1 << 12, 1 << 14]
+    N = max(sizes)
+    B = C.synth_bases(c, N + 1)
+    key = CommitmentKey(c, B[:N], precompute=True)
+    insts, provers, dev_insts = [], [], []
+    for k, n in enumerate(sizes):
+        A, Bm, Cm, W, X = SF.synth_product_instance(sf, n, n, 2, seed=30 + k)
+        E = np.zeros((n, 4), dtype=np.uint64)
+        cw = key.commit(W)
+        insts.append(dict(mats=(A, Bm, Cm), num_cons=n, num_vars=n, X=X, u=1, W=W, E=E, comm_W=SF._aff(c, cw), comm_E=None))
+        provers.append(SpartanProver(c, q, [(M[0], M[1], C.to_mont(sf, M[2])) for M in (A, Bm, Cm)], n, n, len(X)))
+        dev_insts.append(dict(X=X, u=1, d_W=_dev(C.to_mont(sf, W)), d_E=_dev(E), comm_W=cw, comm_E=np.zeros(12, dtype=np.uint64)))
+    want = SF.prove_batched(c, insts, B)
+    got = BatchedSpartanProver(provers).prove(dev_insts, _dev(B), key=key)
+    assert got == want
+    assert SF.verify_batched(c, [{k: v for k, v in it.items() if k not in ("W", "E")} for it in insts], B, got)
+    key.close()
+    for p in provers:
+        p.close()

@@ -145,3 +145,59 @@ def test_fast_oracle_at_2_12():
     proof = SF.prove(curve_id, (A, B, Cm), nc, nv, X, key, comm_W, None, 1, W, E)
     assert SF.verify(curve_id, (A, B, Cm), nc, nv, X, key, comm_W, None, 1, proof)
     assert not SF.verify(curve_id, (A, B, Cm), nc, nv, X, key, comm_W, None, 2, proof)
+
+
+def test_batched_oracle_complete_and_sound():
+    """oracle/spartan_fast.py prove_batched / verify_batched (the structure of arecibo's BatchedRelaxedR1CSSNARK, which SuperNova compresses
+    with: /root/reference/src/proof/supernova.rs:110,293-302): three instances of different shapes and sizes - strict and folded - under
+    one key; honest proofs verify, tampered proofs and wrong statements do not."""
+    import numpy as np
+
+    from oracle import coracle as C
+    from oracle import spartan_fast as SF
+
+    curve_id, curve = 0, "pallas"
+    q = R.CURVES[curve]["order"]
+    dims = [(16, 64, True, 11), (64, 128, False, 12), (8, 16, True, 13)]  # (num_cons, num_vars, folded, seed): the middle one is the largest
+    N = max(max(nc, nv) for nc, nv, _, _ in dims)
+    key = C.synth_bases(curve_id, N + 1)
+    insts = []
+    for nc, nv, folded, seed in dims:
+        mats, X, u, W, E = product_instance(curve, nc, nv, 2, seed, folded)
+        m_arr, W_arr, E_arr = _to_arrays(mats, X, W, E)
+        insts.append(dict(mats=m_arr, num_cons=nc, num_vars=nv, X=X, u=u, W=W_arr, E=E_arr,
+                          comm_W=SF._aff(curve_id, SF._commit(curve_id, key, W_arr)), comm_E=SF._aff(curve_id, SF._commit(curve_id, key, E_arr))))
+    proof = SF.prove_batched(curve_id, insts, key)
+    pub = [{k: v for k, v in it.items() if k not in ("W", "E")} for it in insts]
+    assert SF.verify_batched(curve_id, pub, key, proof)
+    # one instance alone through the batched protocol as well
+    p1 = SF.prove_batched(curve_id, insts[:1], key)
+    assert SF.verify_batched(curve_id, pub[:1], key, p1)
+    # wrong statements
+    for i in range(3):
+        bad = copy.deepcopy(pub)
+        bad[i]["X"] = [(bad[i]["X"][0] + 1) % q] + bad[i]["X"][1:]
+        assert not SF.verify_batched(curve_id, bad, key, proof), i
+        bad = copy.deepcopy(pub)
+        bad[i]["u"] = (bad[i]["u"] + 1) % q
+        assert not SF.verify_batched(curve_id, bad, key, proof), i
+    assert not SF.verify_batched(curve_id, [pub[1], pub[0], pub[2]], key, proof)  # the order of the instances is part of the statement
+    # tampered proofs
+    for field, idx in (("evals_W", 0), ("evals_W", 2), ("evals_E", 1), ("evals_batch", 3)):
+        bad = copy.deepcopy(proof)
+        bad[field][idx] = (bad[field][idx] + 1) % q
+        assert not SF.verify_batched(curve_id, pub, key, bad), (field, idx)
+    bad = copy.deepcopy(proof)
+    bad["claims_outer"][2][1] = (bad["claims_outer"][2][1] + 1) % q
+    assert not SF.verify_batched(curve_id, pub, key, bad)
+    bad = copy.deepcopy(proof)
+    bad["ipa_a"] = (bad["ipa_a"] + 1) % q
+    assert not SF.verify_batched(curve_id, pub, key, bad)
+    # an unsatisfied instance in the batch: the honest prover's proof is rejected
+    E2 = insts[0]["E"].copy()
+    E2[0, 0] += 1
+    broken = copy.deepcopy(insts)
+    broken[0]["E"] = E2
+    broken[0]["comm_E"] = SF._aff(curve_id, SF._commit(curve_id, key, E2))
+    p2 = SF.prove_batched(curve_id, broken, key)
+    assert not SF.verify_batched(curve_id, [{k: v for k, v in it.items() if k not in ("W", "E")} for it in broken], key, p2)
