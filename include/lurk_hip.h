@@ -137,6 +137,13 @@ int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_s
 int lurk_hip_msm_ctx_submit_dev_mode(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars32, size_t nscalars, int is_mont,
                                      void* stream, int mode);
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out_jacobian96);
+/* A PAIR of commitments with disjoint supports in one pass (the L and R of an inner-product-argument round under the resident key:
+ * arecibo ipa_pc, /root/reference/src/proof/nova.rs:57-62): ONE scalar vector; the scalars whose index has bit `sel_bit` clear commit
+ * to out_lo, the others to out_hi - two key spaces of one sort / accumulate / reduce instead of two commitments that each scan all
+ * n scalars for half of them.  Window-table keys only (precompute flag, more than 2^16 points or a window-bit override). */
+int lurk_hip_msm_ctx_submit_pair_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars32, size_t nscalars, int is_mont, void* stream,
+                                     int sel_bit);
+int lurk_hip_msm_ctx_wait_pair(lurk_hip_msm_ctx* ctx, int slot, void* out_lo_jacobian96, void* out_hi_jacobian96);
 int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx);
 /* Points the context at other device-resident bases (borrowed, plain key) and keeps its workspaces: a key that changes every
  * round (the folded key of the inner-product argument) without re-allocation. */
@@ -424,6 +431,8 @@ int lurk_hip_points_fold_halves_dev(int curve, const void* d_points_affine64, si
  * and after the challenge coef_fold multiplies coef[i] by s_lo / s_hi according to the half (i mod m) lies in (coef starts as
  * all ones; after the last round it is the verifier's s vector: the final key element is commit(ck, coef)).  Two table-mode
  * MSMs per round replace m/2 full-size double scalar multiplications whose 255-step ladder is latency-bound for every m. */
+/* (d_out_r == NULL: ONE merged vector in d_out_l - L's and R's supports are disjoint - for lurk_hip_msm_ctx_submit_pair_dev with
+ *  sel_bit = log2(m / 2): out_hi = L, out_lo = R) */
 int lurk_hip_ipa_round_scalars_dev(int field_id, const void* d_a, size_t m, const void* d_coef, size_t n, void* d_out_l,
                                    void* d_out_r, void* stream);
 int lurk_hip_ipa_coef_fold_dev(int field_id, void* d_coef, size_t n, size_t m, const void* s_lo32_mont, const void* s_hi32_mont,

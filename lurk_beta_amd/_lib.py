@@ -49,6 +49,8 @@ SIGNATURES = {
     "lurk_hip_msm_ctx_submit_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p]),
     "lurk_hip_msm_ctx_submit_dev_mode": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p, c_int]),
     "lurk_hip_msm_ctx_wait": (c_int, [c_void_p, c_int, c_void_p]),
+    "lurk_hip_msm_ctx_submit_pair_dev": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_void_p, c_int]),
+    "lurk_hip_msm_ctx_wait_pair": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "lurk_hip_msm_ctx_destroy": (c_int, [c_void_p]),
     "lurk_hip_msm_ctx_rebind_dev": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lurk_hip_msm_ctx_reserve": (c_int, [c_void_p, c_size_t, c_int]),

@@ -59,6 +59,10 @@ __global__ __launch_bounds__(IPA_BLOCK) void ipa_round_scalars_kernel(const Fe<F
         const size_t p = i & (m - 1);
         const bool hi = p >= h;
         const Fe<F> v = fe_mul<F>(a[hi ? p - h : p + h], coef[i]);
+        if (out_r == nullptr) {  // one merged vector: the supports of L (upper halves) and R (lower halves) are disjoint; the pair is
+            out_l[i] = v;         // committed in one pass with bit log2(m / 2) of the index as the selector (lurk_hip_msm_ctx_submit_pair_dev)
+            continue;
+        }
         out_l[i] = hi ? v : fe_zero<F>();
         out_r[i] = hi ? fe_zero<F>() : v;
     }
@@ -211,7 +215,7 @@ int lurk_hip_ipa_round_scalars_dev(int field_id, const void* d_a, size_t m, cons
     return guarded([&] {
         LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
         LURK_REQUIRE(m >= 2 && (m & (m - 1)) == 0 && n >= m && n % m == 0, "m must be a power of two >= 2 that divides n");
-        LURK_REQUIRE(d_a && d_coef && d_out_l && d_out_r, "null argument");
+        LURK_REQUIRE(d_a && d_coef && d_out_l, "null argument");  // d_out_r == NULL: the merged form
         if (field_id == 0) ipa_round_scalars<PallasFp>(d_a, m, d_coef, n, d_out_l, d_out_r, (hipStream_t)stream);
         else if (field_id == 1) ipa_round_scalars<PallasFq>(d_a, m, d_coef, n, d_out_l, d_out_r, (hipStream_t)stream);
         else ipa_round_scalars<Bn254Fr>(d_a, m, d_coef, n, d_out_l, d_out_r, (hipStream_t)stream);

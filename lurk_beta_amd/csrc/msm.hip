@@ -46,6 +46,8 @@ struct MsmShape {
     int LB;                // low key bits sorted in pass 2 (NB >> LB == P)
     int NG;                // scan groups of MSM_GRP keys
     size_t n, stride;      // scalars in this call; table stride per window (0 in plain mode)
+    int sel;               // >= 0: TWO key spaces chosen by bit `sel` of the scalar's index (a pair of commitments with disjoint supports
+                           // in one pass: the two halves of an inner-product-argument round); -1: off
 };
 
 // Every kernel of a commitment except the bucket accumulation is short and bound by latency, LDS atomics or HBM; with
@@ -86,8 +88,9 @@ __device__ __forceinline__ Fe<SF> msm_load_scalar(const uint4* __restrict__ scal
 }
 
 // entry (w, i) -> key = space * B + |d| - 1 (space = w in plain mode, 0 with the table)
-__device__ __forceinline__ uint32_t msm_key(const MsmShape& sh, uint32_t w, uint32_t mag) {
-    return (sh.G == 1 ? 0u : w * sh.B) + mag - 1u;
+__device__ __forceinline__ uint32_t msm_key(const MsmShape& sh, uint32_t w, uint32_t mag, size_t i) {
+    const uint32_t space = sh.sel >= 0 ? (uint32_t)((i >> sh.sel) & 1u) : (sh.G == 1 ? 0u : w);
+    return space * sh.B + mag - 1u;
 }
 
 // ---- 2a. sort pass 1: coarse partition by the high key bits -------------------------------------
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* 
         uint32_t carry = 0;
         for (int w = 0; w < sh.W; w++) {
             uint32_t mag = msm_digit_step(s.l, w, sh.c, carry) & ~MSM_SIGN;
-            if (mag) atomicAdd(&h[msm_key(sh, (uint32_t)w, mag) >> sh.LB], 1u);
+            if (mag) atomicAdd(&h[msm_key(sh, (uint32_t)w, mag, i) >> sh.LB], 1u);
         }
     }
     __syncthreads();
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
             uint32_t carry = 0;
             for (int w = 0; w < sh.W; w++) {
                 uint32_t mag = msm_digit_step(s.l, w, sh.c, carry) & ~MSM_SIGN;
-                if (mag) atomicAdd(&cnt[msm_key(sh, (uint32_t)w, mag) >> sh.LB], 1u);
+                if (mag) atomicAdd(&cnt[msm_key(sh, (uint32_t)w, mag, i) >> sh.LB], 1u);
             }
         }
         __syncthreads();
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
                 uint32_t d = msm_digit_step(s.l, w, sh.c, carry);
                 uint32_t mag = d & ~MSM_SIGN;
                 if (mag) {
-                    uint32_t key = msm_key(sh, (uint32_t)w, mag);
+                    uint32_t key = msm_key(sh, (uint32_t)w, mag, i);
                     uint32_t p = key >> sh.LB;
                     uint32_t slot = start[p] + atomicAdd(&cnt[p], 1u);
                     stage[slot] = make_uint2(key, ((uint32_t)((size_t)w * sh.stride) + (uint32_t)i) | (d & MSM_SIGN));
@@ -644,6 +647,9 @@ struct MsmCtxBase {
     // asynchronous: enqueue on the slot's own stream (after `after`, the stream that produced the scalars)
     virtual void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int mode) = 0;
     virtual void wait(int slot, void* out_jac96_host) = 0;
+    // two commitments with disjoint supports in one pass: scalars whose index has bit sel_bit clear -> out_lo, set -> out_hi
+    virtual void submit_pair(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int sel_bit) = 0;
+    virtual void wait_pair(int slot, void* out_lo_jac96_host, void* out_hi_jac96_host) = 0;
     // pasta-msm's calling convention: everything in host memory, nothing resident (buffers and workspaces are kept for the next call)
     virtual void run_oneshot(const void* bases, const void* scalars, size_t n, int is_mont, void* out_jac96_host) = 0;
     virtual void rebind(const void* d_bases, size_t n) = 0;  // plain key over other (borrowed) device bases, workspaces kept
@@ -674,6 +680,7 @@ struct MsmCtx : MsmCtxBase {
         hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
         DevBuf cursor;                     // task cursor of the persistent accumulate kernel (+ its per-CU placement counters)
         bool placement_valid = false;
+        int sel = -1;                      // the pending commitment is a PAIR split by this bit of the scalar index (submit_pair)
         bool small_ready = false;          // the small path's buffers exist and its arrival counter is zero
         bool force_persistent = false;     // LURK_MSM_SUBMIT_BACKGROUND
         bool foreground = false;           // LURK_MSM_SUBMIT_FOREGROUND
@@ -696,11 +703,12 @@ struct MsmCtx : MsmCtxBase {
     Work* acc_ring[MSM_SLOTS] = {};
     int acc_ring_pos = 0, acc_ring_count = 0;
 
-    MsmShape shape(size_t n) const {
+    MsmShape shape(size_t n, int sel = -1) const {
         MsmShape sh;
         sh.c = c;
         sh.W = msm_num_windows(c);
-        sh.G = precomputed ? 1 : sh.W;
+        sh.sel = precomputed ? sel : -1;
+        sh.G = precomputed ? (sh.sel >= 0 ? 2 : 1) : sh.W;
         sh.B = 1u << (c - 1);
         sh.NB = (uint32_t)sh.G * sh.B;
         // partitions: as few as let an average partition (W n / P entries) fit the LDS stage of pass 2 with 15 % to
@@ -955,7 +963,7 @@ struct MsmCtx : MsmCtxBase {
             if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
             return;
         }
-        const MsmShape sh = shape(n);
+        const MsmShape sh = shape(n, wk.sel);
         ensure_workspace(wk, sh);
         const size_t chunk = (n + MSM_NB1 - 1) / MSM_NB1;
         const size_t nt = ntask_max(sh);
@@ -1081,6 +1089,14 @@ struct MsmCtx : MsmCtxBase {
         const Xyzz<P> total = msm_planes_horner_windows<P>(wk.host_pts, sh.G, sh.c);  // sum_g 2^(c g) (S_g + sum_k 2^k P_gk)
         put_point(out, jacobian_from_affine<P>(xyzz_to_affine<P>(total)));
     }
+    // a pair: key space g of the two holds the commitment of the scalars whose index has the selector bit = g
+    void host_tail_pair(Work& wk, void* out_lo, void* out_hi) {
+        void* outs[2] = {out_lo, out_hi};
+        for (int g = 0; g < 2; g++) {
+            const Xyzz<P> t = msm_planes_horner_windows<P>(wk.host_pts + (size_t)g * c, 1, c);
+            put_point(outs[g], jacobian_from_affine<P>(xyzz_to_affine<P>(t)));
+        }
+    }
 
     void run(const void* d_scalars, size_t n, int is_mont, hipStream_t s, void* out_jac96_host) override {
         LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
@@ -1092,17 +1108,39 @@ struct MsmCtx : MsmCtxBase {
         Work& wk = work[0];
         std::lock_guard<std::mutex> lk(wk.mu);
         LURK_REQUIRE(!wk.pending, "slot 0 has a submitted commitment that was not waited for");
+        wk.sel = -1;
         enqueue(wk, d_scalars, n, is_mont, s);
         LURK_HIP_CHECK(hipStreamSynchronize(s));
         host_tail(wk, n, out);
     }
 
+    void submit_pair(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int sel_bit) override {
+        LURK_REQUIRE(precomputed && !small, "a pair of commitments in one pass needs the window-table form of a key (precompute flag, more than 2^16 points "
+                                            "or a window-bit override)");
+        LURK_REQUIRE(sel_bit >= 0 && sel_bit < 31, "selector bit out of range");
+        LURK_REQUIRE(n > 0, "empty pair");
+        submit_impl(slot, d_scalars, n, is_mont, after, LURK_MSM_SUBMIT_FOREGROUND, sel_bit);
+    }
+    void wait_pair(int slot, void* out_lo, void* out_hi) override {
+        LURK_REQUIRE(slot >= 0 && slot < MSM_SLOTS, "slot out of range");
+        Work& wk = work[slot];
+        std::lock_guard<std::mutex> lk(wk.mu);
+        LURK_REQUIRE(wk.pending && wk.sel >= 0, "no pair was submitted on this slot");
+        wk.pending = false;
+        LURK_HIP_CHECK(hipStreamSynchronize(wk.pending_stream ? wk.pending_stream : wk.stream));
+        host_tail_pair(wk, out_lo, out_hi);
+        wk.sel = -1;
+    }
     void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int mode) override {
+        submit_impl(slot, d_scalars, n, is_mont, after, mode, -1);
+    }
+    void submit_impl(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int mode, int sel_bit) {
         LURK_REQUIRE(slot >= 0 && slot < MSM_SLOTS, "slot out of range");
         LURK_REQUIRE(n <= npoints, "more scalars than bases in the context");
         Work& wk = work[slot];
         std::lock_guard<std::mutex> lk(wk.mu);
         LURK_REQUIRE(!wk.pending, "slot is busy: wait for it first");
+        wk.sel = sel_bit;
         ensure_streams(wk);
         if (n) {
             // the scalars were produced on the caller's stream: order the slot stream after it
@@ -1151,6 +1189,7 @@ struct MsmCtx : MsmCtxBase {
         Work& wk = work[slot];
         std::lock_guard<std::mutex> lk(wk.mu);
         LURK_REQUIRE(wk.pending, "nothing was submitted on this slot");
+        LURK_REQUIRE(wk.sel < 0, "a pair is pending on this slot: use lurk_hip_msm_ctx_wait_pair");
         void* out = out_jac96_host;
         wk.pending = false;
         if (wk.pending_n == 0) {
@@ -1417,6 +1456,20 @@ int lurk_hip_msm_ctx_submit_dev_mode(lurk_hip_msm_ctx* ctx, int slot, const void
         LURK_REQUIRE(mode >= LURK_MSM_SUBMIT_DEFAULT && mode <= LURK_MSM_SUBMIT_BACKGROUND, "unknown submit mode");
         DeviceGuard dg(ctx->impl->device);
         ctx->impl->submit(slot, d_scalars, n, is_mont, (hipStream_t)stream, mode);
+    });
+}
+int lurk_hip_msm_ctx_submit_pair_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars, size_t n, int is_mont, void* stream, int sel_bit) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && d_scalars, "null argument");
+        DeviceGuard dg(ctx->impl->device);
+        ctx->impl->submit_pair(slot, d_scalars, n, is_mont, (hipStream_t)stream, sel_bit);
+    });
+}
+int lurk_hip_msm_ctx_wait_pair(lurk_hip_msm_ctx* ctx, int slot, void* out_lo, void* out_hi) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && out_lo && out_hi, "null argument");
+        DeviceGuard dg(ctx->impl->device);
+        ctx->impl->wait_pair(slot, out_lo, out_hi);
     });
 }
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out) {

@@ -42,19 +42,29 @@ def _prove_resident_key(curve: int, q: int, key, ck_c: np.ndarray, d_a, d_b, cha
     mont = lambda v: _limbs(v * R % q)
     n0 = d_a.shape[0]
     d_coef = torch.from_numpy(np.tile(mont(1), (n0, 1)).view(np.int64)).to(d_a.device)
-    d_l, d_r = torch.empty_like(d_coef), torch.empty_like(d_coef)
+    pairs = key.supports_pairs()  # a window-table key commits L and R (disjoint supports) as two key spaces of ONE pass
+    d_l = torch.empty_like(d_coef)
+    d_r = None if pairs else torch.empty_like(d_coef)
     Ls, Rs = [], []
     m, j = n0, 0
     while m > 1:
         h = m // 2
         cl, cr = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
         _lib.check(lib.lurk_hip_ipa_round_scalars_dev(sf, _lib.ptr(d_a), m, _lib.ptr(d_coef), n0, _lib.ptr(d_l), _lib.ptr(d_r), _lib.ptr(s)))
-        key.submit_device(0, d_l, n0, is_mont=True, stream=s, mode=1)   # both commitments in flight under the inner products; the host
-        key.submit_device(1, d_r, n0, is_mont=True, stream=s, mode=1)   # waits for both: the foreground class (plain accumulate launch)
+        if pairs:
+            key.submit_pair_device(0, d_l, n0, h.bit_length() - 1, is_mont=True, stream=s)   # bit log2(m / 2) of the index: set = L's support
+        else:
+            key.submit_device(0, d_l, n0, is_mont=True, stream=s, mode=1)   # both commitments in flight under the inner products; the host
+            key.submit_device(1, d_r, n0, is_mont=True, stream=s, mode=1)   # waits for both: the foreground class (plain accumulate launch)
         _lib.check(lib.lurk_hip_inner_product_dev(sf, _lib.ptr(d_a), _lib.ptr(d_b[h:]), h, _lib.ptr(cl), _lib.ptr(s)))
         _lib.check(lib.lurk_hip_inner_product_dev(sf, _lib.ptr(d_a[h:]), _lib.ptr(d_b), h, _lib.ptr(cr), _lib.ptr(s)))
-        L = point_sum(curve, np.stack([key.wait(0), point_mul(curve, ck_c, cl)]))
-        Rr = point_sum(curve, np.stack([key.wait(1), point_mul(curve, ck_c, cr)]))
+        tl, trr = point_mul(curve, ck_c, cl), point_mul(curve, ck_c, cr)  # two 255-bit host scalar multiples (0.2 ms each): under the MSM
+        if pairs:
+            c_r, c_l = key.wait_pair(0)
+        else:
+            c_l, c_r = key.wait(0), key.wait(1)
+        L = point_sum(curve, np.stack([c_l, tl]))
+        Rr = point_sum(curve, np.stack([c_r, trr]))
         Ls.append(L)
         Rs.append(Rr)
         r = int(challenge(j, L, Rr)) % q

@@ -136,6 +136,27 @@ class CommitmentKey:
         getattr(self, "_keep", {}).pop(slot, None)
         return out
 
+    def supports_pairs(self) -> bool:
+        """True for a window-table key (precompute flag and more than 2^16 points, or a window-bit override): the only form that
+        commits a pair in one pass (``submit_pair_device``)."""
+        i = self.info()
+        return bool(i["precomputed"]) and i["window_bits"] >= 16
+
+    def submit_pair_device(self, slot: int, d_scalars, n: int, sel_bit: int, is_mont: bool = False, stream=None) -> None:
+        """Two commitments with disjoint supports in one pass: scalars whose index has bit ``sel_bit`` clear / set; ``wait_pair``."""
+        lib = _lib.load()
+        self._keep = getattr(self, "_keep", {})
+        self._keep[slot] = d_scalars
+        _lib.check(lib.lurk_hip_msm_ctx_submit_pair_dev(self._ctx, slot, _lib.ptr(d_scalars), n, int(is_mont), _lib.ptr(stream), sel_bit))
+
+    def wait_pair(self, slot: int):
+        """(commitment of the bit-clear scalars, commitment of the bit-set scalars)"""
+        lib = _lib.load()
+        lo, hi = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
+        _lib.check(lib.lurk_hip_msm_ctx_wait_pair(self._ctx, slot, _lib.ptr(lo), _lib.ptr(hi)))
+        getattr(self, "_keep", {}).pop(slot, None)
+        return lo, hi
+
     def close(self):
         if self._ctx:
             _lib.load().lurk_hip_msm_ctx_destroy(self._ctx)

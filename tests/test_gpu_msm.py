@@ -489,3 +489,55 @@ def test_key_files_round_trip(hip, tmp_path, cn, c):
         CommitmentKey.load(bad)
     with pytest.raises(LurkHipError):
         CommitmentKey.load(str(tmp_path / "missing.bin"))
+
+
+@pytest.mark.parametrize("cn,c", CURVES)
+def test_pair_of_commitments_in_one_pass(hip, cn, c):
+    """lurk_hip_msm_ctx_submit_pair_dev / wait_pair: ONE scalar vector, bit sel of the index splits it into two commitments (the L and R of
+    an inner-product-argument round have disjoint supports) - two key spaces of one sort / accumulate / reduce.  Must equal the two
+    commitments made separately, for every selector bit, with zero halves, and with two pairs in flight."""
+    import torch
+
+    from lurk_beta_amd import CommitmentKey, LurkHipError, point_to_affine
+
+    sf, n = _sf(c), 1 << 17
+    B = C.synth_bases(c, n)
+    key = CommitmentKey(c, B, precompute=True)  # 2^17 points: the window-table form
+    assert key.supports_pairs()
+    S = C.synth_scalars(sf, 61, 0, n)
+    d_s = torch.from_numpy(C.to_mont(sf, S).view(np.int64)).cuda()
+    idx = np.arange(n)
+    for bit in (0, 1, 7, 16):
+        hi_mask = ((idx >> bit) & 1).astype(bool)
+        lo_v, hi_v = S.copy(), S.copy()
+        lo_v[hi_mask] = 0
+        hi_v[~hi_mask] = 0
+        key.submit_pair_device(0, d_s, n, bit, is_mont=True)
+        lo, hi = key.wait_pair(0)
+        assert point_to_affine(c, lo) == C.jac_to_affine(c, C.msm_fast(c, B, lo_v)), bit
+        assert point_to_affine(c, hi) == C.jac_to_affine(c, C.msm_fast(c, B, hi_v)), bit
+    # one side all zero; a prefix of the key; two pairs in flight on two slots
+    Z = S.copy()
+    Z[(idx >> 3) & 1 == 1] = 0
+    d_z = torch.from_numpy(C.to_mont(sf, Z).view(np.int64)).cuda()
+    key.submit_pair_device(1, d_z, n, 3, is_mont=True)
+    key.submit_pair_device(2, d_s, 1000, 2, is_mont=True)
+    lo, hi = key.wait_pair(1)
+    assert point_to_affine(c, hi) == (0, 0) and point_to_affine(c, lo) == C.jac_to_affine(c, C.msm_fast(c, B, Z))
+    lo, hi = key.wait_pair(2)
+    m = ((np.arange(1000) >> 2) & 1).astype(bool)
+    a, b = S[:1000].copy(), S[:1000].copy()
+    a[m] = 0
+    b[~m] = 0
+    assert point_to_affine(c, lo) == C.jac_to_affine(c, C.msm_fast(c, B[:1000], a)) and point_to_affine(c, hi) == C.jac_to_affine(c, C.msm_fast(c, B[:1000], b))
+    # an ordinary commitment on the same slot afterwards; wait() on a pending pair is refused
+    assert point_to_affine(c, key.commit(S)) == C.jac_to_affine(c, C.msm_fast(c, B, S))
+    key.submit_pair_device(0, d_s, n, 5, is_mont=True)
+    with pytest.raises(LurkHipError, match="pair"):
+        key.wait(0)
+    key.close()
+    small = CommitmentKey(c, B[:5000], precompute=True)  # the small-commitment form has no key spaces
+    assert not small.supports_pairs()
+    with pytest.raises(LurkHipError):
+        small.submit_pair_device(0, d_s, 5000, 1, is_mont=True)
+    small.close()
