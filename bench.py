@@ -166,9 +166,9 @@ def main():
 
     # part of the once-per-process setup, like the key and its slots: the device is brought to its steady clocks with ~0.4 s of the same
     # commitments before the W warm-up steps (the first process on a fresh box measured up to 5 % low without it: 20 steps are 90 ms)
+    # (a FIXED number of commitments: with N > 1 every step is a collective, so all ranks must run the same count)
     t_dev = time.perf_counter()
-    while time.perf_counter() - t_dev < 0.4:
-        run_steps(4)
+    run_steps(max(8, min(512, (96 << 22) >> args.log_n)))
     device_warmup_ms = (time.perf_counter() - t_dev) * 1e3
     result = run_steps(args.warmup)
     lib.lurk_hip_profile_enable(1)
