@@ -53,18 +53,26 @@ struct lurk_hip_fold_ctx {
     std::vector<uint64_t> ux;                          // [u | X] Montgomery, 1 + num_io elements
     std::vector<uint64_t> open_x2;                     // X2 of the open step
     uint64_t open_cw[12] = {0}, open_ct[12] = {0};     // comm_W2, comm_T of the open step
+    uint64_t owed_r[4] = {0};                          // finish(r) leaves the instance fold to fold_instance_settle (off the device's critical path)
+    bool instance_owed = false;
     // fresh instances staged ahead of their step (lurk_hip_fold_step_prefetch): buffer b commits on the key's slot 2 b, T on slot 1
     int staged[2] = {0, 0}, n_staged = 0, next_buf = 0, open_buf = 0;
     bool folded_valid[2] = {false, false}, submitted[2] = {false, false}, partial[2] = {false, false};
     char* pin = nullptr;               // pinned staging for what arrives in pageable host memory (u2, X2, late ranges): an async copy
     size_t pin_cap = 0;                // from pageable memory makes the runtime wait, which held the cross term back by ~0.5 ms
-    hipStream_t stream = nullptr, stage_stream = nullptr;
+    // one staging stream per fresh-instance buffer: staging instance k + 1 (which waits for the kernels that produce its witness) must not
+    // hold back the small uploads begin(k) sends behind instance k's own staging (measured: begin(k) then waited for witness k + 1)
+    hipStream_t stream = nullptr, stage_stream[2] = {nullptr, nullptr};
+    hipEvent_t patch_ev = nullptr;     // the late-range buffer is shared by all steps: zeroed behind step k, written by step k + 1 on the other stream
+    bool patch_ev_valid = false;
     hipEvent_t w2_ready = nullptr, staged_ev[2] = {nullptr, nullptr}, folded_ev[2] = {nullptr, nullptr};
     std::mutex mu;
     ~lurk_hip_fold_ctx() {
         if (pin) (void)hipHostFree(pin);
         if (stream) (void)hipStreamDestroy(stream);
-        if (stage_stream) (void)hipStreamDestroy(stage_stream);
+        for (int k = 0; k < 2; k++)
+            if (stage_stream[k]) (void)hipStreamDestroy(stage_stream[k]);
+        if (patch_ev) (void)hipEventDestroy(patch_ev);
         if (w2_ready) (void)hipEventDestroy(w2_ready);
         for (int k = 0; k < 2; k++) {
             if (staged_ev[k]) (void)hipEventDestroy(staged_ev[k]);
@@ -75,9 +83,40 @@ struct lurk_hip_fold_ctx {
 
 namespace lurk {
 
+// [u | X] <- [u1 + r | X1 + r X2] on the host (1 + num_io elements; u2 = 1)
+template <class F>
+static void fold_ux_host(std::vector<uint64_t>& ux, const std::vector<uint64_t>& x2, const void* r_mont) {
+    Fe<F> r;
+    memcpy(r.l, r_mont, 32);
+    const size_t n = ux.size() / 4;
+    for (size_t i = 0; i < n; i++) {
+        Fe<F> a, b;
+        memcpy(a.l, &ux[4 * i], 32);
+        if (i == 0) b = fe_one<F>();
+        else memcpy(b.l, &x2[4 * (i - 1)], 32);
+        a = fe_add<F>(a, fe_mul<F>(r, b));
+        memcpy(&ux[4 * i], a.l, 32);
+    }
+}
+
+// U1 <- U1 + r U2 (RelaxedR1CSInstance::fold) for the step finish(r) closed last, if it is still owed
+static void fold_instance_settle(lurk_hip_fold_ctx* c) {
+    if (!c->instance_owed) return;
+    c->instance_owed = false;
+    uint64_t pair[24];
+    memcpy(pair, c->comm_w, 96);
+    ok(lurk_hip_point_mul(c->curve, pair + 12, c->open_cw, c->owed_r, 1));
+    ok(lurk_hip_point_sum(c->curve, c->comm_w, pair, 2));
+    memcpy(pair, c->comm_e, 96);
+    ok(lurk_hip_point_mul(c->curve, pair + 12, c->open_ct, c->owed_r, 1));
+    ok(lurk_hip_point_sum(c->curve, c->comm_e, pair, 2));
+    if (c->field_id == LURK_FIELD_PALLAS_FQ) fold_ux_host<PallasFq>(c->ux, c->open_x2, c->owed_r);
+    else fold_ux_host<PallasFp>(c->ux, c->open_x2, c->owed_r);
+}
+
 static void fold_submit_staged(lurk_hip_fold_ctx* c, int b, int mode) {
     if (c->submitted[b]) return;
-    ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 2 * b, c->partial[b] ? c->zstaged[b].p : c->z2[b].p, c->num_vars, 1, c->stage_stream,
+    ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 2 * b, c->partial[b] ? c->zstaged[b].p : c->z2[b].p, c->num_vars, 1, c->stage_stream[b],
                                         mode));  // zero digits cost the sort nothing
     c->submitted[b] = true;
 }
@@ -92,18 +131,18 @@ static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size
     LURK_REQUIRE(count == 0 || w2, "null witness");
     const int b = c->next_buf;
     char* z2 = (char*)c->z2[b].p;
-    if (c->folded_valid[b]) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream, c->folded_ev[b], 0));  // the fold two steps back still reads it
+    if (c->folded_valid[b]) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream[b], c->folded_ev[b], 0));  // the fold two steps back still reads it
     if (on_device) {  // W2 was produced on the caller's stream (e.g. by lurk_hip_slot_witness_dev): order ours after it
         LURK_HIP_CHECK(hipEventRecord(c->w2_ready, (hipStream_t)w2_stream));
-        LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream, c->w2_ready, 0));
+        LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream[b], c->w2_ready, 0));
     }
-    if (count < c->num_vars) LURK_HIP_CHECK(hipMemsetAsync(z2, 0, c->num_vars * 32, c->stage_stream));
+    if (count < c->num_vars) LURK_HIP_CHECK(hipMemsetAsync(z2, 0, c->num_vars * 32, c->stage_stream[b]));
     if (count)
-        LURK_HIP_CHECK(hipMemcpyAsync(z2 + offset * 32, w2, count * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stage_stream));
+        LURK_HIP_CHECK(hipMemcpyAsync(z2 + offset * 32, w2, count * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stage_stream[b]));
     c->partial[b] = count < c->num_vars;
     if (c->partial[b]) {  // late ranges will be written into z2 while the commitment of the staged ones is still in flight: it reads a copy
         if (!c->zstaged[b].p) c->zstaged[b].alloc(c->num_vars * 32);
-        LURK_HIP_CHECK(hipMemcpyAsync(c->zstaged[b].p, z2, c->num_vars * 32, hipMemcpyDeviceToDevice, c->stage_stream));
+        LURK_HIP_CHECK(hipMemcpyAsync(c->zstaged[b].p, z2, c->num_vars * 32, hipMemcpyDeviceToDevice, c->stage_stream[b]));
     }
     c->submitted[b] = false;
     c->staged[c->n_staged++] = b;
@@ -147,22 +186,23 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     if (c->field_id == LURK_FIELD_PALLAS_FQ) mont_one<PallasFq>(c->pin);
     else mont_one<PallasFp>(c->pin);
     if (c->num_io) memcpy(c->pin + 32, x2_mont, c->num_io * 32);
-    LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, (1 + c->num_io) * 32, hipMemcpyHostToDevice, c->stage_stream));
+    LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, (1 + c->num_io) * 32, hipMemcpyHostToDevice, c->stage_stream[b]));
     if (patched) {
+        if (c->patch_ev_valid) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream[b], c->patch_ev, 0));  // the previous step's zeroing
         if (!c->zpatch.p) {
             c->zpatch.alloc(c->num_vars * 32);
-            LURK_HIP_CHECK(hipMemsetAsync(c->zpatch.p, 0, c->num_vars * 32, c->stage_stream));
+            LURK_HIP_CHECK(hipMemsetAsync(c->zpatch.p, 0, c->num_vars * 32, c->stage_stream[b]));
         }
         char* src = c->pin + (1 + c->num_io) * 32;
         for (size_t k = 0; k < n_patches; k++) {
             if (!patches[k].count) continue;
             memcpy(src, patches[k].values, patches[k].count * 32);
-            LURK_HIP_CHECK(hipMemcpyAsync(z2 + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream));
-            LURK_HIP_CHECK(hipMemcpyAsync((char*)c->zpatch.p + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream));
+            LURK_HIP_CHECK(hipMemcpyAsync(z2 + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream[b]));
+            LURK_HIP_CHECK(hipMemcpyAsync((char*)c->zpatch.p + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream[b]));
             src += patches[k].count * 32;
         }
     }
-    LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream));
+    LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream[b]));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
     // Order (measured on MI355X at rc = 100, `bench_tools/sweep_step_order.sh` of round 3, ms per step with the next witness traced
     // behind begin): cross term first, then commit(W2), then commit(T), all in the FOREGROUND class: 3.88 - against commit(W2) first
@@ -174,10 +214,11 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     fold_submit_staged(c, b, fg);
     tt[1] = now();
     ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t.p, c->num_cons, 1, c->stream, fg));     // ... commit(T): what the host waits for
-    if (patched) ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream, fg));  // commitment of the late ranges
+    if (patched) ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream[b], fg));  // commitment of the late ranges
     tt[2] = now();
     if (ahead) fold_submit_staged(c, c->staged[0], LURK_MSM_SUBMIT_BACKGROUND);  // commit(next W2) fills what T leaves
     tt[3] = now();
+    fold_instance_settle(c);  // the previous step's instance fold, while the device works on this step
     if (patched) {
         ok(lurk_hip_msm_ctx_wait(c->key, 2 * b, body));
         ok(lurk_hip_msm_ctx_wait(c->key, 3, late));
@@ -186,7 +227,9 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
         memcpy(two + 12, late, 96);
         ok(lurk_hip_point_sum(c->curve, comm_w2_jac96, two, 2));  // commit is linear: body + late ranges
         for (size_t k = 0; k < n_patches; k++)
-            if (patches[k].count) LURK_HIP_CHECK(hipMemsetAsync((char*)c->zpatch.p + patches[k].offset * 32, 0, patches[k].count * 32, c->stage_stream));
+            if (patches[k].count) LURK_HIP_CHECK(hipMemsetAsync((char*)c->zpatch.p + patches[k].offset * 32, 0, patches[k].count * 32, c->stage_stream[b]));
+        LURK_HIP_CHECK(hipEventRecord(c->patch_ev, c->stage_stream[b]));
+        c->patch_ev_valid = true;
     } else {
         ok(lurk_hip_msm_ctx_wait(c->key, 2 * b, comm_w2_jac96));
     }
@@ -214,9 +257,9 @@ static void fold_commit_multi(lurk_hip_fold_ctx* c, const void* d_vec, size_t n,
         ptrs[i] = sb.buf.p;
         if (sb.first >= n || sb.count == 0) continue;
         const size_t cnt = (sb.first + sb.count < n ? sb.first + sb.count : n) - sb.first;
-        LURK_HIP_CHECK(hipMemcpyPeerAsync(sb.buf.p, sb.device, (const char*)d_vec + sb.first * 32, c->device, cnt * 32, c->stage_stream));
+        LURK_HIP_CHECK(hipMemcpyPeerAsync(sb.buf.p, sb.device, (const char*)d_vec + sb.first * 32, c->device, cnt * 32, c->stage_stream[0]));
     }
-    LURK_HIP_CHECK(hipStreamSynchronize(c->stage_stream));
+    LURK_HIP_CHECK(hipStreamSynchronize(c->stage_stream[0]));
     ok(lurk_hip_msm_multi_commit_dev(c->mkey, out_jac96, ptrs.data(), ptrs.size(), n, 1));
 }
 
@@ -224,12 +267,12 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
                              void* comm_t_jac96) {
     const int b = 0;  // one fresh-instance buffer: nothing is staged ahead with a multi-device key
     char* z2 = (char*)c->z2[b].p;
-    if (c->folded_valid[b]) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream, c->folded_ev[b], 0));  // the previous fold still reads it
+    if (c->folded_valid[b]) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream[0], c->folded_ev[b], 0));  // the previous fold still reads it
     if (on_device) {
         LURK_HIP_CHECK(hipEventRecord(c->w2_ready, (hipStream_t)w2_stream));
-        LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream, c->w2_ready, 0));
+        LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream[0], c->w2_ready, 0));
     }
-    if (c->num_vars) LURK_HIP_CHECK(hipMemcpyAsync(z2, w2, c->num_vars * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stage_stream));
+    if (c->num_vars) LURK_HIP_CHECK(hipMemcpyAsync(z2, w2, c->num_vars * 32, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stage_stream[0]));
     const size_t need = (1 + c->num_io) * 32;
     if (need > c->pin_cap) {
         if (c->pin) LURK_HIP_CHECK(hipHostFree(c->pin));
@@ -241,10 +284,11 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
     if (c->field_id == LURK_FIELD_PALLAS_FQ) mont_one<PallasFq>(c->pin);
     else mont_one<PallasFp>(c->pin);
     if (c->num_io) memcpy(c->pin + 32, x2_mont, c->num_io * 32);
-    LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, need, hipMemcpyHostToDevice, c->stage_stream));
-    LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream));
+    LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, need, hipMemcpyHostToDevice, c->stage_stream[0]));
+    LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream[0]));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
     ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));  // beside commit(W2)
+    fold_instance_settle(c);
     fold_commit_multi(c, z2, c->num_vars, comm_w2_jac96);
     LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
     fold_commit_multi(c, c->t.p, c->num_cons, comm_t_jac96);
@@ -253,22 +297,6 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
     c->open_x2.assign((const uint64_t*)x2_mont, (const uint64_t*)x2_mont + 4 * c->num_io);
     memcpy(c->open_cw, comm_w2_jac96, 96);
     memcpy(c->open_ct, comm_t_jac96, 96);
-}
-
-// [u | X] <- [u1 + r | X1 + r X2] on the host (1 + num_io elements; u2 = 1)
-template <class F>
-static void fold_ux_host(std::vector<uint64_t>& ux, const std::vector<uint64_t>& x2, const void* r_mont) {
-    Fe<F> r;
-    memcpy(r.l, r_mont, 32);
-    const size_t n = ux.size() / 4;
-    for (size_t i = 0; i < n; i++) {
-        Fe<F> a, b;
-        memcpy(a.l, &ux[4 * i], 32);
-        if (i == 0) b = fe_one<F>();
-        else memcpy(b.l, &x2[4 * (i - 1)], 32);
-        a = fe_add<F>(a, fe_mul<F>(r, b));
-        memcpy(&ux[4 * i], a.l, 32);
-    }
 }
 
 static void fold_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
@@ -280,16 +308,10 @@ static void fold_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
     c->folded_valid[c->open_buf] = true;
     c->cur = nx;
     c->begun = false;
-    // the instance side on the host while the device folds the vectors: two 128-bit scalar multiples and two additions
-    uint64_t pair[24];
-    memcpy(pair, c->comm_w, 96);
-    ok(lurk_hip_point_mul(c->curve, pair + 12, c->open_cw, r32_mont, 1));
-    ok(lurk_hip_point_sum(c->curve, c->comm_w, pair, 2));
-    memcpy(pair, c->comm_e, 96);
-    ok(lurk_hip_point_mul(c->curve, pair + 12, c->open_ct, r32_mont, 1));
-    ok(lurk_hip_point_sum(c->curve, c->comm_e, pair, 2));
-    if (c->field_id == LURK_FIELD_PALLAS_FQ) fold_ux_host<PallasFq>(c->ux, c->open_x2, r32_mont);
-    else fold_ux_host<PallasFp>(c->ux, c->open_x2, r32_mont);
+    // the instance side (two 128-bit scalar multiples, two additions, u and X: ~0.1 ms of host work) is owed until somebody reads the
+    // instance or the next step has its device work enqueued - the next cross term must not wait for it
+    memcpy(c->owed_r, r32_mont, 32);
+    c->instance_owed = true;
 }
 
 }  // namespace lurk
@@ -344,7 +366,8 @@ static void fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* s
         ok(lurk_hip_nova_ro_squeeze(c->field_id == LURK_FIELD_PALLAS_FQ ? LURK_FIELD_PALLAS_FP : LURK_FIELD_PALLAS_FQ, one, 1, 128, out));
     }
     LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; k++) LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream[k], hipStreamNonBlocking));
+    LURK_HIP_CHECK(hipEventCreateWithFlags(&c->patch_ev, hipEventDisableTiming));
     LURK_HIP_CHECK(hipEventCreateWithFlags(&c->w2_ready, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
         c->z2[k].alloc(c->ncols * 32);
@@ -389,6 +412,7 @@ int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* c, const void* z1, const vo
         LURK_HIP_CHECK(hipMemcpyAsync(c->z[c->cur].p, z1, c->ncols * 32, hipMemcpyHostToDevice, c->stream));
         LURK_HIP_CHECK(hipMemcpyAsync(c->e[c->cur].p, e1, c->num_cons * 32, hipMemcpyHostToDevice, c->stream));
         LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
+        fold_instance_settle(c);  // the commitments of the last step first: only u and X are replaced here
         memcpy(c->ux.data(), (const char*)z1 + c->num_vars * 32, (1 + c->num_io) * 32);
     });
 }
@@ -399,6 +423,7 @@ int lurk_hip_fold_ctx_set_instance(lurk_hip_fold_ctx* c, const void* comm_w_jac9
         LURK_REQUIRE(c && comm_w_jac96 && comm_e_jac96, "null argument");
         std::lock_guard<std::mutex> lk(c->mu);
         LURK_REQUIRE(!c->begun, "a step is open: finish it first");
+        fold_instance_settle(c);  // u and X of the last step first: only the commitments are replaced
         memcpy(c->comm_w, comm_w_jac96, 96);
         memcpy(c->comm_e, comm_e_jac96, 96);
     });
@@ -408,6 +433,7 @@ int lurk_hip_fold_ctx_instance(lurk_hip_fold_ctx* c, void* comm_w_jac96, void* c
     return guarded([&] {
         LURK_REQUIRE(c, "null ctx");
         std::lock_guard<std::mutex> lk(c->mu);
+        fold_instance_settle(c);
         if (comm_w_jac96) memcpy(comm_w_jac96, c->comm_w, 96);
         if (comm_e_jac96) memcpy(comm_e_jac96, c->comm_e, 96);
         if (u32_mont) memcpy(u32_mont, c->ux.data(), 32);
