@@ -111,8 +111,11 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* 
         Fe<SF> s = msm_scalar_from_words<SF>(nlo, nhi, is_mont);
         if (i + MSM_SORT_BLOCK < hi) { nlo = scalars[2 * (i + MSM_SORT_BLOCK)]; nhi = scalars[2 * (i + MSM_SORT_BLOCK) + 1]; }
         uint32_t carry = 0;
+        uint32_t r[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) r[k] = s.l[k];
         for (int w = 0; w < sh.W; w++) {
-            uint32_t mag = msm_digit_step(s.l, w, sh.c, carry) & ~MSM_SIGN;
+            uint32_t mag = msm_digit_next(r, sh.c, carry) & ~MSM_SIGN;
             if (mag) atomicAdd(&h[msm_key(sh, (uint32_t)w, mag, i) >> sh.LB], 1u);
         }
     }
@@ -217,8 +220,11 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
         if (live) {
             s = msm_load_scalar<SF>(scalars, i, is_mont);
             uint32_t carry = 0;
+            uint32_t r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = s.l[k];
             for (int w = 0; w < sh.W; w++) {
-                uint32_t mag = msm_digit_step(s.l, w, sh.c, carry) & ~MSM_SIGN;
+                uint32_t mag = msm_digit_next(r, sh.c, carry) & ~MSM_SIGN;
                 if (mag) atomicAdd(&cnt[msm_key(sh, (uint32_t)w, mag, i) >> sh.LB], 1u);
             }
         }
@@ -233,8 +239,11 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
         __syncthreads();
         if (live) {
             uint32_t carry = 0;
+            uint32_t r[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) r[k] = s.l[k];
             for (int w = 0; w < sh.W; w++) {
-                uint32_t d = msm_digit_step(s.l, w, sh.c, carry);
+                uint32_t d = msm_digit_next(r, sh.c, carry);
                 uint32_t mag = d & ~MSM_SIGN;
                 if (mag) {
                     uint32_t key = msm_key(sh, (uint32_t)w, mag, i);

@@ -55,6 +55,24 @@ LURK_HD uint32_t msm_digit_step(const uint32_t* s, int w, int c, uint32_t& carry
     return raw;
 }
 
+// The same recoding as a WALK over the windows in ascending order: the scalar sits in r[0..8) and is consumed from the bottom (the
+// registers are shifted down by c bits per digit), so no limb is ever indexed by a run-time value - with msm_digit_step's s[limb]
+// the compiler keeps the scalar in scratch memory and every digit costs two scratch loads.  1 <= c <= 31; past the top window the
+// registers are empty and the carry is 0: the digits are 0.
+LURK_HD uint32_t msm_digit_next(uint32_t (&r)[8], int c, uint32_t& carry) {
+    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1u;
+    uint32_t raw = (r[0] & mask) + carry;
+#pragma unroll
+    for (int k = 0; k < 7; k++) r[k] = (r[k] >> c) | (r[k + 1] << (32 - c));
+    r[7] >>= c;
+    if (raw > half) {
+        carry = 1;
+        return ((1u << c) - raw) | MSM_SIGN;
+    }
+    carry = 0;
+    return raw;
+}
+
 // largest g with start[g] <= t, over start[0..n] (start[n] is the sentinel = total)
 LURK_HD uint32_t msm_upper_slot(const uint32_t* start, uint32_t n, uint32_t t) {
     uint32_t lo = 0, hi = n;  // invariant: start[lo] <= t < start[hi]

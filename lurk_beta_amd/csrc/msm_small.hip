@@ -98,23 +98,6 @@ __device__ __forceinline__ void pt29_shfl_xor(const Xyzz29<P>& v, bool v_id, int
     o_id = __shfl_xor((int)v_id, mask) != 0;
 }
 
-// The next signed c-bit digit of the scalar held in r[0..8) (consumed from the bottom: the registers are shifted down by c bits,
-// so no limb is ever indexed by a run-time value - msm_digit_step's s[limb] would put the scalar into scratch memory here).
-// Same recoding as msm_digit_step: |d| | sign << 31 with |d| <= 2^(c-1), carry threaded through.
-__device__ __forceinline__ uint32_t small_next_digit(uint32_t (&r)[8], int c, uint32_t& carry) {
-    const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1u;
-    uint32_t raw = (r[0] & mask) + carry;
-#pragma unroll
-    for (int k = 0; k < 7; k++) r[k] = (r[k] >> c) | (r[k + 1] << (32 - c));
-    r[7] >>= c;
-    if (raw > half) {
-        carry = 1;
-        return ((1u << c) - raw) | MSM_SIGN;
-    }
-    carry = 0;
-    return raw;
-}
-
 template <class P, class SF>
 __global__ __launch_bounds__(SMALL_BLOCK) void msm_small_kernel(const uint4* __restrict__ scalars, size_t n, int is_mont, const Affine<P>* __restrict__ table,
                                                                   int c, int W, uint32_t S /*lanes per scalar*/, Pt29<P>* __restrict__ group_pts,
@@ -143,13 +126,13 @@ __global__ __launch_bounds__(SMALL_BLOCK) void msm_small_kernel(const uint4* __r
         uint32_t r[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) r[k] = s.l[k];
-        for (uint32_t j = 0; j < sub; j++) (void)small_next_digit(r, c, carry);  // the windows below the first own one
+        for (uint32_t j = 0; j < sub; j++) (void)msm_digit_next(r, c, carry);  // the windows below the first own one
         const Affine<P>* row = table + ((i * (size_t)W) << (c - 1));
         for (uint32_t k = 0; k < K; k++) {
             const uint32_t w = sub + k * S;
             // (past the top window the registers are empty and the carry is 0: the digits are 0)
-            const uint32_t d = small_next_digit(r, c, carry);
-            for (uint32_t j = 1; j < S; j++) (void)small_next_digit(r, c, carry);  // the other lanes' windows up to the next own one
+            const uint32_t d = msm_digit_next(r, c, carry);
+            for (uint32_t j = 1; j < S; j++) (void)msm_digit_next(r, c, carry);  // the other lanes' windows up to the next own one
             const uint32_t mag = d & ~MSM_SIGN;
             if (mag) {
                 const Affine<P> q = row[((size_t)w << (c - 1)) + mag - 1];
