@@ -708,11 +708,16 @@ def compress_workload(args, lib, world, rank):
     lib.lurk_hip_profile_enable(1)
     lib.lurk_hip_profile_reset()
     torch.cuda.synchronize()
+    # (as timeit does: no cyclic-garbage collection inside the timed region - a full collection is a 35 ms pause of the transcript callback)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         proof = step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     lib.lurk_hip_profile_enable(0)
 
     def kernel_ms(name):

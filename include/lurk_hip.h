@@ -437,6 +437,17 @@ int lurk_hip_ipa_round_scalars_dev(int field_id, const void* d_a, size_t m, cons
                                    void* d_out_r, void* stream);
 int lurk_hip_ipa_coef_fold_dev(int field_id, void* d_coef, size_t n, size_t m, const void* s_lo32_mont, const void* s_hi32_mont,
                                void* stream);
+/* The whole inner-product argument under a resident key (arecibo ipa_pc::InnerProductArgument::prove, the opening of CompressedSNARK on
+ * the Pasta cycle: /root/reference/src/proof/nova.rs:57-62, 341-356): log2(n) rounds of { composed scalars, commitment of L and R under
+ * the ORIGINAL key, cross inner products, challenge, folds } with the vectors resident; the transcript is the caller's: `challenge`
+ * receives the round number and L, R (96-byte Jacobians) and writes r as a canonical 32-byte value below the group order (return 0;
+ * anything else aborts the call).  d_a, d_b: n Montgomery scalars on the device, consumed (folded in place); ck_c: the extra base,
+ * already scaled by the transcript's first challenge.  Outputs: L and R per round (log2(n) x 96 bytes each), a_hat canonical, and the
+ * folded key element as an affine Montgomery point ((0, 0) = identity).  n: a power of two, at most the key's points. */
+typedef int (*lurk_hip_ipa_challenge_fn)(void* user, int round, const void* l_jacobian96, const void* r_jacobian96, void* out_r32_canonical);
+int lurk_hip_ipa_prove_dev(lurk_hip_msm_ctx* key, void* d_a32, void* d_b32, size_t n, const void* ck_c_jacobian96,
+                           lurk_hip_ipa_challenge_fn challenge, void* user, void* out_l_jacobian96, void* out_r_jacobian96,
+                           void* out_a_hat32, void* out_ck_hat_affine64, void* stream);
 
 /* ---- synthetic inputs (bench / tests) -------------------------------------
  * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */

@@ -37,6 +37,46 @@ __global__ __launch_bounds__(IPA_BLOCK) void inner_product_kernel(const Fe<F>* _
     if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
 }
 
+template <class F>
+__global__ __launch_bounds__(IPA_BLOCK) void fill_kernel(Fe<F>* __restrict__ v, size_t n, Fe<F> x) {
+    for (size_t i = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * IPA_BLOCK) v[i] = x;
+}
+
+// both cross inner products of a round in one pass: <a_lo, b_hi> and <a_hi, b_lo>, block partials [2 * block + {0, 1}]
+template <class F>
+__global__ __launch_bounds__(IPA_BLOCK) void cross_products_kernel(const Fe<F>* __restrict__ a, const Fe<F>* __restrict__ b, size_t h,
+                                                                     Fe<F>* __restrict__ partial) {
+    __shared__ uint4 raw[2 * 2 * (IPA_BLOCK / 64)];
+    Fe<F>(*sh)[IPA_BLOCK / 64] = reinterpret_cast<Fe<F>(*)[IPA_BLOCK / 64]>(raw);
+    Fe<F> l = fe_zero<F>(), r = fe_zero<F>();
+    for (size_t i = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x; i < h; i += (size_t)gridDim.x * IPA_BLOCK) {
+        const Fe<F> alo = a[i], ahi = a[i + h], blo = b[i], bhi = b[i + h];
+        l = fe_add<F>(l, fe_mul<F>(alo, bhi));
+        r = fe_add<F>(r, fe_mul<F>(ahi, blo));
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        Fe<F> ol, orr;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            ol.l[k] = __shfl_down(l.l[k], off);
+            orr.l[k] = __shfl_down(r.l[k], off);
+        }
+        l = fe_add<F>(l, ol);
+        r = fe_add<F>(r, orr);
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        sh[0][wave] = l;
+        sh[1][wave] = r;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        Fe<F> t = sh[threadIdx.x][0];
+        for (int w = 1; w < IPA_BLOCK / 64; w++) t = fe_add<F>(t, sh[threadIdx.x][w]);
+        partial[2 * blockIdx.x + threadIdx.x] = t;
+    }
+}
+
 // v[i] <- s_lo v[i] + s_hi v[h + i], i < h
 template <class F>
 __global__ __launch_bounds__(IPA_BLOCK) void fold_halves_kernel(Fe<F>* v, size_t h, Fe<F> s_lo, Fe<F> s_hi) {
@@ -184,6 +224,142 @@ static void points_fold_halves(const void* d_pts, size_t len, const void* lo32, 
     LURK_HIP_CHECK(hipGetLastError());
 }
 
+
+// ---- the whole argument under a resident key (arecibo ipa_pc::InnerProductArgument::prove, /root/reference/src/proof/nova.rs:57-62) ----
+// The round loop of lurk_beta_amd/ipa.py: _prove_resident_key as host code of the library: per round one launch for the composed scalars,
+// one pair commitment (window-table key) or two commitments in flight (plain / small key), one launch + one copy for both cross inner
+// products, the two host scalar multiples of the extra base while the commitment runs, the transcript's challenge (a callback), one
+// host inversion and three fold launches.  In Python the glue around the same calls cost 0.4-0.5 ms per round with the device idle.
+template <class P, class F>
+static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, void* d_a, void* d_b, size_t n0, const void* ck_c_jac96,
+                               lurk_hip_ipa_challenge_fn challenge, void* user, uint64_t* out_l, uint64_t* out_r, void* out_a_hat32,
+                               void* out_ck_hat64, hipStream_t s) {
+    auto ok = [](int rc) { if (rc != 0) throw HipFailure{rc, lurk_hip_last_error()}; };
+    int kc = 0, kbits = 0, ktable = 0;
+    size_t kn = 0;
+    ok(lurk_hip_msm_ctx_info(key, &kc, &kn, &kbits, &ktable));
+    LURK_REQUIRE(kc == curve, "the key is over another curve");
+    LURK_REQUIRE(kn >= n0, "the key has fewer points than the vectors have elements");
+    const bool pairs = ktable && kbits >= 16;  // the window-table form commits L and R (disjoint supports) in one pass
+    // stream-ordered scratch (the pool keeps it between calls: a proof opens several of these arguments) and one pinned block per thread
+    struct Scratch {
+        hipStream_t s;
+        void* p = nullptr;
+        Scratch(size_t bytes, hipStream_t s_) : s(s_) { LURK_HIP_CHECK(hipMallocAsync(&p, bytes ? bytes : 32, s)); }
+        ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
+    };
+    const unsigned max_blocks = (unsigned)num_cus() * 8;
+    Scratch coef(n0 * 32, s), dl(n0 * 32, s), dr(pairs ? 0 : n0 * 32, s), partial((size_t)2 * max_blocks * 32, s);
+    {
+        unsigned blocks = div_up(n0, IPA_BLOCK);
+        if (blocks > max_blocks) blocks = max_blocks;
+        hipLaunchKernelGGL((fill_kernel<F>), dim3(blocks), dim3(IPA_BLOCK), 0, s, (Fe<F>*)coef.p, n0, fe_one<F>());
+        LURK_HIP_CHECK(hipGetLastError());
+    }
+    struct Pinned {
+        uint64_t* p = nullptr;
+        size_t cap = 0;
+        ~Pinned() { if (p) (void)hipHostFree(p); }
+    };
+    static thread_local Pinned pinned;
+    if (pinned.cap < (size_t)2 * max_blocks * 32) {
+        if (pinned.p) (void)hipHostFree(pinned.p);
+        pinned.p = nullptr;
+        pinned.cap = 0;
+        LURK_HIP_CHECK(hipHostMalloc((void**)&pinned.p, (size_t)2 * max_blocks * 32));
+        pinned.cap = (size_t)2 * max_blocks * 32;
+    }
+    uint64_t* host_partial = pinned.p;
+    size_t m = n0;
+    int j = 0;
+    while (m > 1) {
+        const size_t h = m / 2;
+        int log_h = 0;
+        while (((size_t)1 << log_h) < h) log_h++;
+        ipa_round_scalars<F>(d_a, m, coef.p, n0, dl.p, pairs ? nullptr : dr.p, s);
+        // whatever fails between here and the wait, the slots are drained before the call returns: the key stays usable
+        struct Drain {
+            lurk_hip_msm_ctx* key;
+            bool pairs;
+            int pending = 0;
+            ~Drain() {
+                uint64_t sink[24];
+                if (pending >= 1) (void)(pairs ? lurk_hip_msm_ctx_wait_pair(key, 0, sink, sink + 12) : lurk_hip_msm_ctx_wait(key, 0, sink));
+                if (pending >= 2) (void)lurk_hip_msm_ctx_wait(key, 1, sink);
+            }
+        } drain{key, pairs};
+        if (pairs) {
+            ok(lurk_hip_msm_ctx_submit_pair_dev(key, 0, dl.p, n0, 1, (void*)s, log_h));  // bit log2(m / 2) of the index set: L's support
+            drain.pending = 1;
+        } else {
+            ok(lurk_hip_msm_ctx_submit_dev_mode(key, 0, dl.p, n0, 1, (void*)s, LURK_MSM_SUBMIT_FOREGROUND));
+            drain.pending = 1;
+            ok(lurk_hip_msm_ctx_submit_dev_mode(key, 1, dr.p, n0, 1, (void*)s, LURK_MSM_SUBMIT_FOREGROUND));
+            drain.pending = 2;
+        }
+        unsigned blocks = div_up(h, IPA_BLOCK);
+        if (blocks > max_blocks) blocks = max_blocks;
+        hipLaunchKernelGGL((cross_products_kernel<F>), dim3(blocks), dim3(IPA_BLOCK), 0, s, (const Fe<F>*)d_a, (const Fe<F>*)d_b, h, (Fe<F>*)partial.p);
+        LURK_HIP_CHECK(hipGetLastError());
+        LURK_HIP_CHECK(hipMemcpyAsync(host_partial, partial.p, (size_t)2 * blocks * 32, hipMemcpyDeviceToHost, s));
+        LURK_HIP_CHECK(hipStreamSynchronize(s));
+        Fe<F> cl = fe_zero<F>(), cr = fe_zero<F>();
+        for (unsigned b = 0; b < blocks; b++) {
+            Fe<F> x, y;
+            memcpy(x.l, host_partial + (size_t)(2 * b) * 4, 32);
+            memcpy(y.l, host_partial + (size_t)(2 * b + 1) * 4, 32);
+            cl = fe_add<F>(cl, x);
+            cr = fe_add<F>(cr, y);
+        }
+        uint64_t two[24], c_l[12], c_r[12];
+        uint64_t* L = out_l + (size_t)12 * j;
+        uint64_t* R = out_r + (size_t)12 * j;
+        uint64_t tl[12], tr[12];
+        ok(lurk_hip_point_mul(curve, tl, ck_c_jac96, cl.l, 1));  // two 255-bit host scalar multiples, under the commitment
+        ok(lurk_hip_point_mul(curve, tr, ck_c_jac96, cr.l, 1));
+        if (pairs) {
+            drain.pending = 0;
+            ok(lurk_hip_msm_ctx_wait_pair(key, 0, c_r, c_l));
+        } else {
+            drain.pending = 0;
+            const int rc0 = lurk_hip_msm_ctx_wait(key, 0, c_l), rc1 = lurk_hip_msm_ctx_wait(key, 1, c_r);
+            ok(rc0);
+            ok(rc1);
+        }
+        memcpy(two, c_l, 96);
+        memcpy(two + 12, tl, 96);
+        ok(lurk_hip_point_sum(curve, L, two, 2));
+        memcpy(two, c_r, 96);
+        memcpy(two + 12, tr, 96);
+        ok(lurk_hip_point_sum(curve, R, two, 2));
+        uint64_t r_can[4] = {0, 0, 0, 0};
+        LURK_REQUIRE(challenge(user, j, L, R, r_can) == 0, "the transcript callback failed");
+        Fe<F> r;
+        memcpy(r.l, r_can, 32);
+        LURK_REQUIRE(!fe_canonical_ge_mod<F>(r.l), "the challenge is not reduced modulo the group order");
+        r = fe_to_mont<F>(r);
+        LURK_REQUIRE(!fe_is_zero<F>(r), "zero challenge");
+        const Fe<F> ri = fe_inv<F>(r);
+        fold_halves<F>(d_a, m, r.l, ri.l, s);
+        fold_halves<F>(d_b, m, ri.l, r.l, s);
+        ipa_coef_fold<F>(coef.p, n0, m, ri.l, r.l, s);
+        m = h;
+        j++;
+    }
+    // the final key element is the commitment of the coefficient vector (the verifier's s vector)
+    uint64_t ck_hat[12];
+    ok(lurk_hip_msm_ctx_run_dev(key, ck_hat, coef.p, n0, 1, (void*)s));
+    Jacobian<P> jp;
+    memcpy(&jp, ck_hat, 96);
+    const Affine<P> aff = xyzz_to_affine<P>(xyzz_from_jacobian<P>(jp));  // Montgomery coordinates, (0, 0) for the identity
+    memcpy(out_ck_hat64, &aff, 64);
+    Fe<F> a0;
+    LURK_HIP_CHECK(hipMemcpyAsync(a0.l, d_a, 32, hipMemcpyDeviceToHost, s));
+    LURK_HIP_CHECK(hipStreamSynchronize(s));
+    a0 = fe_from_mont<F>(a0);
+    memcpy(out_a_hat32, a0.l, 32);
+}
+
 }  // namespace lurk
 
 using namespace lurk;
@@ -230,6 +406,26 @@ int lurk_hip_ipa_coef_fold_dev(int field_id, void* d_coef, size_t n, size_t m, c
         if (field_id == 0) ipa_coef_fold<PallasFp>(d_coef, n, m, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
         else if (field_id == 1) ipa_coef_fold<PallasFq>(d_coef, n, m, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
         else ipa_coef_fold<Bn254Fr>(d_coef, n, m, s_lo32_mont, s_hi32_mont, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_ipa_prove_dev(lurk_hip_msm_ctx* key, void* d_a, void* d_b, size_t n, const void* ck_c_jacobian96, lurk_hip_ipa_challenge_fn challenge,
+                           void* user, void* out_l_jacobian96, void* out_r_jacobian96, void* out_a_hat32, void* out_ck_hat_affine64, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(key && d_a && d_b && ck_c_jacobian96 && challenge && out_a_hat32 && out_ck_hat_affine64, "null argument");
+        LURK_REQUIRE(n >= 1 && (n & (n - 1)) == 0, "the vector length must be a power of two");
+        LURK_REQUIRE(n == 1 || (out_l_jacobian96 && out_r_jacobian96), "null argument");
+        int curve = 0, bits = 0, table = 0, device = 0;
+        size_t points = 0;
+        if (lurk_hip_msm_ctx_info(key, &curve, &points, &bits, &table) != 0 || lurk_hip_msm_ctx_device(key, &device) != 0)
+            throw HipFailure{LURK_HIP_ERR_INVALID_ARG, lurk_hip_last_error()};
+        DeviceGuard dg(device);
+        if (curve == LURK_CURVE_PALLAS)
+            ipa_prove_resident<PallasFp, PallasFq>(key, curve, LURK_FIELD_PALLAS_FQ, d_a, d_b, n, ck_c_jacobian96, challenge, user, (uint64_t*)out_l_jacobian96,
+                                                   (uint64_t*)out_r_jacobian96, out_a_hat32, out_ck_hat_affine64, (hipStream_t)stream);
+        else
+            ipa_prove_resident<PallasFq, PallasFp>(key, curve, LURK_FIELD_PALLAS_FP, d_a, d_b, n, ck_c_jacobian96, challenge, user, (uint64_t*)out_l_jacobian96,
+                                                   (uint64_t*)out_r_jacobian96, out_a_hat32, out_ck_hat_affine64, (hipStream_t)stream);
     });
 }
 

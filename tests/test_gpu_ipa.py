@@ -102,3 +102,68 @@ def test_fold_kernels_edge_cases(hip):
             want = R.ec_add(cn, R.ec_mul(cn, lo, half[i]) if half[i] else None, R.ec_mul(cn, hi, half[4 + i]) if half[4 + i] else None)
             g = tuple(C.limbs_to_ints(C.from_mont(bf, got[i].reshape(2, 4))))
             assert (None if g == (0, 0) else g) == want, (lo, hi, i)
+
+
+def test_library_round_loop_contract(hip):
+    """lurk_hip_ipa_prove_dev (the round loop as host code of the library): a one-element argument has no rounds, an exception of the
+    transcript callback aborts the call and comes back as itself, a challenge that is not reduced below the group order or is zero is
+    refused, and so are a length that is no power of two and a key shorter than the vectors."""
+    import ctypes
+
+    import torch
+
+    from lurk_beta_amd import CommitmentKey, LurkHipError, _lib, ipa
+
+    lib = _lib.load()
+    c, cn, sf, bf = 0, "pallas", 1, 0
+    q = R.CURVES[cn]["order"]
+    B = C.synth_bases(c, 9)
+    key = CommitmentKey(c, B[:8], precompute=False)
+    ck_c_jac = np.concatenate([B[8], C.to_mont(bf, C.ints_to_limbs([1])).reshape(4)])
+    a = C.limbs_to_ints(C.synth_scalars(sf, 180, 1, 8))
+    b = C.limbs_to_ints(C.synth_scalars(sf, 181, 0, 8))
+    vec = lambda v: _dev(C.to_mont(sf, C.ints_to_limbs(v)))
+    # n = 1: no rounds, a_hat = a[0], the key element = ck[0]
+    L, Rr, a_hat, ck_hat = ipa.prove(c, q, None, ck_c_jac, vec(a[:1]), vec(b[:1]), 5, lambda j, l, r: 1 / 0, key=key)
+    assert L == [] and Rr == [] and a_hat == a[0]
+    assert tuple(C.limbs_to_ints(C.from_mont(bf, ck_hat.reshape(2, 4)))) == tuple(C.limbs_to_ints(C.from_mont(bf, B[0].reshape(2, 4))))
+
+    class Boom(Exception):
+        pass
+
+    def bad(j, l, r):
+        raise Boom("transcript")
+
+    with pytest.raises(Boom):
+        ipa.prove(c, q, None, ck_c_jac, vec(a), vec(b), 5, bad, key=key)
+    # the slot the aborted call had submitted on must be usable again
+    want = R.ipa_prove(cn, [tuple(C.limbs_to_ints(C.from_mont(bf, B[i].reshape(2, 4)))) for i in range(8)],
+                       tuple(C.limbs_to_ints(C.from_mont(bf, B[8].reshape(2, 4)))), a, b, 5, [3, 4, 6])
+    got = ipa.prove(c, q, None, ck_c_jac, vec(a), vec(b), 5, lambda j, l, r: [3, 4, 6][j], key=key)
+    assert [_aff(c, x) for x in got[0]] == want[0] and got[2] == want[2]
+
+    # raw C ABI: unreduced and zero challenges, bad lengths
+    out = [np.zeros((3, 12), dtype=np.uint64), np.zeros((3, 12), dtype=np.uint64), np.zeros(4, dtype=np.uint64), np.zeros(8, dtype=np.uint64)]
+
+    def call(n, r_value, d_a=None, d_b=None):
+        def cb(_u, j, l, r, o):
+            ctypes.memmove(o, int(r_value).to_bytes(32, "little"), 32)
+            return 0
+
+        fn = _lib.IPA_CHALLENGE_FN(cb)
+        from lurk_beta_amd.step import point_mul
+
+        ck_c = point_mul(c, ck_c_jac, C.to_mont(sf, C.ints_to_limbs([5])).reshape(4))
+        return lib.lurk_hip_ipa_prove_dev(key._ctx, _lib.ptr(d_a if d_a is not None else vec(a)), _lib.ptr(d_b if d_b is not None else vec(b)), n,
+                                          _lib.ptr(ck_c), ctypes.cast(fn, ctypes.c_void_p), None, _lib.ptr(out[0]), _lib.ptr(out[1]), _lib.ptr(out[2]),
+                                          _lib.ptr(out[3]), None)
+
+    assert call(8, q) != 0 and b"reduced" in lib.lurk_hip_last_error()
+    assert call(8, 0) != 0 and b"zero" in lib.lurk_hip_last_error()
+    assert call(6, 3) != 0 and b"power of two" in lib.lurk_hip_last_error()
+    big = torch.zeros((16, 4), dtype=torch.int64, device="cuda")
+    assert call(16, 3, big, big) != 0 and b"fewer points" in lib.lurk_hip_last_error()
+    assert call(8, 3) == 0
+    with pytest.raises(LurkHipError):
+        _lib.check(call(8, q))
+    key.close()
