@@ -457,12 +457,16 @@ def fold_step_workload(args, lib, world, rank):
     torch.cuda.synchronize()
     for k in phase:
         phase[k] = 0.0
+    import gc
+    gc.collect()  # (as timeit does: no cyclic-garbage collection inside the timed region)
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     # (the folds are ordered on the context's own stream; torch.cuda.synchronize() is device-wide)
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     lib.lurk_hip_profile_enable(0)
     if args.stage_ahead:  # drain the instance staged by the last timed step (one was staged before the region: K stagings inside it)
         ctx.begin_prefetched(x2, patches)
