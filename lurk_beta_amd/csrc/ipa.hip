@@ -241,7 +241,7 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
     LURK_REQUIRE(kc == curve, "the key is over another curve");
     LURK_REQUIRE(kn >= n0, "the key has fewer points than the vectors have elements");
     const bool pairs = ktable && kbits >= 16;  // the window-table form commits L and R (disjoint supports) in one pass
-    // stream-ordered scratch (the pool keeps it between calls: a proof opens several of these arguments) and one pinned block per thread
+    // stream-ordered scratch (the pool keeps it between calls: a proof opens several of these arguments)
     struct Scratch {
         hipStream_t s;
         void* p = nullptr;
@@ -256,20 +256,8 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
         hipLaunchKernelGGL((fill_kernel<F>), dim3(blocks), dim3(IPA_BLOCK), 0, s, (Fe<F>*)coef.p, n0, fe_one<F>());
         LURK_HIP_CHECK(hipGetLastError());
     }
-    struct Pinned {
-        uint64_t* p = nullptr;
-        size_t cap = 0;
-        ~Pinned() { if (p) (void)hipHostFree(p); }
-    };
-    static thread_local Pinned pinned;
-    if (pinned.cap < (size_t)2 * max_blocks * 32) {
-        if (pinned.p) (void)hipHostFree(pinned.p);
-        pinned.p = nullptr;
-        pinned.cap = 0;
-        LURK_HIP_CHECK(hipHostMalloc((void**)&pinned.p, (size_t)2 * max_blocks * 32));
-        pinned.cap = (size_t)2 * max_blocks * 32;
-    }
-    uint64_t* host_partial = pinned.p;
+    std::vector<uint64_t> host_partial_buf((size_t)2 * max_blocks * 4);  // <= 128 KiB per round: a pageable copy is a few microseconds more
+    uint64_t* host_partial = host_partial_buf.data();
     size_t m = n0;
     int j = 0;
     while (m > 1) {
