@@ -21,6 +21,8 @@ rm -rf gpurun_out/prof_${TAG}_msm_n22 gpurun_out/prof_${TAG}_msm_n20
   python bench.py --log-n 22 --precompute 0 --pipeline 1 --steps 10 --warmup 3 --no-cpu-baseline --pmc off --no-plain-leg
   python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --verify
   python bench.py --workload fold_step --rc 900 --steps 10 --warmup 3 --verify --no-cpu-baseline
+  python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --stage-ahead 1 --late-ranges 0 --verify --no-cpu-baseline --secondary 0
+  python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --stage-ahead 1 --late-ranges 1 --verify --no-cpu-baseline --secondary 0
   python bench.py --workload compress --steps 5 --warmup 2 --verify
   python bench.py --workload poseidon_tree --steps 5 --warmup 2
   python bench.py --workload ntt --log-n 24 --steps 10 --warmup 3
@@ -30,4 +32,7 @@ python bench_tools/small_commit_probe.py 200 > $E/small_commit_probe.jsonl 2>> $
 # 4. store hydration: per-level kernel times (the level time is the Poseidon hash's dependency chain)
 ( cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}" && rocprofv3 --kernel-trace --stats --output-format csv -d $E/prof_hydrate -- python -m pytest tests/test_gpu_poseidon.py -q -k "hydrat" > $E/hydrate.log 2>&1 )
 cp $(ls $E/prof_hydrate/*/*_kernel_stats.csv | head -1) $E/profiles/${TAG}_store_hydrate_kernel_stats.csv 2>/dev/null; rm -rf $E/prof_hydrate
+# 5. the folding step's kernel timeline (hardware queue and stream per kernel; two consecutive primary-curve steps)
+bash bench_tools/trace_step.sh > $E/trace_step.log 2>&1
+cp gpurun_out/trace_step/timeline.txt $E/profiles/${TAG}_step_timeline_rc100.txt 2>/dev/null
 tail -c 600 $E/bench_default.json; echo; wc -l $E/sweep.jsonl
