@@ -285,3 +285,16 @@ extern "C" void hh_f29_reduce(int field, const uint32_t* in, uint32_t* out, size
         else { F29<PallasFq> v; for (int k = 0; k < 9; k++) v.l[k] = in[9 * i + k]; v = f29_reduce<PallasFq>(v); for (int k = 0; k < 9; k++) out[9 * i + k] = v.l[k]; }
     }
 }
+
+#include "../../lurk_beta_amd/csrc/msm_core.cuh"
+// signed c-bit digits of a canonical scalar two ways: the indexed recoding (msm_digit_step) and the register walk the sort kernels
+// and the small path use (msm_digit_next); out: W digits each, |d| | sign << 31
+extern "C" void hh_msm_digits(const uint32_t* scalar8, int c, uint32_t* by_step, uint32_t* by_walk) {
+    const int W = msm_num_windows(c);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) by_step[w] = msm_digit_step(scalar8, w, c, carry);
+    uint32_t r[8];
+    for (int k = 0; k < 8; k++) r[k] = scalar8[k];
+    carry = 0;
+    for (int w = 0; w < W; w++) by_walk[w] = msm_digit_next(r, c, carry);
+}

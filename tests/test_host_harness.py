@@ -260,3 +260,24 @@ def test_radix29_reduction_tree_with_bound_assertions(cn, c):
     L.hh_curve_tree(c, vp(B7), vp(s7), ctypes.c_size_t(n7), 64, vp(o29))
     L.hh_curve_sum(c, 0, vp(B7), vp(s7), ctypes.c_size_t(n7), vp(o32))
     assert np.array_equal(o29, o32)
+
+
+@pytest.mark.parametrize("c", [6, 8, 13, 16, 17, 18, 20])
+def test_signed_digits_register_walk_equals_indexed_recoding(c):
+    """msm_digit_next (the walk the sort kernels and the small-commitment kernel use: no limb is indexed by a run-time value) against
+    msm_digit_step, and both against the definition: sum_w d_w 2^(c w) = k with |d_w| <= 2^(c-1)."""
+    W = (256 + c - 1) // c
+    q = R.CURVES["pallas"]["order"]
+    ks = [0, 1, q - 1, (1 << 254) - 1, 1 << (c - 1), (1 << (c - 1)) + 1, (1 << c) - 1, int("55" * 32, 16) % q, int("aa" * 31, 16)]
+    ks += [R.uniform_fe(900 + c, i, q) for i in range(40)]
+    for k in ks:
+        s = np.array([(k >> (32 * i)) & 0xFFFFFFFF for i in range(8)], dtype=np.uint32)
+        a, b = np.zeros(W, dtype=np.uint32), np.zeros(W, dtype=np.uint32)
+        H.lib().hh_msm_digits(vp(s), c, vp(a), vp(b))
+        assert (a == b).all(), (c, hex(k))
+        total = 0
+        for w in range(W):
+            mag, neg = int(a[w]) & 0x7FFFFFFF, int(a[w]) >> 31
+            assert mag <= 1 << (c - 1)
+            total += (-mag if neg else mag) << (c * w)
+        assert total == k, (c, hex(k))
