@@ -204,7 +204,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     }
     LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream[b]));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
-    // Order (measured on MI355X at rc = 100, `bench_tools/sweep_step_order.sh` of round 3, ms per step with the next witness traced
+    // Order (measured on MI355X at rc = 100, `profiles/r03_step_order_sweep.txt` and `profiles/r03e_step_experiments.txt`, ms per step with the next witness traced
     // behind begin): cross term first, then commit(W2), then commit(T), all in the FOREGROUND class: 3.88 - against commit(W2) first
     // 3.93; commit(W2) in the BACKGROUND class (persistent one-wave accumulation) 4.11 whichever comes first; commit(T) first and
     // commit(W2)'s accumulation held back until T's sort is through 4.15.  The cross term gathers from HBM while commit(W2) sorts;
