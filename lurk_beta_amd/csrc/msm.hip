@@ -171,9 +171,15 @@ __device__ __forceinline__ uint32_t msm_block_scan(uint32_t v, uint32_t* scr, ui
 }
 
 // single block: part_start[0..P] = exclusive scan of part_cnt
+// (it also zeroes the small counters the later stages start from - the hot-bucket count, the task-length histogram, the persistent
+// kernel's cursor block: three fill launches of ~6 us each in a chain of dependent launches otherwise)
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part_start_kernel(const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ part_start,
-                                                                          int P) {
+                                                                          int P, uint32_t* __restrict__ z0, int n0, uint32_t* __restrict__ z1, int n1,
+                                                                          uint32_t* __restrict__ z2, int n2) {
     msm_set_wave_prio(0);
+    for (int i = threadIdx.x; i < n0; i += MSM_SORT_BLOCK) z0[i] = 0;
+    for (int i = threadIdx.x; i < n1; i += MSM_SORT_BLOCK) z1[i] = 0;
+    for (int i = threadIdx.x; i < n2; i += MSM_SORT_BLOCK) z2[i] = 0;
     __shared__ uint32_t scr[32];
     const int PER = P / MSM_SORT_BLOCK;  // 2, 4 or 8 counters per thread
     const int t = threadIdx.x;
@@ -995,7 +1001,8 @@ struct MsmCtx : MsmCtxBase {
             hipLaunchKernelGGL(msm_scan1_kernel, dim3(sh.P), dim3(MSM_NB1), 0, s, wk.block_hist.template as<uint32_t>(),
                                wk.part_cnt.template as<uint32_t>(), sh.P);
             hipLaunchKernelGGL(msm_part_start_kernel, dim3(1), dim3(MSM_SORT_BLOCK), 0, s, wk.part_cnt.template as<uint32_t>(),
-                               wk.part_start.template as<uint32_t>(), sh.P);
+                               wk.part_start.template as<uint32_t>(), sh.P, wk.big_count.template as<uint32_t>(), 1,
+                               wk.len_hist.template as<uint32_t>(), 2 * (MSM_S + 1), wk.cursor.template as<uint32_t>(), MSM_PLACEMENT_BASE + 512);
             hipLaunchKernelGGL((msm_scatter1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), msm_scatter1_lds(sh.P, sh.W, sh.tile), s,
                                (const uint4*)d_scalars, wk.block_hist.template as<uint32_t>(), wk.part_start.template as<uint32_t>(),
                                wk.inter.template as<uint2>(), sh, chunk, is_mont);
@@ -1005,8 +1012,6 @@ struct MsmCtx : MsmCtxBase {
         }
         {
             ProfScope ps("msm_tasks", s);
-            LURK_HIP_CHECK(hipMemsetAsync(wk.big_count.p, 0, 4, s));
-            LURK_HIP_CHECK(hipMemsetAsync(wk.len_hist.p, 0, 2 * (MSM_S + 1) * 4, s));
             uint32_t* lh = wk.len_hist.template as<uint32_t>();
             hipLaunchKernelGGL(msm_taskscan_kernel, dim3(sh.NG), dim3(1024), 0, s, wk.cnt.template as<uint32_t>(),
                                wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>());
@@ -1028,8 +1033,7 @@ struct MsmCtx : MsmCtxBase {
         const bool persistent = s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 22) : tn.persistent != 0));
         if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));  // sort and plan are enqueued: a background commitment may start behind this point
         if (persistent) {
-            LURK_HIP_CHECK(hipMemsetAsync(wk.cursor.p, 0, 4 * (MSM_PLACEMENT_BASE + 512), s));
-            wk.placement_valid = true;
+            wk.placement_valid = true;  // (the cursor block was zeroed by msm_part_start_kernel)
             LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
             LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, wk.planned, 0));
             if (tn.max_acc >= 1) {
