@@ -40,25 +40,33 @@ def gather_factor():
 
 def launch_classes(trace_csv, needle):
     """per kernel NAME containing `needle` (the plain and the persistent accumulation are different kernels): warm-up / solo / overlapped,
-    where `overlapped` = another full-size launch of ANY kernel matching `needle` runs during it"""
+    where `overlapped` = another full-size launch of ANY kernel matching `needle` runs during it.  A bench run launches the same kernel on
+    different work (the table key's 13 n entries, the plain key's 16 n of the `plain_sync` leg): the solo class is also listed per grid
+    size, and the table-key launches are the largest group of equal grids."""
     rows = []
     with open(trace_csv) as f:
         for r in csv.DictReader(f):
             if needle in r["Kernel_Name"]:
-                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
+                grid = r.get("Grid_Size_X") or r.get("Grid_Size") or "?"
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), str(grid)))
     if not rows:
         return None
     rows.sort()
     out = {"kernels": {}}
-    names = sorted(set(n for _, _, n in rows))
+    names = sorted(set(n for _, _, n, _ in rows))
     big = {}
     for nm in names:
-        dur = sorted(e - s for s, e, n in rows if n == nm)
+        dur = sorted(e - s for s, e, n, _ in rows if n == nm)
         big[nm] = statistics.median(dur[len(dur) // 2:])  # median of the upper half: a typical full launch of this kernel
-    full = [(s, e, n) for s, e, n in rows if e - s >= 0.1 * big[n]]
+    full = [(s, e, n) for s, e, n, _ in rows if e - s >= 0.1 * big[n]]
+
+    def stat(v):
+        return {"count": len(v), "mean_us": round(sum(v) / len(v) / 1e3, 2), "min_us": round(min(v) / 1e3, 2), "max_us": round(max(v) / 1e3, 2)}
+
     for nm in names:
         classes = collections.defaultdict(list)
-        for s, e, n in rows:
+        by_grid = collections.defaultdict(list)
+        for s, e, n, g in rows:
             if n != nm:
                 continue
             if e - s < 0.1 * big[nm]:
@@ -66,9 +74,13 @@ def launch_classes(trace_csv, needle):
                 continue
             overl = any((s2, e2, n2) != (s, e, n) and s2 < e and e2 > s for s2, e2, n2 in full)
             classes["overlapped" if overl else "solo"].append(e - s)
+            if not overl:
+                by_grid[g].append(e - s)
         ent = {"launches": sum(len(v) for v in classes.values())}
         for k, v in classes.items():
-            ent[k] = {"count": len(v), "mean_us": round(sum(v) / len(v) / 1e3, 2), "min_us": round(min(v) / 1e3, 2), "max_us": round(max(v) / 1e3, 2)}
+            ent[k] = stat(v)
+        if len(by_grid) > 1:
+            ent["solo_by_grid_size"] = {g: stat(v) for g, v in sorted(by_grid.items(), key=lambda kv: -len(kv[1]))}
         out["kernels"][nm] = ent
     return out
 
