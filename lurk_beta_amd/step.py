@@ -19,7 +19,6 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .msm import point_sum
 
 
 def public_io(z_ptrs) -> list[int]:
