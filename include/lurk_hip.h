@@ -410,6 +410,16 @@ int lurk_hip_nifs_challenge(int curve, const void* pp_digest32, const void* comm
 int lurk_hip_sumcheck_round_dev(int field_id, int degree, void* const* d_polys, size_t len, const void* bind_r32_mont,
                                 void* evals_out, void* stream);
 /* EqPolynomial::evals: d_out[b] = prod_j (b_j ? r_j : 1 - r_j), r_0 <-> the most significant bit of b; r: ell x 32 B Montgomery, host */
+/* A whole sum-check (SumcheckProof::prove_quad / prove_cubic_with_additive_term of arecibo's Spartan, behind
+ * /root/reference/src/proof/nova.rs:341-356) with the tables resident: log2(len) rounds of lurk_hip_sumcheck_round_dev, the round
+ * polynomial interpolated on the host, the transcript behind a callback: `challenge` receives the round and the polynomial's
+ * degree + 1 canonical coefficients (low to high) and writes r as a canonical 32-byte value (return 0; anything else aborts the call).
+ * The tables are consumed (bound in place).  Outputs, all canonical: the round polynomials (rounds x (degree + 1) x 32 bytes), the
+ * tables' final evaluations (2 or 4 x 32 bytes) and the final claim. */
+typedef int (*lurk_hip_sumcheck_challenge_fn)(void* user, int round, const void* coefficients32_canonical, void* out_r32_canonical);
+int lurk_hip_sumcheck_prove_dev(int field_id, int degree, void* const* d_polys, size_t len, const void* claim32_canonical,
+                                lurk_hip_sumcheck_challenge_fn challenge, void* user, void* out_polys, void* out_finals,
+                                void* out_claim32, void* stream);
 int lurk_hip_eq_evals_dev(int field_id, const void* r32_mont, int ell, void* d_out, void* stream);
 
 /* ---- inner-product argument rounds (the opening half of CompressedSNARK::prove) ------------------

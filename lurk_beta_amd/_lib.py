@@ -118,6 +118,7 @@ SIGNATURES = {
     "lurk_hip_ipa_round_scalars_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_ipa_coef_fold_dev": (c_int, [c_int, c_void_p, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_points_fold_halves_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_sumcheck_prove_dev": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_ipa_prove_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
@@ -168,3 +169,5 @@ def ptr(x) -> c_void_p:
 
 # lurk_hip_ipa_challenge_fn: int (*)(void* user, int round, const void* L96, const void* R96, void* out_r32_canonical)
 IPA_CHALLENGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+# lurk_hip_sumcheck_challenge_fn: int (*)(void* user, int round, const void* coefficients, void* out_r32_canonical)
+SUMCHECK_CHALLENGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)

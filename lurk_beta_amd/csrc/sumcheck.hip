@@ -166,6 +166,72 @@ static void sumcheck_round(int np, void* const* d_polys, size_t len, const void*
     }
 }
 
+
+// ---- a whole sum-check as host code of the library (arecibo SumcheckProof::prove_quad / prove_cubic_with_additive_term behind
+// /root/reference/src/proof/nova.rs:341-356): the round loop of lurk_beta_amd/sumcheck.py: prove - one launch per round, the round
+// polynomial interpolated from its evaluations at 0, 2 (, 3) and the running claim, the transcript's challenge from a callback.
+template <class F>
+static void sumcheck_prove(int np, void* const* d_polys, size_t n, const void* claim32_canonical, lurk_hip_sumcheck_challenge_fn challenge, void* user,
+                           uint64_t* out_polys, uint64_t* out_finals, void* out_claim32, hipStream_t s) {
+    const bool cubic = np == 4;
+    const int nv = cubic ? 3 : 2, ncoef = cubic ? 4 : 3;
+    const Fe<F> two = fe_from_u64<F>(2), three = fe_from_u64<F>(3), inv2 = fe_inv<F>(two), inv6 = fe_inv<F>(fe_from_u64<F>(6));
+    Fe<F> claim;
+    memcpy(claim.l, claim32_canonical, 32);
+    LURK_REQUIRE(!fe_canonical_ge_mod<F>(claim.l), "the claim is not reduced modulo the field order");
+    claim = fe_to_mont<F>(claim);
+    size_t length = n;
+    Fe<F> r = fe_zero<F>();
+    bool have_r = false;
+    int j = 0;
+    for (size_t m = n; m > 1; m /= 2, j++) {
+        Fe<F> ev[3];
+        sumcheck_round<F>(np, d_polys, length, have_r ? (const void*)r.l : nullptr, ev, s);  // Montgomery images of the evaluations at 0, 2 (, 3)
+        if (have_r) length /= 2;
+        const Fe<F> e0 = ev[0], e2 = ev[1], e1 = fe_sub<F>(claim, e0);
+        Fe<F> poly[4];
+        const Fe<F> second = fe_add<F>(fe_sub<F>(e2, fe_mul<F>(two, e1)), e0);  // e2 - 2 e1 + e0
+        if (cubic) {
+            const Fe<F> e3 = ev[2];
+            const Fe<F> a3 = fe_mul<F>(fe_sub<F>(fe_add<F>(fe_sub<F>(e3, fe_mul<F>(three, e2)), fe_mul<F>(three, e1)), e0), inv6);
+            const Fe<F> b = fe_sub<F>(fe_mul<F>(second, inv2), fe_mul<F>(three, a3));
+            poly[0] = e0;
+            poly[1] = fe_sub<F>(fe_sub<F>(fe_sub<F>(e1, e0), a3), b);
+            poly[2] = b;
+            poly[3] = a3;
+        } else {
+            const Fe<F> a2 = fe_mul<F>(second, inv2);
+            poly[0] = e0;
+            poly[1] = fe_sub<F>(fe_sub<F>(e1, e0), a2);
+            poly[2] = a2;
+        }
+        uint64_t* out = out_polys + (size_t)j * ncoef * 4;
+        for (int k = 0; k < ncoef; k++) {
+            const Fe<F> c = fe_from_mont<F>(poly[k]);
+            memcpy(out + 4 * k, c.l, 32);
+        }
+        uint64_t r_can[4] = {0, 0, 0, 0};
+        LURK_REQUIRE(challenge(user, j, out, r_can) == 0, "the transcript callback failed");
+        memcpy(r.l, r_can, 32);
+        LURK_REQUIRE(!fe_canonical_ge_mod<F>(r.l), "the challenge is not reduced modulo the field order");
+        r = fe_to_mont<F>(r);
+        have_r = true;
+        Fe<F> acc = fe_zero<F>();
+        for (int k = ncoef - 1; k >= 0; k--) acc = fe_add<F>(fe_mul<F>(acc, r), poly[k]);
+        claim = acc;
+    }
+    if (have_r) sumcheck_round<F>(np, d_polys, length, r.l, nullptr, s);  // the last bind: every table is down to one element
+    for (int k = 0; k < np; k++) {
+        Fe<F> v;
+        LURK_HIP_CHECK(hipMemcpyAsync(v.l, d_polys[k], 32, hipMemcpyDeviceToHost, s));
+        LURK_HIP_CHECK(hipStreamSynchronize(s));
+        v = fe_from_mont<F>(v);
+        memcpy(out_finals + 4 * k, v.l, 32);
+    }
+    claim = fe_from_mont<F>(claim);
+    memcpy(out_claim32, claim.l, 32);
+}
+
 }  // namespace lurk
 
 using namespace lurk;
@@ -185,6 +251,21 @@ int lurk_hip_sumcheck_round_dev(int field_id, int degree, void* const* d_polys, 
         if (field_id == 0) sumcheck_round<PallasFp>(np, d_polys, len, bind_r32_mont, evals_out, (hipStream_t)stream);
         else if (field_id == 1) sumcheck_round<PallasFq>(np, d_polys, len, bind_r32_mont, evals_out, (hipStream_t)stream);
         else sumcheck_round<Bn254Fr>(np, d_polys, len, bind_r32_mont, evals_out, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_sumcheck_prove_dev(int field_id, int degree, void* const* d_polys, size_t len, const void* claim32_canonical,
+                                lurk_hip_sumcheck_challenge_fn challenge, void* user, void* out_polys, void* out_finals, void* out_claim32, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(degree == 2 || degree == 3, "degree must be 2 (a b) or 3 (a (b c - d))");
+        LURK_REQUIRE(d_polys && claim32_canonical && challenge && out_polys && out_finals && out_claim32, "null argument");
+        LURK_REQUIRE(len >= 2 && (len & (len - 1)) == 0, "table length must be a power of two >= 2");
+        const int np = degree == 3 ? 4 : 2;
+        for (int k = 0; k < np; k++) LURK_REQUIRE(d_polys[k], "null table");
+        if (field_id == 0) sumcheck_prove<PallasFp>(np, d_polys, len, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
+        else if (field_id == 1) sumcheck_prove<PallasFq>(np, d_polys, len, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
+        else sumcheck_prove<Bn254Fr>(np, d_polys, len, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
     });
 }
 

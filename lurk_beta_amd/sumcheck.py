@@ -37,59 +37,42 @@ def eq_evals(field_id: int, r_mont: np.ndarray, stream=None):
 
 def prove(field_id: int, modulus: int, claim: int, tables, challenge, stream=None):
     """tables: 4 device tensors (A, B, C, D: comb = A (B C - D)) or 2 (A, B: comb = A B), Montgomery, length 2^k; they are
-    consumed (bound in place).  challenge(round, poly_coeffs) -> r (int).  All integers here are canonical; the Montgomery
-    factor R = 2^256 is stripped from / applied to what crosses the library boundary.
+    consumed (bound in place).  challenge(round, poly_coeffs) -> r (int); all integers here are canonical.  The round loop is host
+    code of the library (lurk_hip_sumcheck_prove_dev: what a Rust caller binds), the transcript calls back into ``challenge``.
     Returns (round polynomials, final evaluations P_k(r), final claim) like the oracle's sumcheck_prove."""
     import torch
 
     lib = _lib.load()
     p = modulus
-    R = (1 << 256) % p
-    Rinv = pow(R, p - 2, p)
     cubic = len(tables) == 4
     assert len(tables) in (2, 4)
     n = tables[0].shape[0]
     assert all(t.is_cuda and t.shape[0] == n for t in tables) and n >= 2 and n & (n - 1) == 0
     s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
     ptrs = (ctypes.c_void_p * len(tables))(*[_lib.ptr(t) for t in tables])
-    nv = 3 if cubic else 2
-    inv2, inv6 = pow(2, p - 2, p), pow(6, p - 2, p)
-    polys, r_prev, length = [], None, n
-    rounds = n.bit_length() - 1
-    for j in range(rounds):
-        ev = np.zeros((nv, 4), dtype=np.uint64)
-        if r_prev is None:
-            _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 3 if cubic else 2, ptrs, length, None, _lib.ptr(ev), _lib.ptr(s)))
-        else:
-            rm = _limbs([r_prev * R % p])
-            _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 3 if cubic else 2, ptrs, length, _lib.ptr(rm), _lib.ptr(ev), _lib.ptr(s)))
-            length //= 2
-        # comb multiplies 2 (quadratic) or 3 (cubic: a * b * c, and a * d) Montgomery factors; the library's products divide by R
-        # once each, so a sum of a*b carries R^1 like any Montgomery value: strip one R
-        e = [x * Rinv % p for x in _ints(ev)]
-        e0, e2 = e[0], e[1]
-        e1 = (claim - e0) % p
-        if cubic:
-            e3 = e[2]
-            d = e0
-            a3 = (e3 - 3 * e2 + 3 * e1 - e0) * inv6 % p
-            b = ((e2 - 2 * e1 + e0) * inv2 - 3 * a3) % p
-            c = (e1 - d - a3 - b) % p
-            poly = [d, c, b, a3]
-        else:
-            a2 = (e2 - 2 * e1 + e0) * inv2 % p
-            poly = [e0, (e1 - e0 - a2) % p, a2]
-        polys.append(poly)
-        r_prev = int(challenge(j, poly)) % p
-        acc = 0
-        for co in reversed(poly):
-            acc = (acc * r_prev + co) % p
-        claim = acc
-    rm = _limbs([r_prev * R % p])
-    _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 3 if cubic else 2, ptrs, length, _lib.ptr(rm), None, _lib.ptr(s)))
-    torch.cuda.synchronize()
-    finals = [_ints(t[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p for t in tables]
-    return polys, finals, claim
+    rounds, ncoef = n.bit_length() - 1, 4 if cubic else 3
+    out_polys = np.zeros((rounds, ncoef, 4), dtype=np.uint64)
+    out_finals = np.zeros((len(tables), 4), dtype=np.uint64)
+    out_claim = np.zeros(4, dtype=np.uint64)
+    failure = []
+
+    def on_round(_user, j, coef_ptr, out_ptr):
+        try:
+            co = np.ctypeslib.as_array(ctypes.cast(coef_ptr, ctypes.POINTER(ctypes.c_uint64)), shape=(ncoef * 4,)).copy()
+            r = int(challenge(j, _ints(co))) % p
+            ctypes.memmove(out_ptr, r.to_bytes(32, "little"), 32)
+            return 0
+        except BaseException as e:  # noqa: BLE001 - an exception must not unwind through the C frames
+            failure.append(e)
+            return 1
+
+    cb = _lib.SUMCHECK_CHALLENGE_FN(on_round)
+    rc = lib.lurk_hip_sumcheck_prove_dev(field_id, 3 if cubic else 2, ptrs, n, _lib.ptr(_limbs([claim % p])), ctypes.cast(cb, ctypes.c_void_p), None,
+                                         _lib.ptr(out_polys), _lib.ptr(out_finals), _lib.ptr(out_claim), _lib.ptr(s))
+    if failure:
+        raise failure[0]
+    _lib.check(rc)
+    return [_ints(out_polys[j]) for j in range(rounds)], _ints(out_finals), _ints(out_claim)[0]
 
 
 def prove_quad_batch(field_id: int, modulus: int, claims, pairs, coeffs, challenge, stream=None):

@@ -99,3 +99,45 @@ def test_bad_arguments(hip):
         _lib.check(_lib.load().lurk_hip_sumcheck_round_dev(1, 2, ptrs, 6, None, _lib.ptr(ev), None))  # not a power of two
     with pytest.raises(LurkHipError):
         _lib.check(_lib.load().lurk_hip_sumcheck_round_dev(1, 5, ptrs, 4, None, _lib.ptr(ev), None))  # unknown degree
+
+
+def test_library_round_loop_contract(hip):
+    """lurk_hip_sumcheck_prove_dev: an exception of the transcript callback aborts the call and comes back as itself; a challenge or a
+    claim that is not reduced below the field order is refused; so is a table length that is no power of two."""
+    import ctypes
+
+    from lurk_beta_amd import _lib
+    from lurk_beta_amd import sumcheck as S
+
+    lib = _lib.load()
+    f = 1
+    p = R.modulus(f)
+    tabs = lambda: [_dev(C.to_mont(f, C.synth_scalars(f, 150 + k, 0, 8))) for k in range(2)]
+
+    class Boom(Exception):
+        pass
+
+    def bad(j, poly):
+        raise Boom("transcript")
+
+    with pytest.raises(Boom):
+        S.prove(f, p, 5, tabs(), bad)
+
+    def call(n, r_value, claim=5):
+        t = tabs()
+        ptrs = (ctypes.c_void_p * 2)(*[_lib.ptr(x) for x in t])
+
+        def cb(_u, j, co, o):
+            ctypes.memmove(o, int(r_value).to_bytes(32, "little"), 32)
+            return 0
+
+        fn = _lib.SUMCHECK_CHALLENGE_FN(cb)
+        out = [np.zeros((3, 3, 4), dtype=np.uint64), np.zeros((2, 4), dtype=np.uint64), np.zeros(4, dtype=np.uint64)]
+        claim_l = np.array([(claim >> (64 * w)) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
+        return lib.lurk_hip_sumcheck_prove_dev(f, 2, ptrs, n, _lib.ptr(claim_l), ctypes.cast(fn, ctypes.c_void_p), None, _lib.ptr(out[0]), _lib.ptr(out[1]),
+                                               _lib.ptr(out[2]), None)
+
+    assert call(8, p) != 0 and b"challenge is not reduced" in lib.lurk_hip_last_error()
+    assert call(8, 3, claim=p) != 0 and b"claim is not reduced" in lib.lurk_hip_last_error()
+    assert call(6, 3) != 0 and b"power of two" in lib.lurk_hip_last_error()
+    assert call(8, 3) == 0
