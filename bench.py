@@ -71,6 +71,9 @@ def main():
                          "WRITE_SIZE in separate passes) and report the dominant kernel's HBM traffic per launch in roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-plain-leg", action="store_true", help="skip the plain-key synchronous sub-record (plain_sync)")
+    ap.add_argument("--sub-records", choices=["auto", "off"], default="auto",
+                    help="auto = the default msm line at N = 1 also carries the other workloads of the path as verified sub-records "
+                         "(fold_step_rc100, poseidon_tree_2_24, ntt_2_24: each a child run of this file with --verify, same --steps / --warmup)")
     args = ap.parse_args()
 
     # N > 1 without a launcher: become the launcher (one rank per GPU, the same command line the driver uses)
@@ -275,6 +278,13 @@ def main():
             assert out["verified"], "commitment does not match the discrete-log checksum"
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(args, result if args.cpu_sample_log_n >= args.log_n else None)
+        if args.sub_records == "auto" and world == 1:
+            # the metric's own workload (one folding step at rc = 100, both curve halves) and the two other named kernels at their
+            # BASELINE sizes, each verified against the oracle, on the same clock as this line (the key's 3.5 GiB go back first)
+            ck.close()
+            del d_bases, d_scalars
+            torch.cuda.empty_cache()
+            out["sub_records"] = sub_records(args)
         print(json.dumps(out), flush=True)
     ck.close()
     if world > 1:
@@ -812,6 +822,36 @@ def spawn_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def sub_records(args):
+    """The default line's sub-records: child runs of this file (a fresh process each: its own HIP context, nothing shared with the
+    timed region above), each with --verify, so that the driver's one command witnesses the folding step (BASELINE.json's first
+    metric, through its synthetic stand-in), the 2^24 Poseidon tree (configs[2]) and the 2^24 NTT with their parity checks."""
+    import subprocess
+
+    common = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--sub-records", "off", "--pmc", "off", "--verify"]
+    legs = {
+        "fold_step_rc100": ["--workload", "fold_step", "--rc", "100"],
+        "poseidon_tree_2_24": ["--workload", "poseidon_tree", "--log-n", "24"],
+        "ntt_2_24": ["--workload", "ntt", "--log-n", "24"],
+    }
+    if args.no_cpu_baseline:
+        common.append("--no-cpu-baseline")
+    out = {}
+    for name, extra in legs.items():
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + extra + common, capture_output=True, text=True, timeout=240)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+            else:
+                out[name] = json.loads(lines[-1])
+        except Exception as e:  # noqa: BLE001 (a sub-record must never cost the headline line)
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def plain_sync_leg(args, d_bases, d_scalars, n, stream):
     """The same workload through what the literal pasta-msm drop-in does minus PCIe: a plain 64 B/point key (no
     precomputed table, nothing to amortise), one synchronous commitment at a time."""
@@ -1061,14 +1101,34 @@ def other_workloads(args, lib, world, rank):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    verified, cpu_full = None, None
     if args.verify and args.workload == "poseidon_tree" and rank == 0:
+        # the whole tree again on the CPU (oracle/oracle.c, every core): the root must be the same 32 bytes.  2^24 leaves are
+        # 2 396 745 hash8 - tens of seconds of host time, outside the timed region; the same run is the CPU baseline below
         from oracle import coracle as C
 
-        assert n <= 1 << 18, "--verify recomputes the tree on the CPU: use --log-n <= 18"
-        want = [int(x) for x in np.asarray(C.poseidon_tree8(1, C.synth_scalars(1, 2, 0, n))).reshape(-1)[:4]]
+        leaves = C.synth_scalars(1, 2, 0, n)
+        t1 = time.perf_counter()
+        want = [int(x) for x in np.asarray(C.poseidon_tree8(1, leaves)).reshape(-1)[:4]]
+        cpu_full = time.perf_counter() - t1
         got_t = d_levels[-1] if world == 1 else d_root[0]
         got = [int(x) for x in got_t.cpu().numpy().view(np.uint64).reshape(-1)[:4]]
         assert got == want, "tree root differs from the oracle"
+        verified = {"ok": True, "against": f"oracle/oracle.c: the whole 2^{log_n}-leaf tree recomputed on the CPU, root compared", "oracle_s": round(cpu_full, 1)}
+    if args.verify and args.workload == "ntt" and rank == 0:
+        # one forward transform of the workload's input, every element against the oracle's textbook NTT (parity unpinned upstream)
+        from oracle import coracle as C
+
+        d_chk = synth.scalars(F, 3, 0, n)
+        _lib.check(lib.lurk_hip_ntt_dev(F, _lib.ptr(d_chk), log_n, 0, _lib.ptr(stream)))
+        torch.cuda.synchronize()
+        host = C.synth_scalars(1, 3, 0, n)
+        t1 = time.perf_counter()
+        want = C.ntt(1, host)
+        cpu_full = time.perf_counter() - t1
+        assert np.array_equal(d_chk.cpu().numpy().view(np.uint64).reshape(-1, 4), want), "NTT output differs from the oracle"
+        verified = {"ok": True, "against": f"oracle/oracle.c: forward NTT of the same 2^{log_n} elements, all outputs compared", "oracle_s": round(cpu_full, 1)}
+        del d_chk
     tot, cnt = ctypes.c_double(), ctypes.c_uint64()
     _lib.check(lib.lurk_hip_profile_get(kname.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
     if rank == 0:
@@ -1078,7 +1138,7 @@ def other_workloads(args, lib, world, rank):
             "metric": f"{args.workload} throughput", "value": round(per_step_units * world / (elapsed / args.steps) / 1e6, 3), "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u32x8 (255-bit Montgomery, integer VALU)",
-            "data": "synthetic", "config": {"workload": workload, "parallelism": parallelism},
+            "data": "synthetic", "config": {"workload": workload, "parallelism": parallelism, "verified": verified},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 6), "traffic": None, "kernel_ms_per_step": round(kernel_ms_per_step, 4),
                          "algorithmic_bytes_per_step": alg_bytes},
@@ -1095,16 +1155,21 @@ def other_workloads(args, lib, world, rank):
         if not args.no_cpu_baseline:
             from oracle import coracle as C
 
-            m = min(n, 1 << 18)
-            sample = C.synth_scalars(1, 2 if args.workload == "poseidon_tree" else 3, 0, m)
-            t1 = time.perf_counter()
-            if args.workload == "poseidon_tree":
-                C.poseidon_tree8(1, sample)
+            what = "leaves" if args.workload == "poseidon_tree" else "elements"
+            if cpu_full is not None:  # --verify has just run the whole workload on the CPU: that run is the baseline
+                m, dt, sample_desc = n, cpu_full, f"the whole workload (2^{log_n} {what}), the --verify run"
             else:
-                C.ntt(1, sample)
-            dt = time.perf_counter() - t1
+                m = min(n, 1 << 18)
+                sample = C.synth_scalars(1, 2 if args.workload == "poseidon_tree" else 3, 0, m)
+                t1 = time.perf_counter()
+                if args.workload == "poseidon_tree":
+                    C.poseidon_tree8(1, sample)
+                else:
+                    C.ntt(1, sample)
+                dt = time.perf_counter() - t1
+                sample_desc = f"first 2^18 {what} of the same workload"
             out["cpu_baseline"] = {"value": round(m / dt / 1e6, 4), "unit": unit, "cores": C.lib().orc_num_threads(), "kind": "port",
-                                   "sample": f"first 2^18 {'leaves' if args.workload == 'poseidon_tree' else 'elements'} of the same workload, {dt:.2f} s (oracle/oracle.c, OpenMP)"}
+                                   "sample": f"{sample_desc}, {dt:.2f} s (oracle/oracle.c, OpenMP)"}
         print(json.dumps(out), flush=True)
 
 

@@ -75,7 +75,8 @@ int lurk_hip_msm_vesta(void* out_jacobian96, const void* bases_affine64, size_t 
  * dependency; un-vendored: /root/reference/Cargo.toml:128 pulls it in through nova): a pasta-msm whose build script links
  * liblurk_hip.so instead of compiling its own C objects needs no source change.  They return nothing, as the originals; a
  * failure (no device, allocation) prints lurk_hip_last_error() and aborts the process. */
-/* Opt-in key cache of the four one-shot symbols (default off; LURK_MSM_ONESHOT_KEY_CACHE=1 in the environment does the same):
+/* Opt-in key cache of the four one-shot symbols (default off; LURK_MSM_ONESHOT_KEY_CACHE=1 in the environment, read once when the library is loaded, turns it on for
+ * callers that link mult_pippenger_* / cuda_pippenger_* without a source change and so cannot call this function):
  * arecibo commits under ONE immutable key at ONE address for a whole proof, yet the pasta-msm signature makes it hand the
  * bases over on every call (64 of the 96 bytes per point that cross PCIe).  With the cache on, the bases of the previous call
  * stay in HBM; a call with the same `points` pointer, npoints <= the cached length and bit-identical points at 4 096 sampled
@@ -101,7 +102,12 @@ lurk_hip_rust_error cuda_pippenger_vesta(void* out_jacobian96, const void* point
  * with(ctx, scalars) -> point).  flags: bit0 = build the per-window precomputed table
  * (2^(c*k) * P_i for every window k; costs windows x 64 B x npoints of HBM; every window then shares
  * one bucket set, so the window grows to c = 20 bits from 2^19 points on: 13 n mixed additions instead of
- * 16 n); bits 8..15 = window-bit override for the table mode (16..20, 0 = automatic). */
+ * 16 n); bits 8..15 = window-bit override for the table mode (16..20, 0 = automatic).
+ * Footprint of bit0 for keys of <= 2^16 points with no window override: the SMALL form - every multiple m * 2^(c k) * P_i
+ * resident, 256 KiB per point (2.6 GB at 10^4 points, 4.3 GB at 2^14, 5.6 GB at 2^16) plus <= 1 GiB of scratch while it is
+ * built - so that a commitment is one launch (0.13 ms at 2^13 points instead of 0.35).  It is chosen only when it fits a quarter
+ * of the device memory free at creation time; otherwise, and always with LURK_MSM_FLAG_WINDOW_BITS(16), the key takes the window
+ * table (64 B x 16 per point).  lurk_hip_msm_ctx_info reports the form that was taken. */
 typedef struct lurk_hip_msm_ctx lurk_hip_msm_ctx;
 #define LURK_MSM_FLAG_PRECOMPUTE 1
 #define LURK_MSM_FLAG_WINDOW_BITS(c) (((c) & 0xff) << 8)
@@ -151,6 +157,11 @@ int lurk_hip_msm_ctx_rebind_dev(lurk_hip_msm_ctx* ctx, const void* d_bases_affin
 /* Workspaces (sort buffers, task partials, buckets: ~1 GiB per slot at 2^22 points) are allocated on a slot's first use; a
  * prover that wants no allocation inside its first steps reserves them up front for the largest commitment it will make. */
 int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots);
+/* *precomputed receives the FORM of the resident key: 0 = plain (64 B/point), 1 = window table (the only form that commits a
+ * pair in one pass: lurk_hip_msm_ctx_submit_pair_dev), 2 = the small-commitment multiples table (keys of <= 2^16 points). */
+#define LURK_MSM_FORM_PLAIN 0
+#define LURK_MSM_FORM_TABLE 1
+#define LURK_MSM_FORM_SMALL 2
 int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoints, int* window_bits, int* precomputed);
 int lurk_hip_msm_ctx_device(const lurk_hip_msm_ctx* ctx, int* device); /* the device the key is resident on */
 /* Commitment-key generation: arecibo's CommitmentEngine::setup(label, n) = DlogGroup::from_label as

@@ -521,6 +521,7 @@ template <class P, class SF>
 void msm_small_launch(const void* d_scalars, size_t n, int is_mont, const Affine<P>* table, int c, void* group_pts, uint32_t* counter, Xyzz<P>* out,
                       hipStream_t s);
 size_t msm_small_group_bytes();
+size_t msm_small_scratch_bytes();
 
 // ---- 6'. the bucket reduction (msm_reduce.hip): one launch per level of the bit-plane merge tree, radix-2^29 points ----
 size_t msm_reduce_plane_bytes(size_t nb);
@@ -674,7 +675,13 @@ struct MsmCtxBase {
     virtual void adopt_table(DevBuf&& buf, size_t n, bool precomputed_, int c_) = 0;
 };
 
-static std::atomic<int> g_oneshot_key_cache{0};  // lurk_hip_msm_oneshot_key_cache(1) turns it on (default off)
+// lurk_hip_msm_oneshot_key_cache(1) turns it on (default off); LURK_MSM_ONESHOT_KEY_CACHE=1 in the environment does the same at load
+// time, for a pasta-msm drop-in that links the one-shot symbols unchanged and has no way to call that function
+static int oneshot_key_cache_env() {
+    const char* v = getenv("LURK_MSM_ONESHOT_KEY_CACHE");
+    return v && atoi(v) != 0;
+}
+static std::atomic<int> g_oneshot_key_cache{oneshot_key_cache_env()};
 static bool oneshot_key_cache_enabled() { return g_oneshot_key_cache.load() != 0; }
 
 template <class P, class SF>
@@ -750,7 +757,18 @@ struct MsmCtx : MsmCtxBase {
         precomputed = precompute;
         small = false;
         small_table.release();
-        if (precompute && !c_override && n > 0 && n <= MSM_SMALL_MAX_POINTS) {
+        bool small_form = precompute && !c_override && n > 0 && n <= MSM_SMALL_MAX_POINTS;
+        if (small_form) {
+            // the small form is a memory-for-latency trade sized for 288 GB: 256 KiB per point resident (4.3 GB at 2^14 points, 5.6 GB
+            // at 2^16) + <= 1 GiB of build scratch.  It is taken only when that is at most a quarter of what the device has free
+            // right now (several keys per process, slices of a multi-device key and smaller devices then get the window table)
+            const int cs = msm_small_window_bits(n);
+            const size_t need = msm_small_table_entries(n, cs) * sizeof(Affine<P>) + msm_small_scratch_bytes() + (size_t)msm_num_windows(cs) * n * 160;
+            size_t free_b = 0, total_b = 0;
+            LURK_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            if (need > free_b / 4) small_form = false;
+        }
+        if (small_form) {
             // small resident key: all multiples of all window bases (msm_small.hip); the plain bases stay too (key files, rebinding)
             c = msm_small_window_bits(n);
             const int Ws = msm_num_windows(c);
@@ -1619,7 +1637,7 @@ int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoin
         if (curve) *curve = ctx->impl->curve;
         if (npoints) *npoints = ctx->impl->npoints;
         if (window_bits) *window_bits = ctx->impl->c;
-        if (precomputed) *precomputed = ctx->impl->precomputed ? 1 : 0;
+        if (precomputed) *precomputed = ctx->impl->small ? LURK_MSM_FORM_SMALL : ctx->impl->precomputed ? LURK_MSM_FORM_TABLE : LURK_MSM_FORM_PLAIN;
     });
 }
 

@@ -42,9 +42,10 @@ constexpr int SMALL_FINAL_LEVELS = 4;  // the last workgroup folds 16:1; the hos
 // scratch), then ONE inversion and Montgomery's trick walk back over them - the scheme of msm_precompute_kernel.
 template <class P>
 __global__ __launch_bounds__(256) void small_multiples_kernel(const Affine<P>* __restrict__ wbases /*[w * n + i]*/, size_t n, int W, uint32_t H,
-                                                                Affine<P>* __restrict__ table, Fe<P>* __restrict__ scratch) {
-    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;  // = i * W + w
-    if (id >= n * (size_t)W) return;
+                                                                Affine<P>* __restrict__ table, Fe<P>* __restrict__ scratch, size_t id_lo,
+                                                                size_t id_hi) {
+    const size_t id = id_lo + (size_t)blockIdx.x * 256 + threadIdx.x;  // = i * W + w; this launch covers [id_lo, id_hi)
+    if (id >= id_hi) return;
     const size_t i = id / W, w = id % W;
     const Affine<P> b = wbases[w * n + i];
     Affine<P>* out = table + id * H;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void small_multiples_kernel(const Affine<P>* _
         for (uint32_t m = 0; m < H; m++) out[m] = b;
         return;
     }
-    Fe<P>* sc = scratch + id * (size_t)H * 3;  // [m][0] = ZZ, [1] = ZZZ, [2] = product of ZZZ_1..m   (m = 1 .. H-1; index 0 unused)
+    Fe<P>* sc = scratch + (id - id_lo) * (size_t)H * 3;  // [m][0] = ZZ, [1] = ZZZ, [2] = product of ZZZ_1..m   (m = 1 .. H-1; index 0 unused)
     out[0] = b;
     Xyzz<P> p = xyzz_from_affine<P>(b);
     Fe<P> prod = fe_one<P>();
@@ -200,6 +201,7 @@ unsigned msm_small_groups(size_t n, int c) {
     if (g > SMALL_MAX_GROUPS) g = SMALL_MAX_GROUPS;
     return (unsigned)g;
 }
+size_t msm_small_scratch_bytes() { return (size_t)1 << 30; }
 unsigned msm_small_out_points(unsigned groups) { return (groups + (1u << SMALL_FINAL_LEVELS) - 1) >> SMALL_FINAL_LEVELS; }
 
 // wbases: the per-window bases [w * n + i] = 2^(c w) P_i (msm_precompute_kernel's output); table: n * W * 2^(c-1) records
@@ -208,10 +210,17 @@ void msm_small_build_table(const Affine<P>* wbases, size_t n, int c, Affine<P>* 
     if (n == 0) return;
     const int W = msm_num_windows(c);
     const uint32_t H = 1u << (c - 1);
-    DevBuf scratch(n * (size_t)W * H * 3 * sizeof(Fe<P>));
-    {
+    // (i, w) pairs in chunks: the ZZ / ZZZ / running-product scratch of a chunk is 96 B per table entry, bounded to
+    // MSM_SMALL_SCRATCH_BYTES whatever the key size (all at once it was 1.5x the table itself: 6.4 GB at 2^14 points)
+    const size_t ids = n * (size_t)W, per_id = (size_t)H * 3 * sizeof(Fe<P>);
+    size_t chunk = msm_small_scratch_bytes() / per_id;
+    chunk = chunk < 256 ? 256 : (chunk / 256) * 256;
+    if (chunk > ids) chunk = ids;
+    DevBuf scratch(chunk * per_id);
+    for (size_t lo = 0; lo < ids; lo += chunk) {
+        const size_t hi = lo + chunk < ids ? lo + chunk : ids;
         ProfScope ps("msm_small_table", s);
-        hipLaunchKernelGGL((small_multiples_kernel<P>), dim3(div_up(n * (size_t)W, 256)), dim3(256), 0, s, wbases, n, W, H, table, scratch.as<Fe<P>>());
+        hipLaunchKernelGGL((small_multiples_kernel<P>), dim3(div_up(hi - lo, 256)), dim3(256), 0, s, wbases, n, W, H, table, scratch.as<Fe<P>>(), lo, hi);
         LURK_HIP_CHECK(hipGetLastError());
     }
     LURK_HIP_CHECK(hipStreamSynchronize(s));  // the scratch buffer is released here

@@ -102,16 +102,22 @@ static void fold_ux_host(std::vector<uint64_t>& ux, const std::vector<uint64_t>&
 // U1 <- U1 + r U2 (RelaxedR1CSInstance::fold) for the step finish(r) closed last, if it is still owed
 static void fold_instance_settle(lurk_hip_fold_ctx* c) {
     if (!c->instance_owed) return;
-    c->instance_owed = false;
-    uint64_t pair[24];
+    // everything into temporaries first: if a group operation fails the fold stays owed and the instance is untouched (the device
+    // witness was folded by finish(r) already, so a half-updated instance would silently diverge from it)
+    uint64_t pair[24], new_w[12], new_e[12];
     memcpy(pair, c->comm_w, 96);
     ok(lurk_hip_point_mul(c->curve, pair + 12, c->open_cw, c->owed_r, 1));
-    ok(lurk_hip_point_sum(c->curve, c->comm_w, pair, 2));
+    ok(lurk_hip_point_sum(c->curve, new_w, pair, 2));
     memcpy(pair, c->comm_e, 96);
     ok(lurk_hip_point_mul(c->curve, pair + 12, c->open_ct, c->owed_r, 1));
-    ok(lurk_hip_point_sum(c->curve, c->comm_e, pair, 2));
-    if (c->field_id == LURK_FIELD_PALLAS_FQ) fold_ux_host<PallasFq>(c->ux, c->open_x2, c->owed_r);
-    else fold_ux_host<PallasFp>(c->ux, c->open_x2, c->owed_r);
+    ok(lurk_hip_point_sum(c->curve, new_e, pair, 2));
+    std::vector<uint64_t> new_ux = c->ux;
+    if (c->field_id == LURK_FIELD_PALLAS_FQ) fold_ux_host<PallasFq>(new_ux, c->open_x2, c->owed_r);
+    else fold_ux_host<PallasFp>(new_ux, c->open_x2, c->owed_r);
+    memcpy(c->comm_w, new_w, 96);
+    memcpy(c->comm_e, new_e, 96);
+    c->ux.swap(new_ux);
+    c->instance_owed = false;
 }
 
 static void fold_submit_staged(lurk_hip_fold_ctx* c, int b, int mode) {
@@ -173,6 +179,33 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     uint64_t body[12], late[12];
     c->staged[0] = c->staged[1];
     c->n_staged--;
+    // From here on the staged instance is consumed.  If anything below fails (a busy slot, an allocation, a device error) the
+    // commitments this call has in flight are drained, the device work it enqueued is waited for, and the instance goes back to the
+    // head of the staged queue with its commitment to be submitted again: the context, and the key's slots, stay usable and the
+    // same begin can simply be repeated.
+    struct Rollback {
+        lurk_hip_fold_ctx* c;
+        int b;
+        const lurk_hip_w2_patch* patches;
+        size_t n_patches;
+        bool armed = true, t_in_flight = false, late_in_flight = false, patch_written = false;
+        ~Rollback() {
+            if (!armed) return;
+            uint64_t junk[12];
+            if (c->submitted[b]) (void)lurk_hip_msm_ctx_wait(c->key, 2 * b, junk);
+            if (t_in_flight) (void)lurk_hip_msm_ctx_wait(c->key, 1, junk);
+            if (late_in_flight) (void)lurk_hip_msm_ctx_wait(c->key, 3, junk);
+            c->submitted[b] = false;
+            if (patch_written && c->zpatch.p)
+                for (size_t k = 0; k < n_patches; k++)
+                    if (patches[k].count) (void)hipMemsetAsync((char*)c->zpatch.p + patches[k].offset * 32, 0, patches[k].count * 32, c->stage_stream[b]);
+            (void)hipStreamSynchronize(c->stage_stream[b]);
+            (void)hipStreamSynchronize(c->stream);
+            c->staged[1] = c->staged[0];
+            c->staged[0] = b;
+            c->n_staged++;
+        }
+    } rollback{c, b, patches, n_patches};
     const bool ahead = c->n_staged > 0 && !c->submitted[c->staged[0]];  // the NEXT step's instance waits to be submitted behind T
     // u2 = 1 (a fresh instance is strict), X2 and the late ranges go through the pinned staging buffer
     const size_t need = (1 + c->num_io + patched) * 32;
@@ -194,6 +227,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
             LURK_HIP_CHECK(hipMemsetAsync(c->zpatch.p, 0, c->num_vars * 32, c->stage_stream[b]));
         }
         char* src = c->pin + (1 + c->num_io) * 32;
+        rollback.patch_written = true;
         for (size_t k = 0; k < n_patches; k++) {
             if (!patches[k].count) continue;
             memcpy(src, patches[k].values, patches[k].count * 32);
@@ -214,13 +248,19 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     fold_submit_staged(c, b, fg);
     tt[1] = now();
     ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t.p, c->num_cons, 1, c->stream, fg));     // ... commit(T): what the host waits for
-    if (patched) ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream[b], fg));  // commitment of the late ranges
+    rollback.t_in_flight = true;
+    if (patched) {
+        ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream[b], fg));  // commitment of the late ranges
+        rollback.late_in_flight = true;
+    }
     tt[2] = now();
     if (ahead) fold_submit_staged(c, c->staged[0], LURK_MSM_SUBMIT_BACKGROUND);  // commit(next W2) fills what T leaves
     tt[3] = now();
     fold_instance_settle(c);  // the previous step's instance fold, while the device works on this step
     if (patched) {
+        c->submitted[b] = false;  // (a wait consumes the slot's commitment whether it succeeds or not)
         ok(lurk_hip_msm_ctx_wait(c->key, 2 * b, body));
+        rollback.late_in_flight = false;
         ok(lurk_hip_msm_ctx_wait(c->key, 3, late));
         uint64_t two[24];
         memcpy(two, body, 96);
@@ -231,10 +271,13 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
         LURK_HIP_CHECK(hipEventRecord(c->patch_ev, c->stage_stream[b]));
         c->patch_ev_valid = true;
     } else {
+        c->submitted[b] = false;
         ok(lurk_hip_msm_ctx_wait(c->key, 2 * b, comm_w2_jac96));
     }
     tt[4] = now();
+    rollback.t_in_flight = false;
     ok(lurk_hip_msm_ctx_wait(c->key, 1, comm_t_jac96));
+    rollback.armed = false;
     tt[5] = now();
     if (trace)
         fprintf(stderr, "[step] copies %.0f us, cross+T submit %.0f, next-W2 submit %.0f, W2 wait %.0f, T wait %.0f\n", tt[1] - tt[0], tt[2] - tt[1],
@@ -244,6 +287,22 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     c->open_x2.assign((const uint64_t*)x2_mont, (const uint64_t*)x2_mont + 4 * c->num_io);
     memcpy(c->open_cw, comm_w2_jac96, 96);
     memcpy(c->open_ct, comm_t_jac96, 96);
+}
+
+// begin = stage + open in one call: if opening fails, the instance this call staged is taken back as well (fold_begin's own
+// rollback has returned it to the queue with nothing in flight), so that the caller can repeat the call as it stands
+static void fold_stage_and_begin(lurk_hip_fold_ctx* c, const void* w2, int on_device, void* w2_stream, const void* x2_mont, void* comm_w2_jac96,
+                                 void* comm_t_jac96) {
+    fold_stage(c, w2, 0, c->num_vars, on_device, w2_stream);
+    try {
+        fold_begin(c, nullptr, 0, x2_mont, comm_w2_jac96, comm_t_jac96);
+    } catch (...) {
+        if (c->n_staged == 1) {
+            c->next_buf = c->staged[0];
+            c->n_staged = 0;
+        }
+        throw;
+    }
 }
 
 // ---- the key cut across several devices ("witness-commitment batches shard across the GPUs") ----------------------
@@ -456,8 +515,7 @@ int lurk_hip_fold_step(lurk_hip_fold_ctx* c, const void* w2, int w2_on_device, v
         if (c->mkey) {
             fold_begin_multi(c, w2, w2_on_device, w2_stream, x2_mont, cw, ct);
         } else {
-            fold_stage(c, w2, 0, c->num_vars, w2_on_device, w2_stream);
-            fold_begin(c, nullptr, 0, x2_mont, cw, ct);
+            fold_stage_and_begin(c, w2, w2_on_device, w2_stream, x2_mont, cw, ct);
         }
         ok(lurk_hip_nifs_challenge(c->curve, pp_digest32, c->comm_w, c->comm_e, c->ux.data(), c->ux.data() + 4, cw, x2_mont, c->num_io, ct, r));
         fold_finish(c, r);
@@ -481,8 +539,7 @@ int lurk_hip_fold_step_begin(lurk_hip_fold_ctx* c, const void* w2, int w2_on_dev
             fold_begin_multi(c, w2, w2_on_device, w2_stream, x2_mont, comm_w2_jac96, comm_t_jac96);
             return;
         }
-        fold_stage(c, w2, 0, c->num_vars, w2_on_device, w2_stream);
-        fold_begin(c, nullptr, 0, x2_mont, comm_w2_jac96, comm_t_jac96);
+        fold_stage_and_begin(c, w2, w2_on_device, w2_stream, x2_mont, comm_w2_jac96, comm_t_jac96);
     });
 }
 

@@ -104,7 +104,8 @@ class CommitmentKey:
     def info(self) -> dict:
         c, n, w, p = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
         _lib.check(_lib.load().lurk_hip_msm_ctx_info(self._ctx, ctypes.byref(c), ctypes.byref(n), ctypes.byref(w), ctypes.byref(p)))
-        return {"curve": c.value, "npoints": n.value, "window_bits": w.value, "precomputed": bool(p.value)}
+        return {"curve": c.value, "npoints": n.value, "window_bits": w.value, "precomputed": bool(p.value),
+                "form": {0: "plain", 1: "table", 2: "small"}[p.value]}
 
     def commit(self, scalars: np.ndarray, is_mont: bool = False) -> np.ndarray:
         """``CE::commit(ck, v)``: host scalars (len <= n) -> Jacobian commitment."""
@@ -139,8 +140,7 @@ class CommitmentKey:
     def supports_pairs(self) -> bool:
         """True for a window-table key (precompute flag and more than 2^16 points, or a window-bit override): the only form that
         commits a pair in one pass (``submit_pair_device``)."""
-        i = self.info()
-        return bool(i["precomputed"]) and i["window_bits"] >= 16
+        return self.info()["form"] == "table"
 
     def submit_pair_device(self, slot: int, d_scalars, n: int, sel_bit: int, is_mont: bool = False, stream=None) -> None:
         """Two commitments with disjoint supports in one pass: scalars whose index has bit ``sel_bit`` clear / set; ``wait_pair``."""

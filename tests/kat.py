@@ -59,4 +59,11 @@ def compute_all(hash_fn):
     args = H([R.TAG_SYM, x, R.TAG_NIL, nil])  # (x) = cons(x, nil)
     fun = H([R.TAG_CONS, args, R.TAG_SYM, x, R.TAG_ENV, 0, R.TAG_NIL, 0])  # store.rs:623-626
     out["commit_lambda_x_x"] = H([0, R.TAG_FUN, fun])
+    # a zero-argument function: vars = nil, body = nil (src/lem/eval.rs:1178-1181; eval_tests.rs:461)
+    fun0 = H([R.TAG_NIL, nil, R.TAG_NIL, nil, R.TAG_ENV, 0, R.TAG_NIL, 0])
+    out["commit_lambda_noargs_nil"] = H([0, R.TAG_FUN, fun0])
+    # the REPL's own examples: '(13 . 21) committed without and with a secret (src/cli/repl/meta_cmd.rs:246-247, 262-264)
+    cons = H([R.TAG_NUM, 13, R.TAG_NUM, 21])
+    out["commit_cons_13_21"] = H([0, R.TAG_CONS, cons])
+    out["hide_12345_cons_13_21"] = H([12345, R.TAG_CONS, cons])
     return out

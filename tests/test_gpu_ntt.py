@@ -63,3 +63,27 @@ def test_full_size_roundtrip_and_linearity_2_24(hip):
     assert np.array_equal(C.from_mont(f, hc), C.axpy(f, C.from_mont(f, ha), C.from_mont(f, hb), r))
     _lib.check(lib.lurk_hip_ntt_dev(f, _lib.ptr(a), log_n, 1, _lib.ptr(stream)))
     assert torch.equal(a, a0)
+
+
+def test_full_size_2_24_every_output_against_the_oracle(hip):
+    """BASELINE-size transform compared DIRECTLY: all 2^24 outputs of the forward NTT equal the oracle's (a consistent error in the
+    third pass would survive the round trip and the linearity check above), and the inverse of the oracle's output is the input."""
+    import torch
+
+    from lurk_beta_amd import _lib, synth
+
+    lib = _lib.load()
+    f, log_n = 1, 24
+    n = 1 << log_n
+    stream = torch.cuda.current_stream().cuda_stream
+    d = synth.scalars(f, 3, 0, n)
+    host = C.synth_scalars(f, 3, 0, n)
+    assert np.array_equal(d[:4096].cpu().numpy().view(np.uint64), host[:4096])
+    _lib.check(lib.lurk_hip_ntt_dev(f, _lib.ptr(d), log_n, 0, _lib.ptr(stream)))
+    torch.cuda.synchronize()
+    want = C.ntt(f, host)
+    assert np.array_equal(d.cpu().numpy().view(np.uint64).reshape(-1, 4), want)
+    d.copy_(torch.from_numpy(want.view(np.int64)))
+    _lib.check(lib.lurk_hip_ntt_dev(f, _lib.ptr(d), log_n, 1, _lib.ptr(stream)))
+    torch.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy().view(np.uint64).reshape(-1, 4), host)

@@ -332,6 +332,71 @@ def test_staging_into_the_open_steps_buffer_is_refused(hip):
     shape.close()
 
 
+def test_begin_that_fails_midway_leaves_the_context_usable(hip):
+    """A commitment that cannot be submitted in the middle of begin (slot 1 of the key, where commit(T) goes, is held by somebody
+    else's commitment: "slot is busy") must cost nothing but the call: commit(W2), already in flight, is drained, the staged
+    instance goes back to the queue, and the same begin succeeds once the slot is free - with the oracle's results - as does the
+    staged flow with late ranges."""
+    import torch
+
+    from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape, point_to_affine
+
+    curve, f, m, nfree, nio = 0, 1, 6000, 2500, 2
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=77)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    bases = C.synth_bases(curve, max(m, nv))
+    key = CommitmentKey(curve, bases, precompute=True, window_bits=16)  # the bucket pipeline (async slots), not the one-launch small form
+    key.reserve(max(m, nv), 4)
+    ctx = FoldingContext(curve, shape, key)
+    z2, x2 = _fresh(f, A, B, m, nfree, nio, 900)
+    w2m, x2m = C.to_mont(f, z2[:nv]), C.to_mont(f, x2)
+    other = torch.from_numpy(C.to_mont(f, C.synth_scalars(f, 950, 0, 4096)).view(np.int64)).cuda()
+    want_other = C.jac_to_affine(curve, C.msm_pippenger(curve, bases[:4096], C.synth_scalars(f, 950, 0, 4096)))
+    zero = np.zeros_like(z2)
+    want_cw = C.jac_to_affine(curve, C.msm_pippenger(curve, bases[:nv], z2[:nv]))
+    t = C.cross_term(f, *[C.spmv(f, *M, zero) for M in (A, B, Cm)], *[C.spmv(f, *M, z2) for M in (A, B, Cm)], 0, 1)
+    want_ct = C.jac_to_affine(curve, C.msm_pippenger(curve, bases[:m], t))
+    # (i) plain begin
+    key.submit_device(1, other, 4096, is_mont=True)                      # slot 1 is now somebody else's
+    with pytest.raises(LurkHipError, match="busy"):
+        ctx.begin(w2m, x2m)
+    assert point_to_affine(curve, key.wait(1)) == want_other              # the foreign commitment is intact
+    for slot in (0, 2, 3):                                                # nothing of the failed begin is left in flight
+        with pytest.raises(LurkHipError):
+            key.wait(slot)
+    cw, ct = ctx.begin(w2m, x2m)                                          # the same call again
+    assert point_to_affine(curve, cw) == want_cw and point_to_affine(curve, ct) == want_ct
+    r = 0xFEED5
+    ctx.finish(C.to_mont(f, C.ints_to_limbs([r])))
+    gz, ge = ctx.read()
+    assert np.array_equal(C.from_mont(f, gz), C.axpy(f, zero, z2, r))
+    assert np.array_equal(C.from_mont(f, ge), C.axpy(f, np.zeros_like(t), t, r))
+    # (ii) staged flow with late ranges: the instance stays staged, the late-range buffer is clean for the retry
+    z3, x3 = _fresh(f, A, B, m, nfree, nio, 910)
+    w3m, x3m = C.to_mont(f, z3[:nv]), C.to_mont(f, x3)
+    lo, hi = 300, nv - 200
+    ctx.prefetch(w3m[lo:hi], lo)
+    patches = [(0, w3m[:lo]), (hi, w3m[hi:])]
+    key.submit_device(3, other, 4096, is_mont=True)                      # slot 3: where the late ranges' commitment goes
+    with pytest.raises(LurkHipError, match="busy"):
+        ctx.begin_prefetched(x3m, patches)
+    assert point_to_affine(curve, key.wait(3)) == want_other
+    cw3, ct3 = ctx.begin_prefetched(x3m, patches)
+    assert point_to_affine(curve, cw3) == C.jac_to_affine(curve, C.msm_pippenger(curve, bases[:nv], z3[:nv]))
+    z1 = C.axpy(f, zero, z2, r)
+    e1 = C.axpy(f, np.zeros_like(t), t, r)
+    t3 = C.cross_term(f, *[C.spmv(f, *M, z1) for M in (A, B, Cm)], *[C.spmv(f, *M, z3) for M in (A, B, Cm)], r, 1, )
+    assert point_to_affine(curve, ct3) == C.jac_to_affine(curve, C.msm_pippenger(curve, bases[:m], t3))
+    ctx.finish(C.to_mont(f, C.ints_to_limbs([7])))
+    gz, ge = ctx.read()
+    assert np.array_equal(C.from_mont(f, gz), C.axpy(f, z1, z3, 7))
+    assert np.array_equal(C.from_mont(f, ge), C.axpy(f, e1, t3, 7))
+    ctx.close()
+    key.close()
+    shape.close()
+
+
 def test_step_at_the_rc100_size(hip):
     """One folding step at BASELINE config 1's size (rc = 100 on Pallas: 895 164 witness elements, 1 097 300 constraints - the
     sizes bench.py's fold_step workload runs) through lurk_hip_fold_step, every output against the oracle: both commitments

@@ -56,3 +56,34 @@ def test_switch_settings_keep_the_results(hip, env, expect_stderr):
     assert "child ok" in p.stdout
     if expect_stderr:
         assert expect_stderr in p.stderr, p.stderr[-500:]
+
+
+KEY_CACHE_CHILD = r'''
+import sys, time
+import numpy as np
+sys.path.insert(0, %r)
+import lurk_beta_amd as L
+from lurk_beta_amd import _lib
+from oracle import coracle as C
+n = 1 << 18
+B = np.ascontiguousarray(C.synth_bases(0, n))
+S = [C.synth_scalars(1, 70 + k, 0, n) for k in range(3)]
+lib = _lib.load()
+for k in range(3):   # pasta-msm's own symbol, host pointers: the second and third call find the key of the first in HBM
+    out = np.zeros(12, dtype=np.uint64)
+    lib.mult_pippenger_pallas(_lib.ptr(out), _lib.ptr(B), n, _lib.ptr(S[k]), False)
+    assert L.point_to_affine(0, out) == C.jac_to_affine(0, C.msm_fast(0, B, S[k])), k
+B2 = np.ascontiguousarray(C.synth_bases(0, n, first=n))
+B[:] = B2            # same address, another key: the sampled positions differ, the cache must miss
+out = np.zeros(12, dtype=np.uint64)
+lib.mult_pippenger_pallas(_lib.ptr(out), _lib.ptr(B), n, _lib.ptr(S[0]), False)
+assert L.point_to_affine(0, out) == C.jac_to_affine(0, C.msm_fast(0, B2, S[0]))
+print("child ok")
+'''
+
+
+def test_oneshot_key_cache_from_the_environment(hip):
+    """LURK_MSM_ONESHOT_KEY_CACHE=1 (include/lurk_hip.h): the opt-in key cache for callers that link pasta-msm's symbols unchanged."""
+    e = dict(os.environ, LURK_MSM_ONESHOT_KEY_CACHE="1")
+    p = subprocess.run([sys.executable, "-c", KEY_CACHE_CHILD % ROOT], env=e, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "child ok" in p.stdout, p.stderr[-2000:]
