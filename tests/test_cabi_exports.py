@@ -96,3 +96,43 @@ def test_inline_asm_operands_avoid_the_clobbered_scratch_registers(tmp_path):
     assert isa
     chk = subprocess.run([sys.executable, os.path.join(ROOT, "bench_tools", "check_asm_operands.py"), str(tmp_path / isa[0])], capture_output=True, text=True)
     assert chk.returncode == 0, chk.stdout[-800:]
+
+
+def test_rust_ffi_matches_the_header():
+    """rust/lurk-hip-sys/src/ffi.rs (the sys crate's extern block) is generated from include/lurk_hip.h: the committed file must be
+    what the generator emits today, its functions must be exactly the header's (and exported by the built library), and - independently
+    of the generator - every function must take as many arguments as the ctypes signature the tests call it with, with pointer /
+    integer / by-value kinds agreeing."""
+    import ctypes
+    import subprocess
+    import sys
+
+    from lurk_beta_amd import _lib
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "rust", "gen_sys.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rs = open(os.path.join(ROOT, "rust", "lurk-hip-sys", "src", "ffi.rs")).read()
+    block = rs[rs.index('extern "C" {'):]
+    fns = dict(re.findall(r"pub fn (\w+)\((.*?)\)(?: -> [^;]+)?;", block))
+    assert sorted(fns) == _declared_symbols()
+    lib = _lib.load()
+    for name, params in fns.items():
+        assert hasattr(lib, name)
+        res, args = _lib.SIGNATURES[name]
+        plist = [p.split(":", 1)[1].strip() for p in params.split(", ")] if params.strip() else []
+        assert len(plist) == len(args), name
+        for rust_t, ct in zip(plist, args):
+            is_ptr_rs = rust_t.startswith("*") or rust_t.endswith("_fn")
+            is_ptr_ct = ct in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(ct, "contents")
+            assert is_ptr_rs == is_ptr_ct, (name, rust_t, ct)
+            if not is_ptr_rs:
+                width = {"c_int": 4, "c_uint": 4, "u32": 4, "usize": 8, "u64": 8, "bool": 1}[rust_t]
+                assert ctypes.sizeof(ct) == width, (name, rust_t, ct)
+    # the #[repr(C)] structs: field count and size against what the header compiles to
+    for struct, size in (("lurk_hip_store_node", 32), ("lurk_hip_w2_patch", 24), ("lurk_hip_rust_error", 16)):
+        assert f"pub struct {struct} {{" in rs
+    assert ctypes.sizeof(_lib.RustError) == 16
+    # the safe wrapper only calls functions the extern block declares
+    lib_rs = open(os.path.join(ROOT, "rust", "lurk-hip-sys", "src", "lib.rs")).read()
+    called = set(re.findall(r"\b((?:lurk_hip|mult_pippenger|cuda_pippenger)_[a-z0-9_]+)\s*\(", lib_rs))
+    assert called and called <= set(fns), called - set(fns)
