@@ -272,12 +272,37 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
     fold_store<P>(t + row, dot29_finish<P>(acc));
 }
 
-// out = a + r b (r: Montgomery 2^256, broadcast)
+// out = a + r b (r: Montgomery 2^256, broadcast).  A pure 96 B / element stream (two reads, one write): a lane takes FOLD_VEC_E
+// elements FOLD_BLOCK apart, issues all of their 128-bit loads before the first product (8 loads in flight per lane; with one
+// element per trip of a grid-stride loop the kernel sat at 45-53 % of HBM, waiting on each pair of loads in turn), and the grid
+// covers the vector exactly once.
+constexpr int FOLD_VEC_E = 2;
 template <class P>
-__global__ __launch_bounds__(FOLD_BLOCK) void fold_vec_kernel(const Fe<P>* __restrict__ a, const Fe<P>* __restrict__ b, Fe<P> r, size_t n,
-                                                                Fe<P>* __restrict__ out) {
-    for (size_t i = (size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * FOLD_BLOCK)
-        out[i] = fe_add<P>(a[i], fe_mul<P>(r, b[i]));
+__global__ __launch_bounds__(FOLD_BLOCK) void fold_vec_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, Fe<P> r, size_t n,
+                                                                uint4* __restrict__ out) {
+    const size_t base = (size_t)blockIdx.x * (FOLD_BLOCK * FOLD_VEC_E) + threadIdx.x;
+    uint4 al[FOLD_VEC_E], ah[FOLD_VEC_E], bl[FOLD_VEC_E], bh[FOLD_VEC_E];
+#pragma unroll
+    for (int e = 0; e < FOLD_VEC_E; e++) {
+        const size_t i = base + (size_t)e * FOLD_BLOCK;
+        if (i < n) {
+            al[e] = a[2 * i];
+            ah[e] = a[2 * i + 1];
+            bl[e] = b[2 * i];
+            bh[e] = b[2 * i + 1];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < FOLD_VEC_E; e++) {
+        const size_t i = base + (size_t)e * FOLD_BLOCK;
+        if (i >= n) continue;
+        Fe<P> x, y;
+        x.l[0] = al[e].x; x.l[1] = al[e].y; x.l[2] = al[e].z; x.l[3] = al[e].w; x.l[4] = ah[e].x; x.l[5] = ah[e].y; x.l[6] = ah[e].z; x.l[7] = ah[e].w;
+        y.l[0] = bl[e].x; y.l[1] = bl[e].y; y.l[2] = bl[e].z; y.l[3] = bl[e].w; y.l[4] = bh[e].x; y.l[5] = bh[e].y; y.l[6] = bh[e].z; y.l[7] = bh[e].w;
+        x = fe_add<P>(x, fe_mul<P>(r, y));
+        out[2 * i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+        out[2 * i + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -384,10 +409,8 @@ static void fold_vec(const void* a, const void* b, const void* r32, size_t n, vo
     Fe<P> r;
     memcpy(r.l, r32, 32);
     ProfScope ps("fold_vec", s);
-    unsigned blocks = div_up(n, FOLD_BLOCK);
-    unsigned cap = (unsigned)num_cus() * 16;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL((fold_vec_kernel<P>), dim3(blocks), dim3(FOLD_BLOCK), 0, s, (const Fe<P>*)a, (const Fe<P>*)b, r, n, (Fe<P>*)out);
+    const unsigned blocks = div_up(n, (size_t)FOLD_BLOCK * FOLD_VEC_E);
+    hipLaunchKernelGGL((fold_vec_kernel<P>), dim3(blocks), dim3(FOLD_BLOCK), 0, s, (const uint4*)a, (const uint4*)b, r, n, (uint4*)out);
     LURK_HIP_CHECK(hipGetLastError());
 }
 

@@ -32,7 +32,7 @@ def test_sizes_one_to_2_16(hip, cn, c):
     for n in (1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 1000, 4096, 8191, 10000, 1 << 14, (1 << 14) + 1, 40000, 1 << 16):
         B = C.synth_bases(c, n)
         key = CommitmentKey(c, B, precompute=True)
-        assert _info(key)[2:] == (8 if n <= (1 << 14) else 6, 1), n  # the small form: 8-bit windows up to 2^14 points, 6-bit above
+        assert _info(key)[2:] == (8 if n <= (1 << 14) else 6, 2), n  # form 2 = the small form: 8-bit windows up to 2^14 points, 6-bit above
         for dist in (0, 1):
             S = C.synth_scalars(sf, 11 + dist, dist, n)
             want = C.jac_to_affine(c, C.msm_naive(c, B, S) if n <= 256 else C.msm_fast(c, B, S))
