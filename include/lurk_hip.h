@@ -234,6 +234,11 @@ int lurk_hip_poseidon_tree8_dev(int field_id, const void* d_leaves, size_t n_lea
 /* the constants the library generated (canonical): rc has (rf+rp)*(arity+1) elements, mds
  * (arity+1)^2; pass NULL to query sizes only */
 int lurk_hip_poseidon_constants(int field_id, int arity, int* rf, int* rp, void* rc, void* mds);
+/* n hashes on the HOST (no device needed): the same digests as lurk_hip_poseidon_batch, for callers that hash one preimage at a
+ * time, as PoseidonCache::hash{3,4,6,8} does on a cache miss (/root/reference/src/hash.rs:180-204) - a single hash costs a host
+ * core ~20 us and a kernel launch + copies several times that; batches belong on the device.  The store hydration below uses it
+ * for DAG levels too narrow to be worth a kernel's dependency chain. */
+int lurk_hip_poseidon_hash_host(int field_id, int arity, const void* preimages, size_t n, void* digests);
 
 /* ---- store hydration -----------------------------------------------------------------------
  * Replaces the recursive, node-by-node hashing of StoreCore::hydrate_z_cache / hash_ptr

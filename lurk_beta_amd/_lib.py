@@ -76,6 +76,7 @@ SIGNATURES = {
     "lurk_hip_poseidon_tree8": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_poseidon_tree8_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_poseidon_constants": (c_int, [c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), c_void_p, c_void_p]),
+    "lurk_hip_poseidon_hash_host": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "lurk_hip_store_hydrate": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, ctypes.POINTER(c_size_t)]),
     "lurk_hip_slot_witness_size": (c_int, [c_int, c_int, ctypes.POINTER(c_size_t)]),
     "lurk_hip_slot_witness_dev": (c_int, [c_int, c_int, c_void_p, c_size_t, c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),

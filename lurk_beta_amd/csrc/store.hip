@@ -11,13 +11,20 @@
 // Here the caller hands over the nodes in topological order (children before parents); the host only looks at the SHAPE
 // (a node's level = 1 + max level of its children), groups the nodes by (level, arity), and the device does the rest: per
 // group one gather kernel that builds the preimages from the children's tags and digests already in HBM and one batch of the
-// Poseidon kernel (the lane-cooperative one: a level is a few hundred hashes).  Digests come back in one copy at the end;
-// nothing crosses PCIe between levels.  Latency-bound by the DAG's depth (2 launches per level and arity).
+// Poseidon kernel (the lane-cooperative one: a level is a few hundred hashes).
+//
+// WIDE levels stay on the device, NARROW ones go to the host.  A level costs the device one hash's dependency chain whatever its
+// width (0.138 ms for hash4 on MI355X: ~400 dependent products of ~0.34 us on a GPU lane), while a host core runs the same chain in
+// ~20 us: a group of at most STORE_HOST_MAX nodes is hashed by host_poseidon.hpp (the transcript's host permutation, any arity)
+// instead.  The digest array lives on both sides; the ranges one side is missing are copied when a group changes sides (positions are
+// assigned in (level, arity) order, so they are contiguous).  The 409-level list DAG of the tests - 25 wide levels of symbol
+// hashing, then a 384-node spine - went from 74 ms to the figure DESIGN.md section 3.9 quotes; a wide DAG never leaves the device.
 #include <algorithm>
 #include <memory>
 
 #include "common.hpp"
 #include "field.cuh"
+#include "host_poseidon.hpp"
 
 namespace lurk {
 
@@ -61,6 +68,40 @@ __global__ __launch_bounds__(256) void store_gather_kernel(const NodeDev* __rest
     }
     pre[2 * (size_t)t] = lo;
     pre[2 * (size_t)t + 1] = hi;
+}
+
+// groups of at most this many nodes are hashed on the host: device level time / host hash time = 0.138 ms / ~20 us
+constexpr uint32_t STORE_HOST_MAX = 6;
+
+// host twin of store_gather_kernel + one hash: node k of the (level, arity)-ordered list from the host copy of the digest array
+static void store_hash_node_host(int field_id, const NodeDev& nd, const uint64_t* dig, uint64_t* out4) {
+    uint64_t pre[8 * 4] = {0};
+    auto digest = [&](int e, uint32_t pos) { memcpy(pre + 4 * e, dig + 4 * (size_t)pos, 32); };
+    auto tag = [&](int e, uint32_t t) { pre[4 * e] = t; };
+    switch (nd.kind) {
+        case LURK_NODE_TUPLE2:
+        case LURK_NODE_TUPLE3:
+        case LURK_NODE_TUPLE4:
+            for (uint32_t e = 0; e < nd.arity; e++) {
+                if (e & 1) digest((int)e, nd.child_pos[e >> 1]);
+                else tag((int)e, nd.child_tag[e >> 1]);
+            }
+            break;
+        case LURK_NODE_COMPACT:
+            digest(0, nd.child_pos[0]);
+            tag(1, nd.child_tag[1]);
+            digest(2, nd.child_pos[1]);
+            digest(3, nd.child_pos[2]);
+            break;
+        default:  // LURK_NODE_COMM
+            digest(0, nd.secret_pos);
+            tag(1, nd.child_tag[0]);
+            digest(2, nd.child_pos[0]);
+            break;
+    }
+    if (field_id == 0) poseidon_hash_host<PallasFp>(poseidon_host<PallasFp>((int)nd.arity), pre, out4);
+    else if (field_id == 1) poseidon_hash_host<PallasFq>(poseidon_host<PallasFq>((int)nd.arity), pre, out4);
+    else poseidon_hash_host<Bn254Fr>(poseidon_host<Bn254Fr>((int)nd.arity), pre, out4);
 }
 
 static int kind_arity(uint32_t kind) {
@@ -153,17 +194,64 @@ extern "C" int lurk_hip_store_hydrate(int field_id, const lurk_hip_store_node* n
         DevBuf d_nodes(dev_nodes.size() * sizeof(NodeDev)), d_dig((n_values + order.size()) * 32), d_pre(max_group_elems * 32);
         if (!dev_nodes.empty()) LURK_HIP_CHECK(hipMemcpyAsync(d_nodes.p, dev_nodes.data(), dev_nodes.size() * sizeof(NodeDev), hipMemcpyHostToDevice, s));
         if (n_values) LURK_HIP_CHECK(hipMemcpyAsync(d_dig.p, values32, n_values * 32, hipMemcpyHostToDevice, s));
+        // the digest array on both sides: positions below the two marks are valid on the host / on the device
+        std::vector<uint64_t> host((n_values + order.size()) * 4);
+        if (n_values) memcpy(host.data(), values32, n_values * 32);
+        size_t host_valid = n_values, dev_valid = n_values;
+        auto to_host = [&](size_t upto) {  // device-computed positions [host_valid, upto) come down
+            if (upto <= host_valid) return;
+            LURK_HIP_CHECK(hipMemcpyAsync(host.data() + host_valid * 4, (char*)d_dig.p + host_valid * 32, (upto - host_valid) * 32, hipMemcpyDeviceToHost, s));
+            LURK_HIP_CHECK(hipStreamSynchronize(s));
+            host_valid = upto;
+        };
+        auto to_device = [&](size_t upto) {  // host-computed positions [dev_valid, upto) go up
+            if (upto <= dev_valid) return;
+            LURK_HIP_CHECK(hipMemcpyAsync((char*)d_dig.p + dev_valid * 32, host.data() + dev_valid * 4, (upto - dev_valid) * 32, hipMemcpyHostToDevice, s));
+            dev_valid = upto;
+        };
         for (const Group& g : groups) {
+            const size_t first = n_values + g.first, end = first + g.count;
+            if (g.count <= STORE_HOST_MAX) {
+                to_host(first);
+                for (uint32_t k = 0; k < g.count; k++) store_hash_node_host(field_id, dev_nodes[g.first + k], host.data(), host.data() + (first + k) * 4);
+                host_valid = end;
+                continue;
+            }
+            to_device(first);
             ProfScope ps("store_hydrate_level", s);
             hipLaunchKernelGGL(store_gather_kernel, dim3(div_up((size_t)g.count * g.arity, 256)), dim3(256), 0, s, d_nodes.as<NodeDev>(), g.first, g.count,
                                d_dig.as<uint4>(), d_pre.as<uint4>());
             LURK_HIP_CHECK(hipGetLastError());
-            poseidon_batch_device(field_id, g.arity, d_pre.p, (char*)d_dig.p + (n_values + g.first) * 32, g.count, 0, s);
+            poseidon_batch_device(field_id, g.arity, d_pre.p, (char*)d_dig.p + first * 32, g.count, 0, s);
+            dev_valid = end;
+            // (positions the host computed and no device group has needed yet stay below dev_valid: the marks only ever meet at a
+            // group boundary, where whichever side is behind catches up with one copy)
         }
-        std::vector<uint64_t> host((n_values + order.size()) * 4);
-        LURK_HIP_CHECK(hipMemcpyAsync(host.data(), d_dig.p, host.size() * 8, hipMemcpyDeviceToHost, s));
+        to_host(n_values + order.size());
         LURK_HIP_CHECK(hipStreamSynchronize(s));
         for (size_t i = 0; i < n; i++) memcpy((char*)digests32 + i * 32, host.data() + (size_t)pos[i] * 4, 32);
         if (levels_out) *levels_out = max_level;
     });
+}
+
+// pure host computation: usable without a device (the CPU tests run the reference's golden vectors through it)
+extern "C" int lurk_hip_poseidon_hash_host(int field_id, int arity, const void* preimages, size_t n, void* digests) {
+    try {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(arity == 3 || arity == 4 || arity == 6 || arity == 8, "unsupported arity (3, 4, 6 or 8)");  // src/hash.rs:19-29
+        LURK_REQUIRE(n == 0 || (preimages && digests), "null buffer");
+        for (size_t i = 0; i < n; i++) {
+            uint64_t pre[8 * 4], out[4];
+            memcpy(pre, (const char*)preimages + i * (size_t)arity * 32, (size_t)arity * 32);  // caller memory carries no alignment promise
+            if (field_id == 0) poseidon_hash_host<PallasFp>(poseidon_host<PallasFp>(arity), pre, out);
+            else if (field_id == 1) poseidon_hash_host<PallasFq>(poseidon_host<PallasFq>(arity), pre, out);
+            else poseidon_hash_host<Bn254Fr>(poseidon_host<Bn254Fr>(arity), pre, out);
+            memcpy((char*)digests + i * 32, out, 32);
+        }
+        set_error(0, "");
+        return 0;
+    } catch (const HipFailure& e) {
+        set_error(e.code, e.msg);
+        return e.code;
+    }
 }

@@ -23,257 +23,16 @@
 #include <mutex>
 
 #include "common.hpp"
-#include "poseidon_params.hpp"
+#include "host_poseidon.hpp"
 
 namespace lurk {
 
 constexpr int RO_ARITY = 24;  // neptune U24: rate of the sponge arecibo's PoseidonRO is built on
 
 template <class P>
-static const PoseidonParams<P>& ro_params() {
-    static std::once_flag once;
-    static std::unique_ptr<PoseidonParams<P>> pp;
-    std::call_once(once, [] { pp.reset(new PoseidonParams<P>(make_poseidon_params<P>(RO_ARITY))); });
-    return *pp;
-}
-
-// ---- host field arithmetic for the sponge: 4 x 64-bit Montgomery limbs, lazy inner products -----------------------------------------
-// The permutation at width 25 is ~8 000 products, 5 000 of them in the dense layers of the 8 full rounds; a row of a dense layer is
-// an inner product of 25 terms, accumulated here as a 576-bit integer and reduced ONCE (16 + 400 word products instead of 800).
-typedef unsigned __int128 u128;
-struct H4 {
-    uint64_t v[4];
-};
-struct HostField {
-    uint64_t m[4], inv;  // modulus, -m^-1 mod 2^64
-};
-template <class P>
-static HostField host_field() {
-    HostField F;
-    for (int i = 0; i < 4; i++) F.m[i] = (uint64_t)P::mod(2 * i) | ((uint64_t)P::mod(2 * i + 1) << 32);
-    uint64_t ninv = (uint64_t)0 - (uint64_t)P::INV;  // m^-1 mod 2^32 in the low half
-    ninv *= 2 - F.m[0] * ninv;                        // Newton step: exact mod 2^64
-    F.inv = (uint64_t)0 - ninv;
-    return F;
-}
-template <class P>
-static H4 h4_from(const Fe<P>& x) {
-    H4 r;
-    for (int i = 0; i < 4; i++) r.v[i] = (uint64_t)x.l[2 * i] | ((uint64_t)x.l[2 * i + 1] << 32);
-    return r;
-}
-template <class P>
-static Fe<P> h4_to(const H4& x) {
-    Fe<P> r;
-    for (int i = 0; i < 4; i++) {
-        r.l[2 * i] = (uint32_t)x.v[i];
-        r.l[2 * i + 1] = (uint32_t)(x.v[i] >> 32);
-    }
-    return r;
-}
-static inline bool h4_geq(const uint64_t* a, const uint64_t* m) {
-    for (int i = 3; i >= 0; i--) {
-        if (a[i] > m[i]) return true;
-        if (a[i] < m[i]) return false;
-    }
-    return true;
-}
-static inline void h4_sub_m(uint64_t* a, const uint64_t* m) {
-    u128 br = 0;
-    for (int i = 0; i < 4; i++) {
-        const u128 d = (u128)a[i] - m[i] - br;
-        a[i] = (uint64_t)d;
-        br = (d >> 64) & 1;
-    }
-}
-static inline H4 h4_add(const HostField& F, const H4& a, const H4& b) {
-    H4 r;
-    u128 c = 0;
-    for (int i = 0; i < 4; i++) {
-        c += (u128)a.v[i] + b.v[i];
-        r.v[i] = (uint64_t)c;
-        c >>= 64;
-    }
-    if (c || h4_geq(r.v, F.m)) h4_sub_m(r.v, F.m);  // both inputs < m < 2^255: no carry out of 256 bits, but keep the test
-    return r;
-}
-// acc (9 limbs) += a * b
-static inline void h4_mac(uint64_t* acc, const H4& a, const H4& b) {
-    for (int i = 0; i < 4; i++) {
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) {
-            c += (u128)a.v[j] * b.v[i] + acc[i + j];
-            acc[i + j] = (uint64_t)c;
-            c >>= 64;
-        }
-        for (int k = i + 4; c && k < 9; k++) {
-            c += acc[k];
-            acc[k] = (uint64_t)c;
-            c >>= 64;
-        }
-    }
-}
-// Montgomery reduction of a 9-limb T < 2^576 with T / 2^256 < 2^62 m: (T + q m) / 2^256 mod m, fully reduced
-static inline H4 h4_redc9(const HostField& F, uint64_t* acc) {
-    for (int i = 0; i < 4; i++) {
-        const uint64_t q = acc[i] * F.inv;
-        u128 c = 0;
-        for (int j = 0; j < 4; j++) {
-            c += (u128)q * F.m[j] + acc[i + j];
-            acc[i + j] = (uint64_t)c;
-            c >>= 64;
-        }
-        for (int k = i + 4; c && k < 9; k++) {
-            c += acc[k];
-            acc[k] = (uint64_t)c;
-            c >>= 64;
-        }
-    }
-    uint64_t* t = acc + 4;  // 5 limbs: < T / 2^256 + m
-    // quotient estimate against 2^254 <= the Pasta moduli (BN254's r is just below 2^254: the estimate is then low, the loop below fixes it)
-    uint64_t q = (t[4] << 2) | (t[3] >> 62);
-    if (q) {
-        u128 c = 0, br = 0;
-        uint64_t qm[5];
-        for (int j = 0; j < 4; j++) {
-            c += (u128)q * F.m[j];
-            qm[j] = (uint64_t)c;
-            c >>= 64;
-        }
-        qm[4] = (uint64_t)c;
-        bool less = false;  // t < q m ?
-        for (int j = 4; j >= 0; j--) {
-            if (t[j] != qm[j]) { less = t[j] < qm[j]; break; }
-        }
-        if (less) {  // one too many: subtract (q - 1) m instead
-            q--;
-            c = 0;
-            for (int j = 0; j < 4; j++) {
-                c += (u128)q * F.m[j];
-                qm[j] = (uint64_t)c;
-                c >>= 64;
-            }
-            qm[4] = (uint64_t)c;
-        }
-        for (int j = 0; j < 5; j++) {
-            const u128 d = (u128)t[j] - qm[j] - br;
-            t[j] = (uint64_t)d;
-            br = (d >> 64) & 1;
-        }
-    }
-    while (t[4] || h4_geq(t, F.m)) {
-        u128 br = 0;
-        for (int j = 0; j < 5; j++) {
-            const u128 d = (u128)t[j] - (j < 4 ? F.m[j] : 0) - br;
-            t[j] = (uint64_t)d;
-            br = (d >> 64) & 1;
-        }
-    }
-    H4 r;
-    for (int i = 0; i < 4; i++) r.v[i] = t[i];
-    return r;
-}
-// sum_{i < n} a[i] * b[i * bstride] as a 9-limb integer, by columns (product scanning): the three-word column accumulator stays in
-// registers across all n terms, so a row of a dense layer costs its 16 n word products and nothing else
-static inline void h4_dot_columns(uint64_t* out9, const H4* a, const H4* b, int n, int bstride) {
-    u128 lo = 0;
-    uint64_t hi = 0;
-    for (int k = 0; k < 7; k++) {
-        const int i0 = k > 3 ? k - 3 : 0, i1 = k < 3 ? k : 3;
-        for (int t = 0; t < n; t++) {
-            const uint64_t* x = a[t].v;
-            const uint64_t* y = b[(size_t)t * bstride].v;
-            for (int i = i0; i <= i1; i++) {
-                const u128 p = (u128)x[i] * y[k - i];
-                lo += p;
-                hi += lo < p;
-            }
-        }
-        out9[k] = (uint64_t)lo;
-        lo = (lo >> 64) | ((u128)hi << 64);
-        hi = 0;
-    }
-    out9[7] = (uint64_t)lo;
-    out9[8] = (uint64_t)(lo >> 64);
-}
-static inline H4 h4_mul(const HostField& F, const H4& a, const H4& b) {
-    uint64_t acc[9] = {0};
-    h4_mac(acc, a, b);
-    return h4_redc9(F, acc);
-}
-static inline H4 h4_pow5(const HostField& F, const H4& x) {
-    const H4 x2 = h4_mul(F, x, x), x4 = h4_mul(F, x2, x2);
-    return h4_mul(F, x4, x);
-}
-
-// the sponge's constants in host form (the sparse schedule of poseidon_params.hpp), built once per field
-struct RoHost {
-    HostField F;
-    int t, rf, rp;
-    std::vector<H4> rc, mds, pre_sparse, sparse, partial_k, rc_after;
-    H4 r2;  // 2^512 mod m: canonical -> Montgomery
-};
-template <class P>
 static const RoHost& ro_host() {
-    static std::once_flag once;
-    static std::unique_ptr<RoHost> h;
-    std::call_once(once, [] {
-        const PoseidonParams<P>& pp = ro_params<P>();
-        h.reset(new RoHost());
-        h->F = host_field<P>();
-        h->t = pp.t;
-        h->rf = pp.rf;
-        h->rp = pp.rp;
-        auto conv = [](const std::vector<Fe<P>>& v) {
-            std::vector<H4> o;
-            for (auto& x : v) o.push_back(h4_from<P>(x));
-            return o;
-        };
-        h->rc = conv(pp.rc);
-        h->mds = conv(pp.mds);
-        h->pre_sparse = conv(pp.pre_sparse);
-        h->sparse = conv(pp.sparse);
-        h->partial_k = conv(pp.partial_k);
-        h->rc_after = conv(pp.rc_after);
-        h->r2 = h4_from<P>(fe_r2<P>());
-    });
-    return *h;
-}
-
-// u = Mat s, row-major (the Cauchy matrix is symmetric: the same as neptune's row-vector convention); one reduction per row
-static void dense_host(const RoHost& R, std::vector<H4>& s, const H4* mat) {
-    const int t = R.t;
-    std::vector<H4> u(t);
-    for (int j = 0; j < t; j++) {
-        uint64_t acc[9];
-        h4_dot_columns(acc, s.data(), mat + (size_t)j * t, t, 1);
-        u[j] = h4_redc9(R.F, acc);
-    }
-    s.swap(u);
-}
-// the same schedule as poseidon.cuh: poseidon_permute (full rounds, pre-sparse matrix, sparse partial rounds, full rounds)
-static void permute_host(const RoHost& R, std::vector<H4>& s) {
-    const int t = R.t, h = R.rf / 2;
-    for (int r = 0; r < h; r++) {
-        for (int i = 0; i < t; i++) s[i] = h4_pow5(R.F, h4_add(R.F, s[i], R.rc[(size_t)r * t + i]));
-        dense_host(R, s, r == h - 1 ? R.pre_sparse.data() : R.mds.data());
-    }
-    for (int p = 0; p < R.rp; p++) {
-        const H4* sp = &R.sparse[(size_t)p * (2 * t - 1)];
-        const H4 x = h4_pow5(R.F, h4_add(R.F, s[0], R.partial_k[p]));
-        const H4 s0 = s[0];
-        s[0] = x;  // the row (x n00 | s_i v_i) as one inner product over the state with x in front
-        uint64_t acc[9];
-        h4_dot_columns(acc, s.data(), sp, t, 1);
-        for (int i = 1; i < t; i++) s[i] = h4_add(R.F, s[i], h4_mul(R.F, x, sp[t - 1 + i]));
-        (void)s0;
-        s[0] = h4_redc9(R.F, acc);
-    }
-    for (int r = 0; r < h; r++) {
-        const H4* rc = r == 0 ? R.rc_after.data() : &R.rc[(size_t)(h + R.rp + r) * t];
-        for (int i = 0; i < t; i++) s[i] = h4_pow5(R.F, h4_add(R.F, s[i], rc[i]));
-        dense_host(R, s, R.mds.data());
-    }
+    static const RoHost& h = poseidon_host<P>(RO_ARITY);
+    return h;
 }
 
 // neptune sponge/api.rs: IOPattern::value

@@ -148,6 +148,23 @@ def poseidon_tree8(field: int, leaves: np.ndarray, want_levels: bool = False):
     return (root, levels) if want_levels else root
 
 
+def store_hydrate(field: int, records: np.ndarray, values: np.ndarray):
+    """StoreCore::hydrate_z_cache restated (oracle.c: orc_store_hydrate): records (n, 8) u32 {kind, tag, child[4], value, reserved},
+    values (m, 4) u64 canonical -> (digests (n, 4) canonical, number of levels)."""
+    rec = np.ascontiguousarray(records, dtype=np.uint32)
+    vals = np.ascontiguousarray(values, dtype=np.uint64)
+    n = rec.shape[0]
+    consts = [poseidon_consts(field, a) for a in (3, 4, 6, 8)]
+    rf = (ctypes.c_int * 4)(*[c[0] for c in consts])
+    rp = (ctypes.c_int * 4)(*[c[1] for c in consts])
+    rc = (ctypes.c_void_p * 4)(*[c[2].ctypes.data for c in consts])
+    mds = (ctypes.c_void_p * 4)(*[c[3].ctypes.data for c in consts])
+    out = np.empty((n, 4), dtype=np.uint64)
+    levels = ctypes.c_size_t()
+    lib().orc_store_hydrate(field, ctypes.c_void_p(rec.ctypes.data), ctypes.c_size_t(n), _p(vals), rf, rp, rc, mds, _p(out), ctypes.byref(levels))
+    return out, levels.value
+
+
 def msm_naive(curve: int, bases: np.ndarray, scalars: np.ndarray) -> np.ndarray:
     bases = np.ascontiguousarray(bases, dtype=np.uint64)
     scalars = np.ascontiguousarray(scalars, dtype=np.uint64)

@@ -204,6 +204,37 @@ def test_store_hydration_level_batches(hip):
     print("store hydrate: %d nodes, %d levels, %.1f ms" % (len(big), hydrate_device.last_levels, dt * 1e3))
 
 
+def test_store_hydration_deep_and_wide_dags_every_digest(hip):
+    """Both shapes bench.py --workload store_hydrate times, every digest against the oracle's hydration (oracle.c: orc_store_hydrate,
+    itself = the node-by-node recursion, tests/test_oracle_kat.py): the DEEP list DAG (a 400-cell spine: narrow levels go to the
+    library's host Poseidon, wide ones stay on the device, the digest array changes sides once) and a WIDE one (~5 x 10^5 nodes,
+    ~30 levels, all on the device but its top)."""
+    from lurk_beta_amd import store_hasher as SH
+
+    for f, dag in ((1, SH.list_dag(400)), (kat.BN, SH.list_dag(37)), (1, SH.wide_dag(12000))):
+        rec, vals = SH.encode(dag)
+        want, want_levels = C.store_hydrate(f, rec, vals)
+        got, levels = SH.hydrate_records(f, rec, vals)
+        assert levels == want_levels
+        assert np.array_equal(got, want), (f, len(dag))
+    # a DAG whose levels alternate between wide and narrow: the digest array changes sides at every level
+    nodes = []
+    prev = [SH._symbol_nodes(nodes, ["a%d" % j]) for j in range(64)]
+    for rnd in range(6):
+        nodes.append(("tuple2", 1, prev[0], prev[1]))                      # a narrow level (one node) ...
+        top = len(nodes) - 1
+        prev = [top] + prev[2:]
+        nxt = []
+        for j in range(len(prev)):                                         # ... then a wide one that depends on it
+            nodes.append(("tuple2", 1, prev[j], top))
+            nxt.append(len(nodes) - 1)
+        prev = nxt
+    rec, vals = SH.encode(nodes)
+    want, _ = C.store_hydrate(1, rec, vals)
+    got, _ = SH.hydrate_records(1, rec, vals)
+    assert np.array_equal(got, want)
+
+
 def test_full_size_tree_2_24(hip):
     """BASELINE configs[2] size (8^8 = 2^24 leaves, 2 396 745 hash8) through size-independent properties:
     (i) over BN254, a tree of zero leaves must reproduce element 8 of the trie's empty-root chain - the chain the
