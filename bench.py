@@ -71,6 +71,12 @@ def main():
                          "WRITE_SIZE in separate passes) and report the dominant kernel's HBM traffic per launch in roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-plain-leg", action="store_true", help="skip the plain-key synchronous sub-record (plain_sync)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="msm with --gpus N: weak = every rank its own 2^log_n points (the default the driver's --gpus sweep runs); strong = ONE commitment of "
+                         "2^log_n points cut across the ranks (2^log_n / N points per rank) - what a folding step's commitment does on N GPUs")
+    ap.add_argument("--devices", default="",
+                    help="fold_step: comma-separated device list, e.g. 0,0 or 0,1,2,3: the commitment key is cut across these devices inside ONE process "
+                         "(lurk_hip_msm_multi_* + lurk_hip_fold_ctx_create_multi); a repeated id puts several slices on one GPU (functional and overhead check)")
     ap.add_argument("--sub-records", choices=["auto", "off"], default="auto",
                     help="auto = the default msm line at N = 1 also carries the other workloads of the path as verified sub-records "
                          "(fold_step_rc100, poseidon_tree_2_24, ntt_2_24: each a child run of this file with --verify, same --steps / --warmup)")
@@ -121,6 +127,9 @@ def main():
         return other_workloads(args, lib, world, rank)
 
     n = 1 << args.log_n
+    if args.scaling == "strong":  # ONE commitment of 2^log_n points over all ranks
+        assert n % world == 0, "strong scaling: 2^log_n must divide by the number of ranks"
+        n //= world
     dist_id = 0 if args.dist == "uniform" else 1
     first = rank * n  # rank r owns points [r*n, (r+1)*n) of the global commitment
     d_bases = synth.bases(L.CURVE_PALLAS, n, first=first)
@@ -229,16 +238,17 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)",
             "data": "synthetic",
             "config": {
-                "workload": f"2^{args.log_n}-point Pallas Pedersen MSM per GPU ({args.dist} scalars), "
+                "workload": (f"2^{args.log_n}-point Pallas Pedersen MSM per GPU ({args.dist} scalars), " if args.scaling == "weak" else
+                             f"ONE 2^{args.log_n}-point Pallas Pedersen MSM cut across {world} GPU(s), {n} points per GPU ({args.dist} scalars), ") +
                             f"{'precomputed-table' if args.precompute else 'plain'} resident commitment key",
                 "points_per_gpu": n,
                 "total_points": total_points,
-                "window_bits": args.window_bits or ((16 if args.log_n <= 18 else 20) if args.precompute else 16),
+                "window_bits": msm_window_bits(args, n),
                 "parallelism": f"shard{world}+all_gather(96B)" if world > 1 else "single",
                 "commitments_in_flight": depth,
             },
@@ -253,13 +263,13 @@ def main():
                 "traffic_detail": traffic_detail,
                 "avg_launch_ms": round(acc_avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "mixed_additions_per_launch": msm_windows(args) * n,
+                "mixed_additions_per_launch": msm_windows(args, n) * n,
                 "note": "integer-VALU bound (v_mad_u64_u32 issue), not HBM bound: see roofline_valu and DESIGN.md",
             },
             # the honest ceiling for this kernel is VALU issue, not HBM: a mixed addition needs 1224 v_mad_u64_u32
             # (4.6 cycles per wave-instruction per SIMD, measured: profiles/r01_microbench_instr_rates.txt) on
             # 1024 SIMDs at the ~2.15 GHz the chip sustains here; shifts/masks/lazy adds come on top
-            "roofline_valu": valu_roofline(acc_avg_ms, msm_windows(args) * n),
+            "roofline_valu": valu_roofline(acc_avg_ms, msm_windows(args, n) * n),
             "kernel_ms_per_commit_sync": {k: round(v[0] / max(v[1], 1) * (v[1] / nsync), 4) for k, v in kernels.items()},
             "sync_ms_per_commit": round(sync_ms, 4),
             "setup_ms_once": round(setup_ms, 1),
@@ -395,19 +405,28 @@ def fold_step_workload(args, lib, world, rank):
     r_mont = np.array([((r_chal << 256) % q) >> (64 * w) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
     last_r = [r_mont]
     torch.cuda.synchronize()
-    ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else None
+    if devices:  # the key cut across a device list inside this process: slices commit concurrently, 96-byte partials summed on the host
+        assert not args.stage_ahead, "--devices: staging ahead is not available with a multi-device key"
+        ck = L.MultiCommitmentKey(L.CURVE_PALLAS, d_bases.cpu().numpy().view(np.uint64), devices, precompute=bool(args.precompute), window_bits=args.window_bits)
+    else:
+        ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     ctx = L.FoldingContext(L.CURVE_PALLAS, shape, ck)
     z1 = synth.scalars(F, 1, 1, n_w + 1 + n_io, mont=True).cpu().numpy().view(np.uint64)   # a running instance with witness-like values
     e1 = synth.scalars(F, 2, 0, n_t, mont=True).cpu().numpy().view(np.uint64)              # a running error vector (uniform, like any folded T)
     ident = np.zeros(12, dtype=np.uint64)
     # the running instance's commitments are the commitments of the running vectors (what RecursiveSNARK::verify re-computes)
-    ctx.set_running(z1, e1, ck.commit_device(torch.from_numpy(z1[:n_w].view(np.int64)).cuda(), n_w, is_mont=True),
-                    ck.commit_device(torch.from_numpy(e1.view(np.int64)).cuda(), n_t, is_mont=True))
+    if devices:
+        ctx.set_running(z1, e1, ck.commit(z1[:n_w], is_mont=True), ck.commit(e1, is_mont=True))
+    else:
+        ctx.set_running(z1, e1, ck.commit_device(torch.from_numpy(z1[:n_w].view(np.int64)).cuda(), n_w, is_mont=True),
+                        ck.commit_device(torch.from_numpy(e1.view(np.int64)).cuda(), n_t, is_mont=True))
 
     # --stage-ahead 1: the step circuit's range of the NEXT witness is traced and its commitment started before this
     # step opens (lurk-beta synthesizes witnesses ahead of the folding loop, nova.rs:304-326); the augmented circuit's own
     # variables depend on the previous fold and arrive with begin: modelled as the first 9 000 and the last 3 000 positions
-    ck.reserve(n_key, 4)
+    if not devices:
+        ck.reserve(n_key, 4)
     lo, hi = (9000, n_w - 3000) if args.stage_ahead and args.late_ranges else (0, n_w)
     late_host = synth.scalars(F, 10, 1, lo + n_w - hi, mont=True).cpu().numpy().view(np.uint64)
     patches = [(0, late_host[:lo]), (hi, late_host[lo:])] if lo else []
@@ -509,9 +528,10 @@ def fold_step_workload(args, lib, world, rank):
         res = {
             "metric": "equivalent Lurk iterations/s (synthetic stand-in for one Nova folding step, Pallas)",
             "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if devices else "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
             "config": {"staged_ahead": bool(args.stage_ahead), "witness_ahead": bool(args.witness_ahead and not args.stage_ahead),
+                       "devices": devices, "distinct_devices": len(set(devices)) if devices else 1,
                        "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
                                    f"slot blocks traced on the device + {rc} x 1311 body aux over PCIe) -> MSM(W2) + cross term over {n_t} rows ({nnz} non-zeros, "
                                    f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) -> fold of [W|u|X] and E",
@@ -1062,9 +1082,19 @@ def valu_roofline(acc_ms, mixed_adds):
             "unit": "G mixed-add/s", "frac": round(ach / peak, 4)}
 
 
-def msm_windows(args):
-    c = args.window_bits or ((16 if args.log_n <= 18 else 20) if args.precompute else 16)  # the library's own choice (msm.hip: set_bases_device)
-    return -(-256 // c)
+def msm_window_bits(args, n):
+    """the library's own choice for a key of n points (msm.hip: set_bases_device)"""
+    if args.window_bits:
+        return args.window_bits
+    if not args.precompute:
+        return 16
+    if n <= 1 << 16:
+        return 8 if n <= 1 << 14 else 6  # the small-commitment form
+    return 16 if n <= 1 << 18 else 20
+
+
+def msm_windows(args, n):
+    return -(-256 // msm_window_bits(args, n))
 
 
 def other_workloads(args, lib, world, rank):

@@ -203,6 +203,13 @@ int lurk_hip_msm_multi_commit(lurk_hip_msm_multi* ctx, void* out_jacobian96, con
                               int is_mont);
 int lurk_hip_msm_multi_commit_dev(lurk_hip_msm_multi* ctx, void* out_jacobian96, const void* const* d_scalars32,
                                   size_t n_slices, size_t nscalars, int is_mont); /* n_slices must equal num_shards */
+/* Asynchronous form (as lurk_hip_msm_ctx_submit_dev_mode / _wait, LURK_MSM_SLOTS slots): the slices of a commitment are submitted
+ * from the calling thread and run concurrently on their devices; after_streams (or NULL) holds, per slice, the stream ON THAT
+ * SLICE'S DEVICE that produced its scalars (e.g. the stream a peer copy into the device was enqueued on).  wait sums the partial
+ * commitments.  Two slots give commit(W) and commit(T) of a folding step in flight on every device at once. */
+int lurk_hip_msm_multi_submit_dev(lurk_hip_msm_multi* ctx, int slot, const void* const* d_scalars32, void* const* after_streams,
+                                  size_t n_slices, size_t nscalars, int is_mont, int mode);
+int lurk_hip_msm_multi_wait(lurk_hip_msm_multi* ctx, int slot, void* out_jacobian96);
 int lurk_hip_msm_multi_destroy(lurk_hip_msm_multi* ctx);
 
 /* Group helpers used by the multi-GPU gather (sum of per-rank partial commitments) and by tests:

@@ -67,6 +67,8 @@ SIGNATURES = {
     "lurk_hip_msm_multi_shard": (c_int, [c_void_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_size_t)]),
     "lurk_hip_msm_multi_commit": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_int]),
     "lurk_hip_msm_multi_commit_dev": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_size_t, c_size_t, c_int]),
+    "lurk_hip_msm_multi_submit_dev": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), c_size_t, c_size_t, c_int, c_int]),
+    "lurk_hip_msm_multi_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lurk_hip_msm_multi_destroy": (c_int, [c_void_p]),
     "lurk_hip_point_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     "lurk_hip_point_mul": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int]),

@@ -1347,6 +1347,8 @@ struct lurk_hip_msm_multi {
     size_t npoints = 0;
     std::vector<std::unique_ptr<Shard>> shards;
     std::mutex mu;  // one commitment at a time per multi-context
+    size_t pending_n[MSM_SLOTS] = {0, 0, 0, 0};  // asynchronous form: scalars of the commitment in flight on each slot
+    bool pending[MSM_SLOTS] = {false, false, false, false};
 
     // f(shard, count) on every shard that owns some of the first n scalars; waits for all of them
     template <class F>
@@ -1714,6 +1716,75 @@ int lurk_hip_msm_multi_commit_dev(lurk_hip_msm_multi* m, void* out, const void* 
             sh.ctx->run(d_scalars[idx], cnt, is_mont, nullptr, &sh.partial);
         });
         m->sum(n, out);
+    });
+}
+// Asynchronous form: the slices of one commitment are submitted on slot `slot` of every slice's context from the calling thread
+// (each under its own device guard: a submit only enqueues) and run concurrently on their devices; wait collects the partial
+// commitments in slice order and sums them with the host group law.  after_streams[i] (may be NULL) is the stream ON SLICE i's
+// DEVICE that produced slice i's scalars, e.g. the stream a peer copy into that device was enqueued on.
+int lurk_hip_msm_multi_submit_dev(lurk_hip_msm_multi* m, int slot, const void* const* d_scalars, void* const* after_streams, size_t n_slices, size_t n,
+                                  int is_mont, int mode) {
+    return guarded([&] {
+        LURK_REQUIRE(m, "null ctx");
+        LURK_REQUIRE(slot >= 0 && slot < MSM_SLOTS, "slot out of range");
+        LURK_REQUIRE(n_slices == m->shards.size(), "one device pointer per shard is required (n_slices != number of shards)");
+        LURK_REQUIRE(n <= m->npoints, "more scalars than bases in the context");
+        LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
+        LURK_REQUIRE(mode >= LURK_MSM_SUBMIT_DEFAULT && mode <= LURK_MSM_SUBMIT_BACKGROUND, "unknown submit mode");
+        std::lock_guard<std::mutex> lk(m->mu);
+        LURK_REQUIRE(!m->pending[slot], "slot is busy: wait for it first");
+        for (size_t i = 0; i < m->shards.size(); i++)
+            LURK_REQUIRE(m->shards[i]->lo >= n || m->shards[i]->lo == m->shards[i]->hi || d_scalars[i], "null shard pointer");
+        size_t done = 0;
+        try {
+            for (; done < m->shards.size(); done++) {
+                auto& sh = *m->shards[done];
+                if (sh.lo >= n || sh.lo == sh.hi) continue;
+                const size_t cnt = (sh.hi < n ? sh.hi : n) - sh.lo;
+                DeviceGuard dg(sh.worker->device());
+                sh.ctx->submit(slot, d_scalars[done], cnt, is_mont, after_streams ? (hipStream_t)after_streams[done] : nullptr, mode);
+            }
+        } catch (...) {  // what was submitted is drained: the key stays usable
+            for (size_t i = 0; i < done; i++) {
+                auto& sh = *m->shards[i];
+                if (sh.lo >= n || sh.lo == sh.hi) continue;
+                try {
+                    DeviceGuard dg(sh.worker->device());
+                    sh.ctx->wait(slot, &sh.partial);
+                } catch (...) {
+                }
+            }
+            throw;
+        }
+        m->pending[slot] = true;
+        m->pending_n[slot] = n;
+    });
+}
+int lurk_hip_msm_multi_wait(lurk_hip_msm_multi* m, int slot, void* out) {
+    return guarded([&] {
+        LURK_REQUIRE(m && out, "null argument");
+        LURK_REQUIRE(slot >= 0 && slot < MSM_SLOTS, "slot out of range");
+        std::lock_guard<std::mutex> lk(m->mu);
+        LURK_REQUIRE(m->pending[slot], "nothing was submitted on this slot");
+        m->pending[slot] = false;
+        const size_t n = m->pending_n[slot];
+        std::unique_ptr<HipFailure> first;
+        std::vector<Jacobian<PallasFp>> parts;
+        for (auto& sp : m->shards) {
+            auto& sh = *sp;
+            if (sh.lo >= n || sh.lo == sh.hi) continue;
+            Jacobian<PallasFp> part;
+            try {  // every slice is waited for even if one fails: nothing stays in flight
+                DeviceGuard dg(sh.worker->device());
+                sh.ctx->wait(slot, &part);
+                parts.push_back(part);
+            } catch (const HipFailure& e) {
+                if (!first) first.reset(new HipFailure(e));
+            }
+        }
+        if (first) throw *first;
+        if (m->curve == LURK_CURVE_PALLAS) point_sum_host<PallasFp>(parts.data(), parts.size(), out);
+        else point_sum_host<PallasFq>(parts.data(), parts.size(), out);
     });
 }
 int lurk_hip_msm_multi_destroy(lurk_hip_msm_multi* m) {

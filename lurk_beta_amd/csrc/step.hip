@@ -39,8 +39,24 @@ struct lurk_hip_fold_ctx {
     lurk_hip_r1cs* shape = nullptr;    // borrowed
     lurk_hip_msm_ctx* key = nullptr;   // borrowed
     lurk_hip_msm_multi* mkey = nullptr;  // borrowed: the key cut across several devices (lurk_hip_fold_ctx_create_multi) instead of `key`
-    struct ShardBuf { int device = 0; size_t first = 0, count = 0; DevBuf buf; };
-    std::vector<std::unique_ptr<ShardBuf>> shard_bufs;  // per slice of mkey: a scalar buffer on the slice's device
+    struct ShardBuf {  // per slice of mkey, on the slice's device: a buffer and a copy stream for W2's slice [0] and for T's [1]
+        int device = 0;
+        size_t first = 0, count = 0;
+        DevBuf buf[2];
+        hipStream_t copy_stream[2] = {nullptr, nullptr};
+        ~ShardBuf() {
+            for (int k = 0; k < 2; k++)
+                if (copy_stream[k]) {
+                    int prev = 0;
+                    (void)hipGetDevice(&prev);
+                    (void)hipSetDevice(device);
+                    (void)hipStreamDestroy(copy_stream[k]);
+                    (void)hipSetDevice(prev);
+                }
+        }
+    };
+    std::vector<std::unique_ptr<ShardBuf>> shard_bufs;
+    hipEvent_t t_ev = nullptr;         // multi-device key: T is complete on the context's stream
     size_t num_cons = 0, num_vars = 0, num_io = 0, ncols = 0;
     DevBuf z[2], e[2], t;              // running pair ping-pongs between two buffers (cur = index of the live one)
     DevBuf z2[2], zstaged[2], zpatch;  // fresh instances [W2 | 1 | X2]: the open step's and the one staged ahead; the staged ranges alone
@@ -73,6 +89,7 @@ struct lurk_hip_fold_ctx {
         for (int k = 0; k < 2; k++)
             if (stage_stream[k]) (void)hipStreamDestroy(stage_stream[k]);
         if (patch_ev) (void)hipEventDestroy(patch_ev);
+        if (t_ev) (void)hipEventDestroy(t_ev);
         if (w2_ready) (void)hipEventDestroy(w2_ready);
         for (int k = 0; k < 2; k++) {
             if (staged_ev[k]) (void)hipEventDestroy(staged_ev[k]);
@@ -309,17 +326,23 @@ static void fold_stage_and_begin(lurk_hip_fold_ctx* c, const void* w2, int on_de
 // The step's vectors live on the context's device (cross term, folds); a commitment pushes slice i of the vector peer-to-peer into
 // slice i's device, the slices commit concurrently (one host thread per device inside lurk_hip_msm_multi) and the 96-byte partial
 // commitments are summed with the host group law.  Nothing else crosses a link.
-static void fold_commit_multi(lurk_hip_fold_ctx* c, const void* d_vec, size_t n, void* out_jac96) {
+// Slice i of a vector of the step goes to slice i's device on that device's copy stream (ordered after `ready`, an event of the
+// context's device) and its commitment is submitted behind the copy; nothing blocks: both commitments of a step are in flight on
+// every device before the host waits for the first partial.
+static void fold_submit_multi(lurk_hip_fold_ctx* c, int which, const void* d_vec, size_t n, hipEvent_t ready) {
     std::vector<const void*> ptrs(c->shard_bufs.size(), nullptr);
+    std::vector<void*> streams(c->shard_bufs.size(), nullptr);
     for (size_t i = 0; i < c->shard_bufs.size(); i++) {
         auto& sb = *c->shard_bufs[i];
-        ptrs[i] = sb.buf.p;
+        ptrs[i] = sb.buf[which].p;
+        streams[i] = (void*)sb.copy_stream[which];
         if (sb.first >= n || sb.count == 0) continue;
         const size_t cnt = (sb.first + sb.count < n ? sb.first + sb.count : n) - sb.first;
-        LURK_HIP_CHECK(hipMemcpyPeerAsync(sb.buf.p, sb.device, (const char*)d_vec + sb.first * 32, c->device, cnt * 32, c->stage_stream[0]));
+        DeviceGuard dg(sb.device);
+        LURK_HIP_CHECK(hipStreamWaitEvent(sb.copy_stream[which], ready, 0));
+        LURK_HIP_CHECK(hipMemcpyPeerAsync(sb.buf[which].p, sb.device, (const char*)d_vec + sb.first * 32, c->device, cnt * 32, sb.copy_stream[which]));
     }
-    LURK_HIP_CHECK(hipStreamSynchronize(c->stage_stream[0]));
-    ok(lurk_hip_msm_multi_commit_dev(c->mkey, out_jac96, ptrs.data(), ptrs.size(), n, 1));
+    ok(lurk_hip_msm_multi_submit_dev(c->mkey, which, ptrs.data(), streams.data(), ptrs.size(), n, 1, LURK_MSM_SUBMIT_FOREGROUND));
 }
 
 static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device, void* w2_stream, const void* x2_mont, void* comm_w2_jac96,
@@ -346,11 +369,27 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
     LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, need, hipMemcpyHostToDevice, c->stage_stream[0]));
     LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream[0]));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
-    ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));  // beside commit(W2)
-    fold_instance_settle(c);
-    fold_commit_multi(c, z2, c->num_vars, comm_w2_jac96);
-    LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
-    fold_commit_multi(c, c->t.p, c->num_cons, comm_t_jac96);
+    ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));  // beside the slices' copies and commit(W2)'s sorts
+    LURK_HIP_CHECK(hipEventRecord(c->t_ev, c->stream));
+    bool w_in_flight = false, t_in_flight = false;
+    try {
+        fold_submit_multi(c, 0, z2, c->num_vars, c->staged_ev[b]);
+        w_in_flight = true;
+        fold_submit_multi(c, 1, c->t.p, c->num_cons, c->t_ev);
+        t_in_flight = true;
+        fold_instance_settle(c);  // the previous step's instance fold, while the devices work on this step
+        w_in_flight = false;
+        ok(lurk_hip_msm_multi_wait(c->mkey, 0, comm_w2_jac96));
+        t_in_flight = false;
+        ok(lurk_hip_msm_multi_wait(c->mkey, 1, comm_t_jac96));
+    } catch (...) {  // nothing stays in flight: the context and the key remain usable, the same begin can be repeated
+        uint64_t junk[12];
+        if (w_in_flight) (void)lurk_hip_msm_multi_wait(c->mkey, 0, junk);
+        if (t_in_flight) (void)lurk_hip_msm_multi_wait(c->mkey, 1, junk);
+        (void)hipStreamSynchronize(c->stage_stream[0]);
+        (void)hipStreamSynchronize(c->stream);
+        throw;
+    }
     c->open_buf = b;
     c->begun = true;
     c->open_x2.assign((const uint64_t*)x2_mont, (const uint64_t*)x2_mont + 4 * c->num_io);
@@ -409,7 +448,10 @@ static void fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* s
             ok(lurk_hip_msm_multi_shard(mkey, i, &sb->device, &sb->first, &sb->count));
             total += sb->count;
             DeviceGuard sg(sb->device);
-            sb->buf.alloc(sb->count * 32);
+            for (int k = 0; k < 2; k++) {
+                sb->buf[k].alloc(sb->count * 32);
+                LURK_HIP_CHECK(hipStreamCreateWithFlags(&sb->copy_stream[k], hipStreamNonBlocking));
+            }
             c->shard_bufs.push_back(std::move(sb));
         }
         LURK_REQUIRE(total >= c->num_vars && total >= c->num_cons, "the multi-device key is shorter than the step's vectors");
@@ -428,6 +470,7 @@ static void fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* s
     for (int k = 0; k < 2; k++) LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream[k], hipStreamNonBlocking));
     LURK_HIP_CHECK(hipEventCreateWithFlags(&c->patch_ev, hipEventDisableTiming));
     LURK_HIP_CHECK(hipEventCreateWithFlags(&c->w2_ready, hipEventDisableTiming));
+    LURK_HIP_CHECK(hipEventCreateWithFlags(&c->t_ev, hipEventDisableTiming));
     for (int k = 0; k < 2; k++) {
         c->z2[k].alloc(c->ncols * 32);
         LURK_HIP_CHECK(hipEventCreateWithFlags(&c->staged_ev[k], hipEventDisableTiming));

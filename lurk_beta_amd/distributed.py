@@ -20,6 +20,9 @@ import numpy as np
 from .msm import CommitmentKey, point_sum
 
 
+_GATHER_BUFS: dict = {}
+
+
 def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int]:
     """Contiguous slice [lo, hi) of rank `rank`; the first n_total % world ranks get one extra point."""
     base, extra = divmod(n_total, world)
@@ -34,12 +37,26 @@ def gather_partials(partial: np.ndarray, group=None) -> np.ndarray:
 
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
-    t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64).copy())
     if backend == "nccl":
-        t = t.cuda()
+        # RCCL moves device buffers: one pinned staging row in, ONE collective into a resident (world, 12) tensor, one copy out -
+        # the buffers are kept per (group, world) so that a commitment allocates nothing (a step makes two of these exchanges)
+        key = (id(group), world)
+        bufs = _GATHER_BUFS.get(key)
+        if bufs is None:
+            bufs = (torch.empty(12, dtype=torch.int64).pin_memory(), torch.empty(12, dtype=torch.int64, device="cuda"),
+                    torch.empty((world, 12), dtype=torch.int64, device="cuda"), torch.empty((world, 12), dtype=torch.int64).pin_memory())
+            _GATHER_BUFS[key] = bufs
+        h_in, d_in, d_out, h_out = bufs
+        h_in.numpy()[:] = np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64)
+        d_in.copy_(h_in, non_blocking=True)
+        dist.all_gather_into_tensor(d_out, d_in, group=group)
+        h_out.copy_(d_out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return h_out.numpy().view(np.uint64).copy()
+    t = torch.from_numpy(np.ascontiguousarray(partial, dtype=np.uint64).view(np.int64).copy())
     out = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(out, t, group=group)
-    return torch.stack(out).cpu().numpy().view(np.uint64)
+    return torch.stack(out).numpy().view(np.uint64)
 
 
 def allreduce_commitment(curve: int, partial: np.ndarray, group=None) -> np.ndarray:

@@ -212,6 +212,21 @@ class MultiCommitmentKey:
         _lib.check(lib.lurk_hip_msm_multi_commit_dev(self._ctx, _lib.ptr(out), ptrs, len(d_slices), n, int(is_mont)))
         return out
 
+    def submit_device(self, slot: int, d_slices, n: int, is_mont: bool = False, streams=None, mode: int = 0) -> None:
+        """Asynchronous form: slice i's scalars on slice i's device, ordered after ``streams[i]`` (a stream of that device)."""
+        lib = _lib.load()
+        ptrs = (ctypes.c_void_p * len(d_slices))(*[_lib.ptr(x) for x in d_slices])
+        strs = (ctypes.c_void_p * len(d_slices))(*[_lib.ptr(x) for x in (streams or [None] * len(d_slices))])
+        self._keep = getattr(self, "_keep", {})
+        self._keep[slot] = d_slices
+        _lib.check(lib.lurk_hip_msm_multi_submit_dev(self._ctx, slot, ptrs, strs, len(d_slices), n, int(is_mont), mode))
+
+    def wait(self, slot: int) -> np.ndarray:
+        out = np.zeros(12, dtype=np.uint64)
+        _lib.check(_lib.load().lurk_hip_msm_multi_wait(self._ctx, slot, _lib.ptr(out)))
+        getattr(self, "_keep", {}).pop(slot, None)
+        return out
+
     def close(self):
         if self._ctx:
             _lib.load().lurk_hip_msm_multi_destroy(self._ctx)

@@ -390,6 +390,43 @@ def test_multi_device_key_one_process(hip, cn, c):
         MultiCommitmentKey(c, B, [0, 4096])
 
 
+def test_multi_device_key_commitments_in_flight(hip):
+    """lurk_hip_msm_multi_submit_dev / _wait: two commitments in flight on every slice of a device list (the folding step's W2 and T),
+    each slice's scalars produced on a stream of its own, == the oracle; prefixes that end inside a slice; a busy slot is refused and
+    leaves the key usable."""
+    import torch
+
+    from lurk_beta_amd import LurkHipError, MultiCommitmentKey, point_to_affine
+
+    c, sf, n = 0, 1, 70001
+    B = C.synth_bases(c, n)
+    S = [C.synth_scalars(sf, 51 + k, k % 2, n) for k in range(3)]
+    for devices, pre in (([0, 0], True), ([0, 0, 0, 0], False)):
+        mk = MultiCommitmentKey(c, B, devices, precompute=pre, window_bits=16 if pre else 0)
+        sh = mk.shards()
+        streams = [torch.cuda.Stream() for _ in sh]
+        for m_w, m_t in ((n, n - 5), (sh[0][2] + 3, 11), (n, 0)):
+            slices = []
+            for k, m in ((0, m_w), (1, m_t)):
+                row = []
+                for (_, f, cnt), st in zip(sh, streams):
+                    with torch.cuda.stream(st):  # produced on the slice's own stream: the submit must order itself behind it
+                        row.append(torch.from_numpy(np.ascontiguousarray(C.to_mont(sf, S[k][f:f + cnt])).view(np.int64)).cuda(non_blocking=True) + 0)
+                slices.append(row)
+            raw = [st.cuda_stream for st in streams]
+            mk.submit_device(0, slices[0], m_w, is_mont=True, streams=raw, mode=1)
+            mk.submit_device(1, slices[1], m_t, is_mont=True, streams=raw, mode=1)
+            with pytest.raises(LurkHipError, match="busy"):
+                mk.submit_device(1, slices[0], m_w, is_mont=True, streams=raw)
+            got_w, got_t = mk.wait(0), mk.wait(1)
+            assert point_to_affine(c, got_w) == C.jac_to_affine(c, C.msm_pippenger(c, B[:m_w], S[0][:m_w])), (devices, m_w)
+            assert point_to_affine(c, got_t) == (C.jac_to_affine(c, C.msm_pippenger(c, B[:m_t], S[1][:m_t])) if m_t else (0, 0)), (devices, m_t)
+            with pytest.raises(LurkHipError):
+                mk.wait(0)
+        assert point_to_affine(c, mk.commit(S[2])) == C.jac_to_affine(c, C.msm_pippenger(c, B, S[2]))  # the synchronous form still works
+        mk.close()
+
+
 def test_multi_device_full_size(hip):
     """2^22 points over the device list [0, 0] through the host-pointer commit, dlog checksum."""
     from lurk_beta_amd import MultiCommitmentKey, point_to_affine, synth
