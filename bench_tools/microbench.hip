@@ -167,6 +167,100 @@ __global__ void k_feadd(const Fe<P>* in, Fe<P>* out, int iters) {
     out[i] = fe_add<P>(x, y);
 }
 
+// ---- the FP64-FMA field multiplier experiment (round-3 verdict, item 4) ---------------------------------------------------------
+// Pallas Fp in five 52-bit limbs held as doubles; a 52 x 52 -> 104-bit product by the two-FMA split under round-toward-zero
+// (Emmart, Zheng, Weems: "Faster modular exponentiation using double precision floating point arithmetic on the GPU", ARITH 2018):
+//     hi = fma(a, b, 2^104)            mantissa = floor(ab / 2^52)
+//     lo = fma(a, b, (2^104 + 2^52) - hi)   mantissa = ab mod 2^52 (exact)
+// the mantissas are accumulated as 64-bit integers (v_lshl_add_u64), the exponent biases are taken off once per column.  Montgomery
+// form with R' = 2^260, operand scanning, q_i = t_0 * (-p^-1) mod 2^52 by the same split; p's 52-bit limbs are
+// {0xd30ed00000001, 0xfc094cf91b992, 0x224698, 0, 2^46}: 4 of 5 non-zero.  Per product: 25 + 5 + 20 = 50 limb products of
+// 2 FMAs + 1 FP add + 2 integer adds each, all quarter-rate instructions like v_mad_u64_u32 (which covers 32 x 32 + 64 in ONE).
+__device__ __forceinline__ void fp64_split(double a, double b, unsigned long long& hi_acc, unsigned long long& lo_acc) {
+    const double C1 = 0x1p104, C2 = 0x1p104 + 0x1p52;
+    double hi, lo, sub;
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(hi) : "v"(a), "v"(b), "v"(C1));
+    asm volatile("v_add_f64 %0, %1, -%2" : "=v"(sub) : "v"(C2), "v"(hi));
+    asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(lo) : "v"(a), "v"(b), "v"(sub));
+    hi_acc += (unsigned long long)__double_as_longlong(hi);
+    lo_acc += (unsigned long long)__double_as_longlong(lo);
+}
+__device__ __forceinline__ double fp64_from52(unsigned long long m) {  // m < 2^52 -> the double m, exactly
+    return __longlong_as_double((long long)(m | 0x4330000000000000ull)) - 0x1p52;
+}
+struct Fp64x5 { double l[5]; };
+__device__ __forceinline__ Fp64x5 fp64_mont_mul_pallas(const Fp64x5& a, const Fp64x5& b) {
+    const unsigned long long M52 = (1ull << 52) - 1, B_HI = 0x4670000000000000ull /* bits(2^104) */, B_LO = 0x4330000000000000ull /* bits(2^52) */;
+    const double P0 = (double)0xd30ed00000001ull, P1 = (double)0xfc094cf91b992ull, P2 = (double)0x224698ull, P4 = 0x1p46, NINV = (double)0xd30ecffffffffull;
+    unsigned long long t[7] = {0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        unsigned long long hi[5] = {0, 0, 0, 0, 0}, lo[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 5; j++) fp64_split(a.l[j], b.l[i], hi[j], lo[j]);
+#pragma unroll
+        for (int j = 0; j < 5; j++) { t[j] += lo[j] - B_LO; t[j + 1] += hi[j] - B_HI; }
+        unsigned long long qh = 0, ql = 0;
+        fp64_split(fp64_from52(t[0] & M52), NINV, qh, ql);
+        const double q = fp64_from52((ql - B_LO) & M52);
+        unsigned long long h0 = 0, l0 = 0, h1 = 0, l1 = 0, h2 = 0, l2 = 0, h4 = 0, l4 = 0;
+        fp64_split(q, P0, h0, l0);
+        fp64_split(q, P1, h1, l1);
+        fp64_split(q, P2, h2, l2);
+        fp64_split(q, P4, h4, l4);
+        t[0] += l0 - B_LO; t[1] += (h0 - B_HI) + (l1 - B_LO); t[2] += (h1 - B_HI) + (l2 - B_LO); t[3] += h2 - B_HI; t[4] += l4 - B_LO; t[5] += h4 - B_HI;
+        // t[0] is now a multiple of 2^52: shift the accumulator down one limb
+        t[1] += t[0] >> 52;
+        t[0] = t[1]; t[1] = t[2]; t[2] = t[3]; t[3] = t[4]; t[4] = t[5]; t[5] = 0;
+    }
+    // carry the columns into 52-bit limbs; the value is < 2 p
+    unsigned long long c = 0, r[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) { const unsigned long long v = t[j] + c; r[j] = v & M52; c = v >> 52; }
+    // one conditional subtraction of p (limbs as integers)
+    const unsigned long long PL[5] = {0xd30ed00000001ull, 0xfc094cf91b992ull, 0x224698ull, 0ull, 0x400000000000ull};
+    unsigned long long d[5];
+    long long br = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) { const long long v = (long long)r[j] - (long long)PL[j] + br; d[j] = (unsigned long long)v & M52; br = v >> 52; }
+    Fp64x5 o;
+#pragma unroll
+    for (int j = 0; j < 5; j++) o.l[j] = fp64_from52(br < 0 ? r[j] : d[j]);
+    return o;
+}
+__device__ __forceinline__ Fp64x5 fp64_from_fe(const Fe<PallasFp>& x) {
+    unsigned long long w[4];
+    for (int i = 0; i < 4; i++) w[i] = (unsigned long long)x.l[2 * i] | ((unsigned long long)x.l[2 * i + 1] << 32);
+    const unsigned long long M52 = (1ull << 52) - 1;
+    Fp64x5 o;
+    o.l[0] = fp64_from52(w[0] & M52);
+    o.l[1] = fp64_from52(((w[0] >> 52) | (w[1] << 12)) & M52);
+    o.l[2] = fp64_from52(((w[1] >> 40) | (w[2] << 24)) & M52);
+    o.l[3] = fp64_from52(((w[2] >> 28) | (w[3] << 36)) & M52);
+    o.l[4] = fp64_from52(w[3] >> 16);
+    return o;
+}
+__device__ __forceinline__ Fe<PallasFp> fp64_to_fe(const Fp64x5& x) {
+    unsigned long long m[5];
+    for (int j = 0; j < 5; j++) m[j] = (unsigned long long)__double_as_longlong(x.l[j] + 0x1p52) & ((1ull << 52) - 1);
+    unsigned long long w[4] = {m[0] | (m[1] << 52), (m[1] >> 12) | (m[2] << 40), (m[2] >> 24) | (m[3] << 28), (m[3] >> 36) | (m[4] << 16)};
+    Fe<PallasFp> o;
+    for (int i = 0; i < 4; i++) { o.l[2 * i] = (uint32_t)w[i]; o.l[2 * i + 1] = (uint32_t)(w[i] >> 32); }
+    return o;
+}
+// the same chain as k_femul: x <- x * y / 2^256; with R' = 2^260 the multiplier enters as 16 y, so that x * (16 y) / 2^260 = x * y / 2^256
+__global__ void k_fp64mul(const Fe<PallasFp>* in, Fe<PallasFp>* out, int iters) {
+    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);  // MODE.FP_ROUND[3:2] (f64 / f16) = round toward zero
+    size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+    Fe<PallasFp> y16 = in[2 * i + 1];
+    for (int k = 0; k < 4; k++) y16 = fe_add<PallasFp>(y16, y16);
+    Fp64x5 x = fp64_from_fe(in[2 * i]);
+    const Fp64x5 y = fp64_from_fe(y16);
+    for (int k = 0; k < iters; k++) x = fp64_mont_mul_pallas(x, y);
+    out[i] = fp64_to_fe(x);
+    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 0);
+}
+
 static double time_kernel(std::function<void()> f, int reps = 3) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
@@ -234,6 +328,12 @@ int main() {
       CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o1, n * 32, hipMemcpyDeviceToHost));
       size_t bad = 0; for (size_t i = 0; i < n * 8; i++) bad += r0[i] != r1[i];
       printf("  Pallas: radix-2^29 chain vs cios chain mismatching words: %zu (of %zu)\n", bad, n * 8); }
+    { double ms = time_kernel([&] { hipLaunchKernelGGL(k_fp64mul, dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });
+      printf("%-28s %8.3f ms  %8.2f G field-mul/s\n", "fp64-FMA mul Pallas (5x52)", ms, (double)n * MI / ms / 1e6);
+      std::vector<uint32_t> r0(n * 8), r1(n * 8);
+      CK(hipMemcpy(r0.data(), d_o0, n * 32, hipMemcpyDeviceToHost)); CK(hipMemcpy(r1.data(), d_o2, n * 32, hipMemcpyDeviceToHost));
+      size_t bad = 0; for (size_t i = 0; i < n * 8; i++) bad += r0[i] != r1[i];
+      printf("  Pallas: fp64-FMA chain vs cios chain mismatching words: %zu (of %zu)\n", bad, n * 8); }
     { double ms = time_kernel([&] { hipLaunchKernelGGL((k_f29dotmul<PallasFp>), dim3(blocks), dim3(threads), 0, 0, (const Fe<PallasFp>*)d_in, (Fe<PallasFp>*)d_o2, MI); });
       printf("%-28s %8.3f ms  %8.2f G field-mul/s\n", "f29 1-term lazy row (C++)", ms, (double)n * MI / ms / 1e6);
       std::vector<uint32_t> r0(n * 8), r1(n * 8);

@@ -443,6 +443,15 @@ typedef int (*lurk_hip_sumcheck_challenge_fn)(void* user, int round, const void*
 int lurk_hip_sumcheck_prove_dev(int field_id, int degree, void* const* d_polys, size_t len, const void* claim32_canonical,
                                 lurk_hip_sumcheck_challenge_fn challenge, void* user, void* out_polys, void* out_finals,
                                 void* out_claim32, void* stream);
+/* Batched form: sum_i coeff_i * sum_x comb(tables of instance i) with ONE challenge per round shared by all instances - the
+ * evaluation-claim batching of arecibo's RelaxedR1CSSNARK and the outer / inner sum-checks of its BatchedRelaxedR1CSSNARK (SuperNova's
+ * compressor, /root/reference/src/proof/supernova.rs:110, 293-302).  d_polys: n_instances x (4 or 2) device tables, instance-major, all
+ * of length len (shorter instances zero-padded by the caller); coeffs32_canonical: n_instances batching coefficients; claim: the
+ * COMBINED claim sum_i coeff_i claim_i.  out_finals: n_instances x (4 or 2) x 32 B, the tables' final evaluations, instance-major. */
+int lurk_hip_sumcheck_prove_batch_dev(int field_id, int degree, size_t n_instances, void* const* d_polys, size_t len,
+                                      const void* coeffs32_canonical, const void* claim32_canonical,
+                                      lurk_hip_sumcheck_challenge_fn challenge, void* user, void* out_polys, void* out_finals,
+                                      void* out_claim32, void* stream);
 int lurk_hip_eq_evals_dev(int field_id, const void* r32_mont, int ell, void* d_out, void* stream);
 
 /* ---- inner-product argument rounds (the opening half of CompressedSNARK::prove) ------------------

@@ -170,10 +170,21 @@ static void sumcheck_round(int np, void* const* d_polys, size_t len, const void*
 // ---- a whole sum-check as host code of the library (arecibo SumcheckProof::prove_quad / prove_cubic_with_additive_term behind
 // /root/reference/src/proof/nova.rs:341-356): the round loop of lurk_beta_amd/sumcheck.py: prove - one launch per round, the round
 // polynomial interpolated from its evaluations at 0, 2 (, 3) and the running claim, the transcript's challenge from a callback.
+// Batched form (ninst > 1): sum_i coeff_i * sum_x comb(tables of instance i) with ONE challenge per round shared by every instance - the
+// evaluation-claim batching of arecibo's snark.rs and the outer / inner sum-checks of its BatchedRelaxedR1CSSNARK
+// (/root/reference/src/proof/supernova.rs:110, 293-302): per round one launch per instance, the evaluations combined with the
+// coefficients on the host, one interpolation, one callback.  d_polys holds ninst x np tables, instance-major, all of length n.
 template <class F>
-static void sumcheck_prove(int np, void* const* d_polys, size_t n, const void* claim32_canonical, lurk_hip_sumcheck_challenge_fn challenge, void* user,
-                           uint64_t* out_polys, uint64_t* out_finals, void* out_claim32, hipStream_t s) {
+static void sumcheck_prove(int np, size_t ninst, void* const* d_polys, size_t n, const void* coeffs32_canonical, const void* claim32_canonical,
+                           lurk_hip_sumcheck_challenge_fn challenge, void* user, uint64_t* out_polys, uint64_t* out_finals, void* out_claim32, hipStream_t s) {
     const bool cubic = np == 4;
+    std::vector<Fe<F>> coeff(ninst, fe_one<F>());
+    for (size_t i = 0; coeffs32_canonical && i < ninst; i++) {
+        Fe<F> c;
+        memcpy(c.l, (const char*)coeffs32_canonical + 32 * i, 32);
+        LURK_REQUIRE(!fe_canonical_ge_mod<F>(c.l), "a batching coefficient is not reduced modulo the field order");
+        coeff[i] = fe_to_mont<F>(c);
+    }
     const int nv = cubic ? 3 : 2, ncoef = cubic ? 4 : 3;
     const Fe<F> two = fe_from_u64<F>(2), three = fe_from_u64<F>(3), inv2 = fe_inv<F>(two), inv6 = fe_inv<F>(fe_from_u64<F>(6));
     Fe<F> claim;
@@ -185,8 +196,12 @@ static void sumcheck_prove(int np, void* const* d_polys, size_t n, const void* c
     bool have_r = false;
     int j = 0;
     for (size_t m = n; m > 1; m /= 2, j++) {
-        Fe<F> ev[3];
-        sumcheck_round<F>(np, d_polys, length, have_r ? (const void*)r.l : nullptr, ev, s);  // Montgomery images of the evaluations at 0, 2 (, 3)
+        Fe<F> ev[3] = {fe_zero<F>(), fe_zero<F>(), fe_zero<F>()};
+        for (size_t i = 0; i < ninst; i++) {
+            Fe<F> one_ev[3];
+            sumcheck_round<F>(np, d_polys + i * np, length, have_r ? (const void*)r.l : nullptr, one_ev, s);  // Montgomery images of the evaluations at 0, 2 (, 3)
+            for (int k = 0; k < nv; k++) ev[k] = ninst == 1 && !coeffs32_canonical ? one_ev[k] : fe_add<F>(ev[k], fe_mul<F>(coeff[i], one_ev[k]));
+        }
         if (have_r) length /= 2;
         const Fe<F> e0 = ev[0], e2 = ev[1], e1 = fe_sub<F>(claim, e0);
         Fe<F> poly[4];
@@ -220,8 +235,8 @@ static void sumcheck_prove(int np, void* const* d_polys, size_t n, const void* c
         for (int k = ncoef - 1; k >= 0; k--) acc = fe_add<F>(fe_mul<F>(acc, r), poly[k]);
         claim = acc;
     }
-    if (have_r) sumcheck_round<F>(np, d_polys, length, r.l, nullptr, s);  // the last bind: every table is down to one element
-    for (int k = 0; k < np; k++) {
+    for (size_t i = 0; have_r && i < ninst; i++) sumcheck_round<F>(np, d_polys + i * np, length, r.l, nullptr, s);  // the last bind: every table is down to one element
+    for (size_t k = 0; k < ninst * (size_t)np; k++) {
         Fe<F> v;
         LURK_HIP_CHECK(hipMemcpyAsync(v.l, d_polys[k], 32, hipMemcpyDeviceToHost, s));
         LURK_HIP_CHECK(hipStreamSynchronize(s));
@@ -263,9 +278,26 @@ int lurk_hip_sumcheck_prove_dev(int field_id, int degree, void* const* d_polys, 
         LURK_REQUIRE(len >= 2 && (len & (len - 1)) == 0, "table length must be a power of two >= 2");
         const int np = degree == 3 ? 4 : 2;
         for (int k = 0; k < np; k++) LURK_REQUIRE(d_polys[k], "null table");
-        if (field_id == 0) sumcheck_prove<PallasFp>(np, d_polys, len, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
-        else if (field_id == 1) sumcheck_prove<PallasFq>(np, d_polys, len, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
-        else sumcheck_prove<Bn254Fr>(np, d_polys, len, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
+        if (field_id == 0) sumcheck_prove<PallasFp>(np, 1, d_polys, len, nullptr, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
+        else if (field_id == 1) sumcheck_prove<PallasFq>(np, 1, d_polys, len, nullptr, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
+        else sumcheck_prove<Bn254Fr>(np, 1, d_polys, len, nullptr, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_sumcheck_prove_batch_dev(int field_id, int degree, size_t n_instances, void* const* d_polys, size_t len, const void* coeffs32_canonical,
+                                      const void* claim32_canonical, lurk_hip_sumcheck_challenge_fn challenge, void* user, void* out_polys,
+                                      void* out_finals, void* out_claim32, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(degree == 2 || degree == 3, "degree must be 2 (a b) or 3 (a (b c - d))");
+        LURK_REQUIRE(n_instances >= 1 && n_instances <= 4096, "instance count out of range");
+        LURK_REQUIRE(d_polys && coeffs32_canonical && claim32_canonical && challenge && out_polys && out_finals && out_claim32, "null argument");
+        LURK_REQUIRE(len >= 2 && (len & (len - 1)) == 0, "table length must be a power of two >= 2");
+        const int np = degree == 3 ? 4 : 2;
+        for (size_t k = 0; k < n_instances * (size_t)np; k++) LURK_REQUIRE(d_polys[k], "null table");
+        if (field_id == 0) sumcheck_prove<PallasFp>(np, n_instances, d_polys, len, coeffs32_canonical, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
+        else if (field_id == 1) sumcheck_prove<PallasFq>(np, n_instances, d_polys, len, coeffs32_canonical, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
+        else sumcheck_prove<Bn254Fr>(np, n_instances, d_polys, len, coeffs32_canonical, claim32_canonical, challenge, user, (uint64_t*)out_polys, (uint64_t*)out_finals, out_claim32, (hipStream_t)stream);
     });
 }
 

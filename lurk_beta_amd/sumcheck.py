@@ -75,48 +75,51 @@ def prove(field_id: int, modulus: int, claim: int, tables, challenge, stream=Non
     return [_ints(out_polys[j]) for j in range(rounds)], _ints(out_finals), _ints(out_claim)[0]
 
 
-def prove_quad_batch(field_id: int, modulus: int, claims, pairs, coeffs, challenge, stream=None):
-    """sum_i coeff_i * sum_x A_i(x) B_i(x) with ONE challenge per round shared by every pair (the evaluation-claim batching of
-    arecibo's snark.rs).  pairs: [(A_i, B_i)] device tensors of one common length (consumed); challenge(poly) -> r.
-    Returns (round polynomials, challenges, [(A_i(r), B_i(r))], final claim)."""
+def _prove_batch(field_id: int, modulus: int, degree: int, groups, coeffs, claim: int, challenge, stream=None):
+    """The batched round loop is host code of the library (lurk_hip_sumcheck_prove_batch_dev: what a Rust caller binds); this wrapper
+    only marshals.  groups: per instance its 2 (degree 2) or 4 (degree 3) device tables, all of one length (consumed)."""
     import torch
 
     lib = _lib.load()
     p = modulus
-    R = (1 << 256) % p
-    Rinv = pow(R, p - 2, p)
-    inv2 = pow(2, p - 2, p)
-    n = pairs[0][0].shape[0]
+    np_t = 4 if degree == 3 else 2
+    n = groups[0][0].shape[0]
+    assert all(len(g) == np_t and all(t.is_cuda and t.shape[0] == n for t in g) for g in groups) and n >= 2 and n & (n - 1) == 0
     s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-    ptrs = [(ctypes.c_void_p * 2)(_lib.ptr(a), _lib.ptr(b)) for a, b in pairs]
-    claim = sum(c * e for c, e in zip(coeffs, claims)) % p
-    polys, rs, length, r_prev = [], [], n, None
-    for _ in range(n.bit_length() - 1):
-        e0 = e2 = 0
-        rm = None if r_prev is None else _limbs([r_prev * R % p])
-        for c, pp in zip(coeffs, ptrs):
-            ev = np.zeros((2, 4), dtype=np.uint64)
-            _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 2, pp, length, None if rm is None else _lib.ptr(rm), _lib.ptr(ev), _lib.ptr(s)))
-            a0, a2 = [x * Rinv % p for x in _ints(ev)]
-            e0, e2 = (e0 + c * a0) % p, (e2 + c * a2) % p
-        if r_prev is not None:
-            length //= 2
-        e1 = (claim - e0) % p
-        a2c = (e2 - 2 * e1 + e0) * inv2 % p
-        poly = [e0, (e1 - e0 - a2c) % p, a2c]
-        r_prev = int(challenge(poly)) % p
-        polys.append(poly)
-        rs.append(r_prev)
-        acc = 0
-        for co in reversed(poly):
-            acc = (acc * r_prev + co) % p
-        claim = acc
-    rm = _limbs([r_prev * R % p])
-    for pp in ptrs:
-        _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 2, pp, length, _lib.ptr(rm), None, _lib.ptr(s)))
-    torch.cuda.synchronize()
-    finals = [(_ints(a[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p, _ints(b[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p) for a, b in pairs]
-    return polys, rs, finals, claim
+    ptrs = (ctypes.c_void_p * (np_t * len(groups)))(*[_lib.ptr(t) for g in groups for t in g])
+    rounds, ncoef = n.bit_length() - 1, degree + 1
+    out_polys = np.zeros((rounds, ncoef, 4), dtype=np.uint64)
+    out_finals = np.zeros((len(groups) * np_t, 4), dtype=np.uint64)
+    out_claim = np.zeros(4, dtype=np.uint64)
+    rs, failure = [], []
+
+    def on_round(_user, j, coef_ptr, out_ptr):
+        try:
+            co = np.ctypeslib.as_array(ctypes.cast(coef_ptr, ctypes.POINTER(ctypes.c_uint64)), shape=(ncoef * 4,)).copy()
+            r = int(challenge(_ints(co))) % p
+            rs.append(r)
+            ctypes.memmove(out_ptr, r.to_bytes(32, "little"), 32)
+            return 0
+        except BaseException as e:  # noqa: BLE001 - an exception must not unwind through the C frames
+            failure.append(e)
+            return 1
+
+    cb = _lib.SUMCHECK_CHALLENGE_FN(on_round)
+    rc = lib.lurk_hip_sumcheck_prove_batch_dev(field_id, degree, len(groups), ptrs, n, _lib.ptr(_limbs([c % p for c in coeffs])), _lib.ptr(_limbs([claim % p])),
+                                               ctypes.cast(cb, ctypes.c_void_p), None, _lib.ptr(out_polys), _lib.ptr(out_finals), _lib.ptr(out_claim), _lib.ptr(s))
+    if failure:
+        raise failure[0]
+    _lib.check(rc)
+    fin = _ints(out_finals)
+    return [_ints(out_polys[j]) for j in range(rounds)], rs, [tuple(fin[i * np_t:(i + 1) * np_t]) for i in range(len(groups))], _ints(out_claim)[0]
+
+
+def prove_quad_batch(field_id: int, modulus: int, claims, pairs, coeffs, challenge, stream=None):
+    """sum_i coeff_i * sum_x A_i(x) B_i(x) with ONE challenge per round shared by every pair (the evaluation-claim batching of
+    arecibo's snark.rs).  pairs: [(A_i, B_i)] device tensors of one common length (consumed); challenge(poly) -> r.
+    Returns (round polynomials, challenges, [(A_i(r), B_i(r))], final claim)."""
+    claim = sum(c * e for c, e in zip(coeffs, claims)) % modulus
+    return _prove_batch(field_id, modulus, 2, [tuple(pr) for pr in pairs], coeffs, claim, challenge, stream)
 
 
 def prove_cubic_batch(field_id: int, modulus: int, quads, coeffs, challenge, stream=None):
@@ -124,42 +127,4 @@ def prove_cubic_batch(field_id: int, modulus: int, quads, coeffs, challenge, str
     of the batched SNARK (arecibo's spartan::batched; /root/reference/src/proof/supernova.rs:110).  quads: [(A_i, B_i, C_i, D_i)] device
     tensors of one common length (consumed; a table may be shared by several instances only if it is passed as separate copies).  The
     claim starts at 0 (every instance satisfied).  Returns (round polynomials, challenges, [final (A, B, C, D)(r) per instance], claim)."""
-    import torch
-
-    lib = _lib.load()
-    p = modulus
-    R = (1 << 256) % p
-    Rinv = pow(R, p - 2, p)
-    inv2, inv6 = pow(2, p - 2, p), pow(6, p - 2, p)
-    n = quads[0][0].shape[0]
-    assert all(t.is_cuda and t.shape[0] == n for q in quads for t in q)
-    s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-    ptrs = [(ctypes.c_void_p * 4)(*[_lib.ptr(t) for t in q]) for q in quads]
-    claim, polys, rs, length, r_prev = 0, [], [], n, None
-    for _ in range(n.bit_length() - 1):
-        e0 = e2 = e3 = 0
-        rm = None if r_prev is None else _limbs([r_prev * R % p])
-        for c, pp in zip(coeffs, ptrs):
-            ev = np.zeros((3, 4), dtype=np.uint64)
-            _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 3, pp, length, None if rm is None else _lib.ptr(rm), _lib.ptr(ev), _lib.ptr(s)))
-            a0, a2, a3 = [x * Rinv % p for x in _ints(ev)]
-            e0, e2, e3 = (e0 + c * a0) % p, (e2 + c * a2) % p, (e3 + c * a3) % p
-        if r_prev is not None:
-            length //= 2
-        e1 = (claim - e0) % p
-        a3c = (e3 - 3 * e2 + 3 * e1 - e0) * inv6 % p
-        b = ((e2 - 2 * e1 + e0) * inv2 - 3 * a3c) % p
-        poly = [e0, (e1 - e0 - a3c - b) % p, b, a3c]
-        r_prev = int(challenge(poly)) % p
-        polys.append(poly)
-        rs.append(r_prev)
-        acc = 0
-        for co in reversed(poly):
-            acc = (acc * r_prev + co) % p
-        claim = acc
-    rm = _limbs([r_prev * R % p])
-    for pp in ptrs:
-        _lib.check(lib.lurk_hip_sumcheck_round_dev(field_id, 3, pp, length, _lib.ptr(rm), None, _lib.ptr(s)))
-    torch.cuda.synchronize()
-    finals = [tuple(_ints(t[:1].cpu().numpy().view(np.uint64))[0] * Rinv % p for t in q) for q in quads]
-    return polys, rs, finals, claim
+    return _prove_batch(field_id, modulus, 3, [tuple(q) for q in quads], coeffs, 0, challenge, stream)
