@@ -70,6 +70,37 @@ __global__ void k_fma64(uint32_t* out, uint32_t seed) {
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7);
 }
+__global__ void k_lshr64(uint32_t* out, uint32_t seed) {
+    uint64_t a0 = (uint64_t)(seed + threadIdx.x + 0) << 40; uint64_t a1 = (uint64_t)(seed + threadIdx.x + 1) << 40; uint64_t a2 = (uint64_t)(seed + threadIdx.x + 2) << 40; uint64_t a3 = (uint64_t)(seed + threadIdx.x + 3) << 40; uint64_t a4 = (uint64_t)(seed + threadIdx.x + 4) << 40; uint64_t a5 = (uint64_t)(seed + threadIdx.x + 5) << 40; uint64_t a6 = (uint64_t)(seed + threadIdx.x + 6) << 40; uint64_t a7 = (uint64_t)(seed + threadIdx.x + 7) << 40;
+    uint32_t sh = (seed & 1) | 28;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_lshrrev_b64 %0, %8, %0\n v_lshrrev_b64 %1, %8, %1\n v_lshrrev_b64 %2, %8, %2\n v_lshrrev_b64 %3, %8, %3\n v_lshrrev_b64 %4, %8, %4\n v_lshrrev_b64 %5, %8, %5\n v_lshrrev_b64 %6, %8, %6\n v_lshrrev_b64 %7, %8, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sh));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_alignbit(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t y = seed * 7 + 1, sh = 29;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_alignbit_b32 %0, %8, %0, %9\n v_alignbit_b32 %1, %8, %1, %9\n v_alignbit_b32 %2, %8, %2, %9\n v_alignbit_b32 %3, %8, %3, %9\n v_alignbit_b32 %4, %8, %4, %9\n v_alignbit_b32 %5, %8, %5, %9\n v_alignbit_b32 %6, %8, %6, %9\n v_alignbit_b32 %7, %8, %7, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y), "v"(sh));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_and_b32(uint32_t* out, uint32_t seed) {
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t y = seed * 7 + 0x1fffffff;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_and_b32_e32 %0, %0, %8\n v_and_b32_e32 %1, %1, %8\n v_and_b32_e32 %2, %2, %8\n v_and_b32_e32 %3, %3, %8\n v_and_b32_e32 %4, %4, %8\n v_and_b32_e32 %5, %5, %8\n v_and_b32_e32 %6, %6, %8\n v_and_b32_e32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_mov_b64(uint32_t* out, uint32_t seed) {
+    uint64_t a0 = (uint64_t)(seed + threadIdx.x + 0); uint64_t a1 = (uint64_t)(seed + threadIdx.x + 1); uint64_t a2 = (uint64_t)(seed + threadIdx.x + 2); uint64_t a3 = (uint64_t)(seed + threadIdx.x + 3); uint64_t a4 = (uint64_t)(seed + threadIdx.x + 4); uint64_t a5 = (uint64_t)(seed + threadIdx.x + 5); uint64_t a6 = (uint64_t)(seed + threadIdx.x + 6); uint64_t a7 = (uint64_t)(seed + threadIdx.x + 7);
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_mov_b64 %0, %1\n v_mov_b64 %1, %2\n v_mov_b64 %2, %3\n v_mov_b64 %3, %4\n v_mov_b64 %4, %5\n v_mov_b64 %5, %6\n v_mov_b64 %6, %7\n v_mov_b64 %7, %0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
 __global__ void k_lshl_add64(uint32_t* out, uint32_t seed) {
     uint64_t a0 = (uint64_t)(seed + threadIdx.x + 0); uint64_t a1 = (uint64_t)(seed + threadIdx.x + 1); uint64_t a2 = (uint64_t)(seed + threadIdx.x + 2); uint64_t a3 = (uint64_t)(seed + threadIdx.x + 3); uint64_t a4 = (uint64_t)(seed + threadIdx.x + 4); uint64_t a5 = (uint64_t)(seed + threadIdx.x + 5); uint64_t a6 = (uint64_t)(seed + threadIdx.x + 6); uint64_t a7 = (uint64_t)(seed + threadIdx.x + 7);
     uint64_t y = seed * 7 + 1;
@@ -292,6 +323,10 @@ int main() {
     RUN_PROBE(k_xor, 8, "v_xor_b32");
     RUN_PROBE(k_fma64, 8, "v_fma_f64");
     RUN_PROBE(k_lshl_add64, 8, "v_lshl_add_u64");
+    RUN_PROBE(k_lshr64, 8, "v_lshrrev_b64");
+    RUN_PROBE(k_alignbit, 8, "v_alignbit_b32");
+    RUN_PROBE(k_and_b32, 8, "v_and_b32");
+    RUN_PROBE(k_mov_b64, 8, "v_mov_b64");
     RUN_PROBE(k_mad_addc, 16, "mad+addc (dep chain)");
     RUN_PROBE(k_addc_e64, 8, "v_addc_co e64 sgpr-carry");
     RUN_PROBE(k_addc_e32, 8, "v_addc_co e32 vcc (dep)");

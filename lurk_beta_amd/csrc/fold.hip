@@ -194,6 +194,17 @@ __device__ __forceinline__ bool fold_is_long(const R1csDev& s, size_t row, uint3
     return hi[0] - lo[0] > FOLD_LONG || hi[1] - lo[1] > FOLD_LONG || hi[2] - lo[2] > FOLD_LONG;
 }
 
+// Workgroup -> row block, XCD-aware.  Consecutive workgroup ids go round the 8 XCDs (each with its own 4 MiB L2), and the rows of the
+// step circuit are frame-structured: a frame's rows gather almost only that frame's ~9 000 columns of z (multiframe.rs:699-702).  With
+// the identity mapping every XCD's L2 sees every frame's columns (each 32-byte element of z is fetched into up to 8 L2s); here XCD x
+// walks ONE contiguous eighth of the rows, so a frame's columns of z1 / z2 are fetched by one L2 and hit there for the rest of the
+// frame's rows.
+constexpr unsigned FOLD_XCDS = 8;
+__device__ __forceinline__ size_t fold_row_block(unsigned b, unsigned nblocks) {
+    const unsigned per = (nblocks + FOLD_XCDS - 1) / FOLD_XCDS;
+    return (size_t)(b % FOLD_XCDS) * per + b / FOLD_XCDS;
+}
+
 // LONG = false: one lane per row, long rows skipped;  LONG = true: FOLD_GROUP lanes per entry of long_rows
 template <class P, bool LONG>
 __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_multiply_vec_kernel(R1csDev s, const Fe<P>* __restrict__ z, Fe<P>* __restrict__ az,
@@ -203,7 +214,7 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_multiply_vec_kernel(R1csDev s
     uint32_t lo[3], hi[3];
     F29<P> r;
     if (!LONG) {
-        size_t row = (size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x;
+        size_t row = fold_row_block(blockIdx.x, gridDim.x) * FOLD_BLOCK + threadIdx.x;
         if (row >= s.rows || fold_is_long(s, row, lo, hi)) return;
         fold_row_lane<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &r);
         fold_store<P>(az + row, r);
@@ -239,7 +250,7 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
     Dot29<P> acc;
     dot29_init<P>(acc);
     if (!LONG) {
-        row = (size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x;
+        row = fold_row_block(blockIdx.x, gridDim.x) * FOLD_BLOCK + threadIdx.x;
         if (row >= s.rows || fold_is_long(s, row, lo, hi)) return;
         // one vector at a time (a second pass re-reads the 8-byte records from L2 but halves the live accumulators:
         // 3 waves/SIMD instead of 2 with spills); T is built up as the row values arrive
@@ -303,6 +314,12 @@ __global__ __launch_bounds__(FOLD_BLOCK) void fold_vec_kernel(const uint4* __res
         out[2 * i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
         out[2 * i + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
     }
+}
+
+// grid of the one-lane-per-row kernels: a multiple of FOLD_XCDS workgroups, so that fold_row_block is a bijection onto [0, grid)
+static unsigned fold_grid(size_t rows) {
+    const unsigned nb = div_up(rows, FOLD_BLOCK);
+    return (nb + FOLD_XCDS - 1) / FOLD_XCDS * FOLD_XCDS;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -387,7 +404,7 @@ static void multiply_vec(const R1csShape& sh, const void* d_z, void* az, void* b
     if (sh.n_long)  // first: its few latency-bound waves then run beside the lane-per-row launch that follows
         hipLaunchKernelGGL((r1cs_multiply_vec_kernel<P, true>), dim3(div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
                            (const Fe<P>*)d_z, (Fe<P>*)az, (Fe<P>*)bz, (Fe<P>*)cz);
-    hipLaunchKernelGGL((r1cs_multiply_vec_kernel<P, false>), dim3(div_up(sh.num_cons, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z,
+    hipLaunchKernelGGL((r1cs_multiply_vec_kernel<P, false>), dim3(fold_grid(sh.num_cons)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z,
                        (Fe<P>*)az, (Fe<P>*)bz, (Fe<P>*)cz);
     LURK_HIP_CHECK(hipGetLastError());
 }
@@ -399,7 +416,7 @@ static void cross_term(const R1csShape& sh, const void* d_z1, const void* d_z2, 
     if (sh.n_long)
         hipLaunchKernelGGL((r1cs_cross_term_kernel<P, true>), dim3(div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
                            (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, sh.num_vars, (Fe<P>*)d_t);
-    hipLaunchKernelGGL((r1cs_cross_term_kernel<P, false>), dim3(div_up(sh.num_cons, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z1,
+    hipLaunchKernelGGL((r1cs_cross_term_kernel<P, false>), dim3(fold_grid(sh.num_cons)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z1,
                        (const Fe<P>*)d_z2, sh.num_vars, (Fe<P>*)d_t);
     LURK_HIP_CHECK(hipGetLastError());
 }

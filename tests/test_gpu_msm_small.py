@@ -141,7 +141,7 @@ def test_key_file_round_trip(hip, tmp_path):
 
     assert os.path.getsize(path) == 64 + n * 64
     k2 = CommitmentKey.load(path, precompute=True)
-    assert _info(k2)[2:] == (8, 1)
+    assert _info(k2)[2:] == (8, 2)  # form 2: the small form again
     assert point_to_affine(c, k2.commit(S)) == want == C.jac_to_affine(c, C.msm_fast(c, B, S))
     k3 = CommitmentKey.load(path, precompute=False)
     assert point_to_affine(c, k3.commit(S)) == want
