@@ -281,15 +281,17 @@ __device__ __forceinline__ Fe<PallasFp> fp64_to_fe(const Fp64x5& x) {
 }
 // the same chain as k_femul: x <- x * y / 2^256; with R' = 2^260 the multiplier enters as 16 y, so that x * (16 y) / 2^260 = x * y / 2^256
 __global__ void k_fp64mul(const Fe<PallasFp>* in, Fe<PallasFp>* out, int iters) {
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 3);  // MODE.FP_ROUND[3:2] (f64 / f16) = round toward zero
+    // MODE.FP_ROUND[3:2] (f64 / f16) = round toward zero.  As asm volatile, like the FMAs: the compiler keeps volatile asm statements in
+    // order among themselves, but moved the s_setreg BUILTIN (both of them) above the loop of asm FMAs, which then ran in round-to-nearest
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 3");
     size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
     Fe<PallasFp> y16 = in[2 * i + 1];
     for (int k = 0; k < 4; k++) y16 = fe_add<PallasFp>(y16, y16);
     Fp64x5 x = fp64_from_fe(in[2 * i]);
     const Fp64x5 y = fp64_from_fe(y16);
     for (int k = 0; k < iters; k++) x = fp64_mont_mul_pallas(x, y);
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 2, 2), 0");
     out[i] = fp64_to_fe(x);
-    __builtin_amdgcn_s_setreg(1 | (2 << 6) | (1 << 11), 0);
 }
 
 static double time_kernel(std::function<void()> f, int reps = 3) {

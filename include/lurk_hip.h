@@ -419,6 +419,26 @@ int lurk_hip_nifs_challenge(int curve, const void* pp_digest32, const void* comm
                             const void* u1_mont, const void* x1_mont, const void* comm_w2_jacobian96, const void* x2_mont, size_t num_io,
                             const void* comm_t_jacobian96, void* r32_mont);
 
+/* ---- arecibo's Keccak256Transcript (host code; no device needed) --------------------------------------------------------------
+ * The transcript RelaxedR1CSSNARK / BatchedRelaxedR1CSSNARK run behind CompressedSNARK::prove (/root/reference/src/proof/nova.rs:92,
+ * 341-356; supernova.rs:110, 293-302): persona tag "NoTR", domain-separator tag "NoDS", a 64-byte state, a u16 round counter and a
+ * running Keccak-256 hasher; a challenge is Scalar::from_uniform of 64 squeezed bytes.  Restated from arecibo's published source
+ * and UNPINNED (arecibo is an un-vendored dependency, /root/reference/Cargo.toml:128); Keccak-256 itself is pinned by known answers.
+ * absorb_scalars takes canonical little-endian 32-byte elements and absorbs their to_transcript_bytes (the repr reversed);
+ * absorb_point takes a 96-byte Jacobian and absorbs x || y || [finite] of its affine form. */
+typedef struct lurk_hip_keccak_transcript lurk_hip_keccak_transcript;
+int lurk_hip_keccak256(const void* in, size_t len, void* out32);
+int lurk_hip_keccak_transcript_new(lurk_hip_keccak_transcript** t, const void* label, size_t label_len);
+int lurk_hip_keccak_transcript_destroy(lurk_hip_keccak_transcript* t);
+int lurk_hip_keccak_transcript_absorb(lurk_hip_keccak_transcript* t, const void* label, size_t label_len, const void* bytes, size_t len);
+int lurk_hip_keccak_transcript_absorb_scalars(lurk_hip_keccak_transcript* t, const void* label, size_t label_len,
+                                              const void* scalars32_canonical, size_t n);
+int lurk_hip_keccak_transcript_absorb_point(lurk_hip_keccak_transcript* t, const void* label, size_t label_len, int curve,
+                                            const void* point_jacobian96);
+int lurk_hip_keccak_transcript_dom_sep(lurk_hip_keccak_transcript* t, const void* bytes, size_t len);
+int lurk_hip_keccak_transcript_squeeze(lurk_hip_keccak_transcript* t, const void* label, size_t label_len, int field_id,
+                                       void* out32_canonical);
+
 /* ---- sum-check rounds (the data-parallel half of CompressedSNARK::prove) -----------------------
  * CompressedSNARK::prove (/root/reference/src/proof/nova.rs:341-356, supernova.rs:293-302) -> arecibo RelaxedR1CSSNARK::prove ->
  * SumcheckProof::prove_cubic_with_additive_term (outer: eq(tau) (Az Bz - (u Cz + E))) and prove_quad (inner: poly_ABC z).

@@ -114,6 +114,14 @@ SIGNATURES = {
     "lurk_hip_nova_ro_squeeze": (c_int, [c_int, c_void_p, c_size_t, c_uint, c_void_p]),
     "lurk_hip_nova_ro_pattern_tag": (c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_void_p]),
     "lurk_hip_nifs_challenge": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_keccak256": (c_int, [ctypes.c_char_p, c_size_t, c_void_p]),
+    "lurk_hip_keccak_transcript_new": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_size_t]),
+    "lurk_hip_keccak_transcript_destroy": (c_int, [c_void_p]),
+    "lurk_hip_keccak_transcript_absorb": (c_int, [c_void_p, ctypes.c_char_p, c_size_t, ctypes.c_char_p, c_size_t]),
+    "lurk_hip_keccak_transcript_absorb_scalars": (c_int, [c_void_p, ctypes.c_char_p, c_size_t, c_void_p, c_size_t]),
+    "lurk_hip_keccak_transcript_absorb_point": (c_int, [c_void_p, ctypes.c_char_p, c_size_t, c_int, c_void_p]),
+    "lurk_hip_keccak_transcript_dom_sep": (c_int, [c_void_p, ctypes.c_char_p, c_size_t]),
+    "lurk_hip_keccak_transcript_squeeze": (c_int, [c_void_p, ctypes.c_char_p, c_size_t, c_int, c_void_p]),
     "lurk_hip_sumcheck_round_dev": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_eq_evals_dev": (c_int, [c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "lurk_hip_inner_product_dev": (c_int, [c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

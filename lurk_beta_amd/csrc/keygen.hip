@@ -13,39 +13,11 @@
 
 #include "common.hpp"
 #include "curve.cuh"
+#include "keccak.hpp"
 
 namespace lurk {
 
-// ---- SHAKE256 (host) ----------------------------------------------------------------------------------
-static void keccak_f(uint64_t* s) {
-    static const uint64_t RC[24] = {0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL, 0x000000000000808bULL,
-                                    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008aULL, 0x0000000000000088ULL,
-                                    0x0000000080008009ULL, 0x000000008000000aULL, 0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL,
-                                    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
-                                    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
-    static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-    static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
-    for (int r = 0; r < 24; r++) {
-        uint64_t bc[5];
-        for (int i = 0; i < 5; i++) bc[i] = s[i] ^ s[i + 5] ^ s[i + 10] ^ s[i + 15] ^ s[i + 20];
-        for (int i = 0; i < 5; i++) {
-            uint64_t t = bc[(i + 4) % 5] ^ ((bc[(i + 1) % 5] << 1) | (bc[(i + 1) % 5] >> 63));
-            for (int j = 0; j < 25; j += 5) s[j + i] ^= t;
-        }
-        uint64_t t = s[1];
-        for (int i = 0; i < 24; i++) {
-            int j = PIL[i];
-            uint64_t b = s[j];
-            s[j] = (t << ROT[i]) | (t >> (64 - ROT[i]));
-            t = b;
-        }
-        for (int j = 0; j < 25; j += 5) {
-            for (int i = 0; i < 5; i++) bc[i] = s[j + i];
-            for (int i = 0; i < 5; i++) s[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
-        }
-        s[0] ^= RC[r];
-    }
-}
+// ---- SHAKE256 (host): Keccak-f from keccak.hpp ----------------------------------------------------------------------------------
 void shake256(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len) {
     constexpr size_t RATE = 136;
     uint64_t st[25] = {0};

@@ -12,7 +12,11 @@
 //   * measured and dropped: ALL levels in one persistent launch behind grid barriers (512 workgroups, one monotonic counter, agent-
 //     scope release / relaxed poll / acquire): 1.07 ms per reduction against 0.45 for the launches - a counter barrier costs 13 us
 //     at two workgroups per CU (MI355X_MICROARCH.md, price list: barrier-counter) and its release fence writes the L2 back, a kernel
-//     boundary 1.5 us.  The guide's verdict for all-to-all seams - cut the launch there - holds for this one too.
+//     boundary 1.5 us.  The guide's verdict for all-to-all seams - cut the launch there - holds for this one too;
+//   * measured and dropped in round 4: the last SIX levels (64 segments per key space from level c - 7 on) in one launch, one workgroup
+//     per key space merging through LDS with a barrier per level: 0.339 / 0.390 ms per reduction at 2^20 / 2^22 against 0.343 / 0.384
+//     with one launch per level (profiles/r04_run3_sweep.jsonl) - a level costs its ONE dependent XYZZ addition (~3 000 instructions of
+//     4+ cycles on a single wave: 6 us) whether a kernel boundary follows it or a barrier.
 #include "common.hpp"
 #include "msm_core.cuh"
 #include "curve29.cuh"
@@ -80,53 +84,6 @@ __global__ __launch_bounds__(REDUCE_BLOCK) void msm_planes29_kernel(const Xyzz<P
     }
 }
 
-// The last REDUCE_TAIL levels in ONE launch: from level k0 = c - 1 - REDUCE_TAIL on a key space is down to 2^REDUCE_TAIL = 64 segments
-// (<= 64 x 14 plane records at c = 20), which one workgroup merges through LDS with a barrier between levels - six kernel
-// boundaries (launch gap + a round trip of the records through L2) fewer in a chain whose every link is one addition deep.  The early
-// levels stay one launch each: they are wide (2^18 additions at level 0) and a launch re-packs their lanes fully.
-// One workgroup per key space; LDS: two ping-pong buffers of 32 (k0 + 2) and 16 (k0 + 3) records (118 KB at c = 20).
-constexpr int REDUCE_TAIL = 6;
-template <class P>
-__global__ __launch_bounds__(REDUCE_BLOCK) void msm_planes29_tail_kernel(const Plane29<P>* __restrict__ in, Xyzz<P>* __restrict__ out_host, int k0, int c) {
-    __builtin_amdgcn_s_setprio(3);
-    extern __shared__ uint4 tail_lds[];
-    Plane29<P>* buf[2];
-    buf[0] = reinterpret_cast<Plane29<P>*>(tail_lds);
-    buf[1] = buf[0] + 32 * (k0 + 2);
-    const unsigned g = blockIdx.x;
-    const Plane29<P>* src = in + (size_t)g * 64 * (k0 + 1);  // this key space's 64 segments of k0 + 1 components
-    for (int j = 0; j < REDUCE_TAIL; j++) {
-        const int k = k0 + j;
-        const unsigned nseg_out = 32u >> j, comps_out = (unsigned)k + 2, comps_in = (unsigned)k + 1;
-        const Plane29<P>* from = j == 0 ? src : buf[(j - 1) & 1];
-        for (unsigned id = threadIdx.x; id < nseg_out * comps_out; id += REDUCE_BLOCK) {
-            const unsigned comp = id % comps_out, seg = id / comps_out;
-            const Plane29<P>* lo = from + (size_t)(2 * seg) * comps_in;
-            const Plane29<P>* hi = lo + comps_in;
-            Xyzz29<P> r, h;
-            bool r_id, h_id;
-            if (comp <= (unsigned)k) {
-                plane_load<P>(lo + comp, r, r_id);
-                plane_load<P>(hi + comp, h, h_id);
-                xyzz29_add<P>(r, r_id, h, h_id);
-            } else {
-                plane_load<P>(hi, r, r_id);  // the new plane k: the upper half's S
-            }
-            if (k == c - 2) {
-                out_host[(size_t)g * c + comp] = xyzz29_to_xyzz<P>(r, r_id);  // nseg_out == 1: the G x c plane sums, into pinned host memory
-            } else {
-                Plane29<P> o;
-                o.p = r;
-                o.id = r_id;
-                o.pad[0] = o.pad[1] = o.pad[2] = 0;
-                buf[j & 1][id] = o;
-            }
-        }
-        __syncthreads();
-    }
-}
-static size_t msm_reduce_tail_lds(int k0) { return (size_t)(32 * (k0 + 2) + 16 * (k0 + 3)) * 160; }
-
 size_t msm_reduce_plane_bytes(size_t nb) { return nb * 160; }
 
 // planes_a / planes_b: msm_reduce_plane_bytes(G * B) each; out_host: G * c XYZZ points of pinned host memory
@@ -134,19 +91,6 @@ template <class P>
 void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s) {
     static_assert(sizeof(Plane29<P>) == 160, "plane record");
     Plane29<P>* bufs[2] = {(Plane29<P>*)planes_a, (Plane29<P>*)planes_b};
-    const int k0 = c - 1 - REDUCE_TAIL;  // c >= 16: at least nine single-level launches in front of the tail
-    if (k0 >= 1 && (B >> k0) == 64) {
-        for (int k = 0; k < k0; k++) {
-            const size_t threads = (size_t)G * ((size_t)B >> (k + 1)) * (k + 2);
-            const dim3 grid(div_up(threads, REDUCE_BLOCK)), block(REDUCE_BLOCK);
-            if (k == 0) hipLaunchKernelGGL((msm_planes29_kernel<P, true, false>), grid, block, 0, s, buckets, bufs[(k + 1) & 1], bufs[k & 1], out_host, k, G, B);
-            else hipLaunchKernelGGL((msm_planes29_kernel<P, false, false>), grid, block, 0, s, buckets, bufs[(k + 1) & 1], bufs[k & 1], out_host, k, G, B);
-        }
-        allow_dynamic_lds((const void*)msm_planes29_tail_kernel<P>, (int)msm_reduce_tail_lds(k0));
-        hipLaunchKernelGGL((msm_planes29_tail_kernel<P>), dim3(G), dim3(REDUCE_BLOCK), msm_reduce_tail_lds(k0), s, bufs[(k0 - 1) & 1], out_host, k0, c);
-        LURK_HIP_CHECK(hipGetLastError());
-        return;
-    }
     for (int k = 0; k < c - 1; k++) {
         const size_t threads = (size_t)G * ((size_t)B >> (k + 1)) * (k + 2);
         const dim3 grid(div_up(threads, REDUCE_BLOCK)), block(REDUCE_BLOCK);

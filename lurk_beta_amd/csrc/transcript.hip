@@ -24,6 +24,7 @@
 
 #include "common.hpp"
 #include "host_poseidon.hpp"
+#include "keccak.hpp"
 
 namespace lurk {
 
@@ -165,7 +166,42 @@ static void nifs_challenge(int curve, int base_field_id, const void* pp_digest32
     memcpy(r32_mont, rf.l, 32);
 }
 
+// ---- arecibo's Keccak256Transcript (the transcript of RelaxedR1CSSNARK / BatchedRelaxedR1CSSNARK behind CompressedSNARK::prove,
+// /root/reference/src/proof/nova.rs:92, 341-356, supernova.rs:110, 293-302) -----------------------------------------------------------
+// Restated from arecibo's published source [MEM] and UNPINNED, like the random oracle above (oracle/keccak_transcript.py spells the
+// construction out; Keccak-256 itself is pinned by known answers).  64-byte state, u16 round counter, a running Keccak256 hasher.
+static void keccak_updated_state(const Keccak256& h, const void* input, size_t len, uint8_t out[64]) {
+    Keccak256 k = h;
+    k.update(input, len);
+    Keccak256 lo = k, hi = k;
+    const uint8_t zero = 0, one = 1;
+    lo.update(&zero, 1);
+    hi.update(&one, 1);
+    lo.finalize(out);
+    hi.finalize(out + 32);
+}
+// Scalar::from_uniform: the 64 bytes as a little-endian integer, reduced
+template <class P>
+static void from_uniform64(const uint8_t in[64], uint64_t out4[4]) {
+    const HostField F = host_field<P>();
+    H4 lo, hi;
+    memcpy(lo.v, in, 32);
+    memcpy(hi.v, in + 32, 32);
+    while (h4_geq(lo.v, F.m)) h4_sub_m(lo.v, F.m);
+    while (h4_geq(hi.v, F.m)) h4_sub_m(hi.v, F.m);
+    const H4 r2 = h4_from<P>(fe_r2<P>());
+    const H4 hi_shift = h4_mul(F, hi, r2);  // hi * 2^512 / 2^256 = hi * 2^256
+    const H4 v = h4_add(F, lo, hi_shift);
+    memcpy(out4, v.v, 32);
+}
+
 }  // namespace lurk
+
+struct lurk_hip_keccak_transcript {
+    uint16_t round = 0;
+    uint8_t state[64];
+    lurk::Keccak256 hasher;
+};
 
 using namespace lurk;
 
@@ -219,6 +255,89 @@ int lurk_hip_nifs_challenge(int curve, const void* pp_digest32, const void* comm
         else
             nifs_challenge<PallasFp, PallasFq>(curve, LURK_FIELD_PALLAS_FQ, pp_digest32, comm_w1_jac96, comm_e1_jac96, u1_mont, x1_mont, comm_w2_jac96,
                                                x2_mont, num_io, comm_t_jac96, r32_mont);
+    });
+}
+
+int lurk_hip_keccak256(const void* in, size_t len, void* out32) {
+    return host_guarded([&] {
+        LURK_REQUIRE((in || len == 0) && out32, "null argument");
+        Keccak256 k;
+        k.update(in, len);
+        k.finalize((uint8_t*)out32);
+    });
+}
+
+int lurk_hip_keccak_transcript_new(lurk_hip_keccak_transcript** t, const void* label, size_t label_len) {
+    return host_guarded([&] {
+        LURK_REQUIRE(t && (label || label_len == 0), "null argument");
+        auto tr = std::make_unique<lurk_hip_keccak_transcript>();
+        std::vector<uint8_t> in = {'N', 'o', 'T', 'R'};  // PERSONA_TAG
+        in.insert(in.end(), (const uint8_t*)label, (const uint8_t*)label + label_len);
+        keccak_updated_state(Keccak256(), in.data(), in.size(), tr->state);
+        *t = tr.release();
+    });
+}
+int lurk_hip_keccak_transcript_destroy(lurk_hip_keccak_transcript* t) {
+    delete t;
+    return 0;
+}
+int lurk_hip_keccak_transcript_absorb(lurk_hip_keccak_transcript* t, const void* label, size_t label_len, const void* bytes, size_t len) {
+    return host_guarded([&] {
+        LURK_REQUIRE(t && (label || label_len == 0) && (bytes || len == 0), "null argument");
+        t->hasher.update(label, label_len);
+        t->hasher.update(bytes, len);
+    });
+}
+int lurk_hip_keccak_transcript_absorb_scalars(lurk_hip_keccak_transcript* t, const void* label, size_t label_len, const void* scalars32_canonical, size_t n) {
+    return host_guarded([&] {
+        LURK_REQUIRE(t && (label || label_len == 0) && (scalars32_canonical || n == 0), "null argument");
+        t->hasher.update(label, label_len);
+        for (size_t i = 0; i < n; i++) {  // to_transcript_bytes of a field element: to_repr() reversed
+            uint8_t be[32];
+            const uint8_t* le = (const uint8_t*)scalars32_canonical + 32 * i;
+            for (int k = 0; k < 32; k++) be[k] = le[31 - k];
+            t->hasher.update(be, 32);
+        }
+    });
+}
+int lurk_hip_keccak_transcript_absorb_point(lurk_hip_keccak_transcript* t, const void* label, size_t label_len, int curve, const void* point_jacobian96) {
+    return host_guarded([&] {
+        LURK_REQUIRE(t && (label || label_len == 0) && point_jacobian96, "null argument");
+        uint8_t xy[64], buf[65];
+        LURK_REQUIRE(lurk_hip_point_to_affine_canonical(curve, xy, point_jacobian96) == 0, lurk_hip_last_error());
+        bool finite = false;
+        for (int k = 0; k < 64; k++) finite |= xy[k] != 0;  // the identity comes back as (0, 0): to_coordinates' (0, 0, is_infinity)
+        for (int k = 0; k < 32; k++) { buf[k] = xy[31 - k]; buf[32 + k] = xy[63 - k]; }
+        buf[64] = finite ? 1 : 0;
+        t->hasher.update(label, label_len);
+        t->hasher.update(buf, 65);
+    });
+}
+int lurk_hip_keccak_transcript_dom_sep(lurk_hip_keccak_transcript* t, const void* bytes, size_t len) {
+    return host_guarded([&] {
+        LURK_REQUIRE(t && (bytes || len == 0), "null argument");
+        t->hasher.update("NoDS", 4);
+        t->hasher.update(bytes, len);
+    });
+}
+int lurk_hip_keccak_transcript_squeeze(lurk_hip_keccak_transcript* t, const void* label, size_t label_len, int field_id, void* out32_canonical) {
+    return host_guarded([&] {
+        LURK_REQUIRE(t && (label || label_len == 0) && out32_canonical, "null argument");
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(t->round != 0xffff, "the transcript's round counter would overflow");
+        std::vector<uint8_t> in = {'N', 'o', 'D', 'S', (uint8_t)(t->round & 0xff), (uint8_t)(t->round >> 8)};
+        in.insert(in.end(), t->state, t->state + 64);
+        in.insert(in.end(), (const uint8_t*)label, (const uint8_t*)label + label_len);
+        uint8_t out[64];
+        keccak_updated_state(t->hasher, in.data(), in.size(), out);
+        t->round++;
+        memcpy(t->state, out, 64);
+        t->hasher = Keccak256();
+        uint64_t r[4];
+        if (field_id == 0) from_uniform64<PallasFp>(out, r);
+        else if (field_id == 1) from_uniform64<PallasFq>(out, r);
+        else from_uniform64<Bn254Fr>(out, r);
+        memcpy(out32_canonical, r, 32);
     });
 }
 }

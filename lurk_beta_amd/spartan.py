@@ -9,8 +9,6 @@ zero padding documented in oracle/spartan_ref.py, whose prover this one must mat
 accept the result): no proof bytes exist upstream to be compatible with."""
 from __future__ import annotations
 
-import hashlib
-
 import numpy as np
 
 from . import _lib, ipa, sumcheck
@@ -19,24 +17,51 @@ from .msm import point_to_affine
 
 
 class Transcript:
-    def __init__(self, label: bytes):
-        self.state = hashlib.sha3_256(b"lurk-hip spartan v1" + label).digest()
+    """arecibo's Keccak256Transcript (the transcript of RelaxedR1CSSNARK / BatchedRelaxedR1CSSNARK, /root/reference/src/proof/nova.rs:92,
+    supernova.rs:110) through the library's host implementation (lurk_hip_keccak_transcript_*: restated from arecibo's source, unpinned;
+    oracle/keccak_transcript.py is the independent restatement the tests compare with).  The labels and the order of what this prover
+    absorbs are its own (oracle/spartan_ref.py): the PROTOCOL is not arecibo's byte for byte, the transcript construction is."""
+
+    _FIELD = {0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001: 0,
+              0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001: 1,
+              0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001: 2}
+
+    def __init__(self, label: bytes, curve: int = 0):
+        import ctypes
+
+        self._curve = curve
+        self._h = ctypes.c_void_p()
+        full = b"lurk-hip spartan v2" + label
+        _lib.check(_lib.load().lurk_hip_keccak_transcript_new(ctypes.byref(self._h), full, len(full)))
+
+    def __del__(self):
+        try:
+            if self._h:
+                _lib.load().lurk_hip_keccak_transcript_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
 
     def absorb(self, label: bytes, data: bytes):
-        self.state = hashlib.sha3_256(self.state + label + len(data).to_bytes(8, "little") + data).digest()
+        _lib.check(_lib.load().lurk_hip_keccak_transcript_absorb(self._h, label, len(label), bytes(data), len(data)))
 
     def absorb_scalars(self, label: bytes, xs):
-        self.absorb(label, b"".join(int(x).to_bytes(32, "little") for x in xs))
+        arr = sumcheck._limbs([int(x) for x in xs])
+        _lib.check(_lib.load().lurk_hip_keccak_transcript_absorb_scalars(self._h, label, len(label), _lib.ptr(arr), arr.shape[0]))
 
     def absorb_point(self, label: bytes, xy):
-        self.absorb(label, int(xy[0]).to_bytes(32, "little") + int(xy[1]).to_bytes(32, "little"))
+        """xy: affine canonical integers ((0, 0) = the identity), as point_to_affine returns them."""
+        x, y = int(xy[0]), int(xy[1])
+        self.absorb(label, x.to_bytes(32, "big") + y.to_bytes(32, "big") + (b"\x00" if (x, y) == (0, 0) else b"\x01"))
+
+    def absorb_jacobian(self, label: bytes, jac96: np.ndarray):
+        j = np.ascontiguousarray(jac96, dtype=np.uint64)
+        _lib.check(_lib.load().lurk_hip_keccak_transcript_absorb_point(self._h, label, len(label), self._curve, _lib.ptr(j)))
 
     def squeeze(self, label: bytes, modulus: int) -> int:
-        a = hashlib.sha3_256(self.state + label + b"\x00").digest()
-        b = hashlib.sha3_256(self.state + label + b"\x01").digest()
-        self.state = hashlib.sha3_256(self.state + label + b"\x02").digest()
-        v = int.from_bytes(a + b, "little") % modulus
-        return v if v > 1 else 2
+        out = np.zeros(4, dtype=np.uint64)
+        _lib.check(_lib.load().lurk_hip_keccak_transcript_squeeze(self._h, label, len(label), self._FIELD[modulus], _lib.ptr(out)))
+        return sumcheck._ints(out)[0]
 
 
 def transpose_csr(indptr, indices, data, ncols: int):

@@ -11,36 +11,22 @@ it on each curve of the cycle (/root/reference/src/proof/nova.rs:341-356; arecib
   4. W(r_y[1:]); the two evaluation claims (W at r_y[1:], E at r_x) reduced to one point r_z by a batched quadratic sum-check
      of  sum_x sum_i rho^i eq(x_i, x) P_i(x)
   5. one inner-product-argument opening (oracle/pyref.py: ipa_prove) of P_1 + gamma P_2 at r_z.
-PARITY UNPINNED and deliberately not byte-compatible: the transcript below (SHA3-256 based) stands in for arecibo's Keccak256
-transcript, vectors of different lengths are zero-padded to a common power of two instead of arecibo's claim rescaling, and no proof
-bytes exist upstream.  What the oracle is for: (i) the device-assisted prover (lurk_beta_amd/spartan.py) must produce the SAME proof,
+PARITY UNPINNED and not byte-compatible: the transcript CONSTRUCTION is arecibo's Keccak256Transcript (oracle/keccak_transcript.py,
+restated from its published source), but the labels and the order of what is absorbed are this restatement's own, vectors of
+different lengths are zero-padded to a common power of two instead of arecibo's claim rescaling, and no proof bytes exist upstream.  What the oracle is for: (i) the device-assisted prover (lurk_beta_amd/spartan.py) must produce the SAME proof,
 element for element, and (ii) `verify` below must accept it and reject tampered proofs - the size-independent property."""
 from __future__ import annotations
 
-import hashlib
-
 from . import pyref as R
+from .keccak_transcript import KeccakTranscript
 
 
-class Transcript:
+class Transcript(KeccakTranscript):
+    """arecibo's Keccak256Transcript (oracle/keccak_transcript.py) under this protocol's own label prefix: the construction is
+    arecibo's, the labels and the order of the absorbed values are this restatement's (see the module docstring)."""
+
     def __init__(self, label: bytes):
-        self.state = hashlib.sha3_256(b"lurk-hip spartan v1" + label).digest()
-
-    def absorb(self, label: bytes, data: bytes):
-        self.state = hashlib.sha3_256(self.state + label + len(data).to_bytes(8, "little") + data).digest()
-
-    def absorb_scalars(self, label: bytes, xs):
-        self.absorb(label, b"".join(int(x).to_bytes(32, "little") for x in xs))
-
-    def absorb_point(self, label: bytes, pt):
-        self.absorb(label, b"\x00" * 64 if pt is None else int(pt[0]).to_bytes(32, "little") + int(pt[1]).to_bytes(32, "little"))
-
-    def squeeze(self, label: bytes, modulus: int) -> int:
-        a = hashlib.sha3_256(self.state + label + b"\x00").digest()
-        b = hashlib.sha3_256(self.state + label + b"\x01").digest()
-        self.state = hashlib.sha3_256(self.state + label + b"\x02").digest()
-        v = int.from_bytes(a + b, "little") % modulus
-        return v if v > 1 else 2  # challenges must be invertible (the inner-product argument) and are never 0 / 1
+        super().__init__(b"lurk-hip spartan v2" + label)
 
 
 def mle_eval(p: int, table: list[int], point: list[int]) -> int:
