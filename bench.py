@@ -1072,14 +1072,25 @@ def poseidon_valu_roofline(arity, hashes, kernel_ms):
             "frac": round(ach / peak, 4), "mads_per_hash": mads}
 
 
+# Instruction-issue model of the accumulate loop (bench_tools/issue_model.py over the ISA of msm_acc.hip, profiles/r04_acc_issue_model.txt):
+# per mixed addition 1226 v_mad_u64_u32 at 4.7 cycles per wave-instruction, 437 VOP3 / 64-bit / literal-operand instructions at 4.1
+# and 563 VGPR-only VOP2 instructions at 2.3 (the rates of profiles/r04_microbench_instr_rates.txt): 8 849 issue cycles per wave-trip.
+ACC_ISSUE_CYCLES = 1226 * 4.7 + 437 * 4.1 + 563 * 2.3
+
+
 def valu_roofline(acc_ms, mixed_adds):
     # radix-2^29 XYZZ mixed addition (curve29.cuh): 8 products of 135 + 2 squarings of 99 v_mad_u64_u32, minus the
     # one reduction (54) saved by forming Y3 as a two-term lazy row
     cycles_per_wave_madd = (8 * 135 + 2 * 99 - 54) * 4.6
     peak = 1024 * 2.15e9 * 64 / cycles_per_wave_madd  # mixed additions / s if the SIMDs issued nothing but those mads
+    issue_peak = 1024 * 2.15e9 * 64 / ACC_ISSUE_CYCLES  # ... if they issued the loop's whole instruction mix back to back
     ach = mixed_adds / (acc_ms * 1e-3) if acc_ms > 0 else 0.0
     return {"bound": "valu", "kernel": "msm_accumulate_kernel", "achieved": round(ach / 1e9, 3), "peak": round(peak / 1e9, 3),
-            "unit": "G mixed-add/s", "frac": round(ach / peak, 4)}
+            "unit": "G mixed-add/s", "frac": round(ach / peak, 4),
+            "issue_model": {"peak": round(issue_peak / 1e9, 3), "frac": round(ach / issue_peak, 4), "cycles_per_wave_madd": round(ACC_ISSUE_CYCLES),
+                            "note": "peak = the v_mad-only ceiling (what rounds 1-3 quoted); issue_model.peak = every instruction of the loop at its measured "
+                                    "issue cost - on gfx950 only VGPR-operand VOP2 instructions issue in 2.3 cycles, every VOP3 / 64-bit / literal form "
+                                    "takes 4.1: profiles/r04_acc_issue_model.txt, profiles/r04_microbench_instr_rates.txt"}}
 
 
 def msm_window_bits(args, n):

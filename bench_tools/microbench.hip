@@ -94,6 +94,37 @@ __global__ void k_and_b32(uint32_t* out, uint32_t seed) {
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
 }
+__global__ void k_shr_inline(uint32_t* out, uint32_t seed) {  // VOP2 e32 with an INLINE CONSTANT as src0
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0) | 0x80000000u; uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1) | 0x80000000u; uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2) | 0x80000000u; uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3) | 0x80000000u; uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4) | 0x80000000u; uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5) | 0x80000000u; uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6) | 0x80000000u; uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7) | 0x80000000u;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_add_u32_e32 %0, 3, %0\n v_add_u32_e32 %1, 3, %1\n v_add_u32_e32 %2, 3, %2\n v_add_u32_e32 %3, 3, %3\n v_add_u32_e32 %4, 3, %4\n v_add_u32_e32 %5, 3, %5\n v_add_u32_e32 %6, 3, %6\n v_add_u32_e32 %7, 3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_and_literal(uint32_t* out, uint32_t seed) {  // VOP2 e32 with a 32-bit LITERAL as src0
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_add_u32_e32 %0, 0x1fffffff, %0\n v_add_u32_e32 %1, 0x1fffffff, %1\n v_add_u32_e32 %2, 0x1fffffff, %2\n v_add_u32_e32 %3, 0x1fffffff, %3\n v_add_u32_e32 %4, 0x1fffffff, %4\n v_add_u32_e32 %5, 0x1fffffff, %5\n v_add_u32_e32 %6, 0x1fffffff, %6\n v_add_u32_e32 %7, 0x1fffffff, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_cndmask_vcc(uint32_t* out, uint32_t seed) {  // VOP2 e32 v_cndmask (mask = VCC, implicit)
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t y = seed * 7 + 1;
+    asm volatile("v_cmp_gt_u32_e32 vcc, 32, %0" : : "v"(threadIdx.x & 63) : "vcc");
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(y) : "vcc");
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
+__global__ void k_bpermute(uint32_t* out, uint32_t seed) {  // cross-lane exchange as __shfl_xor compiles it (ds_bpermute_b32)
+    uint32_t a0 = (uint32_t)(seed + threadIdx.x + 0); uint32_t a1 = (uint32_t)(seed + threadIdx.x + 1); uint32_t a2 = (uint32_t)(seed + threadIdx.x + 2); uint32_t a3 = (uint32_t)(seed + threadIdx.x + 3); uint32_t a4 = (uint32_t)(seed + threadIdx.x + 4); uint32_t a5 = (uint32_t)(seed + threadIdx.x + 5); uint32_t a6 = (uint32_t)(seed + threadIdx.x + 6); uint32_t a7 = (uint32_t)(seed + threadIdx.x + 7);
+    uint32_t addr = ((threadIdx.x ^ 8) & 63) << 2;
+    for (int it = 0; it < ITERS; it++) {
+        asm volatile("ds_bpermute_b32 %0, %8, %0\n ds_bpermute_b32 %1, %8, %1\n ds_bpermute_b32 %2, %8, %2\n ds_bpermute_b32 %3, %8, %3\n ds_bpermute_b32 %4, %8, %4\n ds_bpermute_b32 %5, %8, %5\n ds_bpermute_b32 %6, %8, %6\n ds_bpermute_b32 %7, %8, %7\n s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(addr));
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);
+}
 __global__ void k_mov_b64(uint32_t* out, uint32_t seed) {
     uint64_t a0 = (uint64_t)(seed + threadIdx.x + 0); uint64_t a1 = (uint64_t)(seed + threadIdx.x + 1); uint64_t a2 = (uint64_t)(seed + threadIdx.x + 2); uint64_t a3 = (uint64_t)(seed + threadIdx.x + 3); uint64_t a4 = (uint64_t)(seed + threadIdx.x + 4); uint64_t a5 = (uint64_t)(seed + threadIdx.x + 5); uint64_t a6 = (uint64_t)(seed + threadIdx.x + 6); uint64_t a7 = (uint64_t)(seed + threadIdx.x + 7);
     for (int it = 0; it < ITERS; it++) {
@@ -329,6 +360,10 @@ int main() {
     RUN_PROBE(k_alignbit, 8, "v_alignbit_b32");
     RUN_PROBE(k_and_b32, 8, "v_and_b32");
     RUN_PROBE(k_mov_b64, 8, "v_mov_b64");
+    RUN_PROBE(k_shr_inline, 8, "v_add_u32 e32 inline const");
+    RUN_PROBE(k_and_literal, 8, "v_add_u32 e32 literal");
+    RUN_PROBE(k_cndmask_vcc, 8, "v_cndmask e32 (vcc)");
+    RUN_PROBE(k_bpermute, 8, "ds_bpermute_b32");
     RUN_PROBE(k_mad_addc, 16, "mad+addc (dep chain)");
     RUN_PROBE(k_addc_e64, 8, "v_addc_co e64 sgpr-carry");
     RUN_PROBE(k_addc_e32, 8, "v_addc_co e32 vcc (dep)");
