@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-ARGS="--steps 5 --warmup 1 --no-cpu-baseline --pmc off --no-plain-leg $*"   # --pmc off: bench.py must not start its own rocprofv3 passes under this one;
+ARGS="--steps 5 --warmup 1 --no-cpu-baseline --pmc off --no-plain-leg --sub-records off $*"   # --pmc off: bench.py must not start its own rocprofv3 passes under this one;
 # --no-plain-leg: the plain-key sub-record launches the same accumulate kernel on 16 n entries instead of 13 n - kept out of these profiles
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace_err.txt
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch_err.txt
