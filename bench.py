@@ -1073,9 +1073,10 @@ def poseidon_valu_roofline(arity, hashes, kernel_ms):
 
 
 # Instruction-issue model of the accumulate loop (bench_tools/issue_model.py over the ISA of msm_acc.hip, profiles/r04_acc_issue_model.txt):
-# per mixed addition 1226 v_mad_u64_u32 at 4.7 cycles per wave-instruction, 437 VOP3 / 64-bit / literal-operand instructions at 4.1
-# and 563 VGPR-only VOP2 instructions at 2.3 (the rates of profiles/r04_microbench_instr_rates.txt): 8 849 issue cycles per wave-trip.
-ACC_ISSUE_CYCLES = 1226 * 4.7 + 437 * 4.1 + 563 * 2.3
+# per mixed addition 1226 v_mad_u64_u32 at 4.7 cycles per wave-instruction, 376 VOP3 / 64-bit / SGPR-operand instructions at 4.1
+# and 614 VOP2 instructions on VGPRs, inline constants or literals at 2.3 (the rates of profiles/r04_microbench_instr_rates.txt):
+# 8 716 issue cycles per wave-trip.
+ACC_ISSUE_CYCLES = 1226 * 4.7 + 376 * 4.1 + 614 * 2.3
 
 
 def valu_roofline(acc_ms, mixed_adds):
@@ -1089,8 +1090,8 @@ def valu_roofline(acc_ms, mixed_adds):
             "unit": "G mixed-add/s", "frac": round(ach / peak, 4),
             "issue_model": {"peak": round(issue_peak / 1e9, 3), "frac": round(ach / issue_peak, 4), "cycles_per_wave_madd": round(ACC_ISSUE_CYCLES),
                             "note": "peak = the v_mad-only ceiling (what rounds 1-3 quoted); issue_model.peak = every instruction of the loop at its measured "
-                                    "issue cost - on gfx950 only VGPR-operand VOP2 instructions issue in 2.3 cycles, every VOP3 / 64-bit / literal form "
-                                    "takes 4.1: profiles/r04_acc_issue_model.txt, profiles/r04_microbench_instr_rates.txt"}}
+                                    "issue cost - on gfx950 only VOP2 instructions without an SGPR source issue in 2.3 cycles, every VOP3 / 64-bit / SGPR-operand "
+                                    "form takes 4.1: profiles/r04_acc_issue_model.txt, profiles/r04_microbench_instr_rates.txt"}}
 
 
 def msm_window_bits(args, n):

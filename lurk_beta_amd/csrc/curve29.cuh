@@ -26,11 +26,10 @@ template <class P>
 LURK_HD F29<P> f29_carry_signed(const int32_t* t) {
     F29<P> r;
     int32_t c = 0;
-    const uint32_t mask = f29_mask_reg();
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         int32_t x = t[i] + c;
-        r.l[i] = (uint32_t)x & mask;
+        r.l[i] = (uint32_t)x & F29_MASK;
         c = x >> 29;  // arithmetic shift
     }
     r.l[8] = (uint32_t)(t[8] + c);
@@ -48,11 +47,10 @@ LURK_HD F29<P> f29_reduce(const F29<P>& v) {
     // e = (k-1) * eps as normalised 29-bit limbs (eps limbs = modulus limbs 0..4)
     int32_t t[9];
     uint64_t c = 0;
-    const uint32_t mask = f29_mask_reg();
 #pragma unroll
     for (int i = 0; i < 5; i++) {
         c += (uint64_t)km1 * f29_mod<P>(i);
-        t[i] = (int32_t)v.l[i] - (int32_t)((uint32_t)c & mask);
+        t[i] = (int32_t)v.l[i] - (int32_t)((uint32_t)c & F29_MASK);
         c >>= 29;
     }
     t[5] = (int32_t)v.l[5] - (int32_t)(uint32_t)c;      // remaining carry of (k-1) eps (< 2^9)

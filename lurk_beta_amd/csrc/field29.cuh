@@ -52,21 +52,6 @@ struct F29 {
 
 constexpr uint32_t F29_MASK = (1u << 29) - 1u;
 
-// The limb mask for the carry passes of the hot loops, held in a VGPR.  On gfx950 a VOP2 instruction issues in ~2.3 cycles only when
-// its sources are VGPRs (or inline constants); with a 32-bit LITERAL or an SGPR operand it takes ~4.1, like a VOP3 form
-// (profiles/r04_microbench_instr_rates.txt).  The compiler folds `x & 0x1fffffff` into `v_and_b32 v, 0x1fffffff, v` - the slow form,
-// 124 of them per mixed addition.  An asm statement hides the constant: the value lives in one register and every mask becomes
-// `v_and_b32 v, v, v`.  (Not volatile, no inputs: the compiler may hoist it out of loops and merge copies.)
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ uint32_t f29_mask_reg() {
-    uint32_t m;
-    asm("v_mov_b32 %0, 0x1fffffff" : "=v"(m));
-    return m;
-}
-#else
-inline constexpr uint32_t f29_mask_reg() { return F29_MASK; }
-#endif
-
 // modulus limbs in radix 2^29 (constexpr from the 8 x 32 description)
 template <class P>
 LURK_HD constexpr uint32_t f29_mod(int i) {
@@ -94,11 +79,10 @@ template <class P>
 LURK_HD F29<P> f29_carry(const F29<P>& a) {
     F29<P> r;
     uint32_t c = 0;
-    const uint32_t mask = f29_mask_reg();
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         uint32_t x = a.l[i] + c;  // < 2^31 + 2^3
-        r.l[i] = x & mask;
+        r.l[i] = x & F29_MASK;
         c = x >> 29;
     }
     r.l[8] = a.l[8] + c;
@@ -288,7 +272,7 @@ LURK_HD F29<P> f29_from_mont256(const Fe<P>& x) {
             if (limb + 1 < 8) v |= (uint64_t)x.l[limb + 1] << 32;
             v >>= sh;
         }
-        r.l[i] = (uint32_t)v & f29_mask_reg();
+        r.l[i] = (uint32_t)v & F29_MASK;
     }
     return r;
 }
@@ -301,7 +285,7 @@ LURK_HD F29<P> f29_from_plain(const uint32_t* x) {
         const int bit = 29 * i, limb = bit >> 5, sh = bit & 31;
         uint64_t v = limb < 8 ? x[limb] : 0u;
         if (limb + 1 < 8) v |= (uint64_t)x[limb + 1] << 32;
-        r.l[i] = (uint32_t)(v >> sh) & f29_mask_reg();
+        r.l[i] = (uint32_t)(v >> sh) & F29_MASK;
     }
     return r;
 }
