@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--devices", default="",
                     help="fold_step: comma-separated device list, e.g. 0,0 or 0,1,2,3: the commitment key is cut across these devices inside ONE process "
                          "(lurk_hip_msm_multi_* + lurk_hip_fold_ctx_create_multi); a repeated id puts several slices on one GPU (functional and overhead check)")
+    ap.add_argument("--helper-devices", default="",
+                    help="fold_step with --stage-ahead 1: comma-separated devices that each hold a copy of the commitment key and commit the instances staged "
+                         "ahead in turn (lurk_hip_fold_ctx_add_helper: staging ahead across GPUs); e.g. 1,2,3 on a node, 0 on a one-GPU box (functional)")
     ap.add_argument("--sub-records", choices=["auto", "off"], default="auto",
                     help="auto = the default msm line at N = 1 also carries the other workloads of the path as verified sub-records "
                          "(fold_step_rc100, poseidon_tree_2_24, ntt_2_24: each a child run of this file with --verify, same --steps / --warmup)")
@@ -412,6 +415,18 @@ def fold_step_workload(args, lib, world, rank):
     else:
         ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     ctx = L.FoldingContext(L.CURVE_PALLAS, shape, ck)
+    helper_keys = []
+    if args.helper_devices:
+        assert args.stage_ahead and not devices, "--helper-devices goes with --stage-ahead 1 and a single-device key"
+        for hd in [int(x) for x in args.helper_devices.split(",")]:
+            _lib.check(lib.lurk_hip_set_device(hd))
+            with torch.cuda.device(hd):
+                hb = d_bases if d_bases.device.index == hd else d_bases.to(f"cuda:{hd}")
+                hk = L.CommitmentKey(L.CURVE_PALLAS, hb, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
+                hk.reserve(n_key, 3)
+            helper_keys.append(hk)
+            ctx.add_helper(hk)
+        _lib.check(lib.lurk_hip_set_device(torch.cuda.current_device()))
     z1 = synth.scalars(F, 1, 1, n_w + 1 + n_io, mont=True).cpu().numpy().view(np.uint64)   # a running instance with witness-like values
     e1 = synth.scalars(F, 2, 0, n_t, mont=True).cpu().numpy().view(np.uint64)              # a running error vector (uniform, like any folded T)
     ident = np.zeros(12, dtype=np.uint64)
@@ -532,6 +547,7 @@ def fold_step_workload(args, lib, world, rank):
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
             "config": {"staged_ahead": bool(args.stage_ahead), "witness_ahead": bool(args.witness_ahead and not args.stage_ahead),
                        "devices": devices, "distinct_devices": len(set(devices)) if devices else 1,
+                       "helper_devices": args.helper_devices or None,
                        "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
                                    f"slot blocks traced on the device + {rc} x 1311 body aux over PCIe) -> MSM(W2) + cross term over {n_t} rows ({nnz} non-zeros, "
                                    f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) -> fold of [W|u|X] and E",
@@ -624,6 +640,8 @@ def fold_step_workload(args, lib, world, rank):
                                              "(pasta-msm-shaped Pippenger, all cores); fold arithmetic, witness generation and transcript not included"}
         print(json.dumps(res), flush=True)
     ctx.close()
+    for hk in helper_keys:
+        hk.close()
     ck.close()
     shape.close()
 

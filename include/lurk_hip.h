@@ -386,6 +386,13 @@ typedef struct lurk_hip_w2_patch {
     const void* values;     /* count x 32 bytes, host memory */
 } lurk_hip_w2_patch;
 int lurk_hip_fold_step_prefetch(lurk_hip_fold_ctx* ctx, const void* w2_range, size_t offset, size_t count, int on_device, void* stream);
+/* Staging ahead ACROSS DEVICES: helper_key is the same commitment key resident on another device (an ordinary lurk_hip_msm_ctx over
+ * the same bases, created under lurk_hip_set_device(other)).  Instances staged with lurk_hip_fold_step_prefetch then have their
+ * commitment computed on the helpers in turn - the staged ranges are pushed peer-to-peer - while the context's own device folds the
+ * open step; late ranges and T stay on the context's device.  Folding steps are sequential, so this (the reference's witness producer
+ * thread, /root/reference/src/proof/nova.rs:306-317, spread over GPUs) is how IVC itself gains from several devices.  Add helpers
+ * before the first step; they are borrowed for the context's lifetime and use their slots 0 and 2. */
+int lurk_hip_fold_ctx_add_helper(lurk_hip_fold_ctx* ctx, lurk_hip_msm_ctx* helper_key);
 int lurk_hip_fold_step_begin_prefetched(lurk_hip_fold_ctx* ctx, const lurk_hip_w2_patch* patches, size_t n_patches, const void* x2_mont,
                                         void* comm_w2_jac96, void* comm_t_jac96);
 int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* ctx, const void* r32_mont);

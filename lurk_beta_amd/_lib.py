@@ -100,6 +100,7 @@ SIGNATURES = {
     "lurk_hip_fold_vec": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "lurk_hip_fold_ctx_create": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_create_multi": (c_int, [ctypes.POINTER(c_void_p), c_int, c_void_p, c_void_p]),
+    "lurk_hip_fold_ctx_add_helper": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_destroy": (c_int, [c_void_p]),
     "lurk_hip_fold_ctx_set_running": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_begin": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -57,6 +57,28 @@ struct lurk_hip_fold_ctx {
     };
     std::vector<std::unique_ptr<ShardBuf>> shard_bufs;
     hipEvent_t t_ev = nullptr;         // multi-device key: T is complete on the context's stream
+    // Helper keys (lurk_hip_fold_ctx_add_helper): the SAME commitment key resident on other devices.  The commitment of an instance
+    // staged ahead (lurk_hip_fold_step_prefetch) then runs on helper (k mod H) - the staged ranges are pushed peer-to-peer into a
+    // buffer on the helper's device and committed under its key - while this context's device folds the open step; the late ranges
+    // and T stay here.  This is the reference's producer thread (nova.rs:306-317) spread over GPUs: the one way IVC itself gains from
+    // several devices, since the steps are sequential.
+    struct Helper {
+        lurk_hip_msm_ctx* key = nullptr;
+        int device = 0;
+        DevBuf buf[2];                     // the staged ranges of fresh-instance buffer b, on the helper's device
+        hipStream_t stream[2] = {nullptr, nullptr};
+        ~Helper() {
+            int prev = 0;
+            (void)hipGetDevice(&prev);
+            (void)hipSetDevice(device);
+            for (int k = 0; k < 2; k++)
+                if (stream[k]) (void)hipStreamDestroy(stream[k]);
+            (void)hipSetDevice(prev);
+        }
+    };
+    std::vector<std::unique_ptr<Helper>> helpers;
+    size_t helper_next = 0;
+    int helper_of[2] = {-1, -1};       // which helper commits the instance staged in buffer b (-1: this context's own key)
     size_t num_cons = 0, num_vars = 0, num_io = 0, ncols = 0;
     DevBuf z[2], e[2], t;              // running pair ping-pongs between two buffers (cur = index of the live one)
     DevBuf z2[2], zstaged[2], zpatch;  // fresh instances [W2 | 1 | X2]: the open step's and the one staged ahead; the staged ranges alone
@@ -137,15 +159,29 @@ static void fold_instance_settle(lurk_hip_fold_ctx* c) {
     c->instance_owed = false;
 }
 
+// the key and the slot the staged commitment of buffer b runs on
+static lurk_hip_msm_ctx* fold_staged_key(lurk_hip_fold_ctx* c, int b) { return c->helper_of[b] >= 0 ? c->helpers[c->helper_of[b]]->key : c->key; }
+
 static void fold_submit_staged(lurk_hip_fold_ctx* c, int b, int mode) {
     if (c->submitted[b]) return;
-    ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 2 * b, c->partial[b] ? c->zstaged[b].p : c->z2[b].p, c->num_vars, 1, c->stage_stream[b],
-                                        mode));  // zero digits cost the sort nothing
+    const void* src = c->partial[b] ? c->zstaged[b].p : c->z2[b].p;
+    if (c->helper_of[b] >= 0) {  // on another device: push the staged ranges there (ordered after their staging here), commit under the helper's key
+        auto& h = *c->helpers[c->helper_of[b]];
+        LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream[b]));
+        {
+            DeviceGuard dg(h.device);
+            LURK_HIP_CHECK(hipStreamWaitEvent(h.stream[b], c->staged_ev[b], 0));
+            LURK_HIP_CHECK(hipMemcpyPeerAsync(h.buf[b].p, h.device, src, c->device, c->num_vars * 32, h.stream[b]));
+        }
+        ok(lurk_hip_msm_ctx_submit_dev_mode(h.key, 2 * b, h.buf[b].p, c->num_vars, 1, h.stream[b], LURK_MSM_SUBMIT_DEFAULT));
+    } else {
+        ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 2 * b, src, c->num_vars, 1, c->stage_stream[b], mode));  // zero digits cost the sort nothing
+    }
     c->submitted[b] = true;
 }
 
 // Stage positions [offset, offset + count) of the next fresh witness (the rest zero for now) and start its commitment.
-static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size_t count, int on_device, void* w2_stream) {
+static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size_t count, int on_device, void* w2_stream, bool staged_ahead = false) {
     LURK_REQUIRE(c->n_staged < 2, "two fresh instances are already staged: begin a step first");
     // two z2 buffers: while a step is open its instance occupies one of them until finish(r) has folded it, so only ONE more
     // can be staged (the next buffer in turn would be the open step's own)
@@ -168,8 +204,14 @@ static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size
         LURK_HIP_CHECK(hipMemcpyAsync(c->zstaged[b].p, z2, c->num_vars * 32, hipMemcpyDeviceToDevice, c->stage_stream[b]));
     }
     c->submitted[b] = false;
+    c->helper_of[b] = -1;
+    if (!c->helpers.empty() && staged_ahead) c->helper_of[b] = (int)(c->helper_next++ % c->helpers.size());
     c->staged[c->n_staged++] = b;
     c->next_buf = b ^ 1;
+    if (c->helper_of[b] >= 0) {  // another device's queues: nothing this device waits for is delayed by starting now
+        fold_submit_staged(c, b, LURK_MSM_SUBMIT_DEFAULT);
+        return;
+    }
     // Between begin and finish nothing the host waits for is in flight: the commitment starts now, in the background class.
     // Otherwise it is submitted by the begin that comes next, BEHIND that step's commit(T): the device serves its queues
     // roughly in submission order, and T is what the host waits for.
@@ -209,7 +251,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
         ~Rollback() {
             if (!armed) return;
             uint64_t junk[12];
-            if (c->submitted[b]) (void)lurk_hip_msm_ctx_wait(c->key, 2 * b, junk);
+            if (c->submitted[b]) (void)lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, junk);
             if (t_in_flight) (void)lurk_hip_msm_ctx_wait(c->key, 1, junk);
             if (late_in_flight) (void)lurk_hip_msm_ctx_wait(c->key, 3, junk);
             c->submitted[b] = false;
@@ -276,7 +318,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     fold_instance_settle(c);  // the previous step's instance fold, while the device works on this step
     if (patched) {
         c->submitted[b] = false;  // (a wait consumes the slot's commitment whether it succeeds or not)
-        ok(lurk_hip_msm_ctx_wait(c->key, 2 * b, body));
+        ok(lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, body));
         rollback.late_in_flight = false;
         ok(lurk_hip_msm_ctx_wait(c->key, 3, late));
         uint64_t two[24];
@@ -289,7 +331,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
         c->patch_ev_valid = true;
     } else {
         c->submitted[b] = false;
-        ok(lurk_hip_msm_ctx_wait(c->key, 2 * b, comm_w2_jac96));
+        ok(lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, comm_w2_jac96));
     }
     tt[4] = now();
     rollback.t_in_flight = false;
@@ -496,6 +538,32 @@ int lurk_hip_fold_ctx_create_multi(lurk_hip_fold_ctx** out, int curve, lurk_hip_
     });
 }
 
+int lurk_hip_fold_ctx_add_helper(lurk_hip_fold_ctx* c, lurk_hip_msm_ctx* helper_key) {
+    return guarded([&] {
+        LURK_REQUIRE(c && helper_key, "null argument");
+        std::lock_guard<std::mutex> lk(c->mu);
+        LURK_REQUIRE(!c->mkey, "helper keys belong to a context over a single-device key");
+        LURK_REQUIRE(!c->begun && c->n_staged == 0, "add helper keys before the first step");
+        int curve = 0, device = 0;
+        size_t npoints = 0;
+        ok(lurk_hip_msm_ctx_info(helper_key, &curve, &npoints, nullptr, nullptr));
+        ok(lurk_hip_msm_ctx_device(helper_key, &device));
+        LURK_REQUIRE(curve == c->curve, "the helper key is over another curve");
+        LURK_REQUIRE(npoints >= c->num_vars, "the helper key has fewer points than the witness has elements");
+        auto h = std::make_unique<lurk_hip_fold_ctx::Helper>();
+        h->key = helper_key;
+        h->device = device;
+        {
+            DeviceGuard dg(device);
+            for (int k = 0; k < 2; k++) {
+                h->buf[k].alloc(c->num_vars * 32);
+                LURK_HIP_CHECK(hipStreamCreateWithFlags(&h->stream[k], hipStreamNonBlocking));
+            }
+        }
+        c->helpers.push_back(std::move(h));
+    });
+}
+
 int lurk_hip_fold_ctx_destroy(lurk_hip_fold_ctx* c) {
     if (!c) return 0;
     return guarded([&] {
@@ -591,8 +659,8 @@ int lurk_hip_fold_step_prefetch(lurk_hip_fold_ctx* c, const void* w2_range, size
         LURK_REQUIRE(c, "null ctx");
         DeviceGuard dg(c->device);
         std::lock_guard<std::mutex> lk(c->mu);
-        LURK_REQUIRE(!c->mkey, "staging ahead is not available with a multi-device key");
-        fold_stage(c, w2_range, offset, count, on_device, stream);
+        LURK_REQUIRE(!c->mkey, "staging ahead is not available with a key cut across devices: give the context helper keys (lurk_hip_fold_ctx_add_helper)");
+        fold_stage(c, w2_range, offset, count, on_device, stream, /*staged_ahead=*/true);
     });
 }
 

@@ -300,6 +300,8 @@ class FoldingContext {
         open_ = c;
         return c;
     }
+    // staging ahead across devices: `helper` holds the same key on another device; staged commitments run on the helpers in turn
+    void add_helper(CommitmentKey& helper) { check(lurk_hip_fold_ctx_add_helper(h_, helper.handle())); }
     // staging ahead: positions [offset, offset + range.size()) of the next fresh witness, its commitment starts now
     void prefetch(const std::vector<Fe>& w2_range_mont, size_t offset = 0) {
         check(lurk_hip_fold_step_prefetch(h_, w2_range_mont.data(), offset, w2_range_mont.size(), 0, nullptr));

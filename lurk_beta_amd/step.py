@@ -100,6 +100,12 @@ class FoldingContext:
         self._open = (cw, ct)
         return cw, ct
 
+    def add_helper(self, helper_key):
+        """Staging ahead across devices: ``helper_key`` is a ``CommitmentKey`` over the same bases resident on another device; instances
+        staged with ``prefetch`` are committed on the helpers in turn (peer copy of the staged ranges) while this context's device folds."""
+        _lib.check(_lib.load().lurk_hip_fold_ctx_add_helper(self._h, helper_key._ctx))
+        self._helpers = getattr(self, "_helpers", []) + [helper_key]
+
     def prefetch(self, w2_range, offset: int = 0, stream=None):
         """Stage positions [offset, offset + len) of the NEXT fresh witness (host array or device tensor, Montgomery; the rest
         zero until ``begin_prefetched`` supplies it) and start its commitment under whatever the device is doing now."""

@@ -296,6 +296,27 @@ int main() {
         EXPECT(single.last_r == multi.last_r);
         EXPECT(single.read() == multi.read());
         EXPECT(key.to_affine(single.comm_w) == key.to_affine(multi.comm_w) && key.to_affine(single.comm_e) == key.to_affine(multi.comm_e));
+        // staging ahead across devices: two helper keys (the same bases; this box's one GPU as their device), instances staged ahead are
+        // committed under them in turn; two steps with a late range == the single-key staged flow
+        CommitmentKey h0(curve, {G, Affine{g2.x, g2.y}}, false), h1(curve, {G, Affine{g2.x, g2.y}}, false);
+        R1CSShape s3(LURK_FIELD_PALLAS_FQ, 2, 2, 1, A, B, C), s4(LURK_FIELD_PALLAS_FQ, 2, 2, 1, A, B, C);
+        FoldingContext plain(curve, s3, key), helped(curve, s4, key);
+        helped.add_helper(h0);
+        helped.add_helper(h1);
+        const std::vector<std::vector<Fe>> ws = {{three, nine}, {two, four}};
+        const std::vector<Fe> ios = {two, three};
+        for (FoldingContext* fc : {&plain, &helped}) fc->prefetch({ws[0][0]}, 0);
+        for (int k = 0; k < 2; k++) {
+            if (k == 0)
+                for (FoldingContext* fc : {&plain, &helped}) fc->prefetch({ws[1][0]}, 0);  // two instances staged: helpers 0 and 1
+            auto a = plain.begin_prefetched({ios[k]}, {{1, {ws[k][1]}}});
+            auto b = helped.begin_prefetched({ios[k]}, {{1, {ws[k][1]}}});
+            EXPECT(key.to_affine(a[0]) == key.to_affine(b[0]) && key.to_affine(a[1]) == key.to_affine(b[1]));
+            EXPECT(key.to_affine(a[0]) == key.to_affine(key.commit(ws[k], true)));
+            plain.finish(Fe(11 + k));
+            helped.finish(Fe(11 + k));
+            EXPECT(plain.read() == helped.read());
+        }
     }
     printf("host mirror ok\n");
     return 0;

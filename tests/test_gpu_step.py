@@ -99,11 +99,13 @@ def test_three_consecutive_steps(hip, curve, m, nfree):
     shape.close()
 
 
-@pytest.mark.parametrize("curve,m,nfree", [(0, 20000, 9000), (1, 3000, 1500)])
-def test_steps_with_instances_staged_ahead(hip, curve, m, nfree):
+@pytest.mark.parametrize("curve,m,nfree,helpers", [(0, 20000, 9000, 0), (1, 3000, 1500, 0), (0, 20000, 9000, 2), (1, 3000, 1500, 1)])
+def test_steps_with_instances_staged_ahead(hip, curve, m, nfree, helpers):
     """lurk_hip_fold_step_prefetch / begin_prefetched: the step circuit's range of W2 is staged (and its commitment started) one
     step ahead, the augmented circuit's ranges around it arrive with begin.  Every step must give what the plain begin gives:
-    comm_W2 = commit(whole W2) by linearity, same T, same folded pair."""
+    comm_W2 = commit(whole W2) by linearity, same T, same folded pair.  helpers > 0: staging ahead ACROSS DEVICES
+    (lurk_hip_fold_ctx_add_helper; this box's one GPU listed as every helper's device): the staged commitments run under helper keys
+    in turn - table and plain ones -, late ranges and T under the context's own key; same results."""
     import torch
 
     from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape, point_to_affine
@@ -118,6 +120,9 @@ def test_steps_with_instances_staged_ahead(hip, curve, m, nfree):
     key = CommitmentKey(curve, bases, precompute=bool(curve))
     key.reserve(max(m, nv), 4)
     ctx = FoldingContext(curve, shape, key)
+    helper_keys = [CommitmentKey(curve, bases, precompute=bool(h % 2), window_bits=16 if h % 2 else 0) for h in range(helpers)]
+    for hk in helper_keys:
+        ctx.add_helper(hk)
     commit = lambda v: C.jac_to_affine(curve, C.msm_pippenger(curve, bases[: len(v)], v))
     lo, hi = nv // 50, nv - nv // 30  # the staged body is [lo, hi); prefix and suffix arrive late
     steps = 4
@@ -168,7 +173,12 @@ def test_steps_with_instances_staged_ahead(hip, curve, m, nfree):
     ctx.finish(C.to_mont(f, C.ints_to_limbs([3])))
     cw2, _ = ctx.begin(w2m[1], C.to_mont(f, x2))
     assert point_to_affine(curve, cw2) == point_to_affine(curve, cw)
+    if helpers:
+        with pytest.raises(LurkHipError, match="before the first step"):
+            ctx.add_helper(helper_keys[0])  # a step is open
     ctx.close()
+    for hk in helper_keys:
+        hk.close()
     key.close()
     shape.close()
 
