@@ -415,6 +415,7 @@ def fold_step_workload(args, lib, world, rank):
     else:
         ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     ctx = L.FoldingContext(L.CURVE_PALLAS, shape, ck)
+    ctx.set_pp_digest(pp_digest)
     helper_keys = []
     if args.helper_devices:
         assert args.stage_ahead and not devices, "--helper-devices goes with --stage-ahead 1 and a single-device key"
@@ -478,8 +479,7 @@ def fold_step_workload(args, lib, world, rank):
             t_b = time.perf_counter()
             cw, ct = ctx.begin(d_w2, x2, stream=stream)                              # both commitments + the cross term
         t_c = time.perf_counter()
-        ucw, uce, uu, ux = ctx.instance()
-        r = L.nifs_challenge(L.CURVE_PALLAS, pp_digest, ucw, uce, uu, ux, cw, x2, ct)  # r = RO(pp_digest, U1, U2, comm_T)
+        r = ctx.challenge()  # r = RO(pp_digest, U1, U2, comm_T): U1 and U2 were absorbed inside begin, one permutation is left (lurk_hip_fold_step_challenge)
         t_r = time.perf_counter()
         ctx.finish(r)
         last_r[0] = r

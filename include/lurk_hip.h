@@ -396,6 +396,13 @@ int lurk_hip_fold_ctx_add_helper(lurk_hip_fold_ctx* ctx, lurk_hip_msm_ctx* helpe
 int lurk_hip_fold_step_begin_prefetched(lurk_hip_fold_ctx* ctx, const lurk_hip_w2_patch* patches, size_t n_patches, const void* x2_mont,
                                         void* comm_w2_jac96, void* comm_t_jac96);
 int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* ctx, const void* r32_mont);
+/* The challenge of the OPEN step from the library's transcript, for callers of the begin / finish halves who do not bring their own:
+ * set the digest of the public parameters once; every begin then absorbs pp_digest and the running instance U1 - and runs the
+ * permutation that completes - while the device is still working on the step, absorbs U2 when comm_W2 has arrived, and
+ * lurk_hip_fold_step_challenge finishes behind comm_T with ONE permutation: r = RO(pp_digest, U1, U2, comm_T), the value
+ * lurk_hip_nifs_challenge gives (and lurk_hip_fold_step uses the same staging).  r comes back in Montgomery form, ready for finish. */
+int lurk_hip_fold_ctx_set_pp_digest(lurk_hip_fold_ctx* ctx, const void* pp_digest32);
+int lurk_hip_fold_step_challenge(lurk_hip_fold_ctx* ctx, void* r32_mont);
 /* the running pair where it lives (valid until the next finish) and the stream its updates are ordered on */
 int lurk_hip_fold_ctx_running_dev(lurk_hip_fold_ctx* ctx, void** d_z, void** d_e, void** stream);
 /* copies of the running pair for the host (either may be NULL); synchronises the context's stream */

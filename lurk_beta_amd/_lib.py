@@ -107,6 +107,8 @@ SIGNATURES = {
     "lurk_hip_fold_step_prefetch": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_int, c_void_p]),
     "lurk_hip_fold_step_begin_prefetched": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_finish": (c_int, [c_void_p, c_void_p]),
+    "lurk_hip_fold_ctx_set_pp_digest": (c_int, [c_void_p, c_void_p]),
+    "lurk_hip_fold_step_challenge": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_running_dev": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
     "lurk_hip_fold_ctx_read": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_set_instance": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -17,6 +17,7 @@
 
 #include "common.hpp"
 #include "field.cuh"
+#include "nifs_pre.hpp"
 
 namespace lurk {
 
@@ -76,6 +77,11 @@ struct lurk_hip_fold_ctx {
             (void)hipSetDevice(prev);
         }
     };
+    // the transcript in stages (nifs_pre.hpp): with a pp_digest set, begin absorbs U1 (and runs the permutation that completes) while the
+    // device works, absorbs U2 when comm_W2 has arrived, and lurk_hip_fold_step_challenge / lurk_hip_fold_step finish behind comm_T
+    bool has_pp = false;
+    uint8_t pp_digest[32] = {0};
+    NifsPre* pre = nullptr;
     std::vector<std::unique_ptr<Helper>> helpers;
     size_t helper_next = 0;
     int helper_of[2] = {-1, -1};       // which helper commits the instance staged in buffer b (-1: this context's own key)
@@ -106,6 +112,7 @@ struct lurk_hip_fold_ctx {
     hipEvent_t w2_ready = nullptr, staged_ev[2] = {nullptr, nullptr}, folded_ev[2] = {nullptr, nullptr};
     std::mutex mu;
     ~lurk_hip_fold_ctx() {
+        if (pre) nifs_pre_free(pre);
         if (pin) (void)hipHostFree(pin);
         if (stream) (void)hipStreamDestroy(stream);
         for (int k = 0; k < 2; k++)
@@ -157,6 +164,28 @@ static void fold_instance_settle(lurk_hip_fold_ctx* c) {
     memcpy(c->comm_e, new_e, 96);
     c->ux.swap(new_ux);
     c->instance_owed = false;
+}
+
+// r = RO(pp_digest, U1, U2, comm_T) in stages (nifs_pre.hpp).  begin: the settled running instance; a stale precomputation is dropped.
+static void fold_challenge_drop(lurk_hip_fold_ctx* c) {
+    if (c->pre) nifs_pre_free(c->pre);
+    c->pre = nullptr;
+}
+static void fold_challenge_begin(lurk_hip_fold_ctx* c) {
+    fold_challenge_drop(c);
+    if (!c->has_pp) return;
+    c->pre = nifs_pre_begin(c->curve, c->pp_digest, c->comm_w, c->comm_e, c->ux.data(), c->ux.data() + 4, c->num_io);
+}
+static void fold_challenge_finish(lurk_hip_fold_ctx* c, void* r32_mont) {
+    LURK_REQUIRE(c->begun, "no step is open");
+    if (c->pre) {
+        nifs_pre_finish(c->pre, c->open_ct, r32_mont);
+        fold_challenge_drop(c);
+        return;
+    }
+    LURK_REQUIRE(c->has_pp, "no pp_digest: call lurk_hip_fold_ctx_set_pp_digest first");
+    ok(lurk_hip_nifs_challenge(c->curve, c->pp_digest, c->comm_w, c->comm_e, c->ux.data(), c->ux.data() + 4, c->open_cw, c->open_x2.data(), c->num_io,
+                               c->open_ct, r32_mont));
 }
 
 // the key and the slot the staged commitment of buffer b runs on
@@ -263,6 +292,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
             c->staged[1] = c->staged[0];
             c->staged[0] = b;
             c->n_staged++;
+            fold_challenge_drop(c);
         }
     } rollback{c, b, patches, n_patches};
     const bool ahead = c->n_staged > 0 && !c->submitted[c->staged[0]];  // the NEXT step's instance waits to be submitted behind T
@@ -316,6 +346,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     if (ahead) fold_submit_staged(c, c->staged[0], LURK_MSM_SUBMIT_BACKGROUND);  // commit(next W2) fills what T leaves
     tt[3] = now();
     fold_instance_settle(c);  // the previous step's instance fold, while the device works on this step
+    fold_challenge_begin(c);  // ... and the part of this step's transcript that needs no commitment of this step
     if (patched) {
         c->submitted[b] = false;  // (a wait consumes the slot's commitment whether it succeeds or not)
         ok(lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, body));
@@ -333,6 +364,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
         c->submitted[b] = false;
         ok(lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, comm_w2_jac96));
     }
+    if (c->pre) nifs_pre_fresh(c->pre, comm_w2_jac96, x2_mont);  // U2, while commit(T) is still running
     tt[4] = now();
     rollback.t_in_flight = false;
     ok(lurk_hip_msm_ctx_wait(c->key, 1, comm_t_jac96));
@@ -420,8 +452,10 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
         fold_submit_multi(c, 1, c->t.p, c->num_cons, c->t_ev);
         t_in_flight = true;
         fold_instance_settle(c);  // the previous step's instance fold, while the devices work on this step
+        fold_challenge_begin(c);
         w_in_flight = false;
         ok(lurk_hip_msm_multi_wait(c->mkey, 0, comm_w2_jac96));
+        if (c->pre) nifs_pre_fresh(c->pre, comm_w2_jac96, x2_mont);
         t_in_flight = false;
         ok(lurk_hip_msm_multi_wait(c->mkey, 1, comm_t_jac96));
     } catch (...) {  // nothing stays in flight: the context and the key remain usable, the same begin can be repeated
@@ -430,6 +464,7 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
         if (t_in_flight) (void)lurk_hip_msm_multi_wait(c->mkey, 1, junk);
         (void)hipStreamSynchronize(c->stage_stream[0]);
         (void)hipStreamSynchronize(c->stream);
+        fold_challenge_drop(c);
         throw;
     }
     c->open_buf = b;
@@ -452,6 +487,7 @@ static void fold_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
     // instance or the next step has its device work enqueued - the next cross term must not wait for it
     memcpy(c->owed_r, r32_mont, 32);
     c->instance_owed = true;
+    fold_challenge_drop(c);
 }
 
 }  // namespace lurk
@@ -623,12 +659,14 @@ int lurk_hip_fold_step(lurk_hip_fold_ctx* c, const void* w2, int w2_on_device, v
         LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
         LURK_REQUIRE(c->n_staged == 0, "fresh instances are staged: use lurk_hip_fold_step_begin_prefetched");
         uint64_t cw[12], ct[12], r[4];
+        memcpy(c->pp_digest, pp_digest32, 32);
+        c->has_pp = true;
         if (c->mkey) {
             fold_begin_multi(c, w2, w2_on_device, w2_stream, x2_mont, cw, ct);
         } else {
             fold_stage_and_begin(c, w2, w2_on_device, w2_stream, x2_mont, cw, ct);
         }
-        ok(lurk_hip_nifs_challenge(c->curve, pp_digest32, c->comm_w, c->comm_e, c->ux.data(), c->ux.data() + 4, cw, x2_mont, c->num_io, ct, r));
+        fold_challenge_finish(c, r);  // U1 and U2 were absorbed while the device worked: one permutation behind comm_T
         fold_finish(c, r);
         if (comm_w2_jac96) memcpy(comm_w2_jac96, cw, 96);
         if (comm_t_jac96) memcpy(comm_t_jac96, ct, 96);
@@ -674,6 +712,24 @@ int lurk_hip_fold_step_begin_prefetched(lurk_hip_fold_ctx* c, const lurk_hip_w2_
         std::lock_guard<std::mutex> lk(c->mu);
         LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
         fold_begin(c, patches, n_patches, x2_mont, comm_w2_jac96, comm_t_jac96);
+    });
+}
+
+int lurk_hip_fold_ctx_set_pp_digest(lurk_hip_fold_ctx* c, const void* pp_digest32) {
+    return guarded([&] {
+        LURK_REQUIRE(c && pp_digest32, "null argument");
+        std::lock_guard<std::mutex> lk(c->mu);
+        memcpy(c->pp_digest, pp_digest32, 32);
+        c->has_pp = true;
+        fold_challenge_drop(c);
+    });
+}
+
+int lurk_hip_fold_step_challenge(lurk_hip_fold_ctx* c, void* r32_mont) {
+    return guarded([&] {
+        LURK_REQUIRE(c && r32_mont, "null argument");
+        std::lock_guard<std::mutex> lk(c->mu);
+        fold_challenge_finish(c, r32_mont);
     });
 }
 

@@ -50,32 +50,64 @@ static unsigned __int128 io_pattern_tag(uint32_t absorbs, uint32_t squeezes, uin
     return st;
 }
 
+// The sponge as a resumable object: the IO pattern (hence the capacity tag) is fixed by the TOTAL absorb count, elements may then arrive
+// in any number of calls; a permutation runs whenever the rate is full and one more element arrives.  This is what lets the folding
+// context absorb the running instance (and run the permutation it completes) while the device is still computing comm_T.
+template <class P>
+struct RoSponge {
+    const RoHost* R = nullptr;
+    std::vector<H4> s;
+    int pos = 0;
+    size_t total = 0, absorbed = 0;
+    void begin(size_t n) {
+        R = &ro_host<P>();
+        const H4 zero = {{0, 0, 0, 0}};
+        s.assign(R->t, zero);
+        const unsigned __int128 tag = io_pattern_tag((uint32_t)n, 1, 0);
+        H4 c = {{(uint64_t)tag, (uint64_t)(tag >> 64), 0, 0}};
+        s[0] = h4_mul(R->F, c, R->r2);
+        pos = 0;
+        total = n;
+        absorbed = 0;
+    }
+    void absorb(const uint64_t* elems, size_t k) {
+        const int rate = R->t - 1;
+        LURK_REQUIRE(absorbed + k <= total, "random oracle: more elements than the declared IO pattern");
+        for (size_t i = 0; i < k; i++) {
+            if (pos == rate) {
+                permute_host(*R, s);
+                pos = 0;
+            }
+            H4 e;
+            memcpy(e.v, elems + 4 * i, 32);
+            LURK_REQUIRE(!h4_geq(e.v, R->F.m), "random oracle input is not a canonical field element");
+            s[1 + pos] = h4_add(R->F, s[1 + pos], h4_mul(R->F, e, R->r2));
+            pos++;
+        }
+        absorbed += k;
+    }
+    // a permutation that only waits for the NEXT element to arrive can run now (the element then lands in a fresh rate)
+    void permute_if_full() {
+        if (pos == R->t - 1 && absorbed < total) {
+            permute_host(*R, s);
+            pos = 0;
+        }
+    }
+    Fe<P> squeeze() {  // squeeze position = rate after an absorb: one permutation, then read rate element 0
+        LURK_REQUIRE(absorbed == total, "random oracle: fewer elements than the declared IO pattern");
+        const H4 one = {{1, 0, 0, 0}};
+        permute_host(*R, s);
+        return h4_to<P>(h4_mul(R->F, s[1], one));
+    }
+};
+
 // absorb n canonical elements, squeeze one; returns it in canonical form
 template <class P>
 static Fe<P> ro_squeeze_host(const uint64_t* elems, size_t n) {
-    const RoHost& R = ro_host<P>();
-    const int t = R.t, rate = t - 1;
-    const H4 zero = {{0, 0, 0, 0}}, one = {{1, 0, 0, 0}};
-    std::vector<H4> s(t, zero);
-    {
-        const unsigned __int128 tag = io_pattern_tag((uint32_t)n, 1, 0);
-        H4 c = {{(uint64_t)tag, (uint64_t)(tag >> 64), 0, 0}};
-        s[0] = h4_mul(R.F, c, R.r2);
-    }
-    int pos = 0;
-    for (size_t k = 0; k < n; k++) {
-        if (pos == rate) {
-            permute_host(R, s);
-            pos = 0;
-        }
-        H4 e;
-        memcpy(e.v, elems + 4 * k, 32);
-        LURK_REQUIRE(!h4_geq(e.v, R.F.m), "random oracle input is not a canonical field element");
-        s[1 + pos] = h4_add(R.F, s[1 + pos], h4_mul(R.F, e, R.r2));
-        pos++;
-    }
-    permute_host(R, s);  // squeeze position = rate after an absorb: one permutation, then read rate element 0
-    return h4_to<P>(h4_mul(R.F, s[1], one));
+    RoSponge<P> sp;
+    sp.begin(n);
+    sp.absorb(elems, n);
+    return sp.squeeze();
 }
 
 static void ro_squeeze(int field_id, const uint64_t* elems, size_t n, unsigned num_bits, uint64_t* out4) {
@@ -128,43 +160,99 @@ static void absorb_commitment(int curve, const void* jac96, std::vector<uint64_t
     out.push_back(0);
 }
 
-// F = scalar field of `curve`, B = its base field (the RO's field)
+// F = scalar field of `curve`, B = its base field (the RO's field).  In three stages, so that a folding context can run the first two
+// while the device is still busy with the step (nifs_pre.hpp): `begin` absorbs pp_digest and U1 - for a Lurk step (num_io = 6: 44
+// elements in all) that fills the first rate of 24 and its permutation runs at once -, `fresh` absorbs U2 = (comm_W2, X2), `finish`
+// absorbs comm_T and squeezes: one permutation and one affine conversion are all that is left behind commit(T).
 template <class F, class B>
-static void nifs_challenge(int curve, int base_field_id, const void* pp_digest32, const void* comm_w1, const void* comm_e1, const void* u1_mont,
-                           const void* x1_mont, const void* comm_w2, const void* x2_mont, size_t num_io, const void* comm_t, void* r32_mont) {
-    std::vector<uint64_t> el;
-    {
-        // the digest is a scalar's canonical bytes: scalar_as_base through a Montgomery round trip is not needed, reduce directly
-        uint32_t w[8];
-        memcpy(w, pp_digest32, 32);
-        LURK_REQUIRE(!fe_canonical_ge_mod<F>(w), "pp_digest is not a canonical scalar");
-        if (fe_canonical_ge_mod<B>(w)) {
-            uint32_t borrow = 0;
-            for (int i = 0; i < 8; i++) w[i] = subb32(w[i], B::mod(i), borrow);
+struct NifsStages {
+    RoSponge<B> sp;
+    int curve = 0;
+    size_t num_io = 0;
+    void begin(int curve_, const void* pp_digest32, const void* comm_w1, const void* comm_e1, const void* u1_mont, const void* x1_mont, size_t num_io_) {
+        curve = curve_;
+        num_io = num_io_;
+        std::vector<uint64_t> el;
+        {
+            // the digest is a scalar's canonical bytes: scalar_as_base through a Montgomery round trip is not needed, reduce directly
+            uint32_t w[8];
+            memcpy(w, pp_digest32, 32);
+            LURK_REQUIRE(!fe_canonical_ge_mod<F>(w), "pp_digest is not a canonical scalar");
+            if (fe_canonical_ge_mod<B>(w)) {
+                uint32_t borrow = 0;
+                for (int i = 0; i < 8; i++) w[i] = subb32(w[i], B::mod(i), borrow);
+            }
+            uint64_t d[4];
+            memcpy(d, w, 32);
+            el.insert(el.end(), d, d + 4);
         }
-        uint64_t d[4];
-        memcpy(d, w, 32);
-        el.insert(el.end(), d, d + 4);
-    }
-    absorb_commitment(curve, comm_w1, el);   // U1: RelaxedR1CSInstance::absorb_in_ro
-    absorb_commitment(curve, comm_e1, el);
-    uint64_t tmp[4];
-    scalar_as_base<F, B>(u1_mont, tmp);
-    el.insert(el.end(), tmp, tmp + 4);
-    for (size_t i = 0; i < num_io; i++) scalar_limbs<F>((const char*)x1_mont + 32 * i, el);
-    absorb_commitment(curve, comm_w2, el);   // U2: R1CSInstance::absorb_in_ro
-    for (size_t i = 0; i < num_io; i++) {
-        scalar_as_base<F, B>((const char*)x2_mont + 32 * i, tmp);
+        absorb_commitment(curve, comm_w1, el);   // U1: RelaxedR1CSInstance::absorb_in_ro
+        absorb_commitment(curve, comm_e1, el);
+        uint64_t tmp[4];
+        scalar_as_base<F, B>(u1_mont, tmp);
         el.insert(el.end(), tmp, tmp + 4);
+        for (size_t i = 0; i < num_io; i++) scalar_limbs<F>((const char*)x1_mont + 32 * i, el);
+        sp.begin(1 + 3 + 3 + 1 + 4 * num_io + 3 + num_io + 3);
+        sp.absorb(el.data(), el.size() / 4);
+        sp.permute_if_full();
     }
-    absorb_commitment(curve, comm_t, el);
-    uint64_t r[4];
-    ro_squeeze(base_field_id, el.data(), el.size() / 4, 128, r);  // NUM_CHALLENGE_BITS
-    Fe<F> rf;
-    memcpy(rf.l, r, 32);
-    rf = fe_to_mont<F>(rf);
-    memcpy(r32_mont, rf.l, 32);
+    void fresh(const void* comm_w2, const void* x2_mont) {
+        std::vector<uint64_t> el;
+        uint64_t tmp[4];
+        absorb_commitment(curve, comm_w2, el);   // U2: R1CSInstance::absorb_in_ro
+        for (size_t i = 0; i < num_io; i++) {
+            scalar_as_base<F, B>((const char*)x2_mont + 32 * i, tmp);
+            el.insert(el.end(), tmp, tmp + 4);
+        }
+        sp.absorb(el.data(), el.size() / 4);
+        sp.permute_if_full();
+    }
+    void finish(const void* comm_t, void* r32_mont) {
+        std::vector<uint64_t> el;
+        absorb_commitment(curve, comm_t, el);
+        sp.absorb(el.data(), el.size() / 4);
+        Fe<B> sq = sp.squeeze();
+        uint32_t w[8];
+        memcpy(w, sq.l, 32);
+        for (unsigned b = 128; b < 256; b++) w[b >> 5] &= ~(1u << (b & 31));  // NUM_CHALLENGE_BITS
+        Fe<F> rf;
+        memcpy(rf.l, w, 32);
+        rf = fe_to_mont<F>(rf);
+        memcpy(r32_mont, rf.l, 32);
+    }
+};
+template <class F, class B>
+static void nifs_challenge(int curve, int /*base_field_id*/, const void* pp_digest32, const void* comm_w1, const void* comm_e1, const void* u1_mont,
+                           const void* x1_mont, const void* comm_w2, const void* x2_mont, size_t num_io, const void* comm_t, void* r32_mont) {
+    NifsStages<F, B> st;
+    st.begin(curve, pp_digest32, comm_w1, comm_e1, u1_mont, x1_mont, num_io);
+    st.fresh(comm_w2, x2_mont);
+    st.finish(comm_t, r32_mont);
 }
+
+// the staged form behind an opaque handle (nifs_pre.hpp: step.hip holds one per open step)
+struct NifsPre {
+    int curve = 0;
+    NifsStages<PallasFq, PallasFp> pallas;  // curve 0: scalars Fq, the RO over Fp
+    NifsStages<PallasFp, PallasFq> vesta;
+};
+NifsPre* nifs_pre_begin(int curve, const void* pp_digest32, const void* comm_w1, const void* comm_e1, const void* u1_mont, const void* x1_mont, size_t num_io) {
+    LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
+    auto p = std::make_unique<NifsPre>();
+    p->curve = curve;
+    if (curve == LURK_CURVE_PALLAS) p->pallas.begin(curve, pp_digest32, comm_w1, comm_e1, u1_mont, x1_mont, num_io);
+    else p->vesta.begin(curve, pp_digest32, comm_w1, comm_e1, u1_mont, x1_mont, num_io);
+    return p.release();
+}
+void nifs_pre_fresh(NifsPre* p, const void* comm_w2, const void* x2_mont) {
+    if (p->curve == LURK_CURVE_PALLAS) p->pallas.fresh(comm_w2, x2_mont);
+    else p->vesta.fresh(comm_w2, x2_mont);
+}
+void nifs_pre_finish(NifsPre* p, const void* comm_t, void* r32_mont) {
+    if (p->curve == LURK_CURVE_PALLAS) p->pallas.finish(comm_t, r32_mont);
+    else p->vesta.finish(comm_t, r32_mont);
+}
+void nifs_pre_free(NifsPre* p) { delete p; }
 
 // ---- arecibo's Keccak256Transcript (the transcript of RelaxedR1CSSNARK / BatchedRelaxedR1CSSNARK behind CompressedSNARK::prove,
 // /root/reference/src/proof/nova.rs:92, 341-356, supernova.rs:110, 293-302) -----------------------------------------------------------

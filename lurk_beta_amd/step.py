@@ -100,6 +100,18 @@ class FoldingContext:
         self._open = (cw, ct)
         return cw, ct
 
+    def set_pp_digest(self, pp_digest: int):
+        """The digest of the public parameters, once: every ``begin`` then stages the transcript (U1 while the device works, U2 when
+        comm_W2 is there) and ``challenge()`` finishes it behind comm_T with one permutation."""
+        dig = np.array([(pp_digest >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
+        _lib.check(_lib.load().lurk_hip_fold_ctx_set_pp_digest(self._h, _lib.ptr(dig)))
+
+    def challenge(self) -> np.ndarray:
+        """r = RO(pp_digest, U1, U2, comm_T) of the open step (Montgomery, ready for ``finish``) = ``nifs_challenge`` of the same values."""
+        r = np.zeros(4, dtype=np.uint64)
+        _lib.check(_lib.load().lurk_hip_fold_step_challenge(self._h, _lib.ptr(r)))
+        return r
+
     def add_helper(self, helper_key):
         """Staging ahead across devices: ``helper_key`` is a ``CommitmentKey`` over the same bases resident on another device; instances
         staged with ``prefetch`` are committed on the helpers in turn (peer copy of the staged ranges) while this context's device folds."""

@@ -251,6 +251,61 @@ def test_steps_with_the_library_transcript(hip, curve, m, nfree):
     shape.close()
 
 
+@pytest.mark.parametrize("nio", [2, 6])
+def test_challenge_of_the_open_step_staged_inside_begin(hip, nio):
+    """lurk_hip_fold_ctx_set_pp_digest + lurk_hip_fold_step_challenge: the begin / finish halves with the LIBRARY's transcript, staged - U1
+    absorbed (and, at a Lurk step's six public IO elements, the first permutation run) while the device works, U2 when comm_W2 is there,
+    one permutation behind comm_T.  r must be lurk_hip_nifs_challenge's (= the oracle's) for the same values, in the plain flow, in the
+    staged flow with late ranges, after a failed begin, and the one-shot fallback when the digest arrives while a step is open."""
+    from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape, nifs_challenge, point_to_affine
+
+    curve, f, m, nfree = 0, 1, 5000, 2000
+    p = R.modulus(f)
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=61 + nio)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    bases = C.synth_bases(curve, max(m, nv))
+    key = CommitmentKey(curve, bases, precompute=True, window_bits=16)
+    key.reserve(max(m, nv), 4)
+    ctx = FoldingContext(curve, shape, key)
+    pp = R.uniform_fe(99, nio, p)
+    pt = lambda a: None if a == (0, 0) else a
+    with pytest.raises(LurkHipError):
+        ctx.challenge()  # no step is open
+    for step in range(4):
+        z2, x2 = _fresh(f, A, B, m, nfree, nio, 700 + 10 * step)
+        w2m, x2m = C.to_mont(f, z2[:nv]), C.to_mont(f, x2)
+        ucw, uce, uu, ux = ctx.instance()
+        if step == 0:
+            cw, ct = ctx.begin(w2m, x2m)
+            ctx.set_pp_digest(pp)  # the digest arrives while the step is open: the challenge is computed in one go
+        elif step == 2:
+            lo, hi = 100, nv - 50
+            ctx.prefetch(w2m[lo:hi], lo)
+            cw, ct = ctx.begin_prefetched(x2m, [(0, w2m[:lo]), (hi, w2m[hi:])])
+        elif step == 3:
+            other = __import__("torch").from_numpy(C.to_mont(f, C.synth_scalars(f, 5, 0, 512)).view(np.int64)).cuda()
+            key.submit_device(1, other, 512, is_mont=True)
+            with pytest.raises(LurkHipError, match="busy"):
+                ctx.begin(w2m, x2m)  # fails behind the staged part of the transcript: nothing stale may survive
+            key.wait(1)
+            cw, ct = ctx.begin(w2m, x2m)
+        else:
+            cw, ct = ctx.begin(w2m, x2m)
+        r = ctx.challenge()
+        want = nifs_challenge(curve, pp, ucw, uce, uu, ux, cw, x2m, ct)
+        assert np.array_equal(r, want), step
+        r_o = R.nifs_challenge("pallas", pp, pt(point_to_affine(curve, ucw)), pt(point_to_affine(curve, uce)), C.limbs_to_ints(C.from_mont(f, uu.reshape(1, 4)))[0],
+                               C.limbs_to_ints(C.from_mont(f, ux)) if nio else [], pt(point_to_affine(curve, cw)), C.limbs_to_ints(x2), pt(point_to_affine(curve, ct)))
+        assert C.limbs_to_ints(C.from_mont(f, r.reshape(1, 4)))[0] == r_o
+        if step == 1:
+            assert np.array_equal(ctx.challenge(), want)  # asking again is allowed: the staged state is spent, r is recomputed in one go
+        ctx.finish(r)
+    ctx.close()
+    key.close()
+    shape.close()
+
+
 def test_nivc_two_shapes_one_key(hip):
     """SuperNova / NIVC (/root/reference/src/proof/supernova.rs:226-244, circuit selection multiframe.rs:271-356): two R1CS shapes of
     different sizes (the Lurk step circuit and a coprocessor's) under ONE commitment key, pc alternating 0, 1, 1, 0, 1 - every running
