@@ -217,11 +217,7 @@ class BatchedSpartanProver:
         ell = N.bit_length() - 1
         tr = Transcript((b"pallas" if self.curve == 0 else b"vesta") + b"/batched")
         tr.absorb_scalars(b"n", [n])
-        aff0 = lambda J: (lambda xy: None if xy == (0, 0) else xy)(point_to_affine(self.curve, J))
-
-        def absorb_pt(label, J):
-            a = aff0(J)
-            tr.absorb(label, bytes(64) if a is None else int(a[0]).to_bytes(32, "little") + int(a[1]).to_bytes(32, "little"))
+        absorb_pt = lambda label, J: tr.absorb_point(label, point_to_affine(self.curve, J))  # (0, 0) = the identity
 
         for it in instances:
             absorb_pt(b"comm_W", it["comm_W"])

@@ -547,7 +547,7 @@ def test_steps_with_a_multi_device_key(hip, devices):
         cw1, ce1 = pt(commit(z1[:nv])), pt(commit(e1))
         gcw, gce, _, _ = mctx.instance()
         assert _aff_or_none(curve, gcw) == cw1 and _aff_or_none(curve, gce) == ce1
-    with pytest.raises(LurkHipError, match="multi-device"):
+    with pytest.raises(LurkHipError, match="cut across devices"):
         mctx.prefetch(w2m)
     # the two halves with a caller-supplied challenge work too
     z2, x2 = _fresh(f, A, B, m, nfree, nio, 790)
