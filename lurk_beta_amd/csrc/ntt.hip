@@ -135,12 +135,15 @@ __global__ __launch_bounds__(NTT_PASS_BLOCK) void ntt_pass_kernel(const Fe<F>* _
 // The north-star shape: butterflies in registers and across lanes, LDS only as the tile that turns strided sub-transforms into
 // coalesced rows.  A pass covers stages s0+1 .. s0+ns (ns <= 8) of the same twisted decimation-in-time as ntt_pass_kernel.
 // A workgroup of 8 waves owns a tile of 2048 elements = 2^ns rows (index l inside the sub-transform) x 2^(11-ns) neighbouring
-// columns; a wave owns 256 of them as 4 per lane (slot = lane + 64 k: l = slot mod 2^ns, column = slot >> ns), on the
-// radix-2^29 layer (field29.cuh).  Stage st pairs the slots that differ in bit st:
-//   st < 6   partner lane = lane ^ 2^st.  The two lanes hold 4 butterflies between them; each does the twiddle product of TWO
-//            (lane with the bit clear: k = 0, 1, the other: k = 2, 3), so no lane multiplies for nothing: 2 exchanges to bring
-//            the operands together, 2 to hand the partner its results, 2 products per lane per stage
-//   st >= 6  both slots in the lane's own registers (k ^ 1, k ^ 2).
+// columns; a wave owns 256 of them (slot: l = slot mod 2^ns, column = slot >> ns) as 4 per lane, on the radix-2^29 layer
+// (field29.cuh).  Stage st pairs the slots that differ in bit st.  The stages run as RADIX-4 REGISTER ROUNDS (round 4 of the build):
+// in round r a lane holds the four slots that differ in bits (2r, 2r + 1), does stage 2r on (e0, e1), (e2, e3) and stage 2r + 1 on
+// (e0, e2), (e1, e3) - four butterflies, three twiddles, no lane idle - and between rounds the wave's 256 elements are transposed
+// through a wave-private LDS buffer (nine 256-word limb planes, slot index swizzled s ^ (s >> 1) ^ (s >> 2): every round's access
+// pattern is bank-conflict free) that aliases the tile.  Before: stages 1-6 paired LANES (__shfl_xor), which cost 12 selects of a
+// nine-limb value and 4 exchanges per lane-stage - 673 v_cndmask (4.1 issue cycles each on gfx950) and 216 ds_bpermute (24 cycles of
+// the LDS pipeline each) per pass and lane, 10 % of a pass that runs at its instruction-issue bound.  An odd
+// ns ends with a radix-2 round on bit ns - 1 (its second free bit is bit 7, a column bit).
 // Twiddles of the stages come from a per-workgroup LDS table of omega_{2^ns}^j (radix-2^29 records), the twist between passes
 // from the global omega^i table.  The first pass reads the caller's natural-order, canonical input through the bit-reversed
 // tile addressing (no separate permutation pass) and converts on the fly; between passes values are stored as the packed
@@ -197,6 +200,16 @@ __device__ __forceinline__ void ntt_bfly(F29<F>& u, F29<F>& v, const F29<F>& w) 
     u = f29_carry<F>(f29_add<F>(u, x));
 }
 
+// zero bits inserted at positions p < q of a 6-bit lane id: the 8-bit slot of the lane's element 0 in the round that pairs bits p and q
+__device__ __forceinline__ unsigned ntt_ins2(unsigned lane, unsigned p, unsigned q) {
+    const unsigned x = (lane & ((1u << p) - 1u)) | ((lane >> p) << (p + 1));
+    return (x & ((1u << q) - 1u)) | ((x >> q) << (q + 1));
+}
+// position of slot s inside a limb plane of the exchange buffer: with this swizzle the 32 lanes an LDS cycle serves hit 32 different
+// banks in every round's layout (checked exhaustively for ns = 5 .. 8)
+__device__ __forceinline__ unsigned ntt_swz(unsigned s) { return (s ^ (s >> 1) ^ (s >> 2)) & 255u; }
+constexpr unsigned NTT_XCHG_WORDS = 9 * 256;  // per wave
+
 template <class F, bool FIRST>
 __global__ __launch_bounds__(NTT_W_BLOCK) void ntt_wave_pass_kernel(const Fe<F>* __restrict__ in, Fe<F>* __restrict__ out, const Fe<F>* __restrict__ tw,
                                                                       unsigned log_n, unsigned s0, unsigned ns, NttConst29 cst, int last) {
@@ -204,7 +217,8 @@ __global__ __launch_bounds__(NTT_W_BLOCK) void ntt_wave_pass_kernel(const Fe<F>*
     const unsigned cbits = NTT_W_TILE_LOG - ns, rows = 1u << ns, cols = 1u << cbits;
     const unsigned row_words = cols * 8 + 2;  // 8 bytes of padding per row: the column reads of a wave spread over all banks
     uint32_t* tile = lds_w;
-    uint32_t* lt = lds_w + rows * row_words;  // omega_{2^ns}^j, j < 2^(ns-1), radix-2^29 records
+    const unsigned tile_words = rows * row_words, xchg_words = (NTT_W_BLOCK / 64) * NTT_XCHG_WORDS;
+    uint32_t* lt = lds_w + (tile_words > xchg_words ? tile_words : xchg_words);  // omega_{2^ns}^j, j < 2^(ns-1), radix-2^29 records
     const unsigned tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t half_n = (size_t)1 << (log_n - 1);
     size_t H = 0, tbase = 0;
@@ -231,12 +245,15 @@ __global__ __launch_bounds__(NTT_W_BLOCK) void ntt_wave_pass_kernel(const Fe<F>*
         d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w; d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
     }
     __syncthreads();
-    // ---- registers: 4 slots per lane
+    // ---- registers: 4 elements per lane, in the layout of round 0 (slots that differ in bits 0 and 1)
     F29<F> e[4];
     const unsigned lmask = rows - 1, wave_cols = 1u << (8 - ns);
+    const unsigned nrounds = (ns + 1) / 2;
+    unsigned p = 0, q = 1;  // ns >= 5
+    unsigned base = ntt_ins2(lane, p, q);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const unsigned slot = lane + 64u * k, l = slot & lmask, col = wave * wave_cols + (slot >> ns);
+        const unsigned slot = base | ((k & 1u) << p) | ((unsigned)(k >> 1) << q), l = slot & lmask, col = wave * wave_cols + (slot >> ns);
         const unsigned row = FIRST ? (__brev(l) >> (32 - ns)) : l;
         const uint32_t* sp = tile + row * row_words + col * 8;
         uint32_t x[8];
@@ -256,42 +273,50 @@ __global__ __launch_bounds__(NTT_W_BLOCK) void ntt_wave_pass_kernel(const Fe<F>*
             e[k] = f29_mul<F>(e[k], f29_from_mont256<F>(w));
         }
     }
-    // ---- stages
+    __syncthreads();  // every wave has read its elements: the tile's memory now serves as the waves' exchange buffers
+    uint32_t* xb = lds_w + wave * NTT_XCHG_WORDS;
+    // ---- rounds
+#pragma unroll 1
+    for (unsigned r = 0; r < nrounds; r++) {
+        const bool two = 2 * r + 1 < ns;
+        p = 2 * r;
+        q = two ? 2 * r + 1 : 7;
+        base = ntt_ins2(lane, p, q);
+        if (r) {  // the wave's elements back from the exchange buffer, in this round's layout
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (unsigned st = 0; st < 6; st++) {
-        if (st >= ns) break;
-        const int bit = 1 << st;
-        const bool hi = (lane & bit) != 0;
-        const unsigned j = lane & (bit - 1);
-        const F29<F> w = ld_const29<F>(lt + (size_t)(j << (ns - st - 1)) * P29_STRIDE);
-        const F29<F> q0 = f29_lane_xchg<F>(f29_select<F>(hi, e[0], e[2]), bit);
-        const F29<F> q1 = f29_lane_xchg<F>(f29_select<F>(hi, e[1], e[3]), bit);
-        F29<F> u0 = f29_select<F>(hi, q0, e[0]), v0 = f29_select<F>(hi, e[2], q0);
-        F29<F> u1 = f29_select<F>(hi, q1, e[1]), v1 = f29_select<F>(hi, e[3], q1);
-        ntt_bfly<F>(u0, v0, w);
-        ntt_bfly<F>(u1, v1, w);
-        // the lane with the bit clear keeps the sums (its k = 0, 1) and receives the partner's sums for k = 2, 3;
-        // the other keeps the differences (its k = 2, 3) and receives the differences for k = 0, 1
-        const F29<F> r0 = f29_lane_xchg<F>(f29_select<F>(hi, u0, v0), bit);
-        const F29<F> r1 = f29_lane_xchg<F>(f29_select<F>(hi, u1, v1), bit);
-        e[0] = f29_select<F>(hi, r0, u0);
-        e[1] = f29_select<F>(hi, r1, u1);
-        e[2] = f29_select<F>(hi, v0, r0);
-        e[3] = f29_select<F>(hi, v1, r1);
+            for (int k = 0; k < 4; k++) {
+                const unsigned a = ntt_swz(base | ((k & 1u) << p) | ((unsigned)(k >> 1) << q));
+#pragma unroll
+                for (int i = 0; i < 9; i++) e[k].l[i] = xb[i * 256 + a];
+            }
+        }
+        const unsigned l0 = base & lmask;
+        {   // stage p: (e0, e1), (e2, e3); the twiddle depends on the bits of l below p, which the four elements share
+            const F29<F> w = ld_const29<F>(lt + (size_t)((l0 & ((1u << p) - 1u)) << (ns - p - 1)) * P29_STRIDE);
+            ntt_bfly<F>(e[0], e[1], w);
+            ntt_bfly<F>(e[2], e[3], w);
+        }
+        if (two) {  // stage q = p + 1: (e0, e2) with bit p of l clear, (e1, e3) with it set
+            const unsigned j0 = l0 & ((1u << q) - 1u);
+            ntt_bfly<F>(e[0], e[2], ld_const29<F>(lt + (size_t)(j0 << (ns - q - 1)) * P29_STRIDE));
+            ntt_bfly<F>(e[1], e[3], ld_const29<F>(lt + (size_t)((j0 | (1u << p)) << (ns - q - 1)) * P29_STRIDE));
+        }
+        if (r + 1 < nrounds) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned a = ntt_swz(base | ((k & 1u) << p) | ((unsigned)(k >> 1) << q));
+#pragma unroll
+                for (int i = 0; i < 9; i++) xb[i * 256 + a] = e[k].l[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
-    if (ns > 6) {  // slots lane and lane + 64: j = lane
-        const F29<F> w = ld_const29<F>(lt + (size_t)(lane << (ns - 7)) * P29_STRIDE);
-        ntt_bfly<F>(e[0], e[1], w);
-        ntt_bfly<F>(e[2], e[3], w);
-    }
-    if (ns > 7) {  // slots differing by 128: j = lane, lane + 64
-        ntt_bfly<F>(e[0], e[2], ld_const29<F>(lt + (size_t)lane * P29_STRIDE));
-        ntt_bfly<F>(e[1], e[3], ld_const29<F>(lt + (size_t)(lane + 64) * P29_STRIDE));
-    }
-    // ---- tile out (each wave rewrites only its own columns), natural l
+    __syncthreads();  // the exchange buffers are done with: the memory is the tile again
+    // ---- tile out (each wave rewrites only its own columns), natural l; the lane's slots are those of the last round's layout
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const unsigned slot = lane + 64u * k, l = slot & lmask, col = wave * wave_cols + (slot >> ns);
+        const unsigned slot = base | ((k & 1u) << p) | ((unsigned)(k >> 1) << q), l = slot & lmask, col = wave * wave_cols + (slot >> ns);
         uint32_t x[8];
         if (last) {
             F29<F> c;
@@ -329,7 +354,8 @@ __global__ __launch_bounds__(NTT_W_BLOCK) void ntt_wave_pass_kernel(const Fe<F>*
 }
 static size_t ntt_wave_lds(unsigned ns) {
     const size_t rows = (size_t)1 << ns, cols = (size_t)1 << (NTT_W_TILE_LOG - ns);
-    return (rows * (cols * 8 + 2) + (rows / 2 + 1) * P29_STRIDE) * 4;
+    const size_t tile = rows * (cols * 8 + 2), xchg = (size_t)(NTT_W_BLOCK / 64) * NTT_XCHG_WORDS;  // the exchange buffers alias the tile
+    return ((tile > xchg ? tile : xchg) + (rows / 2 + 1) * P29_STRIDE) * 4;
 }
 
 template <class F>
