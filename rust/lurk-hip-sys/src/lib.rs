@@ -180,6 +180,36 @@ impl<'a> FoldingContext<'a> {
     pub fn finish(&mut self, r_mont: &[u8; 32]) -> Result<(), Error> {
         check(unsafe { lurk_hip_fold_step_finish(self.h, r_mont.as_ptr().cast()) })
     }
+    /// The halves with the library's transcript: set the digest of the public parameters once; every `begin` then absorbs pp_digest and
+    /// the running instance while the device works, and `challenge` finishes behind comm_T with one permutation (r in Montgomery form).
+    pub fn set_pp_digest(&mut self, pp_digest: &[u8; 32]) -> Result<(), Error> {
+        check(unsafe { lurk_hip_fold_ctx_set_pp_digest(self.h, pp_digest.as_ptr().cast()) })
+    }
+    pub fn challenge(&mut self) -> Result<[u8; 32], Error> {
+        let mut r = [0u8; 32];
+        check(unsafe { lurk_hip_fold_step_challenge(self.h, r.as_mut_ptr().cast()) })?;
+        Ok(r)
+    }
+    /// Staging ahead across devices: `helper` is the same commitment key resident on another device; instances staged with
+    /// `prefetch` are committed on the helpers in turn while this context's device folds.
+    ///
+    /// # Safety
+    /// `helper` must outlive the context.
+    pub unsafe fn add_helper(&mut self, helper: *mut lurk_hip_msm_ctx) -> Result<(), Error> {
+        check(lurk_hip_fold_ctx_add_helper(self.h, helper))
+    }
+    /// Stage positions `[offset, offset + range.len() / 32)` of the next fresh witness (host memory, Montgomery) and start its commitment.
+    pub fn prefetch(&mut self, range: &[u8], offset: usize) -> Result<(), Error> {
+        check(unsafe { lurk_hip_fold_step_prefetch(self.h, range.as_ptr().cast(), offset, range.len() / 32, 0, core::ptr::null_mut()) })
+    }
+    /// Open the step of the oldest staged instance; `patches`: the ranges of W2 known only now.
+    pub fn begin_prefetched(&mut self, patches: &[lurk_hip_w2_patch], x2: &[u8]) -> Result<([u8; 96], [u8; 96]), Error> {
+        let (mut cw, mut ct) = ([0u8; 96], [0u8; 96]);
+        check(unsafe {
+            lurk_hip_fold_step_begin_prefetched(self.h, patches.as_ptr(), patches.len(), x2.as_ptr().cast(), cw.as_mut_ptr().cast(), ct.as_mut_ptr().cast())
+        })?;
+        Ok((cw, ct))
+    }
 }
 impl Drop for FoldingContext<'_> {
     fn drop(&mut self) {
