@@ -217,7 +217,8 @@ class BatchedSpartanProver:
         ell = N.bit_length() - 1
         tr = Transcript((b"pallas" if self.curve == 0 else b"vesta") + b"/batched")
         tr.absorb_scalars(b"n", [n])
-        absorb_pt = lambda label, J: tr.absorb_point(label, point_to_affine(self.curve, J))  # (0, 0) = the identity
+        aff0 = lambda J: (lambda xy: None if xy == (0, 0) else xy)(point_to_affine(self.curve, J))  # the proof's point form: None = the identity
+        absorb_pt = lambda label, J: tr.absorb_point(label, point_to_affine(self.curve, J))          # the transcript's: (0, 0) = the identity
 
         for it in instances:
             absorb_pt(b"comm_W", it["comm_W"])
