@@ -244,13 +244,33 @@ __global__ __launch_bounds__(NTT_W_BLOCK) void ntt_wave_pass_kernel(const Fe<F>*
         uint32_t* d = tile + row * row_words + col * 8;
         d[0] = lo.x; d[1] = lo.y; d[2] = lo.z; d[3] = lo.w; d[4] = hi.x; d[5] = hi.y; d[6] = hi.z; d[7] = hi.w;
     }
+    // ---- the twist factors of the lane's four elements (passes after the first): one random 32-byte gather each from the omega table
+    // (HBM in the last pass: 2^23 distinct entries), issued ahead of the barrier so that their latency runs under the wait for the
+    // other waves' tile rows and under the LDS reads behind it.  (Ahead of the tile-in they gain nothing: the returns are counted in
+    // order, so the tile loop's first wait would wait for the gathers too.)
+    const unsigned lmask = rows - 1, wave_cols = 1u << (8 - ns);
+    const unsigned base0 = ntt_ins2(lane, 0, 1);
+    uint4 twist_lo[4], twist_hi[4];
+    bool twist_neg[4];
+    if (!FIRST) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned slot = base0 | (unsigned)k, l = slot & lmask, col = wave * wave_cols + (slot >> ns);
+            const size_t t = tbase + col;
+            const size_t idx = (t * (size_t)(__brev(l) >> (32 - ns))) << (log_n - s0 - ns);
+            const uint4* g = reinterpret_cast<const uint4*>(tw + (idx & (half_n - 1)));
+            twist_lo[k] = g[0];
+            twist_hi[k] = g[1];
+            twist_neg[k] = (idx & half_n) != 0;
+        }
+        __builtin_amdgcn_sched_barrier(0);  // keep the gathers up here: the scheduler otherwise sinks them to their first use
+    }
     __syncthreads();
     // ---- registers: 4 elements per lane, in the layout of round 0 (slots that differ in bits 0 and 1)
     F29<F> e[4];
-    const unsigned lmask = rows - 1, wave_cols = 1u << (8 - ns);
     const unsigned nrounds = (ns + 1) / 2;
     unsigned p = 0, q = 1;  // ns >= 5
-    unsigned base = ntt_ins2(lane, p, q);
+    unsigned base = base0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const unsigned slot = base | ((k & 1u) << p) | ((unsigned)(k >> 1) << q), l = slot & lmask, col = wave * wave_cols + (slot >> ns);
@@ -266,10 +286,10 @@ __global__ __launch_bounds__(NTT_W_BLOCK) void ntt_wave_pass_kernel(const Fe<F>*
             e[k] = f29_mul<F>(f29_from_plain<F>(x), c);
         } else {
             e[k] = f29_from_plain<F>(x);
-            const size_t t = tbase + col;
-            const size_t idx = (t * (size_t)(__brev(l) >> (32 - ns))) << (log_n - s0 - ns);
-            Fe<F> w = tw[idx & (half_n - 1)];
-            if (idx & half_n) w = fe_neg<F>(w);
+            Fe<F> w;
+            w.l[0] = twist_lo[k].x; w.l[1] = twist_lo[k].y; w.l[2] = twist_lo[k].z; w.l[3] = twist_lo[k].w;
+            w.l[4] = twist_hi[k].x; w.l[5] = twist_hi[k].y; w.l[6] = twist_hi[k].z; w.l[7] = twist_hi[k].w;
+            if (twist_neg[k]) w = fe_neg<F>(w);
             e[k] = f29_mul<F>(e[k], f29_from_mont256<F>(w));
         }
     }
