@@ -12,7 +12,7 @@ python - <<PY
 lines = open("gpurun_out/trace_step/timeline_all.txt").read().splitlines()
 # the steps' cross terms run on the folding context's own stream; the three launches at the very end (default stream) are bench.py's
 # roofline leg
-idx = [i for i, l in enumerate(lines) if "r1cs_cross_term_kernel<PallasFq, t" in l and " s  0 " not in l]
+idx = [i for i, l in enumerate(lines) if "r1cs_cross_term_kernel<PallasFq" in l and " s  0 " not in l]
 first, last = idx[-3], idx[-1]
 t0 = float(lines[first].split()[0])
 out = []

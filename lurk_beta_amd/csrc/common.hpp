@@ -132,7 +132,7 @@ class Profiler {
     void query(const char* prefix, double* total_ms, uint64_t* launches);
 
   private:
-    struct Rec { std::string name; hipEvent_t a, b; int device; };
+    struct Rec { std::string name; hipEvent_t a, b; int device; hipStream_t s; };
     std::mutex mu_;
     bool enabled_ = false;
     std::vector<Rec> recs_;

@@ -239,9 +239,10 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_multiply_vec_kernel(R1csDev s
 
 // -u1, -u2 (u_i = z_i[num_vars]) are negated and converted by every lane that finishes a row: two broadcast loads and two
 // limb repackings, so that a call keeps no state outside its arguments (concurrent calls on one shape are independent)
+// bid / nb: this workgroup's index among the nb workgroups of its kind (the long-row and the short-row blocks of ONE launch)
 template <class P, bool LONG>
-__global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2,
-                                                                       size_t u_index, Fe<P>* __restrict__ t) {
+__device__ __forceinline__ void r1cs_cross_term_body(const R1csDev& s, const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2, size_t u_index,
+                                                     Fe<P>* __restrict__ t, unsigned bid, unsigned nb) {
     const uint32_t* one29 = s.dict + s.dict_size * P29_STRIDE;
     const Fe<P>* zs[2] = {z1, z2};
     uint32_t lo[3], hi[3];
@@ -250,7 +251,7 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
     Dot29<P> acc;
     dot29_init<P>(acc);
     if (!LONG) {
-        row = fold_row_block(blockIdx.x, gridDim.x) * FOLD_BLOCK + threadIdx.x;
+        row = fold_row_block(bid, nb) * FOLD_BLOCK + threadIdx.x;
         if (row >= s.rows || fold_is_long(s, row, lo, hi)) return;
         // one vector at a time (a second pass re-reads the 8-byte records from L2 but halves the live accumulators:
         // 3 waves/SIMD instead of 2 with spills); T is built up as the row values arrive
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
 #pragma unroll
         for (int v = 0; v < 2; v++) fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs + v, c + v);
     } else {
-        size_t w = ((size_t)blockIdx.x * FOLD_BLOCK + threadIdx.x) / FOLD_GROUP;
+        size_t w = ((size_t)bid * FOLD_BLOCK + threadIdx.x) / FOLD_GROUP;
         const bool live = w < s.n_long;  // a group without a row shadows the last one (the shuffles need every lane)
         row = s.long_rows[live ? w : s.n_long - 1];
         fold_is_long(s, row, lo, hi);
@@ -281,6 +282,16 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
     dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(z1[u_index])), c[1]);  // 32 (-u) 2^256: lazy Montgomery-2^261 form, tight, < 2^259
     dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(z2[u_index])), c[0]);
     fold_store<P>(t + row, dot29_finish<P>(acc));
+}
+// ONE launch: the first long_blocks workgroups take the few long rows (bit decompositions: ~255 entries, FOLD_GROUP lanes per row - a
+// latency-bound handful of waves), the rest one short row per lane.  As two launches on one stream the long-row kernel ran ALONE first:
+// 0.14 ms of a 0.42 ms cross term at rc = 100 with the device nearly idle (profiles/r04_step_timeline_rc100.txt), and commit(T) - which
+// waits for T - started that much later.
+template <class P>
+__global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2,
+                                                                       size_t u_index, Fe<P>* __restrict__ t, unsigned long_blocks) {
+    if (blockIdx.x < long_blocks) r1cs_cross_term_body<P, true>(s, z1, z2, u_index, t, blockIdx.x, long_blocks);
+    else r1cs_cross_term_body<P, false>(s, z1, z2, u_index, t, blockIdx.x - long_blocks, gridDim.x - long_blocks);
 }
 
 // out = a + r b (r: Montgomery 2^256, broadcast).  A pure 96 B / element stream (two reads, one write): a lane takes FOLD_VEC_E
@@ -413,11 +424,9 @@ static void cross_term(const R1csShape& sh, const void* d_z1, const void* d_z2, 
     if (!sh.num_cons) return;
     ProfScope ps("r1cs_cross_term", s);
     const R1csDev d = dev_view(sh);
-    if (sh.n_long)
-        hipLaunchKernelGGL((r1cs_cross_term_kernel<P, true>), dim3(div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK)), dim3(FOLD_BLOCK), 0, s, d,
-                           (const Fe<P>*)d_z1, (const Fe<P>*)d_z2, sh.num_vars, (Fe<P>*)d_t);
-    hipLaunchKernelGGL((r1cs_cross_term_kernel<P, false>), dim3(fold_grid(sh.num_cons)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z1,
-                       (const Fe<P>*)d_z2, sh.num_vars, (Fe<P>*)d_t);
+    const unsigned long_blocks = sh.n_long ? div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK) : 0;
+    hipLaunchKernelGGL((r1cs_cross_term_kernel<P>), dim3(long_blocks + fold_grid(sh.num_cons)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z1,
+                       (const Fe<P>*)d_z2, sh.num_vars, (Fe<P>*)d_t, long_blocks);
     LURK_HIP_CHECK(hipGetLastError());
 }
 template <class P>
