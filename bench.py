@@ -48,9 +48,10 @@ def main():
     ap.add_argument("--stage-ahead", type=int, default=0,
                     help="fold_step: 1 = the next step's witness is traced and its commitment started one step ahead (lurk_hip_fold_step_prefetch); "
                          "0 = plain begin (default: measured 4.4 ms against 4.05 ms staged whole / 5.1 ms staged with late ranges at rc = 100, DESIGN.md)")
-    ap.add_argument("--witness-ahead", type=int, default=2,
-                    help="fold_step: the witness of step k+1 is traced while step k is in progress (the reference's producer thread): 2 = enqueued behind begin, so that "
-                         "it runs while the host derives r (default: 3.88 vs 4.27 ms at rc = 100); 1 = enqueued ahead of this step's commitments; 0 = traced at the start of its own step")
+    ap.add_argument("--witness-ahead", type=int, default=3,
+                    help="fold_step: the witness of step k+1 is traced while step k is in progress (the reference's producer thread): 3 = enqueued from the step's submit hook "
+                         "(lurk_hip_fold_ctx_set_submit_hook: behind the step's opening kernels, beside its commitments; default: 3.5 ms at rc = 100); 2 = enqueued after begin "
+                         "has returned, so that it runs while the host derives r (3.85); 1 = enqueued ahead of this step's commitments (4.2); 0 = traced at the start of its own step")
     ap.add_argument("--secondary", type=int, default=1, help="fold_step: 1 = also time the secondary-curve (Vesta, ~10^4 constraints) half of a step")
     ap.add_argument("--late-ranges", type=int, default=1, help="fold_step with --stage-ahead: 1 = 12 000 positions of W2 arrive with begin (the augmented circuit's), 0 = none")
     ap.add_argument("--ipa-resident-key", type=int, default=1, help="compress: 1 = inner-product rounds under the resident key (composed scalars), 0 = fold the key")
@@ -471,6 +472,8 @@ def fold_step_workload(args, lib, world, rank):
             if args.witness_ahead == 1:
                 mf.assemble(d_w2s[(k + 1) & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[(k + 1) & 1].cuda_stream)
             t_b = time.perf_counter()
+            if args.witness_ahead == 3:  # traced from the step's submit hook: behind the step's opening kernels, beside its commitments
+                hook_k[0] = k + 1
             cw, ct = ctx.begin(d_w2s[k & 1], x2, stream=wstreams[k & 1].cuda_stream)  # both commitments + the cross term
             if args.witness_ahead == 2:
                 mf.assemble(d_w2s[(k + 1) & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[(k + 1) & 1].cuda_stream)
@@ -494,6 +497,9 @@ def fold_step_workload(args, lib, world, rank):
         stage()
     elif args.witness_ahead:
         wstreams = [torch.cuda.Stream(), torch.cuda.Stream()]  # witness k is produced on stream k & 1, into buffer k & 1
+        hook_k = [0]
+        if args.witness_ahead == 3:
+            ctx.set_submit_hook(lambda: mf.assemble(d_w2s[hook_k[0] & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[hook_k[0] & 1].cuda_stream))
         mf.assemble(d_w2s[0], pre, globals_host, bodies_np, mont=True, stream=wstreams[0].cuda_stream)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
@@ -514,6 +520,8 @@ def fold_step_workload(args, lib, world, rank):
     elapsed = time.perf_counter() - t0
     gc.enable()
     lib.lurk_hip_profile_enable(0)
+    if not args.stage_ahead and args.witness_ahead == 3:
+        ctx.set_submit_hook(None)
     if args.stage_ahead:  # drain the instance staged by the last timed step (one was staged before the region: K stagings inside it)
         ctx.begin_prefetched(x2, patches)
         ctx.finish(r_mont)
@@ -545,7 +553,7 @@ def fold_step_workload(args, lib, world, rank):
             "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if devices else "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
-            "config": {"staged_ahead": bool(args.stage_ahead), "witness_ahead": bool(args.witness_ahead and not args.stage_ahead),
+            "config": {"staged_ahead": bool(args.stage_ahead), "witness_ahead": 0 if args.stage_ahead else args.witness_ahead,
                        "devices": devices, "distinct_devices": len(set(devices)) if devices else 1,
                        "helper_devices": args.helper_devices or None,
                        "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "

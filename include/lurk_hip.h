@@ -403,6 +403,16 @@ int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* ctx, const void* r32_mont);
  * lurk_hip_nifs_challenge gives (and lurk_hip_fold_step uses the same staging).  r comes back in Montgomery form, ready for finish. */
 int lurk_hip_fold_ctx_set_pp_digest(lurk_hip_fold_ctx* ctx, const void* pp_digest32);
 int lurk_hip_fold_step_challenge(lurk_hip_fold_ctx* ctx, void* r32_mont);
+/* A hook into the open step, for the caller's own device work that should run BESIDE the step - the slot traces of the next witness
+ * (lurk_hip_slot_witness_dev), what the reference's witness-producer thread does while prove_step folds
+ * (/root/reference/src/proof/nova.rs:304-326).  begin / begin_prefetched / lurk_hip_fold_step call hook(user) ONCE per step, on the
+ * calling thread, after the step's device work (cross term, both commitments) has been enqueued and before they block on the
+ * commitments.  Work enqueued from the hook queues behind the step's opening kernels and fills what the commitments leave (their
+ * sorts and bucket reductions); enqueued before begin it would run first and hold the cross term back, enqueued after begin has
+ * returned it runs alone: 3.50-3.59 ms per step at rc = 100 against 4.22 and 3.85 (profiles/r04_step_witness_placement.txt).
+ * The hook must not call into this context; a non-zero return fails the begin (the step is rolled back).  NULL removes it. */
+typedef int (*lurk_hip_fold_submit_hook_fn)(void* user);
+int lurk_hip_fold_ctx_set_submit_hook(lurk_hip_fold_ctx* ctx, lurk_hip_fold_submit_hook_fn hook, void* user);
 /* the running pair where it lives (valid until the next finish) and the stream its updates are ordered on */
 int lurk_hip_fold_ctx_running_dev(lurk_hip_fold_ctx* ctx, void** d_z, void** d_e, void** stream);
 /* copies of the running pair for the host (either may be NULL); synchronises the context's stream */

@@ -108,6 +108,7 @@ SIGNATURES = {
     "lurk_hip_fold_step_begin_prefetched": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_finish": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_set_pp_digest": (c_int, [c_void_p, c_void_p]),
+    "lurk_hip_fold_ctx_set_submit_hook": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_challenge": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_running_dev": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
     "lurk_hip_fold_ctx_read": (c_int, [c_void_p, c_void_p, c_void_p]),
@@ -184,5 +185,7 @@ def ptr(x) -> c_void_p:
 
 # lurk_hip_ipa_challenge_fn: int (*)(void* user, int round, const void* L96, const void* R96, void* out_r32_canonical)
 IPA_CHALLENGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p)
+# lurk_hip_fold_submit_hook_fn: int (*)(void* user)
+FOLD_SUBMIT_HOOK_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p)
 # lurk_hip_sumcheck_challenge_fn: int (*)(void* user, int round, const void* coefficients, void* out_r32_canonical)
 SUMCHECK_CHALLENGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p)

@@ -82,6 +82,8 @@ struct lurk_hip_fold_ctx {
     bool has_pp = false;
     uint8_t pp_digest[32] = {0};
     NifsPre* pre = nullptr;
+    lurk_hip_fold_submit_hook_fn submit_hook = nullptr;  // lurk_hip_fold_ctx_set_submit_hook
+    void* submit_hook_user = nullptr;
     std::vector<std::unique_ptr<Helper>> helpers;
     size_t helper_next = 0;
     int helper_of[2] = {-1, -1};       // which helper commits the instance staged in buffer b (-1: this context's own key)
@@ -247,6 +249,10 @@ static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size
     if (c->begun) fold_submit_staged(c, b, LURK_MSM_SUBMIT_BACKGROUND);
 }
 
+static void fold_run_submit_hook(lurk_hip_fold_ctx* c) {
+    if (c->submit_hook) LURK_REQUIRE(c->submit_hook(c->submit_hook_user) == 0, "the submit hook failed");
+}
+
 // The oldest staged instance becomes this step's: late ranges, u2 = 1, X2, then T and its commitment.
 static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, size_t n_patches, const void* x2_mont, void* comm_w2_jac96,
                        void* comm_t_jac96) {
@@ -345,6 +351,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     tt[2] = now();
     if (ahead) fold_submit_staged(c, c->staged[0], LURK_MSM_SUBMIT_BACKGROUND);  // commit(next W2) fills what T leaves
     tt[3] = now();
+    fold_run_submit_hook(c);  // the caller's device work beside the step (the next witness's traces)
     fold_instance_settle(c);  // the previous step's instance fold, while the device works on this step
     fold_challenge_begin(c);  // ... and the part of this step's transcript that needs no commitment of this step
     if (patched) {
@@ -451,6 +458,7 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
         w_in_flight = true;
         fold_submit_multi(c, 1, c->t.p, c->num_cons, c->t_ev);
         t_in_flight = true;
+        fold_run_submit_hook(c);
         fold_instance_settle(c);  // the previous step's instance fold, while the devices work on this step
         fold_challenge_begin(c);
         w_in_flight = false;
@@ -712,6 +720,15 @@ int lurk_hip_fold_step_begin_prefetched(lurk_hip_fold_ctx* c, const lurk_hip_w2_
         std::lock_guard<std::mutex> lk(c->mu);
         LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
         fold_begin(c, patches, n_patches, x2_mont, comm_w2_jac96, comm_t_jac96);
+    });
+}
+
+int lurk_hip_fold_ctx_set_submit_hook(lurk_hip_fold_ctx* c, lurk_hip_fold_submit_hook_fn hook, void* user) {
+    return guarded([&] {
+        LURK_REQUIRE(c, "null ctx");
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->submit_hook = hook;
+        c->submit_hook_user = user;
     });
 }
 

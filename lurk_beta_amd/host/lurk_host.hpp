@@ -12,6 +12,7 @@
 #include <array>
 #include <cstdint>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -300,6 +301,12 @@ class FoldingContext {
         open_ = c;
         return c;
     }
+    // called once per step from inside begin / begin_prefetched / step, after the step's device work has been enqueued and before the
+    // call blocks on the commitments: where the next witness's slot traces are enqueued (lurk_hip_fold_ctx_set_submit_hook)
+    void set_submit_hook(std::function<void()> fn) {
+        hook_ = std::move(fn);
+        check(lurk_hip_fold_ctx_set_submit_hook(h_, hook_ ? &FoldingContext::hook_trampoline : nullptr, this));
+    }
     // staging ahead across devices: `helper` holds the same key on another device; staged commitments run on the helpers in turn
     void add_helper(CommitmentKey& helper) { check(lurk_hip_fold_ctx_add_helper(h_, helper.handle())); }
     // staging ahead: positions [offset, offset + range.size()) of the next fresh witness, its commitment starts now
@@ -348,6 +355,15 @@ class FoldingContext {
 
   private:
     void refresh() { check(lurk_hip_fold_ctx_instance(h_, &comm_w, &comm_e, nullptr, nullptr)); }
+    static int hook_trampoline(void* self) {
+        try {
+            static_cast<FoldingContext*>(self)->hook_();
+            return 0;
+        } catch (...) {  // (an exception must not unwind through the library's frames: the begin fails and is rolled back)
+            return 1;
+        }
+    }
+    std::function<void()> hook_;
     int curve_;
     R1CSShape& shape_;
     lurk_hip_fold_ctx* h_ = nullptr;

@@ -84,7 +84,7 @@ class FoldingContext:
         x2 = np.ascontiguousarray(x2_mont, dtype=np.uint64)
         dig = np.array([(pp_digest >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for k in range(4)], dtype=np.uint64)
         cw, ct, r = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
-        _lib.check(_lib.load().lurk_hip_fold_step(self._h, _lib.ptr(w2), int(on_dev), _lib.ptr(stream), _lib.ptr(x2), _lib.ptr(dig), _lib.ptr(cw),
+        self._check_begin(_lib.load().lurk_hip_fold_step(self._h, _lib.ptr(w2), int(on_dev), _lib.ptr(stream), _lib.ptr(x2), _lib.ptr(dig), _lib.ptr(cw),
                                                   _lib.ptr(ct), _lib.ptr(r)))
         return cw, ct, r
 
@@ -96,7 +96,7 @@ class FoldingContext:
             w2 = np.ascontiguousarray(w2, dtype=np.uint64)
         x2 = np.ascontiguousarray(x2_mont, dtype=np.uint64)
         cw, ct = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
-        _lib.check(lib.lurk_hip_fold_step_begin(self._h, _lib.ptr(w2), int(on_dev), _lib.ptr(stream), _lib.ptr(x2), _lib.ptr(cw), _lib.ptr(ct)))
+        self._check_begin(lib.lurk_hip_fold_step_begin(self._h, _lib.ptr(w2), int(on_dev), _lib.ptr(stream), _lib.ptr(x2), _lib.ptr(cw), _lib.ptr(ct)))
         self._open = (cw, ct)
         return cw, ct
 
@@ -111,6 +111,38 @@ class FoldingContext:
         r = np.zeros(4, dtype=np.uint64)
         _lib.check(_lib.load().lurk_hip_fold_step_challenge(self._h, _lib.ptr(r)))
         return r
+
+    def _check_begin(self, rc):
+        err = getattr(self, "_hook_error", None)
+        if err is not None:  # the submit hook raised: the library has rolled the step back (rc != 0); hand the caller its own exception
+            self._hook_error = None
+            raise err
+        _lib.check(rc)
+
+    def set_submit_hook(self, fn):
+        """``fn()`` is called once per step from inside ``begin`` / ``begin_prefetched`` / ``step``, after the step's device work has been
+        enqueued and before the call blocks on the commitments: the place to enqueue the next witness's slot traces (they queue behind the
+        step's opening kernels and fill what its commitments leave).  ``None`` removes the hook.  An exception raised by ``fn`` fails
+        the begin (the step is rolled back) and is re-raised."""
+        import ctypes
+
+        if fn is None:
+            _lib.check(_lib.load().lurk_hip_fold_ctx_set_submit_hook(self._h, None, None))
+            self._hook = None
+            return
+        self._hook_error = None
+
+        def tramp(_user):
+            try:
+                fn()
+                return 0
+            except BaseException as e:  # noqa: BLE001 - an exception must not unwind through the C frames
+                self._hook_error = e
+                return 1
+
+        cb = _lib.FOLD_SUBMIT_HOOK_FN(tramp)
+        _lib.check(_lib.load().lurk_hip_fold_ctx_set_submit_hook(self._h, ctypes.cast(cb, ctypes.c_void_p), None))
+        self._hook = cb  # (the library keeps the pointer: the trampoline lives as long as the context)
 
     def add_helper(self, helper_key):
         """Staging ahead across devices: ``helper_key`` is a ``CommitmentKey`` over the same bases resident on another device; instances
@@ -142,7 +174,7 @@ class FoldingContext:
             arr[k] = Patch(int(off), v.size // 4, v.ctypes.data)
         x2 = np.ascontiguousarray(x2_mont, dtype=np.uint64)
         cw, ct = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
-        _lib.check(_lib.load().lurk_hip_fold_step_begin_prefetched(self._h, ctypes.cast(arr, ctypes.c_void_p), len(keep), _lib.ptr(x2),
+        self._check_begin(_lib.load().lurk_hip_fold_step_begin_prefetched(self._h, ctypes.cast(arr, ctypes.c_void_p), len(keep), _lib.ptr(x2),
                                                                     _lib.ptr(cw), _lib.ptr(ct)))
         self._open = (cw, ct)
         return cw, ct

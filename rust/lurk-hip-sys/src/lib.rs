@@ -190,6 +190,16 @@ impl<'a> FoldingContext<'a> {
         check(unsafe { lurk_hip_fold_step_challenge(self.h, r.as_mut_ptr().cast()) })?;
         Ok(r)
     }
+    /// A hook into every step: called once per `step` / `begin` / `begin_prefetched`, on the calling thread, after the step's device work
+    /// has been enqueued and before the call blocks on the commitments - where the next witness's slot traces are enqueued
+    /// (`lurk_hip_slot_witness_dev`), so that they run beside the step.  A non-zero return fails the step (it is rolled back).
+    ///
+    /// # Safety
+    /// `hook` and `user` must stay valid until the hook is replaced, removed (`None`) or the context dropped; the hook must not call
+    /// into this context.
+    pub unsafe fn set_submit_hook(&mut self, hook: lurk_hip_fold_submit_hook_fn, user: *mut c_void) -> Result<(), Error> {
+        check(lurk_hip_fold_ctx_set_submit_hook(self.h, hook, user))
+    }
     /// Staging ahead across devices: `helper` is the same commitment key resident on another device; instances staged with
     /// `prefetch` are committed on the helpers in turn while this context's device folds.
     ///

@@ -317,6 +317,30 @@ int main() {
             helped.finish(Fe(11 + k));
             EXPECT(plain.read() == helped.read());
         }
+        // the submit hook: once per step, from inside the step; a hook that throws fails the step, which can then be repeated
+        R1CSShape s5(LURK_FIELD_PALLAS_FQ, 2, 2, 1, A, B, C), s6(LURK_FIELD_PALLAS_FQ, 2, 2, 1, A, B, C);
+        FoldingContext quiet(curve, s5, key), hooked(curve, s6, key);
+        int calls = 0;
+        bool fail = true;
+        hooked.set_submit_hook([&] {
+            calls++;
+            if (fail) throw std::runtime_error("producer failed");
+        });
+        bool hook_threw = false;
+        try {
+            hooked.step({three, nine}, {two}, Fe(5));
+        } catch (const std::exception&) {
+            hook_threw = true;
+        }
+        EXPECT(hook_threw && calls == 1);
+        fail = false;
+        auto q1 = quiet.step({three, nine}, {two}, Fe(5));
+        auto h1s = hooked.step({three, nine}, {two}, Fe(5));
+        EXPECT(calls == 2 && key.to_affine(q1[0]) == key.to_affine(h1s[0]) && key.to_affine(q1[1]) == key.to_affine(h1s[1]));
+        EXPECT(quiet.last_r == hooked.last_r && quiet.read() == hooked.read());
+        hooked.set_submit_hook(nullptr);
+        hooked.step({two, four}, {three}, Fe(5));
+        EXPECT(calls == 2);
     }
     printf("host mirror ok\n");
     return 0;

@@ -462,6 +462,86 @@ def test_begin_that_fails_midway_leaves_the_context_usable(hip):
     shape.close()
 
 
+def test_submit_hook_runs_inside_begin_and_a_failing_hook_rolls_the_step_back(hip):
+    """lurk_hip_fold_ctx_set_submit_hook: the hook is called once per step, from inside begin, when the step's commitments are in flight
+    (slot 1 of the key - commit(T) - is busy there) and before begin collects them; the next step's witness produced on the device from
+    inside the hook folds to the oracle's values; a hook that raises fails the begin with its own exception, nothing stays in flight
+    and the same begin succeeds afterwards.  Reference: the witness producer beside prove_step, /root/reference/src/proof/nova.rs:304-326."""
+    import torch
+
+    from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape, point_to_affine
+
+    curve, f, m, nfree, nio = 0, 1, 6000, 2500, 2
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=81)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    bases = C.synth_bases(curve, max(m, nv))
+    key = CommitmentKey(curve, bases, precompute=True, window_bits=16)
+    key.reserve(max(m, nv), 4)
+    ctx = FoldingContext(curve, shape, key)
+    commit = lambda v: C.jac_to_affine(curve, C.msm_pippenger(curve, bases[: len(v)], v))
+    fresh = [_fresh(f, A, B, m, nfree, nio, 960 + 7 * k) for k in range(3)]
+    pinned = [torch.from_numpy(C.to_mont(f, z2[:nv]).view(np.int64)).pin_memory() for z2, _ in fresh]
+    dev = [torch.empty((nv, 4), dtype=torch.int64, device="cuda") for _ in range(2)]
+    producer = torch.cuda.Stream()
+    probe = torch.from_numpy(C.to_mont(f, C.synth_scalars(f, 951, 0, 64)).view(np.int64)).cuda()
+    calls, seen_busy, fail = [], [], [False]
+
+    def hook():
+        k = len(calls)
+        calls.append(k)
+        try:
+            key.submit_device(1, probe, 64, is_mont=True)
+            seen_busy.append(False)
+            key.wait(1)
+        except LurkHipError as e:
+            seen_busy.append("busy" in str(e))
+        if fail[0]:
+            raise ValueError("producer failed")
+        if k + 1 < len(fresh):  # the NEXT witness, on the device, on the producer's stream
+            with torch.cuda.stream(producer):
+                dev[(k + 1) & 1].copy_(pinned[k + 1], non_blocking=True)
+
+    ctx.set_submit_hook(hook)
+    dev[0].copy_(pinned[0])
+    torch.cuda.synchronize()
+    z1 = np.zeros((nv + 1 + nio, 4), dtype=np.uint64)
+    e1 = np.zeros((m, 4), dtype=np.uint64)
+    for k, (z2, x2) in enumerate(fresh):
+        cw, ct = ctx.begin(dev[k & 1], C.to_mont(f, x2), stream=producer.cuda_stream)
+        assert calls == list(range(k + 1)) and seen_busy[-1] is True
+        u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+        t = C.cross_term(f, *[C.spmv(f, *M, z1) for M in (A, B, Cm)], *[C.spmv(f, *M, z2) for M in (A, B, Cm)], u1, 1)
+        assert point_to_affine(curve, cw) == commit(z2[:nv]) and point_to_affine(curve, ct) == commit(t)
+        r = 0xABCDE + k
+        ctx.finish(C.to_mont(f, C.ints_to_limbs([r])))
+        z1, e1 = C.axpy(f, z1, z2, r), C.axpy(f, e1, t, r)
+        gz, ge = ctx.read()
+        assert np.array_equal(C.from_mont(f, gz), z1) and np.array_equal(C.from_mont(f, ge), e1)
+    # a hook that raises: the caller gets its own exception, the step is rolled back, the key's slots are free, the retry succeeds
+    z2, x2 = _fresh(f, A, B, m, nfree, nio, 990)
+    w2m, x2m = C.to_mont(f, z2[:nv]), C.to_mont(f, x2)
+    fail[0] = True
+    with pytest.raises(ValueError, match="producer failed"):
+        ctx.begin(w2m, x2m)
+    for slot in range(4):
+        with pytest.raises(LurkHipError):
+            key.wait(slot)
+    ctx.set_submit_hook(None)
+    n_calls = len(calls)
+    cw, ct = ctx.begin(w2m, x2m)
+    assert len(calls) == n_calls  # removed: not called
+    u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+    t = C.cross_term(f, *[C.spmv(f, *M, z1) for M in (A, B, Cm)], *[C.spmv(f, *M, z2) for M in (A, B, Cm)], u1, 1)
+    assert point_to_affine(curve, cw) == commit(z2[:nv]) and point_to_affine(curve, ct) == commit(t)
+    ctx.finish(C.to_mont(f, C.ints_to_limbs([5])))
+    gz, ge = ctx.read()
+    assert np.array_equal(C.from_mont(f, gz), C.axpy(f, z1, z2, 5)) and np.array_equal(C.from_mont(f, ge), C.axpy(f, e1, t, 5))
+    ctx.close()
+    key.close()
+    shape.close()
+
+
 def test_step_at_the_rc100_size(hip):
     """One folding step at BASELINE config 1's size (rc = 100 on Pallas: 895 164 witness elements, 1 097 300 constraints - the
     sizes bench.py's fold_step workload runs) through lurk_hip_fold_step, every output against the oracle: both commitments
