@@ -16,7 +16,10 @@
 //   * measured and dropped in round 4: the last SIX levels (64 segments per key space from level c - 7 on) in one launch, one workgroup
 //     per key space merging through LDS with a barrier per level: 0.339 / 0.390 ms per reduction at 2^20 / 2^22 against 0.343 / 0.384
 //     with one launch per level (profiles/r04_run3_sweep.jsonl) - a level costs its ONE dependent XYZZ addition (~3 000 instructions of
-//     4+ cycles on a single wave: 6 us) whether a kernel boundary follows it or a barrier.
+//     4+ cycles on a single wave: 6 us) whether a kernel boundary follows it or a barrier;
+//   * measured and dropped in round 4: a component-major thread order (the copied component of every pair in waves of its own, so that
+//     level 0 runs half the adding waves, level 1 two thirds): 0.341 / 0.373 ms per reduction at 2^20 / 2^22 against 0.343 / 0.379 -
+//     the early levels are not bound by the additions of their idle lanes either.
 #include "common.hpp"
 #include "msm_core.cuh"
 #include "curve29.cuh"
