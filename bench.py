@@ -823,8 +823,11 @@ def compress_workload(args, lib, world, rank):
                "roofline": compress_roofline(lib, args, nc),
                "kernels_ms_per_proof": {k: kernel_ms(k) for k in ("sumcheck_round", "eq_evals", "r1cs_multiply_vec", "fold_vec", "ipa_inner_product",
                                                                    "ipa_fold_halves", "ipa_points_fold", "ipa_round_scalars", "ipa_coef_fold", "msm_accumulate", "msm_sort",
-                                                                   "msm_reduce")},
-               "ipa": "rounds under the resident table key (no key fold)" if args.ipa_resident_key else "published form: key folded every round"}
+                                                                   "msm_reduce", "key_fold", "msm_precompute")},
+               "ipa": ("rounds under the resident table key; the key folded ONCE after four rounds (lurk_hip_msm_ctx_fold_key_dev inside lurk_hip_ipa_prove_dev), the "
+                       "other sixteen under the folded key" if os.environ.get("LURK_IPA_FOLD_MIN_LOG", "18") != "0" else
+                       "rounds under the resident table key (LURK_IPA_FOLD_MIN_LOG=0: no key fold, the round-3 form)")
+               if args.ipa_resident_key else "published form: key folded every round"}
         print(json.dumps(out), flush=True)
     key.close()
     prover.close()

@@ -530,6 +530,14 @@ int lurk_hip_ipa_coef_fold_dev(int field_id, void* d_coef, size_t n, size_t m, c
  * anything else aborts the call).  d_a, d_b: n Montgomery scalars on the device, consumed (folded in place); ck_c: the extra base,
  * already scaled by the transcript's first challenge.  Outputs: L and R per round (log2(n) x 96 bytes each), a_hat canonical, and the
  * folded key element as an affine Montgomery point ((0, 0) = identity).  n: a power of two, at most the key's points. */
+/* The key folded by the weights of k rounds at once: d_out[p] = sum_{b < n_weights} weights[b] * key[b m + p], m = n / n_weights affine
+ * Montgomery points on the device ((0, 0) = identity) - what k rounds of ck' = [r^-1] ck_L + [r] ck_R leave, the weights being the
+ * products of the rounds' fold weights by block (arecibo ipa_pc.rs; /root/reference/src/proof/nova.rs:57-62).  The key must be in the
+ * window-table form; weights: host memory, Montgomery, n_weights a power of two <= 2^12; n a multiple of it, at most the key's points.
+ * lurk_hip_ipa_prove_dev does this by itself after its fourth round under a key of >= 2^18 points and continues under the folded key
+ * (LURK_IPA_FOLD_MIN_LOG in the environment moves the threshold, 0 = never): 2^20 elements in 21 ms instead of 39. */
+int lurk_hip_msm_ctx_fold_key_dev(lurk_hip_msm_ctx* key, size_t n, const void* weights32_mont, size_t n_weights, void* d_out_affine64,
+                                  void* stream);
 typedef int (*lurk_hip_ipa_challenge_fn)(void* user, int round, const void* l_jacobian96, const void* r_jacobian96, void* out_r32_canonical);
 int lurk_hip_ipa_prove_dev(lurk_hip_msm_ctx* key, void* d_a32, void* d_b32, size_t n, const void* ck_c_jacobian96,
                            lurk_hip_ipa_challenge_fn challenge, void* user, void* out_l_jacobian96, void* out_r_jacobian96,

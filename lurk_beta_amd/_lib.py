@@ -135,6 +135,7 @@ SIGNATURES = {
     "lurk_hip_points_fold_halves_dev": (c_int, [c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_sumcheck_prove_dev": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_sumcheck_prove_batch_dev": (c_int, [c_int, c_int, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_msm_ctx_fold_key_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_ipa_prove_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),

@@ -180,6 +180,16 @@ class DeviceWorker {
     std::thread th_;
 };
 
+// A commitment key's device-resident points as the other translation units may read them (msm.hip): table[w * npoints + i] =
+// 2^(window_bits w) P_i, 64-byte Montgomery affine records ((0, 0) = identity); windows = 1 for a plain key (and for the small-commitment
+// form, whose multiples table is not exposed: its first npoints records are the points themselves)
+struct MsmTableView {
+    const void* table = nullptr;
+    size_t npoints = 0;
+    int curve = 0, window_bits = 0, windows = 1, form = 0, device = 0;
+};
+MsmTableView msm_ctx_table_view(const lurk_hip_msm_ctx* ctx);
+
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 int num_cus();  // multiprocessor count of the current device

@@ -14,8 +14,12 @@
 // launch takes the same branch at every bit - the scalars are launch-wide - and finishes with its own inversion.
 #include <memory>
 
+#include <vector>
+
 #include "common.hpp"
 #include "curve.cuh"
+#include "curve29.cuh"
+#include "msm_core.cuh"
 
 namespace lurk {
 
@@ -225,15 +229,250 @@ static void points_fold_halves(const void* d_pts, size_t len, const void* lo32, 
 }
 
 
+// ---- the key folded by k rounds' weights at once --------------------------------------------------------------------------------
+// After k rounds the folded key is  ck_k[p] = sum_{b < T} s_b * ck[b m + p],  T = 2^k, m = n / T, with ONE set of T weights s_b (the
+// products of the rounds' fold weights) for every p: m small multi-scalar multiplications that share their scalars.  Under a window-table
+// key the table already holds 2^(kb j) ck[i] (kb = the key's window width, j < Wt), so with s_b = sum_j 2^(kb j) chunk_{b,j} and every
+// chunk split into U signed sub-digits (widths wd_u, offsets off_u)
+//     ck_k[p] = sum_u 2^(off_u) * sum_{j, b} digit_{b,j,u} * table[j n + b m + p]
+// - U independent bucket problems per output with Wt T terms each and digits of <= 2^(wd - 1) in magnitude, and only off_{U-1} < kb
+// doublings at the end.  The digit pattern is the same for every p: the host sorts the (j, b) pairs of every sub-digit slot by digit
+// magnitude ONCE (T <= 2^12 weights), a lane takes one (p, slot) and walks the list from the largest magnitude down - a running sum
+// that gains the points of the current magnitude (mixed additions from the table, radix-2^29 layer) and is added into the total once
+// per magnitude: Wt T mixed + 2^(wd - 1) full additions per lane, every lane of a wave in the same iteration of the same loop, the
+// loads of a wave 64 consecutive table records.  When m U is too few lanes to fill the chip a slot's window range is cut into groups.
+constexpr int KEYFOLD_MAX_T = 1 << 12;
+
+struct KeyFoldPlan {
+    int U = 0, groups = 0, maxmag = 0;  // sub-digit slots per window, window groups per slot, largest digit magnitude
+    int off[8] = {0}, wd[8] = {0};
+    int jlo[65] = {0};                  // window group g covers table windows [jlo[g], jlo[g + 1])
+    std::vector<uint32_t> ord;          // per (u, g): the (j - jlo[g]) * T + b of its non-zero digits, largest magnitude first; bit 31 = negative
+    std::vector<uint32_t> dstart;       // per (u, g): maxmag + 1 offsets into its part of ord: magnitude v in [dstart[maxmag - v], dstart[maxmag - v + 1])
+    std::vector<size_t> ord_base;       // per (u, g): where its part of ord begins
+};
+
+// weights: T canonical 256-bit integers (4 x u64, below 2^255)
+static KeyFoldPlan keyfold_plan(const uint64_t* weights, size_t T, size_t m, int kb, int Wt) {
+    KeyFoldPlan pl;
+    // sub-digit split of a kb-bit chunk: U slots of ceil(kb / U) bits; cost per output ~ U (Wt T + 1.4 * 2^(wd - 1))
+    double best = 0;
+    for (int U = 1; U <= 8 && U <= kb; U++) {
+        const int w = (kb + U - 1) / U;
+        if (w > 12) continue;
+        const double cost = U * ((double)Wt * (double)T + 1.4 * (double)(1u << (w - 1)));
+        if (!pl.U || cost < best) {
+            pl.U = U;
+            best = cost;
+        }
+    }
+    {
+        int left = kb, at = 0;
+        for (int u = 0; u < pl.U; u++) {
+            const int w = (left + (pl.U - u) - 1) / (pl.U - u);
+            pl.off[u] = at;
+            pl.wd[u] = w;
+            at += w;
+            left -= w;
+            if ((1 << (w - 1)) > pl.maxmag) pl.maxmag = 1 << (w - 1);
+        }
+    }
+    // enough lanes to fill the chip: ~128 K; a group never holds less than one window
+    pl.groups = 1;
+    while (pl.groups < Wt && m * (size_t)pl.U * (size_t)pl.groups < ((size_t)1 << 17)) pl.groups++;
+    for (int g = 0; g <= pl.groups; g++) pl.jlo[g] = (int)((long)Wt * g / pl.groups);
+    // signed digits of every weight, slot by slot in increasing weight (a digit above 2^(wd - 1) borrows from the next slot)
+    std::vector<int16_t> dig((size_t)Wt * pl.U * T);
+    for (size_t b = 0; b < T; b++) {
+        const uint64_t* s = weights + 4 * b;
+        int carry = 0;
+        for (int j = 0; j < Wt; j++)
+            for (int u = 0; u < pl.U; u++) {
+                const int pos = j * kb + pl.off[u], w = pl.wd[u];
+                uint64_t raw = 0;
+                if (pos < 256) {
+                    raw = s[pos / 64] >> (pos % 64);
+                    if (pos % 64 + w > 64 && pos / 64 + 1 < 4) raw |= s[pos / 64 + 1] << (64 - pos % 64);
+                    raw &= ((uint64_t)1 << w) - 1;
+                }
+                int d = (int)raw + carry;
+                carry = 0;
+                if (d > (1 << (w - 1))) {
+                    d -= 1 << w;
+                    carry = 1;
+                }
+                dig[((size_t)j * pl.U + u) * T + b] = (int16_t)d;
+            }
+        LURK_REQUIRE(carry == 0, "fold weight is not below 2^255");
+    }
+    pl.ord_base.assign((size_t)pl.U * pl.groups + 1, 0);
+    pl.dstart.assign((size_t)pl.U * pl.groups * (pl.maxmag + 1), 0);
+    std::vector<uint32_t> count(pl.maxmag + 1);
+    for (int u = 0; u < pl.U; u++)
+        for (int g = 0; g < pl.groups; g++) {
+            const size_t sg = (size_t)u * pl.groups + g;
+            std::fill(count.begin(), count.end(), 0u);
+            for (int j = pl.jlo[g]; j < pl.jlo[g + 1]; j++)
+                for (size_t b = 0; b < T; b++) {
+                    const int d = dig[((size_t)j * pl.U + u) * T + b];
+                    if (d) count[d < 0 ? -d : d]++;
+                }
+            uint32_t* ds = pl.dstart.data() + sg * (pl.maxmag + 1);
+            uint32_t at = 0;
+            for (int v = pl.maxmag; v >= 1; v--) {
+                ds[pl.maxmag - v] = at;
+                at += count[v];
+            }
+            ds[pl.maxmag] = at;
+            const size_t base = pl.ord.size();
+            pl.ord_base[sg] = base;
+            pl.ord.resize(base + at);
+            std::vector<uint32_t> cur(ds, ds + pl.maxmag);  // next free position per magnitude
+            for (int j = pl.jlo[g]; j < pl.jlo[g + 1]; j++)
+                for (size_t b = 0; b < T; b++) {
+                    const int d = dig[((size_t)j * pl.U + u) * T + b];
+                    if (!d) continue;
+                    const int v = d < 0 ? -d : d;
+                    pl.ord[base + cur[pl.maxmag - v]++] = (uint32_t)((size_t)(j - pl.jlo[g]) * T + b) | (d < 0 ? 0x80000000u : 0u);
+                }
+        }
+    pl.ord_base[(size_t)pl.U * pl.groups] = pl.ord.size();
+    return pl;
+}
+
+struct KeyFoldDev {
+    const uint32_t* ord;
+    const uint32_t* dstart;
+    const uint32_t* ord_base;  // U * groups entries (as 32-bit offsets)
+    const uint32_t* jlo;       // groups entries
+    uint32_t m, log_t, groups, maxmag, lanes_per_slot;
+    size_t stride;             // the key's points: table[j * stride + i]
+};
+
+// lane (p, slot = u * groups + g): partial[slot * m + p] = sum over the slot's (j, b) of digit * table[j stride + b m + p]
+template <class P>
+__global__ __launch_bounds__(IPA_BLOCK) void key_fold_slots_kernel(const Affine<P>* __restrict__ table, KeyFoldDev d, uint32_t nslots, Xyzz<P>* __restrict__ partial) {
+    const size_t gid = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x;
+    if (gid >= (size_t)nslots * d.m) return;
+    const uint32_t p = (uint32_t)(gid % d.m), slot = (uint32_t)(gid / d.m);
+    const uint32_t* ord = d.ord + d.ord_base[slot];
+    const uint32_t* ds = d.dstart + (size_t)slot * (d.maxmag + 1);
+    const Affine<P>* base = table + (size_t)d.jlo[slot % d.groups] * d.stride + p;
+    const uint32_t tmask = (1u << d.log_t) - 1u;
+    Xyzz29<P> run, tot;
+    run.x = run.y = run.zz = run.zzz = f29_zero<P>();
+    tot = run;
+    bool run_id = true, tot_id = true;
+    uint32_t t = ds[0];
+#pragma unroll 1
+    for (uint32_t k = 0; k < d.maxmag; k++) {  // magnitude maxmag - k
+        const uint32_t end = ds[k + 1];
+#pragma unroll 1
+        for (; t < end; t++) {
+            const uint32_t e = ord[t], jb = e & 0x7fffffffu;
+            const Affine<P> q = base[(size_t)(jb >> d.log_t) * d.stride + (size_t)(jb & tmask) * d.m];
+            xyzz29_madd<P>(run, run_id, q, (e & 0x80000000u) != 0);
+        }
+        xyzz29_add<P>(tot, tot_id, run, run_id);
+    }
+    partial[gid] = xyzz29_to_xyzz<P>(tot, tot_id);
+}
+
+// lane p: out[p] = sum_u 2^(off_u) sum_g partial[(u, g)][p], as an affine point
+template <class P>
+__global__ __launch_bounds__(IPA_BLOCK) void key_fold_combine_kernel(const Xyzz<P>* __restrict__ partial, uint32_t m, int U, int groups, int off1, int off2,
+                                                                       int off3, int off4, int off5, int off6, int off7, Affine<P>* __restrict__ out) {
+    const size_t p = (size_t)blockIdx.x * IPA_BLOCK + threadIdx.x;
+    if (p >= m) return;
+    const int off[8] = {0, off1, off2, off3, off4, off5, off6, off7};
+    Xyzz<P> acc = xyzz_identity<P>();
+#pragma unroll 1
+    for (int u = U - 1; u >= 0; u--) {
+        if (u != U - 1) acc = xyzz_dbl_n<P>(acc, off[u + 1] - off[u]);
+#pragma unroll 1
+        for (int g = 0; g < groups; g++) xyzz_add<P>(acc, partial[((size_t)u * groups + g) * m + p]);
+    }
+    out[p] = xyzz_to_affine<P>(acc);
+}
+
+// weights: T Montgomery scalars on the host; out: m = n / T affine points on the device
+template <class P, class F>
+static void key_fold(const MsmTableView& v, size_t n, const void* weights32_mont, size_t T, void* d_out, hipStream_t s) {
+    LURK_REQUIRE(T >= 1 && (T & (T - 1)) == 0 && T <= (size_t)KEYFOLD_MAX_T, "the number of fold weights must be a power of two, at most 2^12");
+    LURK_REQUIRE(n >= T && n % T == 0 && n <= v.npoints, "the folded length must be a multiple of the weights and at most the key's points");
+    const size_t m = n / T;
+    LURK_REQUIRE(m < ((size_t)1 << 31), "too many output points");
+    std::vector<uint64_t> canon(4 * T);
+    for (size_t b = 0; b < T; b++) {
+        Fe<F> x;
+        memcpy(x.l, (const char*)weights32_mont + 32 * b, 32);
+        x = fe_from_mont<F>(x);
+        memcpy(canon.data() + 4 * b, x.l, 32);
+    }
+    LURK_REQUIRE(v.form == LURK_MSM_FORM_TABLE, "the key fold needs the window-table form of the key (LURK_MSM_FLAG_PRECOMPUTE, more than 2^16 points or a window-bit override)");
+    const int kb = v.window_bits, Wt = v.windows;
+    const KeyFoldPlan pl = keyfold_plan(canon.data(), T, m, kb, Wt);
+    int log_t = 0;
+    while (((size_t)1 << log_t) < T) log_t++;
+    const uint32_t nslots = (uint32_t)(pl.U * pl.groups);
+    struct Scratch {
+        hipStream_t s;
+        void* p = nullptr;
+        Scratch(size_t bytes, hipStream_t s_) : s(s_) { LURK_HIP_CHECK(hipMallocAsync(&p, bytes ? bytes : 32, s)); }
+        ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
+    };
+    std::vector<uint32_t> base32(nslots), jlo32(pl.groups);
+    for (uint32_t i = 0; i < nslots; i++) {
+        LURK_REQUIRE(pl.ord_base[i] < ((size_t)1 << 32), "fold plan too large");
+        base32[i] = (uint32_t)pl.ord_base[i];
+    }
+    for (int g = 0; g < pl.groups; g++) jlo32[g] = (uint32_t)pl.jlo[g];
+    Scratch d_ord(pl.ord.size() * 4, s), d_ds(pl.dstart.size() * 4, s), d_base(nslots * 4, s), d_jlo(pl.groups * 4, s), d_part((size_t)nslots * m * sizeof(Xyzz<P>), s);
+    if (!pl.ord.empty()) LURK_HIP_CHECK(hipMemcpyAsync(d_ord.p, pl.ord.data(), pl.ord.size() * 4, hipMemcpyHostToDevice, s));
+    LURK_HIP_CHECK(hipMemcpyAsync(d_ds.p, pl.dstart.data(), pl.dstart.size() * 4, hipMemcpyHostToDevice, s));
+    LURK_HIP_CHECK(hipMemcpyAsync(d_base.p, base32.data(), nslots * 4, hipMemcpyHostToDevice, s));
+    LURK_HIP_CHECK(hipMemcpyAsync(d_jlo.p, jlo32.data(), pl.groups * 4, hipMemcpyHostToDevice, s));
+    KeyFoldDev d;
+    d.ord = (const uint32_t*)d_ord.p;
+    d.dstart = (const uint32_t*)d_ds.p;
+    d.ord_base = (const uint32_t*)d_base.p;
+    d.jlo = (const uint32_t*)d_jlo.p;
+    d.m = (uint32_t)m;
+    d.log_t = (uint32_t)log_t;
+    d.groups = (uint32_t)pl.groups;
+    d.maxmag = (uint32_t)pl.maxmag;
+    d.lanes_per_slot = (uint32_t)m;
+    d.stride = v.npoints;
+    {
+        ProfScope ps("key_fold", s);
+        hipLaunchKernelGGL((key_fold_slots_kernel<P>), dim3(div_up((size_t)nslots * m, IPA_BLOCK)), dim3(IPA_BLOCK), 0, s, (const Affine<P>*)v.table, d, nslots,
+                           (Xyzz<P>*)d_part.p);
+        hipLaunchKernelGGL((key_fold_combine_kernel<P>), dim3(div_up(m, IPA_BLOCK)), dim3(IPA_BLOCK), 0, s, (const Xyzz<P>*)d_part.p, (uint32_t)m, pl.U, pl.groups,
+                           pl.off[1], pl.off[2], pl.off[3], pl.off[4], pl.off[5], pl.off[6], pl.off[7], (Affine<P>*)d_out);
+        LURK_HIP_CHECK(hipGetLastError());
+    }
+    LURK_HIP_CHECK(hipStreamSynchronize(s));  // the plan's host vectors are read by the copies above
+}
+
 // ---- the whole argument under a resident key (arecibo ipa_pc::InnerProductArgument::prove, /root/reference/src/proof/nova.rs:57-62) ----
 // The round loop of lurk_beta_amd/ipa.py: _prove_resident_key as host code of the library: per round one launch for the composed scalars,
 // one pair commitment (window-table key) or two commitments in flight (plain / small key), one launch + one copy for both cross inner
 // products, the two host scalar multiples of the extra base while the commitment runs, the transcript's challenge (a callback), one
 // host inversion and three fold launches.  In Python the glue around the same calls cost 0.4-0.5 ms per round with the device idle.
+// Rounds under a long key cost a full-size commitment each however short the vectors have become.  So after IPA_FOLD_ROUNDS rounds under
+// a window-table key of >= 2^ipa_fold_min_log() points the key IS folded - once, by the product weights of those rounds (key_fold: about
+// two commitments' worth of additions) - into a window-table key of n / 2^IPA_FOLD_ROUNDS points, and the argument continues under that
+// one (which folds again if it is still long).  2^20: 4 rounds at 1.9 ms + the fold instead of 20 rounds at 1.9 ms.
+constexpr int IPA_FOLD_ROUNDS = 4;
+static int ipa_fold_min_log() {
+    const char* e = getenv("LURK_IPA_FOLD_MIN_LOG");  // 0 = never fold the key (the round-3 form); default 2^18 points; read per call (tests move it)
+    return e ? atoi(e) : 18;
+}
+
 template <class P, class F>
 static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, void* d_a, void* d_b, size_t n0, const void* ck_c_jac96,
                                lurk_hip_ipa_challenge_fn challenge, void* user, uint64_t* out_l, uint64_t* out_r, void* out_a_hat32,
-                               void* out_ck_hat64, hipStream_t s) {
+                               void* out_ck_hat64, hipStream_t s, int round0 = 0) {
     auto ok = [](int rc) { if (rc != 0) throw HipFailure{rc, lurk_hip_last_error()}; };
     int kc = 0, kbits = 0, ktable = 0;
     size_t kn = 0;
@@ -260,7 +499,26 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
     uint64_t* host_partial = host_partial_buf.data();
     size_t m = n0;
     int j = 0;
+    const int fold_log = ipa_fold_min_log();
+    const bool will_fold = pairs && fold_log > 0 && n0 >= ((size_t)1 << fold_log) && n0 >= ((size_t)1 << (IPA_FOLD_ROUNDS + 1));
     while (m > 1) {
+        if (will_fold && j == IPA_FOLD_ROUNDS) {
+            const size_t T = (size_t)1 << IPA_FOLD_ROUNDS;  // coef[i] depends on i / m only: the weight of block b is coef[b m]
+            std::vector<uint64_t> w(4 * T);
+            LURK_HIP_CHECK(hipMemcpy2DAsync(w.data(), 32, coef.p, m * 32, 32, T, hipMemcpyDeviceToHost, s));
+            LURK_HIP_CHECK(hipStreamSynchronize(s));
+            Scratch folded(m * sizeof(Affine<P>), s);
+            key_fold<P, F>(msm_ctx_table_view(key), n0, w.data(), T, folded.p, s);
+            lurk_hip_msm_ctx* key2 = nullptr;
+            ok(lurk_hip_msm_ctx_create_dev(&key2, curve, folded.p, m, LURK_MSM_FLAG_PRECOMPUTE | LURK_MSM_FLAG_WINDOW_BITS(16), (void*)s));
+            struct Drop {
+                lurk_hip_msm_ctx* k;
+                ~Drop() { lurk_hip_msm_ctx_destroy(k); }
+            } drop{key2};
+            ipa_prove_resident<P, F>(key2, curve, field_id, d_a, d_b, m, ck_c_jac96, challenge, user, out_l + (size_t)12 * j, out_r + (size_t)12 * j, out_a_hat32,
+                                     out_ck_hat64, s, round0 + j);
+            return;
+        }
         const size_t h = m / 2;
         int log_h = 0;
         while (((size_t)1 << log_h) < h) log_h++;
@@ -321,7 +579,7 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
         memcpy(two + 12, tr, 96);
         ok(lurk_hip_point_sum(curve, R, two, 2));
         uint64_t r_can[4] = {0, 0, 0, 0};
-        LURK_REQUIRE(challenge(user, j, L, R, r_can) == 0, "the transcript callback failed");
+        LURK_REQUIRE(challenge(user, round0 + j, L, R, r_can) == 0, "the transcript callback failed");
         Fe<F> r;
         memcpy(r.l, r_can, 32);
         LURK_REQUIRE(!fe_canonical_ge_mod<F>(r.l), "the challenge is not reduced modulo the group order");
@@ -414,6 +672,16 @@ int lurk_hip_ipa_prove_dev(lurk_hip_msm_ctx* key, void* d_a, void* d_b, size_t n
         else
             ipa_prove_resident<PallasFq, PallasFp>(key, curve, LURK_FIELD_PALLAS_FP, d_a, d_b, n, ck_c_jacobian96, challenge, user, (uint64_t*)out_l_jacobian96,
                                                    (uint64_t*)out_r_jacobian96, out_a_hat32, out_ck_hat_affine64, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_msm_ctx_fold_key_dev(lurk_hip_msm_ctx* key, size_t n, const void* weights32_mont, size_t n_weights, void* d_out_affine64, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(key && weights32_mont && d_out_affine64, "null argument");
+        const MsmTableView v = msm_ctx_table_view(key);
+        DeviceGuard dg(v.device);
+        if (v.curve == LURK_CURVE_PALLAS) key_fold<PallasFp, PallasFq>(v, n, weights32_mont, n_weights, d_out_affine64, (hipStream_t)stream);
+        else key_fold<PallasFq, PallasFp>(v, n, weights32_mont, n_weights, d_out_affine64, (hipStream_t)stream);
     });
 }
 

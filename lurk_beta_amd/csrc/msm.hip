@@ -1648,6 +1648,26 @@ int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoin
     });
 }
 
+}  // extern "C"
+
+namespace lurk {
+MsmTableView msm_ctx_table_view(const lurk_hip_msm_ctx* ctx) {
+    LURK_REQUIRE(ctx, "null ctx");
+    const MsmCtxBase& c = *ctx->impl;
+    MsmTableView v;
+    v.table = c.device_table();
+    v.npoints = c.npoints;
+    v.curve = c.curve;
+    v.window_bits = c.c;
+    v.form = c.small ? LURK_MSM_FORM_SMALL : c.precomputed ? LURK_MSM_FORM_TABLE : LURK_MSM_FORM_PLAIN;
+    v.windows = v.form == LURK_MSM_FORM_TABLE ? msm_num_windows(c.c) : 1;
+    v.device = c.device;
+    return v;
+}
+}  // namespace lurk
+
+extern "C" {
+
 // ---- one process, several devices --------------------------------------------------------------
 int lurk_hip_msm_multi_create(lurk_hip_msm_multi** out, int curve, const void* bases, size_t n, const int* devices, int n_dev, int flags) {
     return guarded([&] {

@@ -137,6 +137,17 @@ class CommitmentKey:
         getattr(self, "_keep", {}).pop(slot, None)
         return out
 
+    def fold_key(self, n: int, weights_mont: np.ndarray, stream=None):
+        """The key folded by the weights of k inner-product rounds at once (lurk_hip_msm_ctx_fold_key_dev): a device tensor of
+        m = n / len(weights) affine Montgomery points, out[p] = sum_b weights[b] * key[b m + p].  Window-table form only."""
+        import torch
+
+        w = np.ascontiguousarray(weights_mont, dtype=np.uint64).reshape(-1, 4)
+        out = torch.empty((n // w.shape[0], 8), dtype=torch.int64, device="cuda")
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.load().lurk_hip_msm_ctx_fold_key_dev(self._ctx, n, _lib.ptr(w), w.shape[0], _lib.ptr(out), _lib.ptr(s)))
+        return out
+
     def supports_pairs(self) -> bool:
         """True for a window-table key (precompute flag and more than 2^16 points, or a window-bit override): the only form that
         commits a pair in one pass (``submit_pair_device``)."""

@@ -48,10 +48,18 @@ def _aff(curve_id, jac):
 
 
 @pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
-@pytest.mark.parametrize("log_n", [1, 4, 7])
-@pytest.mark.parametrize("form", ["folded_key", "resident_plain_key", "resident_table_key"])
-def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n, form):
+@pytest.mark.parametrize("log_n", [1, 4, 7, 9])
+@pytest.mark.parametrize("form", ["folded_key", "resident_plain_key", "resident_table_key", "resident_window_table_key", "window_table_key_folded_after_4_rounds"])
+def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n, form, monkeypatch):
+    """resident_table_key: the small-commitment form at these sizes (two commitments per round); resident_window_table_key: the bucket
+    pipeline with the window table (L and R as one pair commitment), the key never folded; ..._folded_after_4_rounds: the same with the
+    key folded once by the first four rounds' weights (lurk_hip_msm_ctx_fold_key_dev inside lurk_hip_ipa_prove_dev, threshold moved down
+    to these sizes; at 2^9 the folded key of 32 points is folded a second time) - all five forms must give the oracle's proof."""
     from lurk_beta_amd import CommitmentKey, ipa, msm
+
+    if log_n == 9 and form in ("folded_key", "resident_plain_key"):
+        pytest.skip("covered at the smaller sizes")
+    monkeypatch.setenv("LURK_IPA_FOLD_MIN_LOG", "5" if form == "window_table_key_folded_after_4_rounds" else "0")
 
     sf = 1 if c == 0 else 0
     bf = 0 if c == 0 else 1
@@ -60,7 +68,8 @@ def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n, form):
     B, ck, ck_c, a, b, r0, chal, (want_L, want_R, want_a, want_ck), comm_a = _oracle_case(cn, c, log_n)
     ck_c_jac = np.concatenate([B[n], C.to_mont(bf, C.ints_to_limbs([1])).reshape(4)])
     # the resident key may be longer than the argument (Spartan opens under a prefix of the witness key)
-    key = None if form == "folded_key" else CommitmentKey(c, B[: n + 1], precompute=form == "resident_table_key")
+    key = None if form == "folded_key" else CommitmentKey(c, B[: n + 1], precompute=form != "resident_plain_key",
+                                                          window_bits=16 if "window_table" in form else 0)
     got_L, got_R, got_a, got_ck = ipa.prove(c, q, None if key else _dev(B[:n]), ck_c_jac, _dev(C.to_mont(sf, C.ints_to_limbs(a))),
                                             _dev(C.to_mont(sf, C.ints_to_limbs(b))), r0, lambda j, L, Rr: chal[j], key=key)
     if key:
@@ -72,6 +81,43 @@ def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n, form):
         cc = sum(x * y for x, y in zip(a, b)) % q
         assert R.ipa_verify(cn, ck, ck_c, comm_a, b, cc, r0, chal, [_aff(c, x) for x in got_L], [_aff(c, x) for x in got_R], got_a)
         assert not R.ipa_verify(cn, ck, ck_c, comm_a, b, (cc + 1) % q, r0, chal, want_L, want_R, want_a)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+@pytest.mark.parametrize("log_n,log_t,window_bits", [(10, 4, 16), (10, 0, 16), (12, 8, 16), (17, 4, 0), (17, 1, 0), (12, 5, 20)])
+def test_key_fold_against_the_oracle(hip, curve, log_n, log_t, window_bits):
+    """lurk_hip_msm_ctx_fold_key_dev: out[p] = sum_b w_b * key[b m + p] against the oracle's Pippenger on sampled outputs (first, last,
+    random): weights 0, 1, q - 1, 2^254 and uniform ones; identity points and a repeated point among the bases (mixed additions that
+    double or cancel inside a bucket); a key longer than the folded prefix; one window group and several (m U < 2^17 lanes)."""
+    from lurk_beta_amd import CommitmentKey
+
+    sf = 1 if curve == 0 else 0
+    bf = 0 if curve == 0 else 1
+    q = R.modulus(sf)
+    n, T = 1 << log_n, 1 << log_t
+    m = n // T
+    B = C.synth_bases(curve, n + 3).copy()
+    B[5] = 0                      # identity points
+    B[n - 1] = 0
+    if T > 1:
+        B[m + 7] = B[7]           # the same point in two blocks of output 7: equal weights double it, opposite weights cancel it
+    key = CommitmentKey(curve, B, precompute=True, window_bits=window_bits)
+    assert key.info()["form"] == "table"
+    special = [0, 1, q - 1, 1 << 254]
+    w = [special[b] if b < len(special) else R.uniform_fe(180 + curve, b, q) for b in range(T)]
+    if T >= 2:
+        w[1] = (q - w[0]) % q if w[0] else w[1]
+    if T >= 4:
+        w[3] = w[2]
+    got = key.fold_key(n, C.to_mont(sf, C.ints_to_limbs(w))).cpu().numpy().view(np.uint64)
+    rng = np.random.default_rng(4)
+    sample = sorted({0, 5, 7, m - 1, *[int(x) for x in rng.integers(0, m, 12)]} & set(range(m)))
+    wl = C.ints_to_limbs(w)
+    for p in sample:
+        want = C.jac_to_affine(curve, C.msm_pippenger(curve, np.ascontiguousarray(B[p:n:m]), wl))
+        g = tuple(C.limbs_to_ints(C.from_mont(bf, got[p].reshape(2, 4))))
+        assert g == want, (p, log_n, log_t)
+    key.close()
 
 
 def test_fold_kernels_edge_cases(hip):
