@@ -462,6 +462,26 @@ int lurk_hip_keccak_transcript_absorb_point(lurk_hip_keccak_transcript* t, const
 int lurk_hip_keccak_transcript_dom_sep(lurk_hip_keccak_transcript* t, const void* bytes, size_t len);
 int lurk_hip_keccak_transcript_squeeze(lurk_hip_keccak_transcript* t, const void* label, size_t label_len, int field_id,
                                        void* out32_canonical);
+/* Ready-made `challenge` arguments for the round loops below (lurk_hip_sumcheck_prove_dev / _prove_batch_dev, lurk_hip_ipa_prove_dev)
+ * over a Keccak transcript, so that a proof's rounds run without leaving the library: pass the function as `challenge` and a
+ * lurk_hip_keccak_round_binding as `user`.  Sum-check: the round polynomial's n_scalars coefficients are absorbed under absorb_label,
+ * the challenge is squeezed under squeeze_label.  Inner-product argument: L under absorb_label, R under absorb_label2 (points of
+ * `curve`), then the squeeze.  Every challenge is also appended to challenges_out (32 canonical bytes each; NULL = not kept), n_rounds
+ * counts the calls. */
+typedef struct lurk_hip_keccak_round_binding {
+    lurk_hip_keccak_transcript* transcript;
+    int field_id, n_scalars, curve;
+    const void* absorb_label;
+    size_t absorb_label_len;
+    const void* absorb_label2;
+    size_t absorb_label2_len;
+    const void* squeeze_label;
+    size_t squeeze_label_len;
+    void* challenges_out;
+    size_t challenges_cap, n_rounds; /* capacity of challenges_out in challenges; calls so far */
+} lurk_hip_keccak_round_binding;
+int lurk_hip_keccak_sumcheck_challenge(void* binding, int round, const void* coefficients32_canonical, void* out_r32_canonical);
+int lurk_hip_keccak_ipa_challenge(void* binding, int round, const void* l_jacobian96, const void* r_jacobian96, void* out_r32_canonical);
 
 /* ---- sum-check rounds (the data-parallel half of CompressedSNARK::prove) -----------------------
  * CompressedSNARK::prove (/root/reference/src/proof/nova.rs:341-356, supernova.rs:293-302) -> arecibo RelaxedR1CSSNARK::prove ->

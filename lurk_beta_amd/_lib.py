@@ -108,6 +108,8 @@ SIGNATURES = {
     "lurk_hip_fold_step_begin_prefetched": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_finish": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_set_pp_digest": (c_int, [c_void_p, c_void_p]),
+    "lurk_hip_keccak_sumcheck_challenge": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "lurk_hip_keccak_ipa_challenge": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_set_submit_hook": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step_challenge": (c_int, [c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_running_dev": (c_int, [c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
@@ -182,6 +184,47 @@ def ptr(x) -> c_void_p:
     if hasattr(x, "data_ptr"):
         return c_void_p(x.data_ptr())
     return c_void_p(x.ctypes.data)
+
+
+class KeccakRoundBindingStruct(ctypes.Structure):
+    """lurk_hip_keccak_round_binding"""
+    _fields_ = [("transcript", ctypes.c_void_p), ("field_id", ctypes.c_int), ("n_scalars", ctypes.c_int), ("curve", ctypes.c_int),
+                ("absorb_label", ctypes.c_char_p), ("absorb_label_len", ctypes.c_size_t),
+                ("absorb_label2", ctypes.c_char_p), ("absorb_label2_len", ctypes.c_size_t),
+                ("squeeze_label", ctypes.c_char_p), ("squeeze_label_len", ctypes.c_size_t),
+                ("challenges_out", ctypes.c_void_p), ("challenges_cap", ctypes.c_size_t), ("n_rounds", ctypes.c_size_t)]
+
+
+class KeccakRounds:
+    """A ``challenge`` argument that never leaves the library: the rounds of a sum-check / inner-product argument absorb into and squeeze
+    from a Keccak transcript through lurk_hip_keccak_sumcheck_challenge / lurk_hip_keccak_ipa_challenge (no Python in the round loop).
+    ``challenges()`` returns what was squeezed, in order."""
+
+    def __init__(self, transcript_handle, field_id: int, absorb: bytes, squeeze: bytes, absorb2: bytes = b"", curve: int = 0, cap: int = 64):
+        import numpy as np
+
+        self._out = np.zeros((cap, 4), dtype=np.uint64)
+        self._labels = (bytes(absorb), bytes(absorb2), bytes(squeeze))  # kept alive: the struct borrows them
+        self.struct = KeccakRoundBindingStruct(transcript_handle, field_id, 0, curve, self._labels[0], len(absorb), self._labels[1], len(absorb2),
+                                               self._labels[2], len(squeeze), self._out.ctypes.data, cap, 0)
+
+    def callback(self, kind: str):
+        """(function pointer, user pointer) for the library's round loops; kind: 'sumcheck' or 'ipa'."""
+        fn = getattr(load(), "lurk_hip_keccak_sumcheck_challenge" if kind == "sumcheck" else "lurk_hip_keccak_ipa_challenge")
+        return ctypes.cast(fn, ctypes.c_void_p), ctypes.cast(ctypes.pointer(self.struct), ctypes.c_void_p)
+
+    def ipa_round(self, j: int, L, R) -> int:
+        """One inner-product round from Python (the prover that folds its key drives its own loop): absorb L and R, squeeze."""
+        import numpy as np
+
+        out = np.zeros(4, dtype=np.uint64)
+        l, r = np.ascontiguousarray(L, dtype=np.uint64), np.ascontiguousarray(R, dtype=np.uint64)
+        check(load().lurk_hip_keccak_ipa_challenge(ctypes.cast(ctypes.pointer(self.struct), ctypes.c_void_p), j, ptr(l), ptr(r), ptr(out)))
+        return int(out[0]) | int(out[1]) << 64 | int(out[2]) << 128 | int(out[3]) << 192
+
+    def challenges(self) -> list[int]:
+        k = int(self.struct.n_rounds)
+        return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in self._out[:k]]
 
 
 # lurk_hip_ipa_challenge_fn: int (*)(void* user, int round, const void* L96, const void* R96, void* out_r32_canonical)

@@ -189,6 +189,21 @@ struct MsmTableView {
     int curve = 0, window_bits = 0, windows = 1, form = 0, device = 0;
 };
 MsmTableView msm_ctx_table_view(const lurk_hip_msm_ctx* ctx);
+// the parent key's folded-key context with its points replaced by d_points (m affine records on the device): msm.hip
+struct FoldedKeyLease {
+    lurk_hip_msm_ctx* ctx = nullptr;
+    bool owned = false;  // a private context, destroyed with the lease
+    std::unique_lock<std::mutex> lk;
+    FoldedKeyLease() = default;
+    FoldedKeyLease(FoldedKeyLease&& o) noexcept : ctx(o.ctx), owned(o.owned), lk(std::move(o.lk)) {
+        o.ctx = nullptr;
+        o.owned = false;
+    }
+    FoldedKeyLease(const FoldedKeyLease&) = delete;
+    ~FoldedKeyLease();
+};
+FoldedKeyLease msm_ctx_folded_child(lurk_hip_msm_ctx* parent, const void* d_points, size_t m, hipStream_t s);
+void msm_ctx_drop_folded_child(const lurk_hip_msm_ctx* parent);
 
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 

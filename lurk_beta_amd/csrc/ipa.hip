@@ -509,13 +509,8 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
             LURK_HIP_CHECK(hipStreamSynchronize(s));
             Scratch folded(m * sizeof(Affine<P>), s);
             key_fold<P, F>(msm_ctx_table_view(key), n0, w.data(), T, folded.p, s);
-            lurk_hip_msm_ctx* key2 = nullptr;
-            ok(lurk_hip_msm_ctx_create_dev(&key2, curve, folded.p, m, LURK_MSM_FLAG_PRECOMPUTE | LURK_MSM_FLAG_WINDOW_BITS(16), (void*)s));
-            struct Drop {
-                lurk_hip_msm_ctx* k;
-                ~Drop() { lurk_hip_msm_ctx_destroy(k); }
-            } drop{key2};
-            ipa_prove_resident<P, F>(key2, curve, field_id, d_a, d_b, m, ck_c_jac96, challenge, user, out_l + (size_t)12 * j, out_r + (size_t)12 * j, out_a_hat32,
+            FoldedKeyLease key2 = msm_ctx_folded_child(key, folded.p, m, s);  // a window-table key (16-bit windows) that belongs to `key`
+            ipa_prove_resident<P, F>(key2.ctx, curve, field_id, d_a, d_b, m, ck_c_jac96, challenge, user, out_l + (size_t)12 * j, out_r + (size_t)12 * j, out_a_hat32,
                                      out_ck_hat64, s, round0 + j);
             return;
         }

@@ -657,6 +657,8 @@ struct MsmCtxBase {
     bool precomputed = false;
     bool small = false;  // precomputed in the small-commitment form (msm_small.hip): `c` is its window width, no bucket pipeline
     int c = MSM_C_PLAIN;
+    bool keep_buffers = false;  // a context whose points are replaced again and again (the inner-product argument's folded key): the table
+                                // buffer and the precomputation's scratch stay allocated between set_bases_device calls
     virtual ~MsmCtxBase() {}
     // synchronous: enqueue on `s` with slot 0's workspace, wait, host tail
     virtual void run(const void* d_scalars, size_t n, int is_mont, hipStream_t s, void* out_jac96_host) = 0;
@@ -687,6 +689,7 @@ static bool oneshot_key_cache_enabled() { return g_oneshot_key_cache.load() != 0
 template <class P, class SF>
 struct MsmCtx : MsmCtxBase {
     DevBuf own_bases;                // bases (or the whole table when precomputed)
+    DevBuf pre_scratch;              // keep_buffers: the table precomputation's scratch
     const Affine<P>* table = nullptr;
     DevBuf small_table;              // small form: n x W x 2^(c-1) multiples (own_bases then holds the plain bases)
 
@@ -801,9 +804,12 @@ struct MsmCtx : MsmCtxBase {
         // sorted entries carry a 31-bit table index (+ sign bit); the sort's offsets are 32-bit over the W n entries
         LURK_REQUIRE((size_t)W * n < ((size_t)1 << 31), "too many points: windows x points must stay below 2^31");
         if (precompute) {
-            own_bases.alloc((size_t)W * n * sizeof(Affine<P>));
+            if (keep_buffers) own_bases.ensure((size_t)W * n * sizeof(Affine<P>));
+            else own_bases.alloc((size_t)W * n * sizeof(Affine<P>));
             if (n) {
-                DevBuf scratch((size_t)(W - 1) * 3 * n * sizeof(Fe<P>));
+                DevBuf once;
+                DevBuf& scratch = keep_buffers ? pre_scratch : once;
+                scratch.ensure((size_t)(W - 1) * 3 * n * sizeof(Fe<P>));
                 {
                     ProfScope ps("msm_precompute", s);
                     hipLaunchKernelGGL((msm_precompute_kernel<P>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Affine<P>*)d_bases, n,
@@ -1521,6 +1527,7 @@ int lurk_hip_msm_ctx_destroy(lurk_hip_msm_ctx* ctx) {
     if (!ctx) return 0;
     return guarded([&] {
         DeviceGuard dg(ctx->impl->device);
+        lurk::msm_ctx_drop_folded_child(ctx);
         delete ctx;
     });
 }
@@ -1651,6 +1658,63 @@ int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoin
 }  // extern "C"
 
 namespace lurk {
+// The folded key of the inner-product argument (ipa.hip) as a context that belongs to its parent key: created at the first proof, its
+// points replaced (table rebuilt in place, workspaces kept) at every later one - creating and destroying a 65 536-point table key per
+// proof cost 3-4 ms of hipMalloc / hipFree on the host.  One argument at a time holds it; a second one under the same key at the same
+// moment gets a private context (owned = true).
+struct FoldedChild {
+    std::unique_ptr<lurk_hip_msm_ctx> ctx;
+    std::mutex mu;
+};
+static std::mutex g_children_mu;
+static std::map<const lurk_hip_msm_ctx*, std::unique_ptr<FoldedChild>> g_children;
+
+FoldedKeyLease::~FoldedKeyLease() {
+    if (owned && ctx) (void)lurk_hip_msm_ctx_destroy(ctx);
+}
+FoldedKeyLease msm_ctx_folded_child(lurk_hip_msm_ctx* parent, const void* d_points, size_t m, hipStream_t s) {
+    LURK_REQUIRE(parent && d_points && m, "null argument");
+    const int curve = parent->impl->curve;
+    const int flags = LURK_MSM_FLAG_PRECOMPUTE | LURK_MSM_FLAG_WINDOW_BITS(16);
+    FoldedChild* fc = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_children_mu);
+        auto& slot = g_children[parent];
+        if (!slot) slot.reset(new FoldedChild);
+        fc = slot.get();
+    }
+    FoldedKeyLease lease;
+    lease.lk = std::unique_lock<std::mutex>(fc->mu, std::try_to_lock);
+    if (!lease.lk.owns_lock()) {  // somebody else's argument holds the parent's child: a private one
+        if (lurk_hip_msm_ctx_create_dev(&lease.ctx, curve, d_points, m, flags, (void*)s) != 0) throw HipFailure{LURK_HIP_ERR_HIP, lurk_hip_last_error()};
+        lease.owned = true;
+        return lease;
+    }
+    if (!fc->ctx) {
+        std::unique_ptr<MsmCtxBase> c(new_ctx(curve));
+        c->keep_buffers = true;
+        ctx_set_bases(c.get(), d_points, m, /*copy=*/false, flags, s);
+        fc->ctx.reset(new lurk_hip_msm_ctx{std::move(c)});
+    } else {
+        ctx_set_bases(fc->ctx->impl.get(), d_points, m, /*copy=*/false, flags, s);
+    }
+    lease.ctx = fc->ctx.get();
+    return lease;
+}
+void msm_ctx_drop_folded_child(const lurk_hip_msm_ctx* parent) {
+    std::unique_ptr<FoldedChild> dead;
+    {
+        std::lock_guard<std::mutex> lk(g_children_mu);
+        auto it = g_children.find(parent);
+        if (it == g_children.end()) return;
+        dead = std::move(it->second);
+        g_children.erase(it);
+    }
+    if (dead->ctx) {
+        msm_ctx_drop_folded_child(dead->ctx.get());  // (a folded key long enough to have been folded again)
+        dead->ctx.reset();
+    }
+}
 MsmTableView msm_ctx_table_view(const lurk_hip_msm_ctx* ctx) {
     LURK_REQUIRE(ctx, "null ctx");
     const MsmCtxBase& c = *ctx->impl;

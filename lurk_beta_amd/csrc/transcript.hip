@@ -428,4 +428,30 @@ int lurk_hip_keccak_transcript_squeeze(lurk_hip_keccak_transcript* t, const void
         memcpy(out32_canonical, r, 32);
     });
 }
+
+static int keccak_round_finish(lurk_hip_keccak_round_binding* b, void* out_r32_canonical) {
+    const int rc = lurk_hip_keccak_transcript_squeeze(b->transcript, b->squeeze_label, b->squeeze_label_len, b->field_id, out_r32_canonical);
+    if (rc != 0) return rc;
+    if (b->challenges_out) {
+        if (b->n_rounds >= b->challenges_cap) return LURK_HIP_ERR_INVALID_ARG;
+        memcpy((char*)b->challenges_out + 32 * b->n_rounds, out_r32_canonical, 32);
+    }
+    b->n_rounds++;
+    return 0;
+}
+int lurk_hip_keccak_sumcheck_challenge(void* binding, int round, const void* coefficients32_canonical, void* out_r32_canonical) {
+    (void)round;
+    auto* b = (lurk_hip_keccak_round_binding*)binding;
+    if (!b || !b->transcript || !coefficients32_canonical || !out_r32_canonical || b->n_scalars < 1) return LURK_HIP_ERR_INVALID_ARG;
+    const int rc = lurk_hip_keccak_transcript_absorb_scalars(b->transcript, b->absorb_label, b->absorb_label_len, coefficients32_canonical, (size_t)b->n_scalars);
+    return rc != 0 ? rc : keccak_round_finish(b, out_r32_canonical);
+}
+int lurk_hip_keccak_ipa_challenge(void* binding, int round, const void* l_jacobian96, const void* r_jacobian96, void* out_r32_canonical) {
+    (void)round;
+    auto* b = (lurk_hip_keccak_round_binding*)binding;
+    if (!b || !b->transcript || !l_jacobian96 || !r_jacobian96 || !out_r32_canonical) return LURK_HIP_ERR_INVALID_ARG;
+    int rc = lurk_hip_keccak_transcript_absorb_point(b->transcript, b->absorb_label, b->absorb_label_len, b->curve, l_jacobian96);
+    if (rc == 0) rc = lurk_hip_keccak_transcript_absorb_point(b->transcript, b->absorb_label2, b->absorb_label2_len, b->curve, r_jacobian96);
+    return rc != 0 ? rc : keccak_round_finish(b, out_r32_canonical);
+}
 }

@@ -49,8 +49,12 @@ def _prove_resident_key(curve: int, q: int, key, ck_c: np.ndarray, d_a, d_b, cha
             failure.append(e)
             return 1
 
-    cb = _lib.IPA_CHALLENGE_FN(on_round)
-    rc = lib.lurk_hip_ipa_prove_dev(key._ctx, _lib.ptr(d_a), _lib.ptr(d_b), n0, _lib.ptr(ck_c), ctypes.cast(cb, ctypes.c_void_p), None, _lib.ptr(Ls), _lib.ptr(Rs),
+    if isinstance(challenge, _lib.KeccakRounds):  # the transcript is the library's own: no Python in the round loop
+        cb_ptr, user = challenge.callback("ipa")
+    else:
+        cb = _lib.IPA_CHALLENGE_FN(on_round)
+        cb_ptr, user = ctypes.cast(cb, ctypes.c_void_p), None
+    rc = lib.lurk_hip_ipa_prove_dev(key._ctx, _lib.ptr(d_a), _lib.ptr(d_b), n0, _lib.ptr(ck_c), cb_ptr, user, _lib.ptr(Ls), _lib.ptr(Rs),
                                     _lib.ptr(a_hat), _lib.ptr(ck_hat), _lib.ptr(s))
     if failure:
         raise failure[0]
@@ -100,7 +104,7 @@ def prove(curve: int, order: int, d_ck, ck_c_jac: np.ndarray, d_a, d_b, r0: int,
             L, Rr = parts
             Ls.append(L)
             Rs.append(Rr)
-            r = int(challenge(j, L, Rr)) % q
+            r = challenge.ipa_round(j, L, Rr) if isinstance(challenge, _lib.KeccakRounds) else int(challenge(j, L, Rr)) % q
             ri = pow(r, q - 2, q)
             rm, rim = mont(r), mont(ri)  # named: the arrays must outlive the calls that read them
             _lib.check(lib.lurk_hip_fold_halves_dev(sf, _lib.ptr(d_a), n, _lib.ptr(rm), _lib.ptr(rim), _lib.ptr(s)))

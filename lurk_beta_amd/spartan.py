@@ -58,6 +58,11 @@ class Transcript:
         j = np.ascontiguousarray(jac96, dtype=np.uint64)
         _lib.check(_lib.load().lurk_hip_keccak_transcript_absorb_point(self._h, label, len(label), self._curve, _lib.ptr(j)))
 
+    def rounds(self, modulus: int, absorb: bytes, squeeze: bytes, absorb2: bytes = b"", cap: int = 64):
+        """A ``challenge`` argument for sumcheck.prove* / ipa.prove over THIS transcript that stays inside the library (sum-check: the round
+        polynomial under ``absorb``, the challenge under ``squeeze``; inner-product argument: L under ``absorb``, R under ``absorb2``)."""
+        return _lib.KeccakRounds(self._h, self._FIELD[modulus], absorb, squeeze, absorb2=absorb2, curve=self._curve, cap=cap)
+
     def squeeze(self, label: bytes, modulus: int) -> int:
         out = np.zeros(4, dtype=np.uint64)
         _lib.check(_lib.load().lurk_hip_keccak_transcript_squeeze(self._h, label, len(label), self._FIELD[modulus], _lib.ptr(out)))
@@ -120,7 +125,7 @@ class SpartanProver:
         N = max(nc, nv)
         ell = N.bit_length() - 1
         curve_name = b"pallas" if self.curve == 0 else b"vesta"
-        tr = Transcript(curve_name)
+        tr = Transcript(curve_name, self.curve)
         tr.absorb_point(b"comm_W", point_to_affine(self.curve, comm_W_jac))
         tr.absorb_point(b"comm_E", point_to_affine(self.curve, comm_E_jac))
         tr.absorb_scalars(b"uX", [u] + list(X))
@@ -132,12 +137,10 @@ class SpartanProver:
         d_tau = sumcheck.eq_evals(sf, self._mont(tau))
         d_ucze = fold_vec(sf, d_E, d_cz, self._mont([u]))  # E + u Cz
 
-        def chal(j, poly):
-            tr.absorb_scalars(b"p", poly)
-            return tr.squeeze(b"c", q)
-
-        r_x = []
-        polys_outer, finals, _ = sumcheck.prove(sf, q, 0, [d_tau, d_az.clone(), d_bz.clone(), d_ucze], lambda j, poly: r_x.append(chal(j, poly)) or r_x[-1])
+        # the rounds' transcript work (absorb the round polynomial under "p", squeeze the challenge under "c") happens inside the library
+        rounds_outer = tr.rounds(q, b"p", b"c")
+        polys_outer, finals, _ = sumcheck.prove(sf, q, 0, [d_tau, d_az.clone(), d_bz.clone(), d_ucze], rounds_outer)
+        r_x = rounds_outer.challenges()
         claim_Az, claim_Bz = finals[1], finals[2]
         claim_Cz, eval_E = self._mle(d_cz, r_x), self._mle(d_E, r_x)
         tr.absorb_scalars(b"claims_outer", [claim_Az, claim_Bz, claim_Cz, eval_E])
@@ -146,8 +149,9 @@ class SpartanProver:
         d_eq_rx = sumcheck.eq_evals(sf, self._mont(r_x))
         d_ea, d_eb, d_ec = self.shape_t.multiply_vec(d_eq_rx)
         d_abc = fold_vec(sf, fold_vec(sf, d_ea, d_eb, self._mont([r])), d_ec, self._mont([r * r % q]))
-        r_y = []
-        polys_inner, _, _ = sumcheck.prove(sf, q, claim_inner, [d_abc, d_z.clone()], lambda j, poly: r_y.append(chal(j, poly)) or r_y[-1])
+        rounds_inner = tr.rounds(q, b"p", b"c")
+        polys_inner, _, _ = sumcheck.prove(sf, q, claim_inner, [d_abc, d_z.clone()], rounds_inner)
+        r_y = rounds_inner.challenges()
         eval_W = self._mle(d_W, r_y[1:])
         tr.absorb_scalars(b"eval_W", [eval_W])
         # ---- the two evaluation claims -> one point
@@ -159,17 +163,14 @@ class SpartanProver:
         x2 = [0] * (ell - ell_x) + r_x
         rho = tr.squeeze(b"rho", q)
         pairs = [(sumcheck.eq_evals(sf, self._mont(x1)), d_p1.clone()), (sumcheck.eq_evals(sf, self._mont(x2)), d_p2.clone())]
-        polys_batch, r_z, fin, _ = sumcheck.prove_quad_batch(sf, q, [eval_W, eval_E], pairs, [1, rho], lambda poly: chal(0, poly))
+        polys_batch, r_z, fin, _ = sumcheck.prove_quad_batch(sf, q, [eval_W, eval_E], pairs, [1, rho], tr.rounds(q, b"p", b"c"))
         evals_batch = [fin[0][1], fin[1][1]]
         tr.absorb_scalars(b"evals_batch", evals_batch)
         gamma = tr.squeeze(b"gamma", q)
         d_joint = fold_vec(sf, d_p1, d_p2, self._mont([gamma]))
         r0 = tr.squeeze(b"ipa_r0", q)
 
-        def ipa_chal(j, L, Rr):
-            tr.absorb_point(b"L", point_to_affine(self.curve, L))
-            tr.absorb_point(b"R", point_to_affine(self.curve, Rr))
-            return tr.squeeze(b"r", q)
+        ipa_chal = tr.rounds(q, b"L", b"r", absorb2=b"R")  # L, R absorbed as affine points, r squeezed: inside the library's round loop
 
         ck_c = d_ck[N].cpu().numpy().view(np.uint64).reshape(8)
         bf = 0 if self.curve == 0 else 1
@@ -215,7 +216,7 @@ class BatchedSpartanProver:
         ell_y = max(p.num_vars for p in self.provers).bit_length()
         N = max(max(p.num_cons, p.num_vars) for p in self.provers)
         ell = N.bit_length() - 1
-        tr = Transcript((b"pallas" if self.curve == 0 else b"vesta") + b"/batched")
+        tr = Transcript((b"pallas" if self.curve == 0 else b"vesta") + b"/batched", self.curve)
         tr.absorb_scalars(b"n", [n])
         aff0 = lambda J: (lambda xy: None if xy == (0, 0) else xy)(point_to_affine(self.curve, J))  # the proof's point form: None = the identity
         absorb_pt = lambda label, J: tr.absorb_point(label, point_to_affine(self.curve, J))          # the transcript's: (0, 0) = the identity
@@ -239,11 +240,9 @@ class BatchedSpartanProver:
             czs.append(d_cz)
             quads.append((d_tau.clone(), pad(d_az, 1 << ell_x), pad(d_bz, 1 << ell_x), pad(d_ucze, 1 << ell_x)))
 
-        def chal(poly):
-            tr.absorb_scalars(b"p", poly)
-            return tr.squeeze(b"c", q)
+        chal = lambda: tr.rounds(q, b"p", b"c")  # every round's absorb / squeeze inside the library's loop
 
-        polys_outer, r_x, fin, _ = sumcheck.prove_cubic_batch(sf, q, quads, [pow(rho_o, i, q) for i in range(n)], chal)
+        polys_outer, r_x, fin, _ = sumcheck.prove_cubic_batch(sf, q, quads, [pow(rho_o, i, q) for i in range(n)], chal())
         d_eq_rx = sumcheck.eq_evals(sf, mont(r_x))
         claims_outer, evals_E = [], []
         for p, it, f4, d_cz in zip(self.provers, instances, fin, czs):
@@ -260,7 +259,7 @@ class BatchedSpartanProver:
             d_abc = fold_vec(sf, fold_vec(sf, d_ea, d_eb, mont([r])), d_ec, mont([r * r % q]))
             pairs.append((pad(d_abc, 1 << ell_y), pad(d_z, 1 << ell_y)))
             claims_inner.append((cl[0] + r * cl[1] + r * r * cl[2]) % q)
-        polys_inner, r_y, _, _ = sumcheck.prove_quad_batch(sf, q, claims_inner, pairs, [pow(rho_i, i, q) for i in range(n)], chal)
+        polys_inner, r_y, _, _ = sumcheck.prove_quad_batch(sf, q, claims_inner, pairs, [pow(rho_i, i, q) for i in range(n)], chal())
         evals_W = []
         for p, it in zip(self.provers, instances):
             py = ell_y - p.num_vars.bit_length()
@@ -275,7 +274,7 @@ class BatchedSpartanProver:
             claims += [eW, eE]
         rho = tr.squeeze(b"rho", q)
         bp = [(sumcheck.eq_evals(sf, mont(x)), pl.clone()) for x, pl in zip(points, polys)]
-        polys_batch, r_z, finb, _ = sumcheck.prove_quad_batch(sf, q, claims, bp, [pow(rho, k, q) for k in range(2 * n)], chal)
+        polys_batch, r_z, finb, _ = sumcheck.prove_quad_batch(sf, q, claims, bp, [pow(rho, k, q) for k in range(2 * n)], chal())
         evals_batch = [fb[1] for fb in finb]
         tr.absorb_scalars(b"evals_batch", evals_batch)
         gamma = tr.squeeze(b"gamma", q)
@@ -284,10 +283,7 @@ class BatchedSpartanProver:
             d_joint = fold_vec(sf, d_joint, polys[k], mont([pow(gamma, k, q)]))
         r0 = tr.squeeze(b"ipa_r0", q)
 
-        def ipa_chal(j, L, Rr):
-            absorb_pt(b"L", L)
-            absorb_pt(b"R", Rr)
-            return tr.squeeze(b"r", q)
+        ipa_chal = tr.rounds(q, b"L", b"r", absorb2=b"R")
 
         ck_c = d_ck[N].cpu().numpy().view(np.uint64).reshape(8)
         ck_c_jac = np.concatenate([ck_c, _mont_one(0 if self.curve == 0 else 1)])

@@ -37,7 +37,8 @@ def eq_evals(field_id: int, r_mont: np.ndarray, stream=None):
 
 def prove(field_id: int, modulus: int, claim: int, tables, challenge, stream=None):
     """tables: 4 device tensors (A, B, C, D: comb = A (B C - D)) or 2 (A, B: comb = A B), Montgomery, length 2^k; they are
-    consumed (bound in place).  challenge(round, poly_coeffs) -> r (int); all integers here are canonical.  The round loop is host
+    consumed (bound in place).  challenge(round, poly_coeffs) -> r (int), or a ``_lib.KeccakRounds`` (the library's own transcript: its
+    ``challenges()`` then holds the r's); all integers here are canonical.  The round loop is host
     code of the library (lurk_hip_sumcheck_prove_dev: what a Rust caller binds), the transcript calls back into ``challenge``.
     Returns (round polynomials, final evaluations P_k(r), final claim) like the oracle's sumcheck_prove."""
     import torch
@@ -66,8 +67,13 @@ def prove(field_id: int, modulus: int, claim: int, tables, challenge, stream=Non
             failure.append(e)
             return 1
 
-    cb = _lib.SUMCHECK_CHALLENGE_FN(on_round)
-    rc = lib.lurk_hip_sumcheck_prove_dev(field_id, 3 if cubic else 2, ptrs, n, _lib.ptr(_limbs([claim % p])), ctypes.cast(cb, ctypes.c_void_p), None,
+    if isinstance(challenge, _lib.KeccakRounds):  # the transcript is the library's own: no Python in the round loop
+        challenge.struct.n_scalars = ncoef
+        cb_ptr, user = challenge.callback("sumcheck")
+    else:
+        cb = _lib.SUMCHECK_CHALLENGE_FN(on_round)
+        cb_ptr, user = ctypes.cast(cb, ctypes.c_void_p), None
+    rc = lib.lurk_hip_sumcheck_prove_dev(field_id, 3 if cubic else 2, ptrs, n, _lib.ptr(_limbs([claim % p])), cb_ptr, user,
                                          _lib.ptr(out_polys), _lib.ptr(out_finals), _lib.ptr(out_claim), _lib.ptr(s))
     if failure:
         raise failure[0]
@@ -104,12 +110,20 @@ def _prove_batch(field_id: int, modulus: int, degree: int, groups, coeffs, claim
             failure.append(e)
             return 1
 
-    cb = _lib.SUMCHECK_CHALLENGE_FN(on_round)
+    if isinstance(challenge, _lib.KeccakRounds):
+        challenge.struct.n_scalars = ncoef
+        first = int(challenge.struct.n_rounds)
+        cb_ptr, user = challenge.callback("sumcheck")
+    else:
+        cb = _lib.SUMCHECK_CHALLENGE_FN(on_round)
+        cb_ptr, user = ctypes.cast(cb, ctypes.c_void_p), None
     rc = lib.lurk_hip_sumcheck_prove_batch_dev(field_id, degree, len(groups), ptrs, n, _lib.ptr(_limbs([c % p for c in coeffs])), _lib.ptr(_limbs([claim % p])),
-                                               ctypes.cast(cb, ctypes.c_void_p), None, _lib.ptr(out_polys), _lib.ptr(out_finals), _lib.ptr(out_claim), _lib.ptr(s))
+                                               cb_ptr, user, _lib.ptr(out_polys), _lib.ptr(out_finals), _lib.ptr(out_claim), _lib.ptr(s))
     if failure:
         raise failure[0]
     _lib.check(rc)
+    if isinstance(challenge, _lib.KeccakRounds):
+        rs = challenge.challenges()[first:]
     fin = _ints(out_finals)
     return [_ints(out_polys[j]) for j in range(rounds)], rs, [tuple(fin[i * np_t:(i + 1) * np_t]) for i in range(len(groups))], _ints(out_claim)[0]
 

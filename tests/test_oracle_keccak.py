@@ -85,6 +85,49 @@ def test_library_transcript_equals_the_oracles():
         assert t_lib.squeeze(b"end", q) == t_orc.squeeze(b"end", q)
 
 
+def test_round_bindings_equal_the_oracles_rounds():
+    """lurk_hip_keccak_sumcheck_challenge / lurk_hip_keccak_ipa_challenge (the `challenge` arguments that keep a proof's rounds inside
+    the library): round by round the oracle's transcript, absorbing the same coefficients / points under the same labels, squeezes the
+    same challenges; the binding keeps them in order and refuses to overrun its buffer."""
+    from lurk_beta_amd import _lib
+    from lurk_beta_amd.spartan import Transcript
+
+    lib = _lib.load()
+    for curve, f in ((0, 1), (1, 0)):
+        q = R.modulus(f)
+        t_lib = Transcript(b"rounds", curve)
+        t_orc = K.KeccakTranscript(b"lurk-hip spartan v2" + b"rounds")
+        sc = t_lib.rounds(q, b"p", b"c", cap=5)
+        sc.struct.n_scalars = 4
+        fn_ptr, user = sc.callback("sumcheck")
+        want = []
+        for j in range(5):
+            coeffs = C.limbs_to_ints(C.synth_scalars(f, 400 + j, 0, 4))
+            arr = C.ints_to_limbs(coeffs)
+            out = np.zeros(4, dtype=np.uint64)
+            _lib.check(lib.lurk_hip_keccak_sumcheck_challenge(user, j, _lib.ptr(arr), _lib.ptr(out)))
+            t_orc.absorb_scalars(b"p", coeffs)
+            want.append(t_orc.squeeze(b"c", q))
+            assert C.limbs_to_ints(out.reshape(1, 4))[0] == want[-1]
+        assert sc.challenges() == want
+        arr, out = C.ints_to_limbs([1, 2, 3, 4]), np.zeros(4, dtype=np.uint64)
+        assert lib.lurk_hip_keccak_sumcheck_challenge(user, 5, _lib.ptr(arr), _lib.ptr(out)) != 0  # a sixth challenge does not fit
+        ip = t_lib.rounds(q, b"L", b"r", absorb2=b"R", cap=4)
+        t_orc2 = K.KeccakTranscript(b"lurk-hip spartan v2" + b"rounds2")
+        t_lib2 = Transcript(b"rounds2", curve)
+        ip = t_lib2.rounds(q, b"L", b"r", absorb2=b"R", cap=4)
+        pts = [C.gen_mul(curve, 7), C.gen_mul(curve, 0), C.gen_mul(curve, 99), C.gen_mul(curve, 3)]
+        got, want = [], []
+        for j in range(3):
+            L, Rr = pts[j], pts[j + 1]
+            got.append(ip.ipa_round(j, L, Rr))
+            t_orc2.absorb_point(b"L", C.jac_to_affine(curve, L))
+            t_orc2.absorb_point(b"R", C.jac_to_affine(curve, Rr))
+            want.append(t_orc2.squeeze(b"r", q))
+        assert got == want == ip.challenges()
+        assert fn_ptr and user
+
+
 def test_from_uniform_reduction_edges():
     """Scalar::from_uniform on the extremes of the 512-bit range (through the squeeze's reduction, fed directly)."""
     from lurk_beta_amd import _lib
