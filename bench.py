@@ -83,7 +83,7 @@ def main():
                          "ahead in turn (lurk_hip_fold_ctx_add_helper: staging ahead across GPUs); e.g. 1,2,3 on a node, 0 on a one-GPU box (functional)")
     ap.add_argument("--sub-records", choices=["auto", "off"], default="auto",
                     help="auto = the default msm line at N = 1 also carries the other workloads of the path as verified sub-records "
-                         "(fold_step_rc100, poseidon_tree_2_24, ntt_2_24: each a child run of this file with --verify, same --steps / --warmup)")
+                         "(fold_step_rc100, poseidon_tree_2_24, ntt_2_24, compress_2_20: each a child run of this file with --verify, same --steps / --warmup)")
     args = ap.parse_args()
 
     # N > 1 without a launcher: become the launcher (one rank per GPU, the same command line the driver uses)
@@ -931,7 +931,8 @@ def spawn_ranks(args):
 def sub_records(args):
     """The default line's sub-records: child runs of this file (a fresh process each: its own HIP context, nothing shared with the
     timed region above), each with --verify, so that the driver's one command witnesses the folding step (BASELINE.json's first
-    metric, through its synthetic stand-in), the 2^24 Poseidon tree (configs[2]) and the 2^24 NTT with their parity checks."""
+    metric, through its synthetic stand-in), the 2^24 Poseidon tree (configs[2]), the 2^24 NTT and the compressing proof (f3) with
+    their parity checks."""
     import subprocess
 
     common = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--sub-records", "off", "--pmc", "off", "--verify"]
@@ -939,6 +940,7 @@ def sub_records(args):
         "fold_step_rc100": ["--workload", "fold_step", "--rc", "100"],
         "poseidon_tree_2_24": ["--workload", "poseidon_tree", "--log-n", "24"],
         "ntt_2_24": ["--workload", "ntt", "--log-n", "24"],
+        "compress_2_20": ["--workload", "compress", "--log-n", "20"],  # the compressing proof of a 2^20 x 2^20 instance; --verify = the oracle's verifier
     }
     if args.no_cpu_baseline:
         common.append("--no-cpu-baseline")
