@@ -165,6 +165,10 @@ class CommitmentKey {
         return xy;
     }
 
+    // the key folded by the weights of k inner-product rounds at once: n / weights.size() affine points into device memory (window-table keys)
+    void fold_key(size_t n, const std::vector<Fe>& weights_mont, void* d_out_affine64, void* stream = nullptr) const {
+        check(lurk_hip_msm_ctx_fold_key_dev(ctx_, n, weights_mont.data(), weights_mont.size(), d_out_affine64, stream));
+    }
     lurk_hip_msm_ctx* handle() const { return ctx_; }
 
   private:

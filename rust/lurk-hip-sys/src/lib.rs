@@ -92,6 +92,15 @@ pub mod pasta_msm {
                     check(unsafe { lurk_hip_msm_ctx_wait(self.0, slot, (&mut out as *mut $m::Point).cast()) })?;
                     Ok(out)
                 }
+                /// The key folded by the weights of k inner-product rounds at once (`ck_k[p] = sum_b w_b * ck[b m + p]`, arecibo `ipa_pc`):
+                /// `weights` are Montgomery scalars (a power of two of them, at most 2^12), the `n / weights.len()` affine points land in
+                /// device memory.  Window-table keys only; `lurk_hip_ipa_prove_dev` calls this by itself.
+                ///
+                /// # Safety
+                /// `d_out` must point to `n / weights.len()` 64-byte records of device memory.
+                pub unsafe fn fold_key(&self, n: usize, weights: &[$m::Scalar], d_out: *mut c_void, stream: *mut c_void) -> Result<(), Error> {
+                    check(lurk_hip_msm_ctx_fold_key_dev(self.0, n, weights.as_ptr().cast(), weights.len(), d_out, stream))
+                }
                 pub fn as_ptr(&self) -> *mut lurk_hip_msm_ctx {
                     self.0
                 }
