@@ -47,6 +47,7 @@ def main():
                     help="commitments in flight (1 = synchronous; 2..3 = async slots: the tail of one overlaps the accumulation of the next)")
     ap.add_argument("--stage-ahead", type=int, default=0,
                     help="fold_step: 1 = the next step's witness is traced and its commitment started one step ahead (lurk_hip_fold_step_prefetch); "
+                         "2 = the same from inside begin (the submit hook calls prefetch: the staged commitment runs in the background class beside commit(T)); "
                          "0 = plain begin (default: measured 4.4 ms against 4.05 ms staged whole / 5.1 ms staged with late ranges at rc = 100, DESIGN.md)")
     ap.add_argument("--witness-ahead", type=int, default=3,
                     help="fold_step: the witness of step k+1 is traced while step k is in progress (the reference's producer thread): 3 = enqueued from the step's submit hook "
@@ -460,9 +461,10 @@ def fold_step_workload(args, lib, world, rank):
     def step():
         t_a = time.perf_counter()
         if args.stage_ahead:
-            stage()                                                                   # the next step's, under this step's work
+            if args.stage_ahead == 1:
+                stage()                                                               # the next step's, under this step's work
             t_b = time.perf_counter()
-            cw, ct = ctx.begin_prefetched(x2, patches)                               # late ranges + cross term + commit(T)
+            cw, ct = ctx.begin_prefetched(x2, patches)                               # late ranges + cross term + commit(T) (2: + stage() from the submit hook)
         elif args.witness_ahead:
             # the witness of step k+1 is produced while step k folds (lurk-beta's producer thread, nova.rs:304-326); this step's W2 was
             # produced a step ago.  --witness-ahead 1: its trace kernels are enqueued BEFORE this step's commitments and run beside
@@ -495,6 +497,8 @@ def fold_step_workload(args, lib, world, rank):
 
     if args.stage_ahead:
         stage()
+        if args.stage_ahead == 2:  # the next instance is traced, staged and its commitment started from inside begin (the submit hook)
+            ctx.set_submit_hook(stage)
     elif args.witness_ahead:
         wstreams = [torch.cuda.Stream(), torch.cuda.Stream()]  # witness k is produced on stream k & 1, into buffer k & 1
         hook_k = [0]
@@ -520,7 +524,7 @@ def fold_step_workload(args, lib, world, rank):
     elapsed = time.perf_counter() - t0
     gc.enable()
     lib.lurk_hip_profile_enable(0)
-    if not args.stage_ahead and args.witness_ahead == 3:
+    if args.stage_ahead == 2 or (not args.stage_ahead and args.witness_ahead == 3):
         ctx.set_submit_hook(None)
     if args.stage_ahead:  # drain the instance staged by the last timed step (one was staged before the region: K stagings inside it)
         ctx.begin_prefetched(x2, patches)
@@ -553,7 +557,7 @@ def fold_step_workload(args, lib, world, rank):
             "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if devices else "weak", "vs_baseline": None,
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
-            "config": {"staged_ahead": bool(args.stage_ahead), "witness_ahead": 0 if args.stage_ahead else args.witness_ahead,
+            "config": {"staged_ahead": args.stage_ahead, "witness_ahead": 0 if args.stage_ahead else args.witness_ahead,
                        "devices": devices, "distinct_devices": len(set(devices)) if devices else 1,
                        "helper_devices": args.helper_devices or None,
                        "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "

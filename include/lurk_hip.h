@@ -410,7 +410,9 @@ int lurk_hip_fold_step_challenge(lurk_hip_fold_ctx* ctx, void* r32_mont);
  * commitments.  Work enqueued from the hook queues behind the step's opening kernels and fills what the commitments leave (their
  * sorts and bucket reductions); enqueued before begin it would run first and hold the cross term back, enqueued after begin has
  * returned it runs alone: 3.50-3.59 ms per step at rc = 100 against 4.22 and 3.85 (profiles/r04_step_witness_placement.txt).
- * The hook must not call into this context; a non-zero return fails the begin (the step is rolled back).  NULL removes it. */
+ * Of this context's own functions the hook may call lurk_hip_fold_step_prefetch only (the next instance is then staged AND its
+ * commitment started in the background class, beside the open step's commit(T)); a non-zero return fails the begin (the step is rolled
+ * back).  NULL removes it. */
 typedef int (*lurk_hip_fold_submit_hook_fn)(void* user);
 int lurk_hip_fold_ctx_set_submit_hook(lurk_hip_fold_ctx* ctx, lurk_hip_fold_submit_hook_fn hook, void* user);
 /* the running pair where it lives (valid until the next finish) and the stream its updates are ordered on */

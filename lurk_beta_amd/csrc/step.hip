@@ -82,6 +82,12 @@ struct lurk_hip_fold_ctx {
     bool has_pp = false;
     uint8_t pp_digest[32] = {0};
     NifsPre* pre = nullptr;
+    // The late ranges' own key: the key's points at the late positions as a separate (small-commitment form) context, built the first
+    // time a begin brings late ranges and kept while their layout stays the same: their commitment is then one launch over ~10^4 scalars
+    // instead of a pass of the bucket pipeline over a num_vars-long vector that is zero everywhere else.
+    lurk_hip_msm_ctx* late_key = nullptr;
+    std::vector<std::pair<size_t, size_t>> late_layout;
+    DevBuf late_vals;
     lurk_hip_fold_submit_hook_fn submit_hook = nullptr;  // lurk_hip_fold_ctx_set_submit_hook
     void* submit_hook_user = nullptr;
     std::vector<std::unique_ptr<Helper>> helpers;
@@ -112,7 +118,8 @@ struct lurk_hip_fold_ctx {
     hipEvent_t patch_ev = nullptr;     // the late-range buffer is shared by all steps: zeroed behind step k, written by step k + 1 on the other stream
     bool patch_ev_valid = false;
     hipEvent_t w2_ready = nullptr, staged_ev[2] = {nullptr, nullptr}, folded_ev[2] = {nullptr, nullptr};
-    std::mutex mu;
+    std::recursive_mutex mu;           // recursive: the submit hook runs inside begin and may stage the next instance (lurk_hip_fold_step_prefetch)
+    bool in_hook = false;
     ~lurk_hip_fold_ctx() {
         if (pre) nifs_pre_free(pre);
         if (pin) (void)hipHostFree(pin);
@@ -216,7 +223,7 @@ static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size
     LURK_REQUIRE(c->n_staged < 2, "two fresh instances are already staged: begin a step first");
     // two z2 buffers: while a step is open its instance occupies one of them until finish(r) has folded it, so only ONE more
     // can be staged (the next buffer in turn would be the open step's own)
-    LURK_REQUIRE(!(c->begun && c->n_staged >= 1), "a step is open and the other buffer is already staged: finish the step first");
+    LURK_REQUIRE(!((c->begun || c->in_hook) && c->n_staged >= 1), "a step is open and the other buffer is already staged: finish the step first");
     LURK_REQUIRE(offset <= c->num_vars && count <= c->num_vars - offset, "witness range out of bounds");
     LURK_REQUIRE(count == 0 || w2, "null witness");
     const int b = c->next_buf;
@@ -246,11 +253,46 @@ static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size
     // Between begin and finish nothing the host waits for is in flight: the commitment starts now, in the background class.
     // Otherwise it is submitted by the begin that comes next, BEHIND that step's commit(T): the device serves its queues
     // roughly in submission order, and T is what the host waits for.
-    if (c->begun) fold_submit_staged(c, b, LURK_MSM_SUBMIT_BACKGROUND);
+    if (c->begun || c->in_hook) fold_submit_staged(c, b, LURK_MSM_SUBMIT_BACKGROUND);
+}
+
+constexpr size_t FOLD_LATE_KEY_MAX = (size_t)1 << 16;  // late positions a key of their own is built for (the small-commitment form's limit)
+
+// true: c->late_key commits exactly the positions of these patches, in their order
+static bool fold_late_key(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, size_t n_patches, size_t patched, hipStream_t s) {
+    if (!c->key || patched == 0 || patched > FOLD_LATE_KEY_MAX) return false;
+    const char* sw = getenv("LURK_FOLD_LATE_KEY");  // 0: late ranges through the key's slot 3 as a num_vars-long vector (the form above 2^16 late positions)
+    if (sw && atoi(sw) == 0) return false;
+    std::vector<std::pair<size_t, size_t>> layout;
+    for (size_t k = 0; k < n_patches; k++)
+        if (patches[k].count) layout.emplace_back(patches[k].offset, patches[k].count);
+    if (c->late_key && layout == c->late_layout) return true;
+    if (c->late_key) {
+        (void)lurk_hip_msm_ctx_destroy(c->late_key);
+        c->late_key = nullptr;
+    }
+    const MsmTableView v = msm_ctx_table_view(c->key);  // the first npoints records of every form are the points themselves
+    DevBuf pts(patched * 64);
+    size_t at = 0;
+    for (auto& r : layout) {
+        LURK_REQUIRE(r.first + r.second <= v.npoints, "late range beyond the key");
+        LURK_HIP_CHECK(hipMemcpyAsync((char*)pts.p + at * 64, (const char*)v.table + r.first * 64, r.second * 64, hipMemcpyDeviceToDevice, s));
+        at += r.second;
+    }
+    LURK_HIP_CHECK(hipStreamSynchronize(s));
+    ok(lurk_hip_msm_ctx_create_dev(&c->late_key, c->curve, pts.p, patched, LURK_MSM_FLAG_PRECOMPUTE, (void*)s));
+    c->late_layout = layout;
+    return true;
 }
 
 static void fold_run_submit_hook(lurk_hip_fold_ctx* c) {
-    if (c->submit_hook) LURK_REQUIRE(c->submit_hook(c->submit_hook_user) == 0, "the submit hook failed");
+    if (!c->submit_hook) return;
+    struct InHook {
+        lurk_hip_fold_ctx* c;
+        ~InHook() { c->in_hook = false; }
+    } guard{c};
+    c->in_hook = true;  // lurk_hip_fold_step_prefetch from inside the hook stages AND submits: the open step's commitments are in flight
+    LURK_REQUIRE(c->submit_hook(c->submit_hook_user) == 0, "the submit hook failed");
 }
 
 // The oldest staged instance becomes this step's: late ranges, u2 = 1, X2, then T and its commitment.
@@ -282,13 +324,13 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
         int b;
         const lurk_hip_w2_patch* patches;
         size_t n_patches;
-        bool armed = true, t_in_flight = false, late_in_flight = false, patch_written = false;
+        bool armed = true, t_in_flight = false, late_in_flight = false, patch_written = false, late_own_key = false;
         ~Rollback() {
             if (!armed) return;
             uint64_t junk[12];
             if (c->submitted[b]) (void)lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, junk);
             if (t_in_flight) (void)lurk_hip_msm_ctx_wait(c->key, 1, junk);
-            if (late_in_flight) (void)lurk_hip_msm_ctx_wait(c->key, 3, junk);
+            if (late_in_flight) (void)(late_own_key ? lurk_hip_msm_ctx_wait(c->late_key, 0, junk) : lurk_hip_msm_ctx_wait(c->key, 3, junk));
             c->submitted[b] = false;
             if (patch_written && c->zpatch.p)
                 for (size_t k = 0; k < n_patches; k++)
@@ -315,21 +357,30 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     else mont_one<PallasFp>(c->pin);
     if (c->num_io) memcpy(c->pin + 32, x2_mont, c->num_io * 32);
     LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, (1 + c->num_io) * 32, hipMemcpyHostToDevice, c->stage_stream[b]));
+    const bool late_own_key = patched && fold_late_key(c, patches, n_patches, patched, c->stage_stream[b]);
+    rollback.late_own_key = late_own_key;
     if (patched) {
-        if (c->patch_ev_valid) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream[b], c->patch_ev, 0));  // the previous step's zeroing
-        if (!c->zpatch.p) {
-            c->zpatch.alloc(c->num_vars * 32);
-            LURK_HIP_CHECK(hipMemsetAsync(c->zpatch.p, 0, c->num_vars * 32, c->stage_stream[b]));
-        }
         char* src = c->pin + (1 + c->num_io) * 32;
-        rollback.patch_written = true;
+        if (late_own_key) {  // the late values, contiguous in patch order: what the late ranges' own key commits
+            c->late_vals.ensure(patched * 32);
+        } else {
+            if (c->patch_ev_valid) LURK_HIP_CHECK(hipStreamWaitEvent(c->stage_stream[b], c->patch_ev, 0));  // the previous step's zeroing
+            if (!c->zpatch.p) {
+                c->zpatch.alloc(c->num_vars * 32);
+                LURK_HIP_CHECK(hipMemsetAsync(c->zpatch.p, 0, c->num_vars * 32, c->stage_stream[b]));
+            }
+            rollback.patch_written = true;
+        }
         for (size_t k = 0; k < n_patches; k++) {
             if (!patches[k].count) continue;
             memcpy(src, patches[k].values, patches[k].count * 32);
             LURK_HIP_CHECK(hipMemcpyAsync(z2 + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream[b]));
-            LURK_HIP_CHECK(hipMemcpyAsync((char*)c->zpatch.p + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream[b]));
+            if (!late_own_key)
+                LURK_HIP_CHECK(hipMemcpyAsync((char*)c->zpatch.p + patches[k].offset * 32, src, patches[k].count * 32, hipMemcpyHostToDevice, c->stage_stream[b]));
             src += patches[k].count * 32;
         }
+        if (late_own_key)
+            LURK_HIP_CHECK(hipMemcpyAsync(c->late_vals.p, c->pin + (1 + c->num_io) * 32, patched * 32, hipMemcpyHostToDevice, c->stage_stream[b]));
     }
     LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream[b]));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
@@ -344,8 +395,9 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     tt[1] = now();
     ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t.p, c->num_cons, 1, c->stream, fg));     // ... commit(T): what the host waits for
     rollback.t_in_flight = true;
-    if (patched) {
-        ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream[b], fg));  // commitment of the late ranges
+    if (patched) {  // commitment of the late ranges: under their own key, or as a num_vars-long vector that is zero elsewhere
+        if (late_own_key) ok(lurk_hip_msm_ctx_submit_dev_mode(c->late_key, 0, c->late_vals.p, patched, 1, c->stage_stream[b], fg));
+        else ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 3, c->zpatch.p, c->num_vars, 1, c->stage_stream[b], fg));
         rollback.late_in_flight = true;
     }
     tt[2] = now();
@@ -358,15 +410,17 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
         c->submitted[b] = false;  // (a wait consumes the slot's commitment whether it succeeds or not)
         ok(lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, body));
         rollback.late_in_flight = false;
-        ok(lurk_hip_msm_ctx_wait(c->key, 3, late));
+        ok(late_own_key ? lurk_hip_msm_ctx_wait(c->late_key, 0, late) : lurk_hip_msm_ctx_wait(c->key, 3, late));
         uint64_t two[24];
         memcpy(two, body, 96);
         memcpy(two + 12, late, 96);
         ok(lurk_hip_point_sum(c->curve, comm_w2_jac96, two, 2));  // commit is linear: body + late ranges
-        for (size_t k = 0; k < n_patches; k++)
-            if (patches[k].count) LURK_HIP_CHECK(hipMemsetAsync((char*)c->zpatch.p + patches[k].offset * 32, 0, patches[k].count * 32, c->stage_stream[b]));
-        LURK_HIP_CHECK(hipEventRecord(c->patch_ev, c->stage_stream[b]));
-        c->patch_ev_valid = true;
+        if (!late_own_key) {
+            for (size_t k = 0; k < n_patches; k++)
+                if (patches[k].count) LURK_HIP_CHECK(hipMemsetAsync((char*)c->zpatch.p + patches[k].offset * 32, 0, patches[k].count * 32, c->stage_stream[b]));
+            LURK_HIP_CHECK(hipEventRecord(c->patch_ev, c->stage_stream[b]));
+            c->patch_ev_valid = true;
+        }
     } else {
         c->submitted[b] = false;
         ok(lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, comm_w2_jac96));
@@ -585,7 +639,7 @@ int lurk_hip_fold_ctx_create_multi(lurk_hip_fold_ctx** out, int curve, lurk_hip_
 int lurk_hip_fold_ctx_add_helper(lurk_hip_fold_ctx* c, lurk_hip_msm_ctx* helper_key) {
     return guarded([&] {
         LURK_REQUIRE(c && helper_key, "null argument");
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_REQUIRE(!c->mkey, "helper keys belong to a context over a single-device key");
         LURK_REQUIRE(!c->begun && c->n_staged == 0, "add helper keys before the first step");
         int curve = 0, device = 0;
@@ -612,6 +666,7 @@ int lurk_hip_fold_ctx_destroy(lurk_hip_fold_ctx* c) {
     if (!c) return 0;
     return guarded([&] {
         DeviceGuard dg(c->device);
+        if (c->late_key) (void)lurk_hip_msm_ctx_destroy(c->late_key);
         delete c;
     });
 }
@@ -621,7 +676,7 @@ int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* c, const void* z1, const vo
     return guarded([&] {
         LURK_REQUIRE(c && z1 && e1, "null argument");
         DeviceGuard dg(c->device);
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_REQUIRE(!c->begun, "a step is open: finish it first");
         LURK_HIP_CHECK(hipMemcpyAsync(c->z[c->cur].p, z1, c->ncols * 32, hipMemcpyHostToDevice, c->stream));
         LURK_HIP_CHECK(hipMemcpyAsync(c->e[c->cur].p, e1, c->num_cons * 32, hipMemcpyHostToDevice, c->stream));
@@ -635,7 +690,7 @@ int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* c, const void* z1, const vo
 int lurk_hip_fold_ctx_set_instance(lurk_hip_fold_ctx* c, const void* comm_w_jac96, const void* comm_e_jac96) {
     return guarded([&] {
         LURK_REQUIRE(c && comm_w_jac96 && comm_e_jac96, "null argument");
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_REQUIRE(!c->begun, "a step is open: finish it first");
         fold_instance_settle(c);  // u and X of the last step first: only the commitments are replaced
         memcpy(c->comm_w, comm_w_jac96, 96);
@@ -646,7 +701,7 @@ int lurk_hip_fold_ctx_set_instance(lurk_hip_fold_ctx* c, const void* comm_w_jac9
 int lurk_hip_fold_ctx_instance(lurk_hip_fold_ctx* c, void* comm_w_jac96, void* comm_e_jac96, void* u32_mont, void* x_mont) {
     return guarded([&] {
         LURK_REQUIRE(c, "null ctx");
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         fold_instance_settle(c);
         if (comm_w_jac96) memcpy(comm_w_jac96, c->comm_w, 96);
         if (comm_e_jac96) memcpy(comm_e_jac96, c->comm_e, 96);
@@ -663,8 +718,8 @@ int lurk_hip_fold_step(lurk_hip_fold_ctx* c, const void* w2, int w2_on_device, v
         LURK_REQUIRE(c->num_vars == 0 || w2, "null witness");
         LURK_REQUIRE(c->num_io == 0 || x2_mont, "null public IO");
         DeviceGuard dg(c->device);
-        std::lock_guard<std::mutex> lk(c->mu);
-        LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        LURK_REQUIRE(!c->begun && !c->in_hook, "a step is already open: finish it first");
         LURK_REQUIRE(c->n_staged == 0, "fresh instances are staged: use lurk_hip_fold_step_begin_prefetched");
         uint64_t cw[12], ct[12], r[4];
         memcpy(c->pp_digest, pp_digest32, 32);
@@ -689,8 +744,8 @@ int lurk_hip_fold_step_begin(lurk_hip_fold_ctx* c, const void* w2, int w2_on_dev
         LURK_REQUIRE(c->num_vars == 0 || w2, "null witness");
         LURK_REQUIRE(c->num_io == 0 || x2_mont, "null public IO");
         DeviceGuard dg(c->device);
-        std::lock_guard<std::mutex> lk(c->mu);
-        LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        LURK_REQUIRE(!c->begun && !c->in_hook, "a step is already open: finish it first");
         LURK_REQUIRE(c->n_staged == 0, "fresh instances are staged: use lurk_hip_fold_step_begin_prefetched");
         if (c->mkey) {
             fold_begin_multi(c, w2, w2_on_device, w2_stream, x2_mont, comm_w2_jac96, comm_t_jac96);
@@ -704,7 +759,7 @@ int lurk_hip_fold_step_prefetch(lurk_hip_fold_ctx* c, const void* w2_range, size
     return guarded([&] {
         LURK_REQUIRE(c, "null ctx");
         DeviceGuard dg(c->device);
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_REQUIRE(!c->mkey, "staging ahead is not available with a key cut across devices: give the context helper keys (lurk_hip_fold_ctx_add_helper)");
         fold_stage(c, w2_range, offset, count, on_device, stream, /*staged_ahead=*/true);
     });
@@ -717,8 +772,8 @@ int lurk_hip_fold_step_begin_prefetched(lurk_hip_fold_ctx* c, const lurk_hip_w2_
         LURK_REQUIRE(n_patches == 0 || patches, "null patches");
         LURK_REQUIRE(c->num_io == 0 || x2_mont, "null public IO");
         DeviceGuard dg(c->device);
-        std::lock_guard<std::mutex> lk(c->mu);
-        LURK_REQUIRE(!c->begun, "a step is already open: finish it first");
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
+        LURK_REQUIRE(!c->begun && !c->in_hook, "a step is already open: finish it first");
         fold_begin(c, patches, n_patches, x2_mont, comm_w2_jac96, comm_t_jac96);
     });
 }
@@ -726,7 +781,7 @@ int lurk_hip_fold_step_begin_prefetched(lurk_hip_fold_ctx* c, const lurk_hip_w2_
 int lurk_hip_fold_ctx_set_submit_hook(lurk_hip_fold_ctx* c, lurk_hip_fold_submit_hook_fn hook, void* user) {
     return guarded([&] {
         LURK_REQUIRE(c, "null ctx");
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         c->submit_hook = hook;
         c->submit_hook_user = user;
     });
@@ -735,7 +790,7 @@ int lurk_hip_fold_ctx_set_submit_hook(lurk_hip_fold_ctx* c, lurk_hip_fold_submit
 int lurk_hip_fold_ctx_set_pp_digest(lurk_hip_fold_ctx* c, const void* pp_digest32) {
     return guarded([&] {
         LURK_REQUIRE(c && pp_digest32, "null argument");
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         memcpy(c->pp_digest, pp_digest32, 32);
         c->has_pp = true;
         fold_challenge_drop(c);
@@ -745,7 +800,7 @@ int lurk_hip_fold_ctx_set_pp_digest(lurk_hip_fold_ctx* c, const void* pp_digest3
 int lurk_hip_fold_step_challenge(lurk_hip_fold_ctx* c, void* r32_mont) {
     return guarded([&] {
         LURK_REQUIRE(c && r32_mont, "null argument");
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         fold_challenge_finish(c, r32_mont);
     });
 }
@@ -754,7 +809,7 @@ int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
     return guarded([&] {
         LURK_REQUIRE(c && r32_mont, "null argument");
         DeviceGuard dg(c->device);
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_REQUIRE(c->begun, "no step is open");
         fold_finish(c, r32_mont);
     });
@@ -763,7 +818,7 @@ int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
 int lurk_hip_fold_ctx_running_dev(lurk_hip_fold_ctx* c, void** d_z, void** d_e, void** stream) {
     return guarded([&] {
         LURK_REQUIRE(c, "null ctx");
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         if (d_z) *d_z = c->z[c->cur].p;
         if (d_e) *d_e = c->e[c->cur].p;
         if (stream) *stream = (void*)c->stream;
@@ -774,7 +829,7 @@ int lurk_hip_fold_ctx_read(lurk_hip_fold_ctx* c, void* z_host, void* e_host) {
     return guarded([&] {
         LURK_REQUIRE(c, "null ctx");
         DeviceGuard dg(c->device);
-        std::lock_guard<std::mutex> lk(c->mu);
+        std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
         if (z_host) LURK_HIP_CHECK(hipMemcpy(z_host, c->z[c->cur].p, c->ncols * 32, hipMemcpyDeviceToHost));
         if (e_host) LURK_HIP_CHECK(hipMemcpy(e_host, c->e[c->cur].p, c->num_cons * 32, hipMemcpyDeviceToHost));

@@ -397,7 +397,8 @@ def test_staging_into_the_open_steps_buffer_is_refused(hip):
     shape.close()
 
 
-def test_begin_that_fails_midway_leaves_the_context_usable(hip):
+@pytest.mark.parametrize("late_key", [1, 0])
+def test_begin_that_fails_midway_leaves_the_context_usable(hip, late_key, monkeypatch):
     """A commitment that cannot be submitted in the middle of begin (slot 1 of the key, where commit(T) goes, is held by somebody
     else's commitment: "slot is busy") must cost nothing but the call: commit(W2), already in flight, is drained, the staged
     instance goes back to the queue, and the same begin succeeds once the slot is free - with the oracle's results - as does the
@@ -406,6 +407,7 @@ def test_begin_that_fails_midway_leaves_the_context_usable(hip):
 
     from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape, point_to_affine
 
+    monkeypatch.setenv("LURK_FOLD_LATE_KEY", str(late_key))  # 1: the late ranges under their own key; 0: through slot 3 of the key
     curve, f, m, nfree, nio = 0, 1, 6000, 2500, 2
     A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=77)
     mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
@@ -443,10 +445,26 @@ def test_begin_that_fails_midway_leaves_the_context_usable(hip):
     lo, hi = 300, nv - 200
     ctx.prefetch(w3m[lo:hi], lo)
     patches = [(0, w3m[:lo]), (hi, w3m[hi:])]
-    key.submit_device(3, other, 4096, is_mont=True)                      # slot 3: where the late ranges' commitment goes
-    with pytest.raises(LurkHipError, match="busy"):
-        ctx.begin_prefetched(x3m, patches)
-    assert point_to_affine(curve, key.wait(3)) == want_other
+    if late_key:  # the late ranges' commitment runs under a key of its own: fail the begin AFTER it was submitted (a submit hook that raises)
+        boom = [True]
+
+        def hook():
+            if boom[0]:
+                boom[0] = False
+                raise ValueError("producer failed")
+
+        ctx.set_submit_hook(hook)
+        with pytest.raises(ValueError, match="producer failed"):
+            ctx.begin_prefetched(x3m, patches)
+        ctx.set_submit_hook(None)
+        for slot in range(4):                                             # nothing of the failed begin is left in flight on the key
+            with pytest.raises(LurkHipError):
+                key.wait(slot)
+    else:
+        key.submit_device(3, other, 4096, is_mont=True)                  # slot 3: where the late ranges' commitment goes
+        with pytest.raises(LurkHipError, match="busy"):
+            ctx.begin_prefetched(x3m, patches)
+        assert point_to_affine(curve, key.wait(3)) == want_other
     cw3, ct3 = ctx.begin_prefetched(x3m, patches)
     assert point_to_affine(curve, cw3) == C.jac_to_affine(curve, C.msm_pippenger(curve, bases[:nv], z3[:nv]))
     z1 = C.axpy(f, zero, z2, r)
