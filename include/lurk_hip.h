@@ -380,7 +380,10 @@ int lurk_hip_fold_step_begin(lurk_hip_fold_ctx* ctx, const void* w2, int w2_on_d
  *                    own variables around the step circuit's: they depend on the previous step's fold), host memory,
  *                    Montgomery; commit is linear, so comm_W2 = commit(staged ranges) + commit(late ranges).
  * The context uses the key's four async slots (lurk_hip_msm_ctx_reserve(key, n, 4)): W2 commitments alternate between slots 0
- * and 2, T uses slot 1, the late ranges slot 3.  lurk_hip_fold_step_begin is prefetch(whole W2) + begin_prefetched(no patches). */
+ * and 2, T uses slot 1, the late ranges slot 3 - or, up to 2^16 late positions, a small-commitment key of their own: the key's points
+ * at those positions, built at the first begin that brings late ranges and kept while their layout stays the same (one launch per
+ * step instead of a pass over a num_vars-long vector; LURK_FOLD_LATE_KEY=0 in the environment keeps slot 3).
+ * lurk_hip_fold_step_begin is prefetch(whole W2) + begin_prefetched(no patches). */
 typedef struct lurk_hip_w2_patch {
     size_t offset, count;   /* positions [offset, offset + count) of W2 */
     const void* values;     /* count x 32 bytes, host memory */
