@@ -139,6 +139,7 @@ class Profiler {
     std::map<int, std::vector<hipEvent_t>> pool_;  // events belong to the device they were created on
     std::map<std::string, std::pair<double, uint64_t>> done_;
     hipEvent_t get_event(int device);
+    void dump_timeline();  // (mu_ held)
 };
 
 // scopes may be open on several host threads / devices at once (the multi-device MSM): the opening event travels

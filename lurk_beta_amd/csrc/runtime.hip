@@ -97,8 +97,29 @@ void Profiler::end(const char* name, hipEvent_t a, hipStream_t s) {
     (void)hipEventRecord(b, s);  // called from a destructor: never throws
     recs_.push_back({name, a, b, dev, s});
 }
+// LURK_PROF_TIMELINE=<file>: the scopes recorded since the last query / reset, as a device-side timeline (start relative to the first
+// scope's opening event, microseconds; one line per scope: start, end, duration, stream, name) - what rocprofv3 cannot give for commitments
+// in flight, since under it every launch call costs the submitting thread ~30 us and the queues drift apart (bench_tools/scope_timeline.py)
+void Profiler::dump_timeline() {
+    static const char* tl = getenv("LURK_PROF_TIMELINE");
+    if (!tl || recs_.empty()) return;
+    FILE* f = fopen(tl, "a");
+    if (!f) return;
+    fprintf(f, "# %zu scopes\n", recs_.size());
+    for (auto& r : recs_) {
+        if (r.device != recs_[0].device) continue;
+        DeviceGuard g(r.device);
+        float t0 = 0, t1 = 0;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t0, recs_[0].a, r.a) != hipSuccess ||
+            hipEventElapsedTime(&t1, recs_[0].a, r.b) != hipSuccess)
+            continue;
+        fprintf(f, "%10.1f %10.1f %8.1f  %p  %s\n", t0 * 1e3, t1 * 1e3, (t1 - t0) * 1e3, (void*)r.s, r.name.c_str());
+    }
+    fclose(f);
+}
 void Profiler::reset() {
     std::lock_guard<std::mutex> lk(mu_);
+    dump_timeline();
     for (auto& r : recs_) {
         DeviceGuard g(r.device);
         (void)hipEventSynchronize(r.b);
@@ -110,25 +131,7 @@ void Profiler::reset() {
 }
 void Profiler::query(const char* prefix, double* total_ms, uint64_t* launches) {
     std::lock_guard<std::mutex> lk(mu_);
-    // LURK_PROF_TIMELINE=<file>: the scopes still open to a query, as a device-side timeline (start relative to the first scope's
-    // opening event, microseconds; one line per scope: start, end, stream, name) - what rocprofv3 cannot give for commitments in flight,
-    // since under it every launch call costs the submitting thread ~30 us and the queues drift apart (bench_tools/trace_step.sh)
-    static const char* tl = getenv("LURK_PROF_TIMELINE");
-    if (tl && !recs_.empty()) {
-        if (FILE* f = fopen(tl, "a")) {
-            fprintf(f, "# %zu scopes\n", recs_.size());
-            for (auto& r : recs_) {
-                if (r.device != recs_[0].device) continue;
-                DeviceGuard g(r.device);
-                float t0 = 0, t1 = 0;
-                if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&t0, recs_[0].a, r.a) != hipSuccess ||
-                    hipEventElapsedTime(&t1, recs_[0].a, r.b) != hipSuccess)
-                    continue;
-                fprintf(f, "%10.1f %10.1f %8.1f  %p  %s\n", t0 * 1e3, t1 * 1e3, (t1 - t0) * 1e3, (void*)r.s, r.name.c_str());
-            }
-            fclose(f);
-        }
-    }
+    dump_timeline();
     for (auto& r : recs_) {
         DeviceGuard g(r.device);
         LURK_HIP_CHECK(hipEventSynchronize(r.b));
