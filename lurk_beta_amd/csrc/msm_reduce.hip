@@ -19,7 +19,13 @@
 //     4+ cycles on a single wave: 6 us) whether a kernel boundary follows it or a barrier;
 //   * measured and dropped in round 4: a component-major thread order (the copied component of every pair in waves of its own, so that
 //     level 0 runs half the adding waves, level 1 two thirds): 0.341 / 0.373 ms per reduction at 2^20 / 2^22 against 0.343 / 0.379 -
-//     the early levels are not bound by the additions of their idle lanes either.
+//     the early levels are not bound by the additions of their idle lanes either;
+//   * round 4, adopted: the kernel is held to 128 VGPRs (__launch_bounds__(256, 4): 11 of its 183 registers spill).  With 183 a level's
+//     workgroups could not be placed on a SIMD beside two resident one-wave accumulations (2 x 176 + 184 > 512): with commitments in
+//     flight every one of the 19 dependent levels waited for an accumulation to END - reductions of 4-6 ms in the device-side timeline,
+//     0.7-1.4 ms now - and the slot came back that much later.  2^22, three in flight: 953-961 -> 969-972 Mscalar-mul/s on one box
+//     (alternating runs), 2^20, two in flight: 790 -> 812; alone the reduction got 4 % faster too (four waves per SIMD in the early
+//     levels): profiles/r04_msm_pipeline_coresidency.txt.
 #include "common.hpp"
 #include "msm_core.cuh"
 #include "curve29.cuh"
@@ -44,7 +50,7 @@ __device__ __forceinline__ void plane_load(const Plane29<P>* __restrict__ src, X
 // level k: in[g][seg][0..k] (segments of 2^k buckets; level 0 reads the buckets themselves) -> out[g][seg / 2][0..k+1]
 // LAST: the G x c plane sums leave as ordinary XYZZ points (out_host, pinned host memory) instead of plane records
 template <class P, bool FIRST, bool LAST>
-__global__ __launch_bounds__(REDUCE_BLOCK) void msm_planes29_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
+__global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
                                                                       Plane29<P>* __restrict__ out, Xyzz<P>* __restrict__ out_host, int k, int G, uint32_t B) {
     __builtin_amdgcn_s_setprio(3);  // a latency-bound tail kernel: issue ahead of an accumulation sharing the SIMD
     const size_t nseg_out = (size_t)B >> (k + 1);
