@@ -1667,7 +1667,9 @@ struct FoldedChild {
     std::mutex mu;
 };
 static std::mutex g_children_mu;
-static std::map<const lurk_hip_msm_ctx*, std::unique_ptr<FoldedChild>> g_children;
+// (never destroyed: a key its owner forgot to destroy must not have its child's streams and buffers released by a static destructor
+// after the HIP runtime has shut down)
+static auto& g_children = *new std::map<const lurk_hip_msm_ctx*, std::unique_ptr<FoldedChild>>();
 
 FoldedKeyLease::~FoldedKeyLease() {
     if (owned && ctx) (void)lurk_hip_msm_ctx_destroy(ctx);
