@@ -498,7 +498,9 @@ int lurk_hip_keccak_ipa_challenge(void* binding, int round, const void* l_jacobi
  *   degree 3: d_polys = {A, B, C, D}, evals_out = [e(0), e(2), e(3)] of sum_i A (B C - D)     (3 x 32 B)
  *   degree 2: d_polys = {A, B},       evals_out = [e(0), e(2)]       of sum_i A B             (2 x 32 B)
  * A prover calls it with (NULL, evals) for the first round, (r_j, evals) in between and (r_last, NULL) at the end, after which
- * P[0] of every table is its evaluation at the challenge point. */
+ * P[0] of every table is its evaluation at the challenge point.  (A whole sum-check is cheaper through lurk_hip_sumcheck_prove_dev /
+ * _prove_batch_dev below: they keep the rounds' scratch - workgroup partial sums, ticket counter, the pinned words the totals land in -
+ * for the whole proof, this entry point sets it up per call.) */
 int lurk_hip_sumcheck_round_dev(int field_id, int degree, void* const* d_polys, size_t len, const void* bind_r32_mont,
                                 void* evals_out, void* stream);
 /* EqPolynomial::evals: d_out[b] = prod_j (b_j ? r_j : 1 - r_j), r_0 <-> the most significant bit of b; r: ell x 32 B Montgomery, host */
