@@ -298,3 +298,47 @@ extern "C" void hh_msm_digits(const uint32_t* scalar8, int c, uint32_t* by_step,
     carry = 0;
     for (int w = 0; w < W; w++) by_walk[w] = msm_digit_next(r, c, carry);
 }
+
+// ---------------------------------------------------------------------------------------------
+// The key fold's host plan (keyfold_plan.hpp, used by ipa.hip: key_fold): digits[(b * Wt + j) * U + u] = the signed sub-digit of weight b in
+// table window j, slot u, READ BACK FROM THE SORTED LISTS the kernel walks (ord / dstart / ord_base: magnitude by position, sign in bit 31).
+// Returns 0, or a negative code when the structure is inconsistent (an entry listed twice, a magnitude range out of order, ...).
+#include "../../lurk_beta_amd/csrc/keyfold_plan.hpp"
+extern "C" int hh_keyfold_plan(const uint64_t* weights, size_t T, size_t m, int kb, int Wt, int* out_U, int* out_groups, int* out_maxmag, int* off, int* wd,
+                               int32_t* digits) {
+    const lurk::KeyFoldPlan pl = lurk::keyfold_plan(weights, T, m, kb, Wt);
+    if (!pl.ok) return 1;
+    *out_U = pl.U;
+    *out_groups = pl.groups;
+    *out_maxmag = pl.maxmag;
+    for (int u = 0; u < pl.U; u++) {
+        off[u] = pl.off[u];
+        wd[u] = pl.wd[u];
+    }
+    for (size_t i = 0; i < T * (size_t)Wt * pl.U; i++) digits[i] = 0;
+    std::vector<char> seen(T * (size_t)Wt * pl.U, 0);
+    for (int u = 0; u < pl.U; u++)
+        for (int g = 0; g < pl.groups; g++) {
+            const size_t sg = (size_t)u * pl.groups + g;
+            const uint32_t* ds = pl.dstart.data() + sg * (pl.maxmag + 1);
+            const uint32_t* ord = pl.ord.data() + pl.ord_base[sg];
+            if (ds[0] != 0) return -1;
+            if (pl.ord_base[sg] + ds[pl.maxmag] != pl.ord_base[sg + 1]) return -2;
+            for (int k = 0; k < pl.maxmag; k++) {
+                if (ds[k + 1] < ds[k]) return -3;
+                for (uint32_t t = ds[k]; t < ds[k + 1]; t++) {
+                    const uint32_t e = ord[t], jb = e & 0x7fffffffu;
+                    const size_t j = pl.jlo[g] + jb / T, b = jb % T;
+                    if ((int)j >= pl.jlo[g + 1]) return -4;
+                    const size_t at = (b * Wt + j) * pl.U + u;
+                    if (seen[at]) return -5;
+                    seen[at] = 1;
+                    const int mag = pl.maxmag - k;
+                    if (mag > (1 << (pl.wd[u] - 1))) return -6;
+                    digits[at] = (e >> 31) ? -mag : mag;
+                }
+            }
+        }
+    return 0;
+}
+

@@ -281,3 +281,46 @@ def test_signed_digits_register_walk_equals_indexed_recoding(c):
             assert mag <= 1 << (c - 1)
             total += (-mag if neg else mag) << (c * w)
         assert total == k, (c, hex(k))
+
+
+@pytest.mark.parametrize("kb,Wt", [(20, 13), (16, 16)])
+@pytest.mark.parametrize("log_t,m", [(0, 1 << 17), (1, 1 << 16), (4, 1 << 16), (4, 64), (8, 16), (12, 4)])
+def test_key_fold_plan_digits_recombine_to_the_weights(kb, Wt, log_t, m):
+    """keyfold_plan.hpp (the host half of lurk_hip_msm_ctx_fold_key_dev): for uniform weights and the edge values (0, 1, 2^k around the
+    slot and window boundaries, q - 1, 2^255 - 1) the signed sub-digits read back from the sorted lists the kernel walks recombine to
+    the weight, every digit is within its slot's range, every (weight, window, slot) is listed at most once, and the window groups grow
+    when there are too few outputs to fill the chip; a weight whose digits carry out of the windows is refused (the library only passes
+    canonical field elements, below 2^255)."""
+    import ctypes
+
+    lib = H.lib()
+    T = 1 << log_t
+    q = R.modulus(1)
+    special = [0, 1, 2, q - 1, (1 << 255) - 1, 1 << 254, (1 << 20) - 1, 1 << 19, (1 << 19) + 1, (1 << 16) - 1, 1 << 15, (1 << 240) + (1 << 239), (1 << 7) + (1 << 6)]
+    ws = [special[b] if b < len(special) else R.uniform_fe(190, b, q) for b in range(T)]
+    if T == 1:
+        ws = [R.uniform_fe(191, 0, q)]
+    arr = np.zeros((T, 4), dtype=np.uint64)
+    for b, w in enumerate(ws):
+        for k in range(4):
+            arr[b, k] = (w >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    U, groups, maxmag = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    off, wd = (ctypes.c_int * 8)(), (ctypes.c_int * 8)()
+    digits = np.zeros(T * Wt * 8, dtype=np.int32)
+    rc = lib.hh_keyfold_plan(arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(T), ctypes.c_size_t(m), kb, Wt, ctypes.byref(U), ctypes.byref(groups),
+                             ctypes.byref(maxmag), off, wd, digits.ctypes.data_as(ctypes.c_void_p))
+    assert rc == 0
+    U, groups, maxmag = U.value, groups.value, maxmag.value
+    assert 1 <= U <= 8 and sum(wd[u] for u in range(U)) == kb and [off[u] for u in range(U)] == [sum(wd[v] for v in range(u)) for u in range(U)]
+    assert maxmag == 1 << (max(wd[u] for u in range(U)) - 1)
+    assert groups == 1 if m * U >= 1 << 17 else groups == min(Wt, -(-(1 << 17) // (m * U)))
+    d = digits[: T * Wt * U].reshape(T, Wt, U)
+    for b, w in enumerate(ws):
+        got = sum(int(d[b, j, u]) << (j * kb + off[u]) for j in range(Wt) for u in range(U))
+        assert got == w, (b, hex(w))
+        assert all(abs(int(d[b, j, u])) <= 1 << (wd[u] - 1) for j in range(Wt) for u in range(U))
+    arr[0] = [0xFFFFFFFFFFFFFFFF] * 4  # 2^256 - 1: its signed digits carry out of a 256-bit window set (16 x 16), 13 x 20 bits hold it
+    rc = lib.hh_keyfold_plan(arr.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(T), ctypes.c_size_t(m), kb, Wt, ctypes.byref(ctypes.c_int()),
+                             ctypes.byref(ctypes.c_int()), ctypes.byref(ctypes.c_int()), off, wd, digits.ctypes.data_as(ctypes.c_void_p))
+    assert rc == (1 if kb * Wt == 256 else 0)
+
