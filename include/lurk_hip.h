@@ -570,6 +570,35 @@ int lurk_hip_ipa_prove_dev(lurk_hip_msm_ctx* key, void* d_a32, void* d_b32, size
                            lurk_hip_ipa_challenge_fn challenge, void* user, void* out_l_jacobian96, void* out_r_jacobian96,
                            void* out_a_hat32, void* out_ck_hat_affine64, void* stream);
 
+/* The single-instance compressing prover as ONE call (what CompressedSNARK::prove runs per curve: /root/reference/src/proof/nova.rs:341-356
+ * -> arecibo RelaxedR1CSSNARK::prove): outer cubic sum-check, inner quadratic sum-check over the transposed shape, the two evaluation claims
+ * batched to one point, one inner-product argument under the resident key - a sequence of the entry points above with the vectors resident
+ * and the Keccak transcript inside.  The protocol is this repository's own (oracle/spartan_ref.py, oracle/spartan_fast.py: the oracle's
+ * prover gives the same proof element for element, its verifier accepts it), not arecibo's byte for byte.
+ *   shape: num_cons x (num_vars + 1 + num_io) columns of z = [W | u | X]; shape_t: its transpose over 2 num_vars rows and num_cons columns
+ *   (created with num_vars' = num_cons - 1, num_io' = 0); num_cons, num_vars: powers of two.  key: >= max(num_cons, num_vars) points, the
+ *   key that committed W and E; ck_c: the inner-product base (a 96-byte Jacobian).  x, u: canonical; d_w (num_vars), d_e (num_cons):
+ *   Montgomery, device memory, not modified.  label: the transcript's label.  Outputs (host memory, caller-sized, canonical):
+ *   polys_outer log2(num_cons) x 4 x 32 B, claims_outer 3 x 32 (Az, Bz, Cz), eval_e 32, polys_inner (log2(num_vars) + 1) x 3 x 32,
+ *   eval_w 32, polys_batch log2(N) x 3 x 32 (N = max(num_cons, num_vars)), evals_batch 2 x 32, ipa_l / ipa_r log2(N) x 96 (Jacobians),
+ *   ipa_a 32. */
+typedef struct lurk_hip_spartan_proof {
+    void* polys_outer;
+    void* claims_outer;
+    void* eval_e;
+    void* polys_inner;
+    void* eval_w;
+    void* polys_batch;
+    void* evals_batch;
+    void* ipa_l;
+    void* ipa_r;
+    void* ipa_a;
+} lurk_hip_spartan_proof;
+int lurk_hip_spartan_prove_dev(const lurk_hip_r1cs* shape, const lurk_hip_r1cs* shape_t, size_t num_cons, size_t num_vars, size_t num_io,
+                               lurk_hip_msm_ctx* key, const void* ck_c_jacobian96, const void* x32_canonical, const void* u32_canonical,
+                               const void* d_w32_mont, const void* d_e32_mont, const void* comm_w_jacobian96, const void* comm_e_jacobian96,
+                               const void* label, size_t label_len, lurk_hip_spartan_proof* out, void* stream);
+
 /* ---- synthetic inputs (bench / tests) -------------------------------------
  * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */
 int lurk_hip_synth_scalars_dev(int field_id, uint64_t stream_id, int dist, size_t first, size_t n,

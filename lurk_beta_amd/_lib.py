@@ -138,6 +138,8 @@ SIGNATURES = {
     "lurk_hip_sumcheck_prove_dev": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_sumcheck_prove_batch_dev": (c_int, [c_int, c_int, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_msm_ctx_fold_key_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "lurk_hip_spartan_prove_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_ipa_prove_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
@@ -193,6 +195,11 @@ class KeccakRoundBindingStruct(ctypes.Structure):
                 ("absorb_label2", ctypes.c_char_p), ("absorb_label2_len", ctypes.c_size_t),
                 ("squeeze_label", ctypes.c_char_p), ("squeeze_label_len", ctypes.c_size_t),
                 ("challenges_out", ctypes.c_void_p), ("challenges_cap", ctypes.c_size_t), ("n_rounds", ctypes.c_size_t)]
+
+
+class SpartanProofStruct(ctypes.Structure):
+    """lurk_hip_spartan_proof"""
+    _fields_ = [(k, ctypes.c_void_p) for k in ("polys_outer", "claims_outer", "eval_e", "polys_inner", "eval_w", "polys_batch", "evals_batch", "ipa_l", "ipa_r", "ipa_a")]
 
 
 class KeccakRounds:

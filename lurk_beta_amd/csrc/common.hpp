@@ -209,5 +209,9 @@ void msm_ctx_drop_folded_child(const lurk_hip_msm_ctx* parent);
 inline unsigned div_up(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
 int num_cus();  // multiprocessor count of the current device
+// The current device's stream-ordered memory pool keeps up to 4 GiB of freed blocks instead of handing them back to the driver at the
+// next synchronisation (the default release threshold is 0): the provers take their scratch from it (hipMallocAsync) dozens of times per
+// proof with synchronisations in between - a proof of a 2^20-row instance spent ~5 ms re-allocating.  Once per device, cheap afterwards.
+void stream_pool_retain();
 
 }  // namespace lurk

@@ -383,6 +383,7 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
     LURK_REQUIRE(kc == curve, "the key is over another curve");
     LURK_REQUIRE(kn >= n0, "the key has fewer points than the vectors have elements");
     const bool pairs = ktable == LURK_MSM_FORM_TABLE;  // the window-table form commits L and R (disjoint supports) in one pass
+    stream_pool_retain();
     // stream-ordered scratch (the pool keeps it between calls: a proof opens several of these arguments)
     struct Scratch {
         hipStream_t s;

@@ -65,6 +65,20 @@ void allow_dynamic_lds(const void* kernel, int bytes) {
     have = bytes;
 }
 
+void stream_pool_retain() {
+    static std::mutex mu;
+    static bool done[64] = {false};
+    const int dev = current_device();
+    if (dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done[dev]) return;
+    done[dev] = true;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) != hipSuccess || !pool) return;
+    uint64_t keep = (uint64_t)4 << 30;
+    (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+}
+
 Profiler& Profiler::get() {
     static Profiler p;
     return p;

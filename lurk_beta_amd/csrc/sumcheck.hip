@@ -156,6 +156,7 @@ struct SumcheckScratch {
     void* host_final = nullptr;  // 3 x 32 B, pinned (device-visible)
     hipStream_t s = nullptr;
     explicit SumcheckScratch(hipStream_t s_) : s(s_) {
+        stream_pool_retain();
         const size_t cap = (size_t)num_cus() * 8;
         LURK_HIP_CHECK(hipMallocAsync(&partial, cap * 3 * 32 + 256, s));
         counter = (uint32_t*)((char*)partial + cap * 3 * 32);

@@ -43,6 +43,8 @@ def test_device_prover_matches_the_oracle_and_verifies(hip, cn, c, num_cons, num
     assert got == want
     # the opening argument under the resident key (never folded) gives the identical proof
     assert prover.prove(X, u, d_W, d_E, _dev(B), cw, ce, key=k) == want
+    # ... and so does the whole prover as ONE library call (lurk_hip_spartan_prove_dev), here with a relaxed instance (u != 1, E != 0)
+    assert prover.prove(X, u, d_W, d_E, _dev(B), cw, ce, key=k, in_library=True) == want
     assert S.verify(cn, mats, num_cons, num_vars, X, ck, ck_c, comm_W, comm_E, u, got)
     assert not S.verify(cn, mats, num_cons, num_vars, [(X[0] + 1) % q] + X[1:], ck, ck_c, comm_W, comm_E, u, got)
     k.close()
@@ -78,6 +80,8 @@ def test_device_prover_matches_the_fast_oracle_at_2_14_and_2_16(hip, cn, c, log_
     assert got == want
     assert prover.prove(X, 1, d_W, d_E, d_B, cw, ce, key=plain) == want
     assert prover.prove(X, 1, d_W, d_E, d_B, cw, ce, key=table) == want
+    assert prover.prove(X, 1, d_W, d_E, d_B, cw, ce, key=table, in_library=True) == want   # lurk_hip_spartan_prove_dev: the prover as one library call
+    assert prover.prove(X, 1, d_W, d_E, d_B, cw, ce, key=plain, in_library=True) == want
     assert not SF.verify(c, (A, Bm, Cm), nc, nv, [(X[0] + 1) % q] + X[1:], B, comm_W, None, 1, got)
     for k in (plain, table):
         k.close()
