@@ -147,6 +147,42 @@ impl Drop for R1csShape {
     }
 }
 
+/// The single-instance compressing prover as one call (`lurk_hip_spartan_prove_dev`): sum-checks, claim batching and the opening with the
+/// Keccak transcript inside.  The protocol is the library's own, not arecibo's byte for byte.
+pub struct SpartanProof {
+    pub polys_outer: Vec<u8>,  // log2(num_cons) x 4 x 32 B, canonical
+    pub claims_outer: [u8; 96],
+    pub eval_e: [u8; 32],
+    pub polys_inner: Vec<u8>,  // (log2(num_vars) + 1) x 3 x 32 B
+    pub eval_w: [u8; 32],
+    pub polys_batch: Vec<u8>,  // log2(N) x 3 x 32 B, N = max(num_cons, num_vars)
+    pub evals_batch: [u8; 64],
+    pub ipa_l: Vec<u8>,        // log2(N) x 96 B Jacobians
+    pub ipa_r: Vec<u8>,
+    pub ipa_a: [u8; 32],
+}
+/// # Safety
+/// `d_w` / `d_e`: `num_vars` / `num_cons` Montgomery scalars in device memory; `shape_t` is the transpose of `shape` (2 `num_vars` rows over
+/// `num_cons` columns); `key` holds at least max(`num_cons`, `num_vars`) points and committed W and E.
+#[allow(clippy::too_many_arguments)]
+pub unsafe fn spartan_prove(shape: &R1csShape, shape_t: &R1csShape, num_cons: usize, num_vars: usize, key: *mut lurk_hip_msm_ctx, ck_c: &[u8; 96], x: &[u8], u: &[u8; 32],
+                            d_w: *const c_void, d_e: *const c_void, comm_w: &[u8; 96], comm_e: &[u8; 96], label: &[u8], stream: *mut c_void) -> Result<SpartanProof, Error> {
+    let log2 = |n: usize| n.trailing_zeros() as usize;
+    let (ell_x, ell_y, ell) = (log2(num_cons), log2(num_vars) + 1, log2(num_cons.max(num_vars)));
+    let mut p = SpartanProof {
+        polys_outer: vec![0; ell_x * 128], claims_outer: [0; 96], eval_e: [0; 32], polys_inner: vec![0; ell_y * 96], eval_w: [0; 32],
+        polys_batch: vec![0; ell.max(1) * 96], evals_batch: [0; 64], ipa_l: vec![0; ell.max(1) * 96], ipa_r: vec![0; ell.max(1) * 96], ipa_a: [0; 32],
+    };
+    let mut out = lurk_hip_spartan_proof {
+        polys_outer: p.polys_outer.as_mut_ptr().cast(), claims_outer: p.claims_outer.as_mut_ptr().cast(), eval_e: p.eval_e.as_mut_ptr().cast(),
+        polys_inner: p.polys_inner.as_mut_ptr().cast(), eval_w: p.eval_w.as_mut_ptr().cast(), polys_batch: p.polys_batch.as_mut_ptr().cast(),
+        evals_batch: p.evals_batch.as_mut_ptr().cast(), ipa_l: p.ipa_l.as_mut_ptr().cast(), ipa_r: p.ipa_r.as_mut_ptr().cast(), ipa_a: p.ipa_a.as_mut_ptr().cast(),
+    };
+    check(lurk_hip_spartan_prove_dev(shape.as_ptr(), shape_t.as_ptr(), num_cons, num_vars, x.len() / 32, key, ck_c.as_ptr().cast(), x.as_ptr().cast(), u.as_ptr().cast(),
+                                     d_w, d_e, comm_w.as_ptr().cast(), comm_e.as_ptr().cast(), label.as_ptr().cast(), label.len(), &mut out, stream))?;
+    Ok(p)
+}
+
 /// One curve's half of `RecursiveSNARK::prove_step`: the running relaxed pair (z1 = [W | u | X], E) and the running instance stay in
 /// the context; `step` is `NIFS::prove` (commit W2, cross term, commit T, r from the transcript, fold).
 /// Borrowing the shape and the key ties their lifetimes to the context's, as the C ABI requires.
