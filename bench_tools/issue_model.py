@@ -88,5 +88,68 @@ def main(path, needle, units=1, mode="loop"):
     print(f"  v_mad-only ceiling (the figure rounds 1-3 quoted): {mad_only / 1e9:.2f} G units/s; the mads are {COST['mad64'] * census['mad64'] / cycles:.1%} of the issue cycles")
 
 
+def census_of(lines, needle, mode):
+    """(VALU instructions, issue cycles) of the largest loop (mode "loop") or the whole body (mode "whole") of every kernel whose
+    mangled name contains `needle`, summed over those kernels"""
+    tot_n, tot_c = 0, 0.0
+    starts = [i for i, l in enumerate(lines) if "Begin function" in l and needle in l]
+    for start in starts:
+        end = next(i for i in range(start, len(lines)) if ".end_amdhsa_kernel" in lines[i] or "; -- End function" in lines[i])
+        body = lines[start:end]
+        a, b = 0, len(body) - 1
+        if mode == "loop":
+            labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r"^(\.LBB\d+_\d+):", l)] if m}
+            loops = []
+            for i, l in enumerate(body):
+                m = re.search(r"s_cbranch_\w+\s+(\.LBB\d+_\d+)|s_branch\s+(\.LBB\d+_\d+)", l)
+                if m:
+                    t = m.group(1) or m.group(2)
+                    if t in labels and labels[t] < i:
+                        loops.append((labels[t], i))
+            if loops:
+                longest = max(y - x for x, y in loops)
+                a, b = min((x for x in loops if x[1] - x[0] >= 0.95 * longest), key=lambda x: x[1] - x[0])
+        for l in body[a:b + 1]:
+            l = l.split(";")[0].strip()
+            if not l or l.endswith(":") or l.startswith("."):
+                continue
+            c = classify(l)
+            if c:
+                tot_n += 1
+                tot_c += COST[c]
+    return tot_n, tot_c
+
+
+def mix(out_json, *listings):
+    """`issue_model.py mix <out.json> <listing.s> ...`: the mean issue cost per VALU instruction of every stage of a commitment
+    (bench_workloads/msm.py: KERNEL_GROUPS), from the static instruction mix of the stage's kernels - the accumulation by its loop,
+    the short kernels by their whole bodies (their loops are a few dozen instructions: the static mix IS the dynamic one to within
+    the trip-count weights).  bench.py multiplies these by the SQ_INSTS_VALU it measures per stage (roofline_valu.pipeline)."""
+    import json
+    import os
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench_workloads.msm import KERNEL_GROUPS
+
+    texts = [open(p).read().split("\n") for p in listings]
+    out = {}
+    for stage, needles in KERNEL_GROUPS.items():
+        n, c = 0, 0.0
+        for lines in texts:
+            for needle in needles:
+                dn, dc = census_of(lines, needle, "loop" if stage == "accumulate" else "whole")
+                n, c = n + dn, c + dc
+        if n:
+            out[stage] = {"valu_instructions_static": n, "cycles_per_valu": round(c / n, 3)}
+    out["_source"] = {"listings": [os.path.basename(p) for p in listings], "rates": COST,
+                      "note": "hipcc -O3 --offload-arch=gfx950 -S --cuda-device-only of msm_acc.hip, msm_sort.hip, msm.hip, msm_reduce.hip"}
+    with open(out_json, "w") as fh:
+        json.dump(out, fh, indent=1)
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
-    main(*sys.argv[1:])
+    if len(sys.argv) > 1 and sys.argv[1] == "mix":
+        mix(*sys.argv[2:])
+    else:
+        main(*sys.argv[1:])

@@ -1,0 +1,406 @@
+"""--workload fold_step: the synthetic stand-in for one Nova folding step of benches/fibonacci.rs through the step entry points."""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+import sys
+import time
+
+from .common import BENCH, ROOT
+
+
+def _frame_structured_columns(rng, row_of_entry, num_cons, num_vars, num_io):
+    """Column pattern of the Lurk step circuit: W = [globals | frame 0 aux | frame 1 aux | ...] (frames are
+    synthesized independently and their aux concatenated, /root/reference/src/lem/multiframe.rs:699-702, 11 141
+    constraints and 9 119 aux per frame, src/lem/eval.rs:1966-1967), so frame f's rows touch frame f's block (88 %),
+    the globals at the front (6 %), the previous frame's block (4 %: its outputs) and the constant-one column u (2 %)."""
+    import numpy as np
+
+    nf = max(1, num_cons // 11141)
+    cons_pf, vars_pf = -(-num_cons // nf), max(1, num_vars // nf)
+    frame = np.minimum(row_of_entry // cons_pf, nf - 1)
+    kind = rng.random(row_of_entry.size)
+    local = frame * vars_pf + rng.integers(0, vars_pf, row_of_entry.size)
+    prev = np.maximum(frame - 1, 0) * vars_pf + rng.integers(0, vars_pf, row_of_entry.size)
+    glob = rng.integers(0, min(256, num_vars), row_of_entry.size)
+    cols = np.where(kind < 0.88, local, np.where(kind < 0.94, glob, np.where(kind < 0.98, prev, num_vars)))
+    return np.minimum(cols, num_vars + num_io).astype(np.uint64)
+
+
+def synth_r1cs_shape(field_id, p, num_cons, num_vars, num_io, seed=7, uniform_columns=False):
+    """Synthetic CSR triple shaped like the Lurk step circuit (3-4 entries per row, one row in 300 a 255-entry
+    bit decomposition, coefficients mostly +-1 / small): the bench's own generator (numpy), values in Montgomery form."""
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    ncols = num_vars + 1 + num_io
+    table_ints = [1, p - 1, 2, p - 2, 3, 4, 8, 16, 256, 1 << 32, p - (1 << 16)] + [int(rng.integers(1, 1 << 62)) ** 4 % p for _ in range(21)]
+    table = np.array([[(v << 256) % p >> (64 * w) & 0xFFFFFFFFFFFFFFFF for w in range(4)] for v in table_ints], dtype=np.uint64)
+    weights = np.array([40, 25, 5, 2, 2, 1, 1, 1, 1, 1, 1] + [1] * 21, dtype=np.float64)
+    weights /= weights.sum()
+
+    def sparse(one_per_row=False):
+        cnt = np.ones(num_cons, dtype=np.uint64) if one_per_row else rng.integers(3, 5, num_cons).astype(np.uint64)
+        if not one_per_row:
+            cnt[rng.integers(0, num_cons, max(1, num_cons // 300))] = min(ncols, 255)
+        indptr = np.zeros(num_cons + 1, dtype=np.uint64)
+        np.cumsum(cnt, out=indptr[1:])
+        nnz = int(indptr[-1])
+        rows = np.repeat(np.arange(num_cons, dtype=np.int64), cnt.astype(np.int64))
+        if one_per_row:
+            indices = np.full(nnz, num_vars, dtype=np.uint64)
+        elif uniform_columns:
+            indices = rng.integers(0, ncols, nnz).astype(np.uint64)
+        else:
+            indices = _frame_structured_columns(rng, rows, num_cons, num_vars, num_io)
+        data = np.ascontiguousarray(table[rng.choice(len(table_ints), size=nnz, p=weights)])
+        return indptr, indices, data
+
+    return sparse(), sparse(), sparse(one_per_row=True)
+
+
+def fold_step_workload(args, lib, world, rank):
+    """Synthetic stand-in for the device work of ONE Nova folding step of benches/fibonacci.rs on the primary (Pallas) curve
+    (the bench itself needs cargo + arecibo and cannot run here), through the step entry points:
+      W2 assembled in HBM: 14 hash4 + 6 hash8 + 1 commitment + 3 bit-decomposition slot blocks per frame written by the trace
+        kernels (lurk_hip_slot_witness_dev), the non-slot remainder of every frame (1 311 aux, what the CPU synthesis produces)
+        copied in over PCIe                                                      (src/lem/multiframe.rs:520-592, 699-702)
+      lurk_hip_fold_step_begin: commit(W2) || cross term T over the step circuit's rows || commit(T)   (nova.rs:287-293)
+      lurk_hip_fold_step_finish(r): [W | u | X] <- z1 + r z2, E <- E1 + r T
+    Sizes on Pallas: 8 951 aux per frame (7 640 slot aux: bit decompositions are 298 instead of BN254's 354; + 1 311) and
+    10 973 constraints per frame (11 141 - 3 x 56), from src/lem/eval.rs:1960-1967 and multiframe.rs:495-497.
+    Reported as "equivalent Lurk iterations/s" = rc / t(step).  Left out: what stays on the CPU in the reference (the transcript,
+    circuit synthesis of the frame bodies, the small secondary-curve fold): an upper bound on the end-to-end rate, flagged synthetic."""
+    import numpy as np
+    import torch
+
+    import lurk_beta_amd as L
+    from lurk_beta_amd import _lib, synth
+
+    rc = args.rc
+    F = L.FIELD_PALLAS_FQ
+    mf = L.MultiFrameWitness(F, rc, globals_len=64, body_len=1311)
+    n_w, n_t, n_io = mf.w_len, 10973 * rc, 6
+    n_key = max(n_w, n_t)
+    q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+    stream = torch.cuda.current_stream().cuda_stream
+    d_bases = synth.bases(L.CURVE_PALLAS, n_key)
+    pre = {"hash4": synth.scalars(F, 3, 1, 14 * rc * 4, mont=True), "hash8": synth.scalars(F, 4, 1, 6 * rc * 8, mont=True),
+           "commitment": synth.scalars(F, 5, 1, rc * 3, mont=True), "bit_decomp": synth.scalars(F, 6, 1, 3 * rc, mont=True)}
+    globals_pinned = torch.empty((mf.globals_len, 4), dtype=torch.int64).pin_memory()   # (a pageable source would make the async copy wait for the stream)
+    globals_pinned.copy_(synth.scalars(F, 7, 1, mf.globals_len, mont=True).cpu())
+    globals_host = globals_pinned.numpy().view(np.uint64)
+    bodies_host = torch.empty((rc, mf.body_len, 4), dtype=torch.int64).pin_memory()
+    bodies_host.copy_(synth.scalars(F, 8, 1, rc * mf.body_len, mont=True).reshape(rc, mf.body_len, 4).cpu())
+    bodies_np = bodies_host.numpy().view(np.uint64)
+    d_w2s = [torch.zeros((n_w, 4), dtype=torch.int64, device="cuda") for _ in range(2)]
+    d_w2 = d_w2s[0]
+    x2 = synth.scalars(F, 9, 0, n_io, mont=True).cpu().numpy().view(np.uint64)
+    t_setup = time.perf_counter()
+    host_mats = synth_r1cs_shape(F, q, n_t, n_w, n_io)
+    shape = L.R1CSShape(F, n_t, n_w, n_io, *host_mats)
+    shape_setup_s = time.perf_counter() - t_setup
+    if not args.verify:
+        host_mats = None
+    info = shape.info()
+    # the challenge of every step is derived by the library's transcript (arecibo's PoseidonRO over pp_digest, U1, U2, comm_T: 128 bits),
+    # on the host between begin and finish, as NIFS::prove does
+    pp_digest = 0x1F3C5A7990B2D4E6F8123456789ABCDEF0FEDCBA9876543210AA55AA55AA55
+    r_chal = 0x0FEDCBA0987654321234567890ABCDEF  # the secondary-curve leg below still feeds a constant of that size
+    r_mont = np.array([((r_chal << 256) % q) >> (64 * w) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
+    last_r = [r_mont]
+    torch.cuda.synchronize()
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else None
+    if devices:  # the key cut across a device list inside this process: slices commit concurrently, 96-byte partials summed on the host
+        assert not args.stage_ahead, "--devices: staging ahead is not available with a multi-device key"
+        ck = L.MultiCommitmentKey(L.CURVE_PALLAS, d_bases.cpu().numpy().view(np.uint64), devices, precompute=bool(args.precompute), window_bits=args.window_bits)
+    else:
+        ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
+    ctx = L.FoldingContext(L.CURVE_PALLAS, shape, ck)
+    ctx.set_pp_digest(pp_digest)
+    helper_keys = []
+    if args.helper_devices:
+        assert args.stage_ahead and not devices, "--helper-devices goes with --stage-ahead 1 and a single-device key"
+        for hd in [int(x) for x in args.helper_devices.split(",")]:
+            _lib.check(lib.lurk_hip_set_device(hd))
+            with torch.cuda.device(hd):
+                hb = d_bases if d_bases.device.index == hd else d_bases.to(f"cuda:{hd}")
+                hk = L.CommitmentKey(L.CURVE_PALLAS, hb, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
+                hk.reserve(n_key, 3)
+            helper_keys.append(hk)
+            ctx.add_helper(hk)
+        _lib.check(lib.lurk_hip_set_device(torch.cuda.current_device()))
+    z1 = synth.scalars(F, 1, 1, n_w + 1 + n_io, mont=True).cpu().numpy().view(np.uint64)   # a running instance with witness-like values
+    e1 = synth.scalars(F, 2, 0, n_t, mont=True).cpu().numpy().view(np.uint64)              # a running error vector (uniform, like any folded T)
+    ident = np.zeros(12, dtype=np.uint64)
+    # the running instance's commitments are the commitments of the running vectors (what RecursiveSNARK::verify re-computes)
+    if devices:
+        ctx.set_running(z1, e1, ck.commit(z1[:n_w], is_mont=True), ck.commit(e1, is_mont=True))
+    else:
+        ctx.set_running(z1, e1, ck.commit_device(torch.from_numpy(z1[:n_w].view(np.int64)).cuda(), n_w, is_mont=True),
+                        ck.commit_device(torch.from_numpy(e1.view(np.int64)).cuda(), n_t, is_mont=True))
+
+    # --stage-ahead 1: the step circuit's range of the NEXT witness is traced and its commitment started before this
+    # step opens (lurk-beta synthesizes witnesses ahead of the folding loop, nova.rs:304-326); the augmented circuit's own
+    # variables depend on the previous fold and arrive with begin: modelled as the first 9 000 and the last 3 000 positions
+    if not devices:
+        ck.reserve(n_key, 4)
+    lo, hi = (9000, n_w - 3000) if args.stage_ahead and args.late_ranges else (0, n_w)
+    late_host = synth.scalars(F, 10, 1, lo + n_w - hi, mont=True).cpu().numpy().view(np.uint64)
+    patches = [(0, late_host[:lo]), (hi, late_host[lo:])] if lo else []
+    staged_k = [0]
+
+    def stage():
+        buf = d_w2s[staged_k[0] & 1]
+        staged_k[0] += 1
+        mf.assemble(buf, pre, globals_host, bodies_np, mont=True, stream=stream)     # W2 in HBM (slot traces on the device)
+        ctx.prefetch(buf[lo:hi], lo, stream=stream)                                  # commit(step circuit's range) starts now
+
+    phase = {"assemble_and_stage": 0.0, "begin": 0.0, "transcript": 0.0, "finish": 0.0}  # host wall time per call site (begin blocks on the commitments)
+
+    def step():
+        t_a = time.perf_counter()
+        if args.stage_ahead:
+            if args.stage_ahead == 1:
+                stage()                                                               # the next step's, under this step's work
+            t_b = time.perf_counter()
+            cw, ct = ctx.begin_prefetched(x2, patches)                               # late ranges + cross term + commit(T) (2: + stage() from the submit hook)
+        elif args.witness_ahead:
+            # the witness of step k+1 is produced while step k folds (lurk-beta's producer thread, nova.rs:304-326); this step's W2 was
+            # produced a step ago.  --witness-ahead 1: its trace kernels are enqueued BEFORE this step's commitments and run beside
+            # them; 2: AFTER begin has returned, so that they run while the host derives r (the device is idle there)
+            k = staged_k[0]
+            staged_k[0] += 1
+            if args.witness_ahead == 1:
+                mf.assemble(d_w2s[(k + 1) & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[(k + 1) & 1].cuda_stream)
+            t_b = time.perf_counter()
+            if args.witness_ahead == 3:  # traced from the step's submit hook: behind the step's opening kernels, beside its commitments
+                hook_k[0] = k + 1
+            cw, ct = ctx.begin(d_w2s[k & 1], x2, stream=wstreams[k & 1].cuda_stream)  # both commitments + the cross term
+            if args.witness_ahead == 2:
+                mf.assemble(d_w2s[(k + 1) & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[(k + 1) & 1].cuda_stream)
+        else:
+            mf.assemble(d_w2, pre, globals_host, bodies_np, mont=True, stream=stream)
+            t_b = time.perf_counter()
+            cw, ct = ctx.begin(d_w2, x2, stream=stream)                              # both commitments + the cross term
+        t_c = time.perf_counter()
+        r = ctx.challenge()  # r = RO(pp_digest, U1, U2, comm_T): U1 and U2 were absorbed inside begin, one permutation is left (lurk_hip_fold_step_challenge)
+        t_r = time.perf_counter()
+        ctx.finish(r)
+        last_r[0] = r
+        t_d = time.perf_counter()
+        phase["assemble_and_stage"] += t_b - t_a
+        phase["begin"] += t_c - t_b
+        phase["transcript"] += t_r - t_c
+        phase["finish"] += t_d - t_r
+        return cw, ct
+
+    if args.stage_ahead:
+        stage()
+        if args.stage_ahead == 2:  # the next instance is traced, staged and its commitment started from inside begin (the submit hook)
+            ctx.set_submit_hook(stage)
+    elif args.witness_ahead:
+        wstreams = [torch.cuda.Stream(), torch.cuda.Stream()]  # witness k is produced on stream k & 1, into buffer k & 1
+        hook_k = [0]
+        if args.witness_ahead == 3:
+            ctx.set_submit_hook(lambda: mf.assemble(d_w2s[hook_k[0] & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[hook_k[0] & 1].cuda_stream))
+        mf.assemble(d_w2s[0], pre, globals_host, bodies_np, mont=True, stream=wstreams[0].cuda_stream)
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    lib.lurk_hip_profile_enable(1)
+    lib.lurk_hip_profile_reset()
+    torch.cuda.synchronize()
+    for k in phase:
+        phase[k] = 0.0
+    import gc
+    gc.collect()  # (as timeit does: no cyclic-garbage collection inside the timed region)
+    gc.disable()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    # (the folds are ordered on the context's own stream; torch.cuda.synchronize() is device-wide)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    lib.lurk_hip_profile_enable(0)
+    if args.stage_ahead == 2 or (not args.stage_ahead and args.witness_ahead == 3):
+        ctx.set_submit_hook(None)
+    if args.stage_ahead:  # drain the instance staged by the last timed step (one was staged before the region: K stagings inside it)
+        ctx.begin_prefetched(x2, patches)
+        ctx.finish(r_mont)
+    verified = None
+    if args.verify and rank == 0:
+        verified = verify_fold_step(L, ctx, host_mats, F, q, n_w, n_t, n_io, d_bases, pp_digest, x2,
+                                    lambda buf: mf.assemble(buf, pre, globals_host, bodies_np, mont=True, stream=stream), d_w2s[0])
+
+    def kernel_ms(name):
+        tot, cnt = ctypes.c_double(), ctypes.c_uint64()
+        _lib.check(lib.lurk_hip_profile_get(name.encode(), ctypes.byref(tot), ctypes.byref(cnt)))
+        return tot.value / max(cnt.value, 1), cnt.value
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        nnz = sum(info["nnz"])
+        ct_ms, _ = kernel_ms("r1cs_cross_term")
+        fv_ms, _ = kernel_ms("fold_vec")
+        tr_ms, tr_n = kernel_ms("poseidon_trace")
+        bd_ms, _ = kernel_ms("bit_decomp_trace")
+        acc_ms, acc_n = kernel_ms("msm_accumulate")       # mean launch over the timed region (HIP events on its launch stream): 2 per step
+        acc_bytes = 96.0 * (n_w + n_t) / 2.0              # algorithmic bytes of the mean launch: 32 B scalar + 64 B base per point
+        # algorithmic HBM bytes of the cross-term kernel: 8 B per CSR record + 4 B per row pointer, two 32-byte gathers
+        # per record (z1, z2), 32 B of T per row; fold_vec: two reads + one write of 32 B per element
+        ct_bytes = nnz * 8.0 + 3 * 4.0 * n_t + 2 * 32.0 * nnz + 32.0 * n_t
+        fv_bytes = 96.0 * ((n_w + 1 + n_io) + n_t) / 2
+        res = {
+            "metric": "equivalent Lurk iterations/s (synthetic stand-in for one Nova folding step, Pallas)",
+            "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong" if devices else "weak", "vs_baseline": None,
+            "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
+            "config": {"staged_ahead": args.stage_ahead, "witness_ahead": 0 if args.stage_ahead else args.witness_ahead,
+                       "devices": devices, "distinct_devices": len(set(devices)) if devices else 1,
+                       "helper_devices": args.helper_devices or None,
+                       "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
+                                   f"slot blocks traced on the device + {rc} x 1311 body aux over PCIe) -> MSM(W2) + cross term over {n_t} rows ({nnz} non-zeros, "
+                                   f"{info['distinct_coefficients']} distinct coefficients) + MSM(T) -> fold of [W|u|X] and E",
+                       "note": "device work + the transcript (r derived per step by the library's PoseidonRO on the host); body synthesis not modelled; "
+                               "the secondary-curve half is the separate secondary_curve_step record",
+                       "verified": verified,
+                       "r1cs_columns": "frame-structured (88 % frame-local, 6 % globals, 4 % previous frame, 2 % u): a builder-chosen model of the step circuit's sparsity, "
+                                       "see fold_kernels.r1cs_cross_term_uniform_columns for the structure-free case",
+                       "shape_setup_s_once": round(shape_setup_s, 2)},
+            "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase.items()},
+            # the step's dominant kernel is the bucket accumulation of its two commitments; the cross term (fold_kernels below) is the HBM-side one
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(acc_bytes / (acc_ms * 1e-3) / 1e9, 3) if acc_ms else None,
+                         "peak": 8000.0, "unit": "GB/s", "frac": round(acc_bytes / (acc_ms * 1e-3) / 8e12, 6) if acc_ms else None, "traffic": None,
+                         "avg_launch_ms": round(acc_ms, 4), "launches_per_step": acc_n // max(args.steps, 1), "algorithmic_bytes_per_launch": acc_bytes,
+                         "note": "96 B per point over the mean of the step's two commitments (W2 and T), launches timed inside the step (they share the device with "
+                                 "the cross term and each other's sort); integer-VALU bound as in the msm workload: see its roofline_valu"},
+            "fold_kernels": {
+                "r1cs_cross_term": {"ms": round(ct_ms, 4), "algorithmic_bytes": ct_bytes, "achieved_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms else None,
+                                    "hbm_frac": round(ct_bytes / (ct_ms * 1e-3) / 8e12, 4) if ct_ms else None},
+                "fold_vec": {"ms_per_launch": round(fv_ms, 4), "algorithmic_bytes_per_launch": fv_bytes,
+                             "achieved_GBps": round(fv_bytes / (fv_ms * 1e-3) / 1e9, 1) if fv_ms else None,
+                             "hbm_frac": round(fv_bytes / (fv_ms * 1e-3) / 8e12, 4) if fv_ms else None},
+                "slot_witness_trace": {"poseidon_ms_per_launch": round(tr_ms, 4), "launches_per_step": tr_n // max(args.steps, 1),
+                                       "bit_decomp_ms_per_launch": round(bd_ms, 4), "bytes_written_per_step": mf.slots_len * rc * 32.0},
+            },
+        }
+        # the secondary-curve half of the step (Vesta, scalars in Fp): arecibo's augmented circuit on the other curve of the cycle is
+        # ~10^4 constraints; its NIFS::prove runs BEFORE the primary's in prove_step and the two depend on each other through the
+        # circuits, so a whole step is the sum.  W2 comes from host memory here (that circuit is synthesized on the CPU).
+        if args.secondary:
+            P_MOD = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+            nc2, nv2, nio2 = 10_000, 10_000, 2
+            shape2 = L.R1CSShape(L.FIELD_PALLAS_FP, nc2, nv2, nio2, *synth_r1cs_shape(L.FIELD_PALLAS_FP, P_MOD, nc2, nv2, nio2, seed=11, uniform_columns=True))
+            ck2 = L.CommitmentKey(L.CURVE_VESTA, synth.bases(L.CURVE_VESTA, max(nc2, nv2)), n=max(nc2, nv2), device=True, precompute=bool(args.precompute))
+            ck2.reserve(max(nc2, nv2), 3)
+            ctx2 = L.FoldingContext(L.CURVE_VESTA, shape2, ck2)
+            ctx2.set_running(synth.scalars(L.FIELD_PALLAS_FP, 31, 1, nv2 + 1 + nio2, mont=True).cpu().numpy().view(np.uint64),
+                             synth.scalars(L.FIELD_PALLAS_FP, 32, 0, nc2, mont=True).cpu().numpy().view(np.uint64), ident, ident)
+            w2_sec = torch.empty((nv2, 4), dtype=torch.int64).pin_memory()
+            w2_sec.copy_(synth.scalars(L.FIELD_PALLAS_FP, 33, 1, nv2, mont=True).cpu())
+            w2_sec_np = w2_sec.numpy().view(np.uint64)
+            x2_sec = synth.scalars(L.FIELD_PALLAS_FP, 34, 0, nio2, mont=True).cpu().numpy().view(np.uint64)
+            r_mont2 = np.array([((r_chal << 256) % P_MOD) >> (64 * w) & 0xFFFFFFFFFFFFFFFF for w in range(4)], dtype=np.uint64)
+            for _ in range(3):
+                ctx2.begin(w2_sec_np, x2_sec)
+                ctx2.finish(r_mont2)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            reps2 = max(args.steps, 10)
+            for _ in range(reps2):
+                ctx2.begin(w2_sec_np, x2_sec)
+                ctx2.finish(r_mont2)
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t2) / reps2 * 1e3
+            res["secondary_curve_step"] = {"ms_per_step": round(ms2, 4), "curve": "vesta", "constraints": nc2, "variables": nv2,
+                                           "note": "arecibo's augmented circuit on the secondary curve is ~10^4 constraints [SURVEY 8: MEM]; two latency-bound "
+                                                   "commitments of 10^4 points + cross term + folds, W2 from host memory"}
+            res["both_curves_ms_per_step"] = round(ms + ms2, 4)
+            res["both_curves_iterations_per_s"] = round(rc / ((ms + ms2) * 1e-3), 1)
+            ctx2.close()
+            ck2.close()
+            shape2.close()
+        # the same cross term over a structure-free shape (uniformly random columns): the other end of the sparsity range
+        lib.lurk_hip_profile_enable(1)
+        lib.lurk_hip_profile_reset()
+        shape_u = L.R1CSShape(F, n_t, n_w, n_io, *synth_r1cs_shape(F, q, n_t, n_w, n_io, uniform_columns=True))
+        d_z1 = torch.from_numpy(z1.view(np.int64)).cuda()
+        d_t = torch.empty((n_t, 4), dtype=torch.int64, device="cuda")
+        for _ in range(3):
+            shape_u.cross_term(d_z1, torch.cat([d_w2, d_z1[n_w:]]), out=d_t, stream=stream)
+        torch.cuda.synchronize()
+        cu_ms, _ = kernel_ms("r1cs_cross_term")
+        lib.lurk_hip_profile_enable(0)
+        shape_u.close()
+        res["fold_kernels"]["r1cs_cross_term_uniform_columns"] = {"ms": round(cu_ms, 4), "hbm_frac": round(ct_bytes / (cu_ms * 1e-3) / 8e12, 4) if cu_ms else None}
+        if not args.no_cpu_baseline:
+            from oracle import coracle as C
+
+            m = min(n_t, 1 << 22)
+            B = C.synth_bases(0, m)
+            s_w, s_t = C.synth_scalars(1, 1, 1, min(n_w, m)), C.synth_scalars(1, 2, 0, m)
+            C.msm_fast(0, B[:4096], s_t[:4096])
+            t1 = time.perf_counter()
+            C.msm_fast(0, B[: min(n_w, m)], s_w)
+            C.msm_fast(0, B, s_t)
+            dt = time.perf_counter() - t1
+            scale = (n_w + n_t) / (min(n_w, m) + m)
+            res["cpu_baseline"] = {"value": round(rc / (dt * scale), 2), "unit": "iterations/s", "cores": C.lib().orc_num_threads(), "kind": "port",
+                                   "sample": f"the step's two MSMs ({min(n_w, m)} and {m} points{'' if scale == 1 else ', scaled linearly to the full sizes'}) in {dt:.2f} s with oracle/msm_fast.c "
+                                             "(pasta-msm-shaped Pippenger, all cores); fold arithmetic, witness generation and transcript not included"}
+        print(json.dumps(res), flush=True)
+    ctx.close()
+    for hk in helper_keys:
+        hk.close()
+    ck.close()
+    shape.close()
+
+
+def verify_fold_step(L, ctx, host_mats, F, q, n_w, n_t, n_io, d_bases, pp_digest, x2, assemble, d_w2):
+    """--verify: ONE more step after the timed loop through lurk_hip_fold_step, every output against the oracle at the bench's own size:
+    comm_W2 and comm_T (oracle/msm_fast.c), r (the oracle's transcript over the oracle's instance), T and the folded (z, E) element by
+    element (oracle/oracle.c), the folded instance's commitments.  The checker only: nothing here is timed."""
+    import numpy as np
+    import torch
+
+    from oracle import coracle as C
+    from oracle import pyref as R
+
+    f, curve = 1, 0
+    t0 = time.perf_counter()
+    mats = [(ip, ix, C.from_mont(f, d)) for ip, ix, d in host_mats]
+    bases = d_bases.cpu().numpy().view(np.uint64).reshape(-1, 8)
+    z1m, e1m = ctx.read()
+    z1, e1 = C.from_mont(f, z1m), C.from_mont(f, e1m)
+    cw1, ce1, _, _ = ctx.instance()
+    pt = lambda a: None if a == (0, 0) else a
+    cw1_o = pt(C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_w], z1[:n_w])))   # the running instance's commitments, recomputed
+    ce1_o = pt(C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_t], e1)))
+    ok = {"running_comm_W": pt(L.point_to_affine(curve, cw1)) == cw1_o, "running_comm_E": pt(L.point_to_affine(curve, ce1)) == ce1_o}
+    assemble(d_w2)
+    torch.cuda.synchronize()
+    w2 = C.from_mont(f, d_w2.cpu().numpy().view(np.uint64).reshape(-1, 4))
+    x2c = C.from_mont(f, x2.reshape(-1, 4))
+    cw, ct, r_mont = ctx.step(d_w2, x2, pp_digest, stream=torch.cuda.current_stream().cuda_stream)
+    z2 = np.concatenate([w2, C.ints_to_limbs([1]), x2c])
+    u1 = C.limbs_to_ints(z1[n_w:n_w + 1])[0]
+    t = C.cross_term(f, *[C.spmv(f, *M, z1) for M in mats], *[C.spmv(f, *M, z2) for M in mats], u1, 1)
+    cw2_o, ct_o = C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_w], w2)), C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_t], t))
+    ok["comm_W2"] = L.point_to_affine(curve, cw) == cw2_o
+    ok["comm_T"] = L.point_to_affine(curve, ct) == ct_o
+    r = R.nifs_challenge("pallas", pp_digest, cw1_o, ce1_o, u1, C.limbs_to_ints(z1[n_w + 1:]), pt(cw2_o), C.limbs_to_ints(x2c), pt(ct_o))
+    ok["challenge"] = C.limbs_to_ints(C.from_mont(f, r_mont.reshape(1, 4)))[0] == r
+    zf, ef = C.axpy(f, z1, z2, r), C.axpy(f, e1, t, r)
+    gz, ge = ctx.read()
+    ok["folded_z"] = bool(np.array_equal(C.from_mont(f, gz), zf))
+    ok["folded_E"] = bool(np.array_equal(C.from_mont(f, ge), ef))
+    gcw, gce, _, _ = ctx.instance()
+    ok["folded_comm_W"] = L.point_to_affine(curve, gcw) == C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_w], zf[:n_w]))
+    ok["folded_comm_E"] = L.point_to_affine(curve, gce) == C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_t], ef))
+    if not all(ok.values()):
+        raise SystemExit(f"bench.py --verify: the fold step does not match the oracle: {ok}")
+    return {"ok": True, "checks": sorted(ok), "oracle_s": round(time.perf_counter() - t0, 1),
+            "against": "oracle/oracle.c (spmv, cross term, axpy), oracle/msm_fast.c (6 commitments), oracle/pyref.py (transcript), one extra step after the timed loop"}

@@ -107,10 +107,14 @@ lurk_hip_rust_error cuda_pippenger_vesta(void* out_jacobian96, const void* point
  * resident, 256 KiB per point (2.6 GB at 10^4 points, 4.3 GB at 2^14, 5.6 GB at 2^16) plus <= 1 GiB of scratch while it is
  * built - so that a commitment is one launch (0.13 ms at 2^13 points instead of 0.35).  It is chosen only when it fits a quarter
  * of the device memory free at creation time; otherwise, and always with LURK_MSM_FLAG_WINDOW_BITS(16), the key takes the window
- * table (64 B x 16 per point).  lurk_hip_msm_ctx_info reports the form that was taken. */
+ * table (64 B x 16 per point).  lurk_hip_msm_ctx_form reports the form that was taken; a caller that needs the choice to be
+ * the same on every run and device states it: LURK_MSM_FLAG_SMALL_FORM (the small form, or LURK_HIP_ERR_INVALID_ARG / _OOM) or
+ * LURK_MSM_FLAG_NO_SMALL_FORM (the window table whatever is free). */
 typedef struct lurk_hip_msm_ctx lurk_hip_msm_ctx;
 #define LURK_MSM_FLAG_PRECOMPUTE 1
 #define LURK_MSM_FLAG_WINDOW_BITS(c) (((c) & 0xff) << 8)
+#define LURK_MSM_FLAG_SMALL_FORM (1 << 16)
+#define LURK_MSM_FLAG_NO_SMALL_FORM (1 << 17)
 int lurk_hip_msm_ctx_create(lurk_hip_msm_ctx** ctx, int curve, const void* bases_affine64,
                             size_t npoints, int flags);
 /* same, bases already in device memory (borrowed for the lifetime of the ctx unless precomputed) */
@@ -157,12 +161,14 @@ int lurk_hip_msm_ctx_rebind_dev(lurk_hip_msm_ctx* ctx, const void* d_bases_affin
 /* Workspaces (sort buffers, task partials, buckets: ~1 GiB per slot at 2^22 points) are allocated on a slot's first use; a
  * prover that wants no allocation inside its first steps reserves them up front for the largest commitment it will make. */
 int lurk_hip_msm_ctx_reserve(lurk_hip_msm_ctx* ctx, size_t nscalars, int slots);
-/* *precomputed receives the FORM of the resident key: 0 = plain (64 B/point), 1 = window table (the only form that commits a
- * pair in one pass: lurk_hip_msm_ctx_submit_pair_dev), 2 = the small-commitment multiples table (keys of <= 2^16 points). */
+/* *precomputed is a boolean (1 = the key holds precomputed multiples, in either table form).  The FORM of the resident key comes
+ * from lurk_hip_msm_ctx_form: 0 = plain (64 B/point), 1 = window table (the only form that commits a pair in one pass:
+ * lurk_hip_msm_ctx_submit_pair_dev), 2 = the small-commitment multiples table (keys of <= 2^16 points). */
 #define LURK_MSM_FORM_PLAIN 0
 #define LURK_MSM_FORM_TABLE 1
 #define LURK_MSM_FORM_SMALL 2
 int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoints, int* window_bits, int* precomputed);
+int lurk_hip_msm_ctx_form(const lurk_hip_msm_ctx* ctx, int* form);
 int lurk_hip_msm_ctx_device(const lurk_hip_msm_ctx* ctx, int* device); /* the device the key is resident on */
 /* Commitment-key generation: arecibo's CommitmentEngine::setup(label, n) = DlogGroup::from_label as
  * PublicParams::setup reaches it (/root/reference/src/proof/nova.rs:196-216): SHAKE256(label) squeezed 32 bytes per point (host:

@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblurk_hip.so")
+# LURK_HIP_LIB: another build of the same library (A/B runs of two builds on one GPU box: bench_tools/ab.sh); never a fallback
+LIB_PATH = os.environ.get("LURK_HIP_LIB") or os.path.join(_HERE, "liblurk_hip.so")
 _lib = None
 
 c_void_p, c_size_t, c_int, c_uint, c_u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint, ctypes.c_uint64
@@ -59,6 +60,7 @@ SIGNATURES = {
     "lurk_hip_ck_from_label_dev": (c_int, [c_int, ctypes.c_char_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_msm_ctx_from_label": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.c_char_p, c_size_t, c_size_t, c_int]),
     "lurk_hip_msm_ctx_info": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_size_t), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "lurk_hip_msm_ctx_form": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "lurk_hip_msm_ctx_device": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "lurk_hip_msm_ctx_save": (c_int, [c_void_p, ctypes.c_char_p, c_int]),
     "lurk_hip_msm_ctx_load": (c_int, [ctypes.POINTER(c_void_p), ctypes.c_char_p, c_int]),

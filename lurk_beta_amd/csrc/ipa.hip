@@ -379,7 +379,8 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
     auto ok = [](int rc) { if (rc != 0) throw HipFailure{rc, lurk_hip_last_error()}; };
     int kc = 0, kbits = 0, ktable = 0;
     size_t kn = 0;
-    ok(lurk_hip_msm_ctx_info(key, &kc, &kn, &kbits, &ktable));
+    ok(lurk_hip_msm_ctx_info(key, &kc, &kn, &kbits, nullptr));
+    ok(lurk_hip_msm_ctx_form(key, &ktable));
     LURK_REQUIRE(kc == curve, "the key is over another curve");
     LURK_REQUIRE(kn >= n0, "the key has fewer points than the vectors have elements");
     const bool pairs = ktable == LURK_MSM_FORM_TABLE;  // the window-table form commits L and R (disjoint supports) in one pass

@@ -24,31 +24,14 @@
 
 #include "common.hpp"
 #include "msm_core.cuh"
+#include "msm_sort.hpp"
 
 namespace lurk {
 
 void keygen_from_label_device(int curve, const void* label, size_t label_len, size_t n, void* d_out, hipStream_t s);  // keygen.hip
 
-constexpr int MSM_P_MIN = 2048;    // coarse partitions of the key space (pass 1 of the sort): 2048 up to n = 2^22, then
-constexpr int MSM_P_MAX = 8192;    // doubled until a partition fits the LDS stage of pass 2 (MsmCtx::shape)
-constexpr int MSM_P_PER_MAX = MSM_P_MAX / 1024;
-constexpr int MSM_NB1 = 256;       // workgroups of pass 1 (one per CU)
-constexpr int MSM_SORT_BLOCK = 1024;
-constexpr int MSM_S = 64;          // sorted entries per accumulation task
 constexpr int MSM_SMALL = 16;      // buckets with <= this many task partials are summed by one lane
 constexpr int MSM_ACC_BLOCK = 256;
-
-struct MsmShape {
-    int c, W, G;           // window bits, windows, key spaces
-    uint32_t B, NB;        // buckets per space, total keys
-    int P;                 // coarse partitions of pass 1 (power of two, MSM_P_MIN .. MSM_P_MAX)
-    int tile;              // scalars per pass-1 scatter tile (1024, or less when P counters + W*tile entries exceed the LDS)
-    int LB;                // low key bits sorted in pass 2 (NB >> LB == P)
-    int NG;                // scan groups of MSM_GRP keys
-    size_t n, stride;      // scalars in this call; table stride per window (0 in plain mode)
-    int sel;               // >= 0: TWO key spaces chosen by bit `sel` of the scalar's index (a pair of commitments with disjoint supports
-                           // in one pass: the two halves of an inner-product-argument round); -1: off
-};
 
 // Every kernel of a commitment except the bucket accumulation is short and bound by latency, LDS atomics or HBM; with
 // commitments in flight they share the SIMDs with the (older, VALU-saturating) accumulate waves of the previous
@@ -56,304 +39,7 @@ struct MsmShape {
 // Raising their wave priority lets them issue when they are ready; they need a few percent of the VALU.
 __device__ __forceinline__ void msm_set_wave_prio(int /*cls: 0 sort kernels, 1 plan / finalize / reduce kernels*/) { __builtin_amdgcn_s_setprio(3); }
 
-// ---- 1. digits ---------------------------------------------------------------------------
-// Both sweeps of sort pass 1 read the scalars themselves (32 B each) and recode them on the fly:
-// cheaper than materialising W digits per scalar (4 W bytes written once and read twice).
-// (Montgomery scalars are brought to canonical form once, by msm_canon_kernel, not inside the two sweeps: besides halving that
-// work it keeps the sort kernels at <= 56 VGPRs, so a 1024-thread sort workgroup of the next commitment fits on a SIMD beside
-// two accumulate waves - with the conversion inlined msm_scatter1 needed 63 and had to wait for an accumulation to end.)
-template <class SF>  // scalar field
-__device__ __forceinline__ Fe<SF> msm_scalar_from_words(const uint4& lo, const uint4& hi, int /*is_mont: always canonical here*/) {
-    Fe<SF> s;
-    s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
-    s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
-    return s;
-}
-template <class SF>
-__global__ __launch_bounds__(256) void msm_canon_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
-    msm_set_wave_prio(0);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const uint4 lo = in[2 * i], hi = in[2 * i + 1];
-        Fe<SF> s;
-        s.l[0] = lo.x; s.l[1] = lo.y; s.l[2] = lo.z; s.l[3] = lo.w;
-        s.l[4] = hi.x; s.l[5] = hi.y; s.l[6] = hi.z; s.l[7] = hi.w;
-        s = fe_from_mont<SF>(s);
-        out[2 * i] = make_uint4(s.l[0], s.l[1], s.l[2], s.l[3]);
-        out[2 * i + 1] = make_uint4(s.l[4], s.l[5], s.l[6], s.l[7]);
-    }
-}
-template <class SF>
-__device__ __forceinline__ Fe<SF> msm_load_scalar(const uint4* __restrict__ scalars, size_t i, int is_mont) {
-    return msm_scalar_from_words<SF>(scalars[2 * i], scalars[2 * i + 1], is_mont);
-}
-
-// entry (w, i) -> key = space * B + |d| - 1 (space = w in plain mode, 0 with the table)
-__device__ __forceinline__ uint32_t msm_key(const MsmShape& sh, uint32_t w, uint32_t mag, size_t i) {
-    const uint32_t space = sh.sel >= 0 ? (uint32_t)((i >> sh.sel) & 1u) : (sh.G == 1 ? 0u : w);
-    return space * sh.B + mag - 1u;
-}
-
-// ---- 2a. sort pass 1: coarse partition by the high key bits -------------------------------------
-// block blk owns scalars [blk*chunk, (blk+1)*chunk)
-template <class SF>
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* __restrict__ scalars, uint32_t* __restrict__ block_hist,
-                                                                     MsmShape sh, size_t chunk, int is_mont) {
-    msm_set_wave_prio(0);
-    extern __shared__ uint32_t h[];  // [P]
-    for (int p = threadIdx.x; p < sh.P; p += MSM_SORT_BLOCK) h[p] = 0;
-    __syncthreads();
-    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
-    // the next scalar is in flight while the current one is recoded (16 waves per CU do not hide the load otherwise)
-    size_t i = lo + threadIdx.x;
-    uint4 nlo = make_uint4(0, 0, 0, 0), nhi = nlo;
-    if (i < hi) { nlo = scalars[2 * i]; nhi = scalars[2 * i + 1]; }
-    for (; i < hi; i += MSM_SORT_BLOCK) {
-        Fe<SF> s = msm_scalar_from_words<SF>(nlo, nhi, is_mont);
-        if (i + MSM_SORT_BLOCK < hi) { nlo = scalars[2 * (i + MSM_SORT_BLOCK)]; nhi = scalars[2 * (i + MSM_SORT_BLOCK) + 1]; }
-        uint32_t carry = 0;
-        uint32_t r[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) r[k] = s.l[k];
-        for (int w = 0; w < sh.W; w++) {
-            uint32_t mag = msm_digit_next(r, sh.c, carry) & ~MSM_SIGN;
-            if (mag) atomicAdd(&h[msm_key(sh, (uint32_t)w, mag, i) >> sh.LB], 1u);
-        }
-    }
-    __syncthreads();
-    for (int p = threadIdx.x; p < sh.P; p += MSM_SORT_BLOCK) block_hist[(size_t)blockIdx.x * sh.P + p] = h[p];
-}
-
-// block p: exclusive scan of partition p's counts over the MSM_NB1 pass-1 blocks
-__global__ __launch_bounds__(MSM_NB1) void msm_scan1_kernel(uint32_t* __restrict__ block_hist, uint32_t* __restrict__ part_cnt, int P) {
-    msm_set_wave_prio(0);
-    __shared__ uint32_t sh[MSM_NB1];
-    const int p = blockIdx.x, t = threadIdx.x;
-    uint32_t v = block_hist[(size_t)t * P + p];
-    sh[t] = v;
-    __syncthreads();
-    for (int off = 1; off < MSM_NB1; off <<= 1) {
-        uint32_t a = t >= off ? sh[t - off] : 0;
-        __syncthreads();
-        sh[t] += a;
-        __syncthreads();
-    }
-    block_hist[(size_t)t * P + p] = sh[t] - v;
-    if (t == MSM_NB1 - 1) part_cnt[p] = sh[t];
-}
-
-// Exclusive scan over the 1024 threads of a sort block (wave scans + one scan of the 16 wave totals).
-// scr: >= 17 words of LDS; returns the exclusive prefix of v, *total = sum over the block.
-__device__ __forceinline__ uint32_t msm_block_scan(uint32_t v, uint32_t* scr, uint32_t* total) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-    }
-    if (lane == 63) scr[wave] = inc;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        uint32_t w = threadIdx.x < MSM_SORT_BLOCK / 64 ? scr[threadIdx.x] : 0, winc = w;
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            uint32_t o = __shfl_up(winc, off);
-            if (lane >= off) winc += o;
-        }
-        if (threadIdx.x < MSM_SORT_BLOCK / 64) scr[threadIdx.x] = winc - w;
-        if (threadIdx.x == MSM_SORT_BLOCK / 64 - 1) scr[16] = winc;
-    }
-    __syncthreads();
-    uint32_t ex = scr[wave] + inc - v;
-    *total = scr[16];
-    __syncthreads();  // scr may be reused at once
-    return ex;
-}
-
-// single block: part_start[0..P] = exclusive scan of part_cnt
-// (it also zeroes the small counters the later stages start from - the hot-bucket count, the task-length histogram, the persistent
-// kernel's cursor block: three fill launches of ~6 us each in a chain of dependent launches otherwise)
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part_start_kernel(const uint32_t* __restrict__ part_cnt, uint32_t* __restrict__ part_start,
-                                                                          int P, uint32_t* __restrict__ z0, int n0, uint32_t* __restrict__ z1, int n1,
-                                                                          uint32_t* __restrict__ z2, int n2) {
-    msm_set_wave_prio(0);
-    for (int i = threadIdx.x; i < n0; i += MSM_SORT_BLOCK) z0[i] = 0;
-    for (int i = threadIdx.x; i < n1; i += MSM_SORT_BLOCK) z1[i] = 0;
-    for (int i = threadIdx.x; i < n2; i += MSM_SORT_BLOCK) z2[i] = 0;
-    __shared__ uint32_t scr[32];
-    const int PER = P / MSM_SORT_BLOCK;  // 2, 4 or 8 counters per thread
-    const int t = threadIdx.x;
-    uint32_t c[MSM_P_PER_MAX], sum = 0;
-#pragma unroll
-    for (int j = 0; j < MSM_P_PER_MAX; j++) { c[j] = j < PER ? part_cnt[t * PER + j] : 0u; sum += c[j]; }
-    uint32_t total;
-    uint32_t run = msm_block_scan(sum, scr, &total);
-#pragma unroll
-    for (int j = 0; j < MSM_P_PER_MAX; j++)
-        if (j < PER) { part_start[t * PER + j] = run; run += c[j]; }
-    if (t == 0) part_start[P] = total;
-}
-
-// Scatter of pass 1.  A tile of sh.tile (1024) scalars yields <= W*tile entries; they are first grouped by partition in
-// LDS (a block-local counting sort) and then copied out slot by slot, so that neighbouring lanes write
-// neighbouring addresses: the entries of one partition leave as one run instead of as isolated 8-byte stores
-// (which cost a 32-byte sector each: rocprof showed 3.9x write amplification for the direct scatter).
-// Entry = (key, table index | sign); pass 2 uses the low LB bits of the key.
-template <class SF>
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint4* __restrict__ scalars,
-                                                                        const uint32_t* __restrict__ block_off,
-                                                                        const uint32_t* __restrict__ part_start, uint2* __restrict__ inter,
-                                                                        MsmShape sh, size_t chunk, int is_mont) {
-    msm_set_wave_prio(0);
-    extern __shared__ uint32_t lds[];
-    const int P = sh.P, PER = P / MSM_SORT_BLOCK;
-    uint32_t* goff = lds;          // [P] where this block's next entry of partition p goes
-    uint32_t* cnt = goff + P;      // [P] entries of the current tile, then the placement cursor
-    uint32_t* start = cnt + P;     // [P] exclusive scan of cnt
-    uint32_t* scr = start + P;     // [32]
-    uint2* stage = reinterpret_cast<uint2*>(scr + 32);  // [W * tile]
-    const int t = threadIdx.x;
-    for (int p = t; p < P; p += MSM_SORT_BLOCK) {
-        goff[p] = part_start[p] + block_off[(size_t)blockIdx.x * P + p];
-        cnt[p] = 0;
-    }
-    __syncthreads();
-    size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
-    for (size_t base = lo; base < hi; base += sh.tile) {
-        const size_t i = base + t;
-        const bool live = t < sh.tile && i < hi;
-        Fe<SF> s;
-        if (live) {
-            s = msm_load_scalar<SF>(scalars, i, is_mont);
-            uint32_t carry = 0;
-            uint32_t r[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) r[k] = s.l[k];
-            for (int w = 0; w < sh.W; w++) {
-                uint32_t mag = msm_digit_next(r, sh.c, carry) & ~MSM_SIGN;
-                if (mag) atomicAdd(&cnt[msm_key(sh, (uint32_t)w, mag, i) >> sh.LB], 1u);
-            }
-        }
-        __syncthreads();
-        uint32_t c[MSM_P_PER_MAX], sum = 0, total;
-#pragma unroll
-        for (int j = 0; j < MSM_P_PER_MAX; j++) { c[j] = j < PER ? cnt[t * PER + j] : 0u; sum += c[j]; }
-        uint32_t run = msm_block_scan(sum, scr, &total);
-#pragma unroll
-        for (int j = 0; j < MSM_P_PER_MAX; j++)
-            if (j < PER) { start[t * PER + j] = run; run += c[j]; cnt[t * PER + j] = 0; }
-        __syncthreads();
-        if (live) {
-            uint32_t carry = 0;
-            uint32_t r[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) r[k] = s.l[k];
-            for (int w = 0; w < sh.W; w++) {
-                uint32_t d = msm_digit_next(r, sh.c, carry);
-                uint32_t mag = d & ~MSM_SIGN;
-                if (mag) {
-                    uint32_t key = msm_key(sh, (uint32_t)w, mag, i);
-                    uint32_t p = key >> sh.LB;
-                    uint32_t slot = start[p] + atomicAdd(&cnt[p], 1u);
-                    stage[slot] = make_uint2(key, ((uint32_t)((size_t)w * sh.stride) + (uint32_t)i) | (d & MSM_SIGN));
-                }
-            }
-        }
-        __syncthreads();
-        for (uint32_t j = t; j < total; j += MSM_SORT_BLOCK) {
-            uint2 e = stage[j];
-            uint32_t p = e.x >> sh.LB;
-            inter[goff[p] + (j - start[p])] = e;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < MSM_P_PER_MAX; j++)
-            if (j < PER) { goff[t * PER + j] += c[j]; cnt[t * PER + j] = 0; }
-        __syncthreads();
-    }
-}
-static size_t msm_scatter1_lds(int P, int W, int tile) { return (size_t)(3 * P + 32) * 4 + (size_t)W * tile * 8; }
-
-// ---- 2b. sort pass 2: block p sorts partition p by the low key bits ---------------------------------
-// Emits the final sorted entry list, the bucket sizes and the bucket starts of its 2^LB keys.  A partition of
-// <= cap entries is sorted into LDS and leaves as one contiguous copy; a larger one (very skewed scalars,
-// or more entries than 2048 partitions can split) falls back to scattering straight to global memory.
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part2_kernel(const uint2* __restrict__ inter, const uint32_t* __restrict__ part_start,
-                                                                     uint32_t* __restrict__ sorted, uint32_t* __restrict__ cnt,
-                                                                     uint32_t* __restrict__ bucket_start, MsmShape sh, uint32_t cap) {
-    msm_set_wave_prio(0);
-    extern __shared__ uint32_t lds[];  // [2^LB] counters, [32] scan scratch, [cap] staged output
-    const int p = blockIdx.x, t = threadIdx.x;
-    const uint32_t nbins = 1u << sh.LB, low_mask = nbins - 1u;
-    uint32_t* h = lds;
-    uint32_t* scr = lds + nbins;
-    uint32_t* stage = scr + 32;
-    for (uint32_t b = t; b < nbins; b += MSM_SORT_BLOCK) h[b] = 0;
-    __syncthreads();
-    const uint32_t lo = part_start[p], hi = part_start[p + 1];
-    const bool staged = hi - lo <= cap;
-    constexpr int U = 8;  // independent loads in flight per lane: the sweeps are latency bound otherwise
-    for (uint32_t base = lo; base < hi; base += MSM_SORT_BLOCK * U) {
-        uint32_t k[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint32_t e = base + u * MSM_SORT_BLOCK + t;
-            k[u] = e < hi ? (inter[e].x & low_mask) : 0xffffffffu;
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (k[u] != 0xffffffffu) atomicAdd(&h[k[u]], 1u);
-    }
-    __syncthreads();
-    // exclusive scan over the bins: each thread owns a contiguous run of bins
-    const uint32_t per = (nbins + MSM_SORT_BLOCK - 1) / MSM_SORT_BLOCK;
-    uint32_t sum = 0;
-    for (uint32_t j = 0; j < per; j++) {
-        uint32_t b = t * per + j;
-        if (b < nbins) sum += h[b];
-    }
-    uint32_t total;
-    uint32_t run = lo + msm_block_scan(sum, scr, &total);
-    for (uint32_t j = 0; j < per; j++) {
-        uint32_t b = t * per + j;
-        if (b < nbins) {
-            uint32_t c = h[b];
-            size_t key = ((size_t)p << sh.LB) + b;
-            cnt[key] = c;
-            bucket_start[key] = run;
-            h[b] = run;  // becomes the scatter cursor
-            run += c;
-        }
-    }
-    __syncthreads();
-    for (uint32_t base = lo; base < hi; base += MSM_SORT_BLOCK * U) {
-        uint2 v[U];
-        uint32_t pos[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            uint32_t e = base + u * MSM_SORT_BLOCK + t;
-            v[u] = e < hi ? inter[e] : make_uint2(0xffffffffu, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++)
-            if (v[u].x != 0xffffffffu) pos[u] = atomicAdd(&h[v[u].x & low_mask], 1u);
-        if (staged) {
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (v[u].x != 0xffffffffu) stage[pos[u] - lo] = v[u].y;
-        } else {
-#pragma unroll
-            for (int u = 0; u < U; u++)
-                if (v[u].x != 0xffffffffu) sorted[pos[u]] = v[u].y;
-        }
-    }
-    if (staged) {
-        __syncthreads();
-        for (uint32_t j = t; j < hi - lo; j += MSM_SORT_BLOCK) sorted[lo + j] = stage[j];
-    }
-}
-constexpr size_t MSM_LDS_BYTES = 160 * 1024;  // per workgroup on gfx950
-static size_t msm_part2_cap(int LB) { return (MSM_LDS_BYTES - (((size_t)1 << LB) + 32) * 4) / 4; }
+// ---- 1-2. digits and sort: msm_sort.hip (msm_launch_sort) ---------------------------------------------
 
 // ---- 3. task planning ------------------------------------------------------------------------
 // block g (group of MSM_GRP keys), 1024 threads x 32 keys: task starts inside the group + group total
@@ -728,40 +414,17 @@ struct MsmCtx : MsmCtxBase {
     Work* acc_ring[MSM_SLOTS] = {};
     int acc_ring_pos = 0, acc_ring_count = 0;
 
-    MsmShape shape(size_t n, int sel = -1) const {
-        MsmShape sh;
-        sh.c = c;
-        sh.W = msm_num_windows(c);
-        sh.sel = precomputed ? sel : -1;
-        sh.G = precomputed ? (sh.sel >= 0 ? 2 : 1) : sh.W;
-        sh.B = 1u << (c - 1);
-        sh.NB = (uint32_t)sh.G * sh.B;
-        // partitions: as few as let an average partition (W n / P entries) fit the LDS stage of pass 2 with 15 % to
-        // spare - 2048 up to n = 2^22, 4096 for the rc = 900 step circuit (n ~ 10^7), 8192 beyond
-        sh.P = MSM_P_MIN;
-        while (sh.P < MSM_P_MAX && (uint32_t)sh.P < sh.NB) {
-            int lb = 0;
-            while ((sh.NB >> lb) > (uint32_t)sh.P) lb++;
-            if ((double)sh.W * (double)n / sh.P <= 0.85 * (double)msm_part2_cap(lb)) break;
-            sh.P *= 2;
-        }
-        sh.LB = 0;
-        while ((sh.NB >> sh.LB) > (uint32_t)sh.P) sh.LB++;
-        sh.tile = MSM_SORT_BLOCK;
-        while (sh.tile > 64 && msm_scatter1_lds(sh.P, sh.W, sh.tile) > MSM_LDS_BYTES) sh.tile /= 2;
-        sh.NG = (int)(sh.NB / MSM_GRP);
-        sh.n = n;
-        sh.stride = precomputed ? npoints : 0;
-        return sh;
-    }
+    MsmShape shape(size_t n, int sel = -1) const { return msm_make_shape(c, precomputed, npoints, n, sel); }
 
-    void set_bases_device(const void* d_bases, size_t n, bool copy, bool precompute, int c_override, hipStream_t s) {
+    // small_pref: 0 = the small form when it fits a quarter of the free memory (the default), 1 = the small form or an error, -1 = never
+    void set_bases_device(const void* d_bases, size_t n, bool copy, bool precompute, int c_override, hipStream_t s, int small_pref = 0) {
         npoints = n;
         precomputed = precompute;
         small = false;
         small_table.release();
-        bool small_form = precompute && !c_override && n > 0 && n <= MSM_SMALL_MAX_POINTS;
-        if (small_form) {
+        bool small_form = precompute && !c_override && n > 0 && n <= MSM_SMALL_MAX_POINTS && small_pref >= 0;
+        LURK_REQUIRE(small_pref <= 0 || small_form, "LURK_MSM_FLAG_SMALL_FORM: the small form needs the precompute flag, no window override and 1 .. 2^16 points");
+        if (small_form && small_pref == 0) {
             // the small form is a memory-for-latency trade sized for 288 GB: 256 KiB per point resident (4.3 GB at 2^14 points, 5.6 GB
             // at 2^16) + <= 1 GiB of build scratch.  It is taken only when that is at most a quarter of what the device has free
             // right now (several keys per process, slices of a multi-device key and smaller devices then get the window table)
@@ -964,7 +627,7 @@ struct MsmCtx : MsmCtxBase {
         // keys) to a plain one (c = 16: 16 n entries, 16 x 2^15 keys) keeps its workspaces and must grow them
         const size_t entries = (size_t)sh.W * sh.n, nt = ntask_max(sh);
         if (wk.ws_n != 0 && entries <= wk.ws_entries && nt <= wk.ws_nt && sh.NB <= wk.ws_NB) return;
-        wk.inter.ensure(entries * 8);
+        wk.inter.ensure(msm_inter_bytes(entries));
         wk.sorted.ensure(entries * 4);
         wk.block_hist.ensure((size_t)MSM_NB1 * MSM_P_MAX * 4);
         wk.part_cnt.ensure(MSM_P_MAX * 4);
@@ -1004,35 +667,24 @@ struct MsmCtx : MsmCtxBase {
         }
         const MsmShape sh = shape(n, wk.sel);
         ensure_workspace(wk, sh);
-        const size_t chunk = (n + MSM_NB1 - 1) / MSM_NB1;
         const size_t nt = ntask_max(sh);
-        allow_dynamic_lds((const void*)msm_scatter1_kernel<SF>, (int)MSM_LDS_BYTES);
-        allow_dynamic_lds((const void*)msm_part2_kernel, (int)MSM_LDS_BYTES);
-        LURK_REQUIRE(msm_scatter1_lds(sh.P, sh.W, sh.tile) <= MSM_LDS_BYTES, "pass-1 tile does not fit the LDS");
-        if (is_mont) {  // one conversion pass; both sweeps of sort pass 1 then read canonical scalars
-            wk.canon.ensure(n * 32);
-            ProfScope ps("msm_sort", s);
-            unsigned blocks = div_up(n, 256), cap = (unsigned)num_cus() * 8;
-            if (blocks > cap) blocks = cap;
-            hipLaunchKernelGGL((msm_canon_kernel<SF>), dim3(blocks), dim3(256), 0, s, (const uint4*)d_scalars, wk.canon.template as<uint4>(), n);
-            d_scalars = wk.canon.p;
-            is_mont = 0;
-        }
         {
+            // canonical scalars (when they arrive in Montgomery form) + the two-pass sort: msm_sort.hip
+            if (is_mont) wk.canon.ensure(n * 32);
             ProfScope ps("msm_sort", s);
-            hipLaunchKernelGGL((msm_hist1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), (size_t)sh.P * 4, s, (const uint4*)d_scalars,
-                               wk.block_hist.template as<uint32_t>(), sh, chunk, is_mont);
-            hipLaunchKernelGGL(msm_scan1_kernel, dim3(sh.P), dim3(MSM_NB1), 0, s, wk.block_hist.template as<uint32_t>(),
-                               wk.part_cnt.template as<uint32_t>(), sh.P);
-            hipLaunchKernelGGL(msm_part_start_kernel, dim3(1), dim3(MSM_SORT_BLOCK), 0, s, wk.part_cnt.template as<uint32_t>(),
-                               wk.part_start.template as<uint32_t>(), sh.P, wk.big_count.template as<uint32_t>(), 1,
-                               wk.len_hist.template as<uint32_t>(), 2 * (MSM_S + 1), wk.cursor.template as<uint32_t>(), MSM_PLACEMENT_BASE + 512);
-            hipLaunchKernelGGL((msm_scatter1_kernel<SF>), dim3(MSM_NB1), dim3(MSM_SORT_BLOCK), msm_scatter1_lds(sh.P, sh.W, sh.tile), s,
-                               (const uint4*)d_scalars, wk.block_hist.template as<uint32_t>(), wk.part_start.template as<uint32_t>(),
-                               wk.inter.template as<uint2>(), sh, chunk, is_mont);
-            hipLaunchKernelGGL(msm_part2_kernel, dim3(sh.P), dim3(MSM_SORT_BLOCK), MSM_LDS_BYTES, s, wk.inter.template as<uint2>(),
-                               wk.part_start.template as<uint32_t>(), wk.sorted.template as<uint32_t>(), wk.cnt.template as<uint32_t>(),
-                               wk.bucket_start.template as<uint32_t>(), sh, (uint32_t)msm_part2_cap(sh.LB));
+            MsmSortBufs sb;
+            sb.inter = wk.inter.p;
+            sb.sorted = wk.sorted.template as<uint32_t>();
+            sb.block_hist = wk.block_hist.template as<uint32_t>();
+            sb.part_cnt = wk.part_cnt.template as<uint32_t>();
+            sb.part_start = wk.part_start.template as<uint32_t>();
+            sb.cnt = wk.cnt.template as<uint32_t>();
+            sb.bucket_start = wk.bucket_start.template as<uint32_t>();
+            sb.canon = wk.canon.p;
+            sb.zero[0] = wk.big_count.template as<uint32_t>(); sb.zero_n[0] = 1;
+            sb.zero[1] = wk.len_hist.template as<uint32_t>(); sb.zero_n[1] = 2 * (MSM_S + 1);
+            sb.zero[2] = wk.cursor.template as<uint32_t>(); sb.zero_n[2] = MSM_PLACEMENT_BASE + 512;
+            msm_launch_sort<SF>(sh, d_scalars, is_mont, sb, s);
         }
         {
             ProfScope ps("msm_tasks", s);
@@ -1077,7 +729,7 @@ struct MsmCtx : MsmCtxBase {
                 if (acc_ring_count < MSM_SLOTS) acc_ring_count++;
             }
             {
-                ProfScope ps("msm_accumulate", s_acc);
+                ProfScope ps("msm_accumulate_persistent", s_acc);  // (prefix "msm_accumulate" still matches both forms)
                 msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
                                                     wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
                                                     wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(), s_acc);
@@ -1263,8 +915,10 @@ static MsmCtxBase* new_ctx(int curve) {
 static void ctx_set_bases(MsmCtxBase* c, const void* d_bases, size_t n, bool copy, int flags, hipStream_t s) {
     bool pre = (flags & LURK_MSM_FLAG_PRECOMPUTE) != 0;
     int c_override = (flags >> 8) & 0xff;
-    if (c->curve == LURK_CURVE_PALLAS) static_cast<MsmCtx<PallasFp, PallasFq>*>(c)->set_bases_device(d_bases, n, copy, pre, c_override, s);
-    else static_cast<MsmCtx<PallasFq, PallasFp>*>(c)->set_bases_device(d_bases, n, copy, pre, c_override, s);
+    LURK_REQUIRE(!((flags & LURK_MSM_FLAG_SMALL_FORM) && (flags & LURK_MSM_FLAG_NO_SMALL_FORM)), "LURK_MSM_FLAG_SMALL_FORM and LURK_MSM_FLAG_NO_SMALL_FORM exclude each other");
+    const int small_pref = (flags & LURK_MSM_FLAG_SMALL_FORM) ? 1 : (flags & LURK_MSM_FLAG_NO_SMALL_FORM) ? -1 : 0;
+    if (c->curve == LURK_CURVE_PALLAS) static_cast<MsmCtx<PallasFp, PallasFq>*>(c)->set_bases_device(d_bases, n, copy, pre, c_override, s, small_pref);
+    else static_cast<MsmCtx<PallasFq, PallasFp>*>(c)->set_bases_device(d_bases, n, copy, pre, c_override, s, small_pref);
 }
 
 template <class P>
@@ -1651,7 +1305,13 @@ int lurk_hip_msm_ctx_info(const lurk_hip_msm_ctx* ctx, int* curve, size_t* npoin
         if (curve) *curve = ctx->impl->curve;
         if (npoints) *npoints = ctx->impl->npoints;
         if (window_bits) *window_bits = ctx->impl->c;
-        if (precomputed) *precomputed = ctx->impl->small ? LURK_MSM_FORM_SMALL : ctx->impl->precomputed ? LURK_MSM_FORM_TABLE : LURK_MSM_FORM_PLAIN;
+        if (precomputed) *precomputed = (ctx->impl->small || ctx->impl->precomputed) ? 1 : 0;  // a boolean, as before the small form existed
+    });
+}
+int lurk_hip_msm_ctx_form(const lurk_hip_msm_ctx* ctx, int* form) {
+    return guarded([&] {
+        LURK_REQUIRE(ctx && form, "null argument");
+        *form = ctx->impl->small ? LURK_MSM_FORM_SMALL : ctx->impl->precomputed ? LURK_MSM_FORM_TABLE : LURK_MSM_FORM_PLAIN;
     });
 }
 

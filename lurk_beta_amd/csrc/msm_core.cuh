@@ -73,6 +73,27 @@ LURK_HD uint32_t msm_digit_next(uint32_t (&r)[8], int c, uint32_t& carry) {
     return raw;
 }
 
+// All W = ceil(256 / C) signed digits of a canonical scalar at once, for a window width known at compile time: after unrolling
+// every digit is cut out at a constant bit position (a shift, at most one funnel from the next limb, a mask) and the W results stay
+// in registers - what the sort kernels use for the widths the library itself chooses (16 and 20); = msm_digit_step digit for digit
+// (tests/host_harness).
+template <int C>
+LURK_HD void msm_digits_ct(const uint32_t (&s)[8], uint32_t (&d)[(256 + C - 1) / C]) {
+    constexpr int W = (256 + C - 1) / C;
+    constexpr uint32_t half = 1u << (C - 1), mask = (1u << C) - 1u;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        const int bit = w * C, limb = bit >> 5, sh = bit & 31;
+        uint32_t raw = s[limb] >> sh;
+        if (sh + C > 32 && limb + 1 < 8) raw |= s[limb + 1] << (32 - sh);
+        raw = (raw & mask) + carry;
+        const bool neg = raw > half;
+        carry = neg ? 1u : 0u;
+        d[w] = neg ? (((1u << C) - raw) | MSM_SIGN) : raw;
+    }
+}
+
 // largest g with start[g] <= t, over start[0..n] (start[n] is the sentinel = total)
 LURK_HD uint32_t msm_upper_slot(const uint32_t* start, uint32_t n, uint32_t t) {
     uint32_t lo = 0, hi = n;  // invariant: start[lo] <= t < start[hi]

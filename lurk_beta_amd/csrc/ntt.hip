@@ -448,6 +448,9 @@ static void ntt_device(void* d_data, unsigned log_n, bool inverse, hipStream_t s
             const size_t lds = ntt_wave_lds(ns);
             const Fe<F>* src = first ? data : tmp;
             Fe<F>* dst = last ? data : tmp;
+            // per-pass HIP-event times beside the whole transform's ("ntt"): what bench.py quotes next to the rocprofv3 summary
+            static const char* const pass_names[4] = {"pass_ntt_0", "pass_ntt_1", "pass_ntt_2", "pass_ntt_3"};
+            ProfScope pp(pass_names[p < 4 ? p : 3], s);
             if (first) {
                 allow_dynamic_lds((const void*)ntt_wave_pass_kernel<F, true>, 160 * 1024);
                 hipLaunchKernelGGL((ntt_wave_pass_kernel<F, true>), dim3((unsigned)(n >> NTT_W_TILE_LOG)), dim3(NTT_W_BLOCK), lds, s, src, tmp, tw, log_n, 0u, ns,

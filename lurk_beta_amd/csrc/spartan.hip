@@ -252,6 +252,19 @@ int lurk_hip_spartan_prove_dev(const lurk_hip_r1cs* shape, const lurk_hip_r1cs* 
         if (lurk_hip_msm_ctx_info(key, &curve, &points, &bits, &form) != 0 || lurk_hip_msm_ctx_device(key, &device) != 0)
             throw HipFailure{LURK_HIP_ERR_INVALID_ARG, lurk_hip_last_error()};
         LURK_REQUIRE(points >= (num_cons > num_vars ? num_cons : num_vars), "the key has fewer points than the padded polynomials have elements");
+        // every scratch vector below is sized from (num_cons, num_vars, num_io) while the mat-vecs write what the shapes say: the two must agree
+        // (the transposed shape is 2 num_vars rows over the num_cons columns, stored as num_vars = num_cons - 1, num_io = 0), and the shapes'
+        // field must be the scalar field of the key's curve
+        {
+            const int want_field = curve == LURK_CURVE_PALLAS ? LURK_FIELD_PALLAS_FQ : LURK_FIELD_PALLAS_FP;
+            int f = -1, ft = -1;
+            size_t c = 0, v = 0, io = 0, ct = 0, vt = 0, iot = 0;
+            if (lurk_hip_r1cs_dims(shape, &f, &c, &v, &io) != 0 || lurk_hip_r1cs_dims(shape_t, &ft, &ct, &vt, &iot) != 0)
+                throw HipFailure{LURK_HIP_ERR_INVALID_ARG, lurk_hip_last_error()};
+            LURK_REQUIRE(c == num_cons && v == num_vars && io == num_io, "shape: its (num_cons, num_vars, num_io) differ from the arguments");
+            LURK_REQUIRE(ct == 2 * num_vars && vt + 1 + iot == num_cons, "shape_t: not the transpose of the shape (2 num_vars rows over num_cons columns)");
+            LURK_REQUIRE(f == want_field && ft == want_field, "the shapes are not over the scalar field of the key's curve");
+        }
         DeviceGuard dg(device);
         if (curve == LURK_CURVE_PALLAS)
             spartan_prove<PallasFq>(curve, LURK_FIELD_PALLAS_FQ, shape, shape_t, num_cons, num_vars, num_io, key, ck_c_jacobian96, x32_canonical, u32_canonical, d_w, d_e,

@@ -86,6 +86,7 @@ struct lurk_hip_fold_ctx {
     // time a begin brings late ranges and kept while their layout stays the same: their commitment is then one launch over ~10^4 scalars
     // instead of a pass of the bucket pipeline over a num_vars-long vector that is zero everywhere else.
     lurk_hip_msm_ctx* late_key = nullptr;
+    bool late_key_refused = false;  // the device could not hold the late ranges' small-form table: they go through slot 3 from then on
     std::vector<std::pair<size_t, size_t>> late_layout;
     DevBuf late_vals;
     lurk_hip_fold_submit_hook_fn submit_hook = nullptr;  // lurk_hip_fold_ctx_set_submit_hook
@@ -202,6 +203,8 @@ static lurk_hip_msm_ctx* fold_staged_key(lurk_hip_fold_ctx* c, int b) { return c
 
 static void fold_submit_staged(lurk_hip_fold_ctx* c, int b, int mode) {
     if (c->submitted[b]) return;
+    // (an instance staged whole is read in place: begin refuses late ranges for it, and what begin does write - u2 and X2 - lies
+    // behind the num_vars elements a commitment, or a helper's peer copy, reads)
     const void* src = c->partial[b] ? c->zstaged[b].p : c->z2[b].p;
     if (c->helper_of[b] >= 0) {  // on another device: push the staged ranges there (ordered after their staging here), commit under the helper's key
         auto& h = *c->helpers[c->helper_of[b]];
@@ -260,7 +263,7 @@ constexpr size_t FOLD_LATE_KEY_MAX = (size_t)1 << 16;  // late positions a key o
 
 // true: c->late_key commits exactly the positions of these patches, in their order
 static bool fold_late_key(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, size_t n_patches, size_t patched, hipStream_t s) {
-    if (!c->key || patched == 0 || patched > FOLD_LATE_KEY_MAX) return false;
+    if (!c->key || patched == 0 || patched > FOLD_LATE_KEY_MAX || c->late_key_refused) return false;
     const char* sw = getenv("LURK_FOLD_LATE_KEY");  // 0: late ranges through the key's slot 3 as a num_vars-long vector (the form above 2^16 late positions)
     if (sw && atoi(sw) == 0) return false;
     std::vector<std::pair<size_t, size_t>> layout;
@@ -280,7 +283,15 @@ static bool fold_late_key(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches
         at += r.second;
     }
     LURK_HIP_CHECK(hipStreamSynchronize(s));
-    ok(lurk_hip_msm_ctx_create_dev(&c->late_key, c->curve, pts.p, patched, LURK_MSM_FLAG_PRECOMPUTE, (void*)s));
+    // the small-commitment form, stated (not left to what happens to be free at this moment): a device that cannot hold its table
+    // (256 KiB per late position) sends the late ranges through slot 3 of the key instead - the same answer on every later step
+    if (lurk_hip_msm_ctx_create_dev(&c->late_key, c->curve, pts.p, patched, LURK_MSM_FLAG_PRECOMPUTE | LURK_MSM_FLAG_SMALL_FORM, (void*)s) != 0) {
+        c->late_key = nullptr;
+        if (last_error_code() != LURK_HIP_ERR_OOM) throw HipFailure{last_error_code(), lurk_hip_last_error()};
+        c->late_layout.clear();
+        c->late_key_refused = true;
+        return false;
+    }
     c->late_layout = layout;
     return true;
 }
@@ -445,14 +456,32 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
 // rollback has returned it to the queue with nothing in flight), so that the caller can repeat the call as it stands
 static void fold_stage_and_begin(lurk_hip_fold_ctx* c, const void* w2, int on_device, void* w2_stream, const void* x2_mont, void* comm_w2_jac96,
                                  void* comm_t_jac96) {
+    const int n_before = c->n_staged, mine = c->next_buf;  // the buffer fold_stage is about to take
     fold_stage(c, w2, 0, c->num_vars, on_device, w2_stream);
     try {
         fold_begin(c, nullptr, 0, x2_mont, comm_w2_jac96, comm_t_jac96);
     } catch (...) {
-        if (c->n_staged == 1) {
-            c->next_buf = c->staged[0];
-            c->n_staged = 0;
+        // fold_begin's rollback has put the instance it consumed back at the head of the queue with nothing of it in flight.  Take
+        // back EXACTLY what this call added, whatever else is queued: the instance this call staged, and - when the submit hook
+        // staged the next one before the failure (the queue was empty when the call started, so anything behind `mine` is the
+        // hook's) - that one too, with its background commitment drained: the hook runs again when the call is repeated.
+        auto drain = [&](int b) {
+            if (c->submitted[b]) {
+                uint64_t junk[12];
+                (void)lurk_hip_msm_ctx_wait(fold_staged_key(c, b), 2 * b, junk);
+                c->submitted[b] = false;
+            }
+            (void)hipStreamSynchronize(c->stage_stream[b]);
+        };
+        int kept[2], n_kept = 0;
+        for (int k = 0; k < c->n_staged; k++) {
+            const int b = c->staged[k];
+            if (b == mine || n_before == 0) drain(b);
+            else kept[n_kept++] = b;
         }
+        for (int k = 0; k < n_kept; k++) c->staged[k] = kept[k];
+        c->n_staged = n_kept;
+        c->next_buf = mine;
         throw;
     }
 }
@@ -722,8 +751,23 @@ int lurk_hip_fold_step(lurk_hip_fold_ctx* c, const void* w2, int w2_on_device, v
         LURK_REQUIRE(!c->begun && !c->in_hook, "a step is already open: finish it first");
         LURK_REQUIRE(c->n_staged == 0, "fresh instances are staged: use lurk_hip_fold_step_begin_prefetched");
         uint64_t cw[12], ct[12], r[4];
-        memcpy(c->pp_digest, pp_digest32, 32);
-        c->has_pp = true;
+        // the digest belongs to THIS call: only lurk_hip_fold_ctx_set_pp_digest makes the staged transcript a property of the context
+        // (a caller with its own transcript that once used this entry point must not pay for - or fail in - nifs_pre_begin afterwards)
+        struct DigestScope {
+            lurk_hip_fold_ctx* c;
+            bool had;
+            uint8_t saved[32];
+            DigestScope(lurk_hip_fold_ctx* cc, const void* d) : c(cc), had(cc->has_pp) {
+                memcpy(saved, c->pp_digest, 32);
+                memcpy(c->pp_digest, d, 32);
+                c->has_pp = true;
+            }
+            ~DigestScope() {
+                memcpy(c->pp_digest, saved, 32);
+                c->has_pp = had;
+                if (!had) fold_challenge_drop(c);
+            }
+        } digest_scope(c, pp_digest32);
         if (c->mkey) {
             fold_begin_multi(c, w2, w2_on_device, w2_stream, x2_mont, cw, ct);
         } else {

@@ -174,6 +174,26 @@ struct SumcheckScratch {
     SumcheckScratch(const SumcheckScratch&) = delete;
 };
 
+struct SumcheckCachedScratch {
+    std::mutex mu;  // rounds that share a stream are ordered on it; their host sides take turns here
+    SumcheckScratch sc;
+    explicit SumcheckCachedScratch(hipStream_t s) : sc(s) {}
+};
+static SumcheckScratch* sumcheck_cached_scratch(hipStream_t s, std::unique_lock<std::mutex>& lk) {
+    static std::mutex map_mu;
+    static auto& cache = *new std::map<std::pair<int, hipStream_t>, SumcheckCachedScratch*>();  // never torn down (process lifetime)
+    SumcheckCachedScratch* e;
+    {
+        std::lock_guard<std::mutex> g(map_mu);
+        auto key = std::make_pair(current_device(), s);
+        auto it = cache.find(key);
+        if (it == cache.end()) it = cache.emplace(key, new SumcheckCachedScratch(s)).first;
+        e = it->second;
+    }
+    lk = std::unique_lock<std::mutex>(e->mu);
+    return &e->sc;
+}
+
 template <class F>
 static void sumcheck_round(int np, void* const* d_polys, size_t len, const void* r32_mont, void* evals_out, hipStream_t s, SumcheckScratch* sc = nullptr) {
     LURK_REQUIRE(len >= 2 && (len & (len - 1)) == 0, "table length must be a power of two >= 2");
@@ -185,11 +205,11 @@ static void sumcheck_round(int np, void* const* d_polys, size_t len, const void*
     const int nv = np == 4 ? 3 : 2;
     Fe<F> r = fe_zero<F>();
     if (bind) memcpy(r.l, r32_mont, 32);
-    std::unique_ptr<SumcheckScratch> own;
-    if (!sc) {
-        own.reset(new SumcheckScratch(s));
-        sc = own.get();
-    }
+    // a caller that drives its own round loop through the per-round entry point gets ONE scratch per (device, stream), made at its
+    // first round and kept: no pinned allocation, no synchronisation beyond the one that hands the round's totals to the host - and
+    // none at all for the last bind (evals_out == NULL)
+    std::unique_lock<std::mutex> cached_lk;
+    if (!sc) sc = sumcheck_cached_scratch(s, cached_lk);
     Fe<F>* partial = (Fe<F>*)sc->partial;
     uint32_t* counter = evals_out ? sc->counter : nullptr;
     Fe<F>* fin = evals_out ? (Fe<F>*)sc->host_final : nullptr;

@@ -53,11 +53,13 @@ class CommitmentKey:
     """Resident commitment key (``ck``): n affine bases kept in HBM for the lifetime of the object."""
 
     def __init__(self, curve: int, bases, n: int | None = None, precompute: bool = False, device: bool = False, stream=None,
-                 window_bits: int = 0):
+                 window_bits: int = 0, small_form: bool | None = None):
+        """small_form: None = the library decides for keys of <= 2^16 points (by the memory that is free); True = the small-commitment
+        form or an error (LURK_MSM_FLAG_SMALL_FORM); False = never (LURK_MSM_FLAG_NO_SMALL_FORM)"""
         lib = _lib.load()
         self.curve = curve
         self._ctx = ctypes.c_void_p()
-        flags = (1 if precompute else 0) | ((window_bits & 0xFF) << 8)
+        flags = (1 if precompute else 0) | ((window_bits & 0xFF) << 8) | ((1 << 16) if small_form else (1 << 17) if small_form is False else 0)
         if device:
             assert n is not None
             self.n = n
@@ -103,9 +105,11 @@ class CommitmentKey:
 
     def info(self) -> dict:
         c, n, w, p = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
+        f = ctypes.c_int()
         _lib.check(_lib.load().lurk_hip_msm_ctx_info(self._ctx, ctypes.byref(c), ctypes.byref(n), ctypes.byref(w), ctypes.byref(p)))
+        _lib.check(_lib.load().lurk_hip_msm_ctx_form(self._ctx, ctypes.byref(f)))
         return {"curve": c.value, "npoints": n.value, "window_bits": w.value, "precomputed": bool(p.value),
-                "form": {0: "plain", 1: "table", 2: "small"}[p.value]}
+                "form": {0: "plain", 1: "table", 2: "small"}[f.value]}
 
     def commit(self, scalars: np.ndarray, is_mont: bool = False) -> np.ndarray:
         """``CE::commit(ck, v)``: host scalars (len <= n) -> Jacobian commitment."""

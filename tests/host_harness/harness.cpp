@@ -299,6 +299,28 @@ extern "C" void hh_msm_digits(const uint32_t* scalar8, int c, uint32_t* by_step,
     for (int w = 0; w < W; w++) by_walk[w] = msm_digit_next(r, c, carry);
 }
 
+// the compile-time recoding of the sort kernels (msm_digits_ct<C>: all W digits at constant bit positions); returns W, or 0 for a width
+// that has no instantiation here
+template <int C>
+static int hh_digits_ct(const uint32_t* scalar8, uint32_t* out) {
+    uint32_t s[8], d[(256 + C - 1) / C];
+    for (int k = 0; k < 8; k++) s[k] = scalar8[k];
+    msm_digits_ct<C>(s, d);
+    for (int w = 0; w < (256 + C - 1) / C; w++) out[w] = d[w];
+    return (256 + C - 1) / C;
+}
+extern "C" int hh_msm_digits_ct(const uint32_t* scalar8, int c, uint32_t* out) {
+    switch (c) {
+        case 6: return hh_digits_ct<6>(scalar8, out);
+        case 8: return hh_digits_ct<8>(scalar8, out);
+        case 13: return hh_digits_ct<13>(scalar8, out);
+        case 16: return hh_digits_ct<16>(scalar8, out);
+        case 17: return hh_digits_ct<17>(scalar8, out);
+        case 20: return hh_digits_ct<20>(scalar8, out);
+        default: return 0;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The key fold's host plan (keyfold_plan.hpp, used by ipa.hip: key_fold): digits[(b * Wt + j) * U + u] = the signed sub-digit of weight b in
 // table window j, slot u, READ BACK FROM THE SORTED LISTS the kernel walks (ord / dstart / ord_base: magnitude by position, sign in bit 31).

@@ -21,6 +21,8 @@ def _info(key):
 
     cv, n, wb, pre = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_int(), ctypes.c_int()
     _lib.check(_lib.load().lurk_hip_msm_ctx_info(key._ctx, ctypes.byref(cv), ctypes.byref(n), ctypes.byref(wb), ctypes.byref(pre)))
+    assert pre.value in (0, 1)  # a boolean; the form comes from lurk_hip_msm_ctx_form
+    _lib.check(_lib.load().lurk_hip_msm_ctx_form(key._ctx, ctypes.byref(pre)))
     return cv.value, n.value, wb.value, pre.value
 
 

@@ -275,6 +275,10 @@ def test_signed_digits_register_walk_equals_indexed_recoding(c):
         a, b = np.zeros(W, dtype=np.uint32), np.zeros(W, dtype=np.uint32)
         H.lib().hh_msm_digits(vp(s), c, vp(a), vp(b))
         assert (a == b).all(), (c, hex(k))
+        if c != 18:  # the compile-time recoding of the sort kernels (msm_digits_ct<C>; the library instantiates 16 and 20)
+            ct = np.zeros(W, dtype=np.uint32)
+            assert H.lib().hh_msm_digits_ct(vp(s), c, vp(ct)) == W
+            assert (ct == a).all(), (c, hex(k))
         total = 0
         for w in range(W):
             mag, neg = int(a[w]) & 0x7FFFFFFF, int(a[w]) >> 31

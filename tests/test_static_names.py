@@ -12,6 +12,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MODULES = ["lurk_beta_amd." + m[:-3] for m in sorted(os.listdir(os.path.join(ROOT, "lurk_beta_amd"))) if m.endswith(".py") and m != "__init__.py"]
 MODULES += ["oracle.coracle", "oracle.pyref", "oracle.spartan_ref", "oracle.spartan_fast", "oracle.keccak_transcript", "oracle.circuit_ref", "oracle.keygen_ref"]
+MODULES += ["bench_workloads." + m[:-3] for m in sorted(os.listdir(os.path.join(ROOT, "bench_workloads"))) if m.endswith(".py") and m != "__init__.py"]
 FILES = ["bench.py", "__graft_entry__.py"]
 
 
