@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reps", type=int, default=5,
+                    help="msm: repetitions of the --steps region (each bracketed by barrier + synchronize); the MEDIAN region is what the line reports")
     ap.add_argument("--log-n", type=int, default=22)
     ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--precompute", type=int, default=1,
@@ -62,6 +64,8 @@ def main():
     ap.add_argument("--secondary", type=int, default=1, help="fold_step: 1 = also time the secondary-curve (Vesta, ~10^4 constraints) half of a step")
     ap.add_argument("--late-ranges", type=int, default=1, help="fold_step with --stage-ahead: 1 = 12 000 positions of W2 arrive with begin (the augmented circuit's), 0 = none")
     ap.add_argument("--ipa-resident-key", type=int, default=1, help="compress: 1 = inner-product rounds under the resident key (composed scalars), 0 = fold the key")
+    ap.add_argument("--spartan-prover", choices=["library", "python"], default="library",
+                    help="compress: library = lurk_hip_spartan_prove_dev, the prover as one call (default); python = the same entry points sequenced by lurk_beta_amd/spartan.py")
     ap.add_argument("--window-bits", type=int, default=0, help="window-bit override for the precomputed-table mode (16..20)")
     ap.add_argument("--workload", choices=["msm", "poseidon_tree", "ntt", "fold_step", "compress", "store_hydrate"], default="msm",
                     help="msm = the headline metric; poseidon_tree / ntt = the other hot-path kernels (BASELINE configs[2], N1); "
@@ -88,6 +92,10 @@ def main():
     ap.add_argument("--helper-devices", default="",
                     help="fold_step with --stage-ahead 1: comma-separated devices that each hold a copy of the commitment key and commit the instances staged "
                          "ahead in turn (lurk_hip_fold_ctx_add_helper: staging ahead across GPUs); e.g. 1,2,3 on a node, 0 on a one-GPU box (functional)")
+    ap.add_argument("--shape-file", default="", help="fold_step: a LURKDUMP R1CS shape (lurk_beta_amd/dump.py; written by rust/lurk-hip-sys/src/dump.rs from arecibo's "
+                                                     "R1CSShape) instead of the synthetic step circuit; needs --witness-file")
+    ap.add_argument("--witness-file", default="", help="fold_step: LURKDUMP witnesses (W, X of consecutive steps + pp_digest) for --shape-file")
+    ap.add_argument("--key-file", default="", help="fold_step with --shape-file: LURKDUMP commitment key (default: the synthetic key of the same length)")
     ap.add_argument("--sub-records", choices=["auto", "off"], default="auto",
                     help="auto = the default msm line at N = 1 also carries the other workloads of the path as verified sub-records "
                          "(fold_step_rc100, poseidon_tree_2_24, ntt_2_24, compress_2_20: each a child run of this file with --verify, same --steps / --warmup)")
@@ -127,6 +135,12 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.workload == "fold_step" and (args.shape_file or args.witness_file):
+        if not (args.shape_file and args.witness_file):
+            sys.exit("bench.py: --shape-file and --witness-file go together")
+        from bench_workloads.fold_step_files import fold_step_from_files
+
+        return fold_step_from_files(args, lib, world, rank)
     if args.workload == "fold_step":
         from bench_workloads.fold_step import fold_step_workload
 

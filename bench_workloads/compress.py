@@ -71,8 +71,10 @@ def compress_workload(args, lib, world, rank):
     ce = key.commit_device(d_E, nc, is_mont=True)
     torch.cuda.synchronize()
 
+    in_library = bool(args.ipa_resident_key) and args.spartan_prover == "library"  # the prover as ONE library call (what a Rust caller binds)
+
     def step():
-        return prover.prove(X, 1, d_W, d_E, d_ck, cw, ce, key=key if args.ipa_resident_key else None)
+        return prover.prove(X, 1, d_W, d_E, d_ck, cw, ce, key=key if args.ipa_resident_key else None, in_library=in_library)
 
     for _ in range(args.warmup):
         step()
@@ -126,7 +128,10 @@ def compress_workload(args, lib, world, rank):
                "config": {"workload": f"Spartan-style proof of a satisfied relaxed R1CS instance, 2^{log_n} constraints x 2^{log_n} variables "
                                       f"({int(A[0][-1]) + int(B[0][-1]) + rows_p} non-zeros): 3 sum-checks ({log_n} + {log_n + 1} + {log_n} rounds), "
                                       f"transposed sparse mat-vec, inner-product argument over a 2^{log_n}-point key",
-                          "note": "functional stand-in, not byte-compatible with arecibo; transcript and round glue in Python on the host",
+                          "note": "functional stand-in, not byte-compatible with arecibo; " +
+                                  ("the whole prover is ONE library call (lurk_hip_spartan_prove_dev: transcript, round loops and scratch arena inside)" if in_library else
+                                   "the prover's sequence driven from Python (lurk_beta_amd/spartan.py), round loops and transcript in the library"),
+                          "prover": "library" if in_library else "python",
                           "verified": verified,
                           "shape_setup_s_once": round(setup_s, 2)},
                "roofline": compress_roofline(lib, args, nc),

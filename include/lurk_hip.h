@@ -605,6 +605,41 @@ int lurk_hip_spartan_prove_dev(const lurk_hip_r1cs* shape, const lurk_hip_r1cs* 
                                const void* d_w32_mont, const void* d_e32_mont, const void* comm_w_jacobian96, const void* comm_e_jacobian96,
                                const void* label, size_t label_len, lurk_hip_spartan_proof* out, void* stream);
 
+/* The BATCHED compressing prover as one call: n relaxed instances of different shapes and sizes under one key, one proof - the structure
+ * of arecibo's spartan::batched::BatchedRelaxedR1CSSNARK, SuperNova's compressor (/root/reference/src/proof/supernova.rs:110, 293-302): one
+ * outer and one inner sum-check shared through powers of a challenge, all 2 n evaluation claims batched to one point, one opening.  The
+ * protocol is the repository's own (oracle/spartan_fast.py: prove_batched / verify_batched), as for the single-instance call.  Per
+ * instance the arguments of lurk_hip_spartan_prove_dev.  With ell_x = log2(max num_cons), ell_y = log2(max num_vars) + 1,
+ * N = max(num_cons, num_vars) over the instances, the outputs (host, canonical) are: polys_outer ell_x x 4 x 32 B, claims_outer
+ * n x 3 x 32, evals_e n x 32, polys_inner ell_y x 3 x 32, evals_w n x 32, polys_batch log2(N) x 3 x 32, evals_batch 2 n x 32 (W_i, E_i
+ * per instance), ipa_l / ipa_r log2(N) x 96 (Jacobians), ipa_a 32. */
+typedef struct lurk_hip_spartan_instance {
+    const lurk_hip_r1cs* shape;
+    const lurk_hip_r1cs* shape_t;
+    size_t num_cons, num_vars, num_io;
+    const void* x32_canonical;
+    const void* u32_canonical;
+    const void* d_w32_mont;
+    const void* d_e32_mont;
+    const void* comm_w_jacobian96;
+    const void* comm_e_jacobian96;
+} lurk_hip_spartan_instance;
+typedef struct lurk_hip_spartan_batch_proof {
+    void* polys_outer;
+    void* claims_outer;
+    void* evals_e;
+    void* polys_inner;
+    void* evals_w;
+    void* polys_batch;
+    void* evals_batch;
+    void* ipa_l;
+    void* ipa_r;
+    void* ipa_a;
+} lurk_hip_spartan_batch_proof;
+int lurk_hip_spartan_prove_batch_dev(const lurk_hip_spartan_instance* instances, size_t n_instances, lurk_hip_msm_ctx* key,
+                                     const void* ck_c_jacobian96, const void* label, size_t label_len, lurk_hip_spartan_batch_proof* out,
+                                     void* stream);
+
 /* ---- synthetic inputs (bench / tests) -------------------------------------
  * SplitMix64 counter mode, seed 0x4C55524B.  dist 0 = uniform, 1 = witness-like. */
 int lurk_hip_synth_scalars_dev(int field_id, uint64_t stream_id, int dist, size_t first, size_t n,

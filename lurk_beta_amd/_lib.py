@@ -143,6 +143,7 @@ SIGNATURES = {
     "lurk_hip_spartan_prove_dev": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                            c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_ipa_prove_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_spartan_prove_batch_dev": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_synth_scalars_dev": (c_int, [c_int, c_u64, c_int, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
     "lurk_hip_synth_bases_dev": (c_int, [c_int, c_size_t, c_size_t, c_void_p, c_void_p]),
 }
@@ -202,6 +203,18 @@ class KeccakRoundBindingStruct(ctypes.Structure):
 class SpartanProofStruct(ctypes.Structure):
     """lurk_hip_spartan_proof"""
     _fields_ = [(k, ctypes.c_void_p) for k in ("polys_outer", "claims_outer", "eval_e", "polys_inner", "eval_w", "polys_batch", "evals_batch", "ipa_l", "ipa_r", "ipa_a")]
+
+
+class SpartanInstanceStruct(ctypes.Structure):
+    """lurk_hip_spartan_instance"""
+    _fields_ = [("shape", ctypes.c_void_p), ("shape_t", ctypes.c_void_p), ("num_cons", ctypes.c_size_t), ("num_vars", ctypes.c_size_t), ("num_io", ctypes.c_size_t),
+                ("x32_canonical", ctypes.c_void_p), ("u32_canonical", ctypes.c_void_p), ("d_w32_mont", ctypes.c_void_p), ("d_e32_mont", ctypes.c_void_p),
+                ("comm_w_jacobian96", ctypes.c_void_p), ("comm_e_jacobian96", ctypes.c_void_p)]
+
+
+class SpartanBatchProofStruct(ctypes.Structure):
+    """lurk_hip_spartan_batch_proof"""
+    _fields_ = [(k, ctypes.c_void_p) for k in ("polys_outer", "claims_outer", "evals_e", "polys_inner", "evals_w", "polys_batch", "evals_batch", "ipa_l", "ipa_r", "ipa_a")]
 
 
 class KeccakRounds:

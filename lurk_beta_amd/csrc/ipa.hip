@@ -164,8 +164,8 @@ template <class F>
 static void inner_product(const void* d_a, const void* d_b, size_t n, void* out32, hipStream_t s) {
     unsigned blocks = n ? div_up(n, IPA_BLOCK) : 1, cap = (unsigned)num_cus() * 8;
     if (blocks > cap) blocks = cap;
-    Fe<F>* partial = nullptr;
-    LURK_HIP_CHECK(hipMallocAsync((void**)&partial, (size_t)blocks * 32, s));
+    ArenaBuf partial_buf((size_t)blocks * 32, s);
+    Fe<F>* partial = (Fe<F>*)partial_buf.p;
     {
         ProfScope ps("ipa_inner_product", s);
         hipLaunchKernelGGL((inner_product_kernel<F>), dim3(blocks), dim3(IPA_BLOCK), 0, s, (const Fe<F>*)d_a, (const Fe<F>*)d_b, n, partial);
@@ -173,7 +173,6 @@ static void inner_product(const void* d_a, const void* d_b, size_t n, void* out3
     hipError_t e = hipGetLastError();
     std::vector<uint64_t> host((size_t)blocks * 4);
     if (e == hipSuccess) e = hipMemcpyAsync(host.data(), partial, host.size() * 8, hipMemcpyDeviceToHost, s);
-    (void)hipFreeAsync(partial, s);
     LURK_HIP_CHECK(e);
     LURK_HIP_CHECK(hipStreamSynchronize(s));
     Fe<F> acc = fe_zero<F>();
@@ -318,12 +317,7 @@ static void key_fold(const MsmTableView& v, size_t n, const void* weights32_mont
     int log_t = 0;
     while (((size_t)1 << log_t) < T) log_t++;
     const uint32_t nslots = (uint32_t)(pl.U * pl.groups);
-    struct Scratch {
-        hipStream_t s;
-        void* p = nullptr;
-        Scratch(size_t bytes, hipStream_t s_) : s(s_) { LURK_HIP_CHECK(hipMallocAsync(&p, bytes ? bytes : 32, s)); }
-        ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
-    };
+    using Scratch = ArenaBuf;  // the stream's scratch arena (common.hpp)
     std::vector<uint32_t> base32(nslots), jlo32(pl.groups);
     for (uint32_t i = 0; i < nslots; i++) {
         LURK_REQUIRE(pl.ord_base[i] < ((size_t)1 << 32), "fold plan too large");
@@ -386,12 +380,7 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
     const bool pairs = ktable == LURK_MSM_FORM_TABLE;  // the window-table form commits L and R (disjoint supports) in one pass
     stream_pool_retain();
     // stream-ordered scratch (the pool keeps it between calls: a proof opens several of these arguments)
-    struct Scratch {
-        hipStream_t s;
-        void* p = nullptr;
-        Scratch(size_t bytes, hipStream_t s_) : s(s_) { LURK_HIP_CHECK(hipMallocAsync(&p, bytes ? bytes : 32, s)); }
-        ~Scratch() { if (p) (void)hipFreeAsync(p, s); }
-    };
+    using Scratch = ArenaBuf;  // the stream's scratch arena (common.hpp)
     const unsigned max_blocks = (unsigned)num_cus() * 8;
     Scratch coef(n0 * 32, s), dl(n0 * 32, s), dr(pairs ? 0 : n0 * 32, s), partial((size_t)2 * max_blocks * 32, s);
     {

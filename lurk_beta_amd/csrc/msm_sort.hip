@@ -196,17 +196,17 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
     }
     __syncthreads();
     size_t lo = (size_t)blockIdx.x * chunk, hi = lo + chunk < sh.n ? lo + chunk : sh.n;
-    // the next tile's scalar is in flight while this tile is sorted (one workgroup per CU: nothing else hides the load)
-    uint4 na = make_uint4(0, 0, 0, 0), nb = na;
-    if (t < sh.tile && lo + t < hi) { na = scalars[2 * (lo + t)]; nb = scalars[2 * (lo + t) + 1]; }
     for (size_t base = lo; base < hi; base += sh.tile) {
         const size_t i = base + t;
         const bool live = t < sh.tile && i < hi;
         uint32_t sl[8];
         uint32_t d[msm_ct_windows(C)];
-        const uint4 a = na, b = nb;
-        if (t < sh.tile && i + sh.tile < hi) { na = scalars[2 * (i + sh.tile)]; nb = scalars[2 * (i + sh.tile) + 1]; }
         if (live) {
+            // (keeping the NEXT tile's scalar in flight across the tile costs 8 registers per lane: 84 instead of 65, one allocation
+            // granule too many for four sort waves to sit on a SIMD beside a resident accumulate wave (4 x 88 + 176 > 512) - the sort
+            // of every commitment in flight then waited for an accumulation to END: 988 -> 839 Mscalar-mul/s at 2^22.  See the
+            // register-fit test, tests/test_cabi_exports.py)
+            const uint4 a = scalars[2 * i], b = scalars[2 * i + 1];
             sl[0] = a.x; sl[1] = a.y; sl[2] = a.z; sl[3] = a.w;
             sl[4] = b.x; sl[5] = b.y; sl[6] = b.z; sl[7] = b.w;
             if constexpr (C != 0) {

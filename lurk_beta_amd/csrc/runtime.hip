@@ -170,6 +170,51 @@ void Profiler::query(const char* prefix, double* total_ms, uint64_t* launches) {
     *launches = cnt;
 }
 
+ScratchArena& ScratchArena::of(hipStream_t s) {
+    static std::mutex map_mu;
+    static auto& arenas = *new std::map<std::pair<int, hipStream_t>, ScratchArena*>();  // never torn down (process lifetime)
+    std::lock_guard<std::mutex> g(map_mu);
+    auto key = std::make_pair(current_device(), s);
+    auto it = arenas.find(key);
+    if (it == arenas.end()) it = arenas.emplace(key, new ScratchArena()).first;
+    return *it->second;
+}
+void* ScratchArena::push(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    // the stack runs over a chain of blocks: the current one, else the next one if it is empty and large enough, else a new block
+    // spliced in behind the current one (a repeated sequence of pushes and pops finds every block where the first run left it)
+    if (blocks_.empty() || blocks_[cur_].cap - blocks_[cur_].top < bytes) {
+        size_t next = blocks_.empty() ? 0 : cur_ + 1;
+        if (next >= blocks_.size() || blocks_[next].top != 0 || blocks_[next].cap < bytes) {
+            const size_t cap = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
+            void* base = nullptr;
+            LURK_HIP_CHECK(hipMalloc(&base, cap));
+            blocks_.insert(blocks_.begin() + next, Block{(char*)base, cap, 0});
+            for (auto& l : live_)
+                if (l.block >= next) l.block++;
+        }
+        cur_ = next;
+    }
+    Block& b = blocks_[cur_];
+    void* p = b.base + b.top;
+    live_.push_back(Live{p, cur_, b.top, false});
+    b.top += bytes;
+    return p;
+}
+void ScratchArena::pop(void* p) {
+    for (size_t i = live_.size(); i-- > 0;)
+        if (live_[i].p == p && !live_[i].freed) {
+            live_[i].freed = true;
+            break;
+        }
+    while (!live_.empty() && live_.back().freed) {  // automatic variables die in reverse order: this loop runs once per pop
+        blocks_[live_.back().block].top = live_.back().prev_top;
+        cur_ = live_.back().block;
+        live_.pop_back();
+    }
+    if (live_.empty()) cur_ = 0;
+}
+
 DeviceWorker::DeviceWorker(int device) : device_(device), th_([this] { loop(); }) {}
 DeviceWorker::~DeviceWorker() {
     {

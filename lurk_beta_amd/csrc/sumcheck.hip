@@ -257,7 +257,9 @@ static void sumcheck_prove(int np, size_t ninst, void* const* d_polys, size_t n,
     Fe<F> r = fe_zero<F>();
     bool have_r = false;
     int j = 0;
-    SumcheckScratch scratch(s);
+    // the (device, stream)'s scratch, made once and kept: a proof runs three of these loops
+    std::unique_lock<std::mutex> scratch_lk;
+    SumcheckScratch& scratch = *sumcheck_cached_scratch(s, scratch_lk);
     for (size_t m = n; m > 1; m /= 2, j++) {
         Fe<F> ev[3] = {fe_zero<F>(), fe_zero<F>(), fe_zero<F>()};
         for (size_t i = 0; i < ninst; i++) {
@@ -369,8 +371,8 @@ int lurk_hip_eq_evals_dev(int field_id, const void* r32_mont, int ell, void* d_o
         LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
         LURK_REQUIRE(ell >= 0 && ell <= 30 && d_out && (ell == 0 || r32_mont), "bad argument");
         hipStream_t s = (hipStream_t)stream;
-        void* d_r = nullptr;
-        LURK_HIP_CHECK(hipMallocAsync(&d_r, (size_t)(ell ? ell : 1) * 32, s));
+        ArenaBuf r_buf((size_t)(ell ? ell : 1) * 32, s);
+        void* d_r = r_buf.p;
         if (ell) LURK_HIP_CHECK(hipMemcpyAsync(d_r, r32_mont, (size_t)ell * 32, hipMemcpyHostToDevice, s));
         const size_t n = (size_t)1 << ell;
         unsigned blocks = div_up(n, SC_BLOCK), cap = (unsigned)num_cus() * 16;
@@ -380,9 +382,7 @@ int lurk_hip_eq_evals_dev(int field_id, const void* r32_mont, int ell, void* d_o
         if (field_id == 0) hipLaunchKernelGGL((eq_evals_kernel<PallasFp>), dim3(blocks), dim3(SC_BLOCK), lds, s, (const Fe<PallasFp>*)d_r, ell, (Fe<PallasFp>*)d_out);
         else if (field_id == 1) hipLaunchKernelGGL((eq_evals_kernel<PallasFq>), dim3(blocks), dim3(SC_BLOCK), lds, s, (const Fe<PallasFq>*)d_r, ell, (Fe<PallasFq>*)d_out);
         else hipLaunchKernelGGL((eq_evals_kernel<Bn254Fr>), dim3(blocks), dim3(SC_BLOCK), lds, s, (const Fe<Bn254Fr>*)d_r, ell, (Fe<Bn254Fr>*)d_out);
-        hipError_t e = hipGetLastError();
-        (void)hipFreeAsync(d_r, s);
-        LURK_HIP_CHECK(e);
+        LURK_HIP_CHECK(hipGetLastError());
     });
 }
 }

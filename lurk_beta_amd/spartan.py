@@ -242,10 +242,17 @@ class BatchedSpartanProver:
         self.provers = list(provers)
         self.curve, self.q, self.sf = provers[0].curve, provers[0].q, provers[0].sf
 
-    def prove(self, instances, d_ck, key=None) -> dict:
+    def prove(self, instances, d_ck, key=None, in_library=None) -> dict:
         """instances[i] = dict(X, u, d_W, d_E, comm_W, comm_E) for provers[i] (device tensors Montgomery, commitments 96-byte Jacobians).
-        d_ck: (N + 1, 8) affine Montgomery points, N = the largest num_cons / num_vars; key: the resident CommitmentKey over d_ck[:N]."""
+        d_ck: (N + 1, 8) affine Montgomery points, N = the largest num_cons / num_vars; key: the resident CommitmentKey over d_ck[:N].
+        in_library (with a resident key): the whole prover as ONE library call, lurk_hip_spartan_prove_batch_dev - what a Rust caller binds;
+        the sequence below is its mirror, kept for the tests (both must give the oracle's proof)."""
         import torch
+
+        if in_library is None:
+            in_library = os.environ.get("LURK_SPARTAN_PROVER", "python") == "library"
+        if key is not None and in_library:
+            return self._prove_lib(instances, d_ck, key)
 
         q, sf, n = self.q, self.sf, len(self.provers)
         P0 = self.provers[0]
@@ -329,6 +336,44 @@ class BatchedSpartanProver:
                                      ipa_chal, key=key)
         return dict(polys_outer=polys_outer, claims_outer=claims_outer, evals_E=evals_E, polys_inner=polys_inner, evals_W=evals_W, polys_batch=polys_batch,
                     evals_batch=evals_batch, ipa_L=[aff0(x) for x in Ls], ipa_R=[aff0(x) for x in Rs], ipa_a=a_hat)
+
+    def _prove_lib(self, instances, d_ck, key) -> dict:
+        import ctypes
+
+        import torch
+
+        q, n = self.q, len(self.provers)
+        ell_x = max(p.num_cons for p in self.provers).bit_length() - 1
+        ell_y = max(p.num_vars for p in self.provers).bit_length()
+        N = max(max(p.num_cons, p.num_vars) for p in self.provers)
+        ell = N.bit_length() - 1
+        bufs = dict(polys_outer=np.zeros((ell_x, 4, 4), dtype=np.uint64), claims_outer=np.zeros((n, 3, 4), dtype=np.uint64), evals_e=np.zeros((n, 4), dtype=np.uint64),
+                    polys_inner=np.zeros((ell_y, 3, 4), dtype=np.uint64), evals_w=np.zeros((n, 4), dtype=np.uint64), polys_batch=np.zeros((max(ell, 1), 3, 4), dtype=np.uint64),
+                    evals_batch=np.zeros((2 * n, 4), dtype=np.uint64), ipa_l=np.zeros((max(ell, 1), 12), dtype=np.uint64), ipa_r=np.zeros((max(ell, 1), 12), dtype=np.uint64),
+                    ipa_a=np.zeros(4, dtype=np.uint64))
+        out = _lib.SpartanBatchProofStruct(*[bufs[k].ctypes.data for k, _ in _lib.SpartanBatchProofStruct._fields_])
+        keep, arr = [], (_lib.SpartanInstanceStruct * n)()
+        for i, (p, it) in enumerate(zip(self.provers, instances)):
+            X = list(it["X"])
+            x = sumcheck._limbs([int(v) % q for v in X]) if X else np.zeros((1, 4), dtype=np.uint64)
+            uu = sumcheck._limbs([int(it["u"]) % q])
+            cw, ce = np.ascontiguousarray(it["comm_W"], dtype=np.uint64), np.ascontiguousarray(it["comm_E"], dtype=np.uint64)
+            d_w, d_e = it["d_W"].contiguous(), it["d_E"].contiguous()
+            keep += [x, uu, cw, ce, d_w, d_e]
+            arr[i] = _lib.SpartanInstanceStruct(p.shape._h.value, p.shape_t._h.value, p.num_cons, p.num_vars, len(X), x.ctypes.data, uu.ctypes.data, d_w.data_ptr(),
+                                                d_e.data_ptr(), cw.ctypes.data, ce.ctypes.data)
+        ck_c = d_ck[N].cpu().numpy().view(np.uint64).reshape(8)
+        ck_c_jac = np.concatenate([ck_c, _mont_one(0 if self.curve == 0 else 1)])
+        label = (b"pallas" if self.curve == 0 else b"vesta") + b"/batched"
+        s = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.load().lurk_hip_spartan_prove_batch_dev(ctypes.cast(arr, ctypes.c_void_p), n, key._ctx, _lib.ptr(ck_c_jac), label, len(label), ctypes.byref(out),
+                                                                _lib.ptr(s)))
+        ints = sumcheck._ints
+        aff = lambda P: (lambda xy: None if xy == (0, 0) else xy)(point_to_affine(self.curve, P))
+        return dict(polys_outer=[ints(bufs["polys_outer"][j]) for j in range(ell_x)], claims_outer=[ints(bufs["claims_outer"][i]) for i in range(n)],
+                    evals_E=ints(bufs["evals_e"]), polys_inner=[ints(bufs["polys_inner"][j]) for j in range(ell_y)], evals_W=ints(bufs["evals_w"]),
+                    polys_batch=[ints(bufs["polys_batch"][j]) for j in range(ell)], evals_batch=ints(bufs["evals_batch"]),
+                    ipa_L=[aff(bufs["ipa_l"][j]) for j in range(ell)], ipa_R=[aff(bufs["ipa_r"][j]) for j in range(ell)], ipa_a=ints(bufs["ipa_a"])[0])
 
     def _ip(self, d_a, d_b) -> int:
         import torch

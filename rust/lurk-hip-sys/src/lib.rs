@@ -5,11 +5,18 @@
 //!   `DlogGroup::vartime_multiscalar_mul` calls from `CommitmentEngine::commit`
 //!   (callers in lurk-beta: `/root/reference/src/proof/nova.rs:287-293`, `supernova.rs:231-244`);
 //! * [`FoldingContext`]: one curve's half of `RecursiveSNARK::prove_step` (`NIFS::prove`) with the running pair resident in HBM;
-//! * [`poseidon`]: batched `PoseidonCache::hash{3,4,6,8}` (`/root/reference/src/hash.rs:180-204`).
+//! * [`poseidon`]: batched `PoseidonCache::hash{3,4,6,8}` (`/root/reference/src/hash.rs:180-204`);
+//! * [`store`]: `HipPoseidonCache` (the shape of `PoseidonCache<F>`), `HipStoreHasher` (the shape of `StoreHasher`,
+//!   `/root/reference/src/lem/store_core.rs:10-14`, layouts of `/root/reference/src/lem/store.rs:29-78`) and `hydrate`
+//!   (`hydrate_z_cache`, `store_core.rs:256-269`, as one level-batched call);
+//! * [`dump`]: LURKDUMP writers - `R1CSShape`, the fresh witnesses of consecutive steps and the `CommitmentKey` as the files
+//!   `bench.py --workload fold_step --shape-file .. --witness-file ..` measures (`/root/reference/benches/fibonacci.rs:98-122`).
 //!
 //! Never compiled in the container this repository is built in (no Rust toolchain); the extern block cannot drift from the header
 //! (see `rust/gen_sys.py`), the wrappers are a reading aid for the maintainer who wires the feature in.
+pub mod dump;
 pub mod ffi;
+pub mod store;
 pub use ffi::*;
 
 use core::ffi::{c_int, c_void};
@@ -180,6 +187,43 @@ pub unsafe fn spartan_prove(shape: &R1csShape, shape_t: &R1csShape, num_cons: us
     };
     check(lurk_hip_spartan_prove_dev(shape.as_ptr(), shape_t.as_ptr(), num_cons, num_vars, x.len() / 32, key, ck_c.as_ptr().cast(), x.as_ptr().cast(), u.as_ptr().cast(),
                                      d_w, d_e, comm_w.as_ptr().cast(), comm_e.as_ptr().cast(), label.as_ptr().cast(), label.len(), &mut out, stream))?;
+    Ok(p)
+}
+
+/// The batched compressing prover as one call (`lurk_hip_spartan_prove_batch_dev`): n relaxed instances of different shapes under one key,
+/// one proof - the structure of arecibo's `BatchedRelaxedR1CSSNARK`, SuperNova's compressor (`/root/reference/src/proof/supernova.rs:110,
+/// 293-302`).  Sizes of the outputs: `include/lurk_hip.h`.
+pub struct SpartanBatchProof {
+    pub polys_outer: Vec<u8>,   // log2(max num_cons) x 4 x 32 B, canonical
+    pub claims_outer: Vec<u8>,  // n x 3 x 32 B
+    pub evals_e: Vec<u8>,       // n x 32 B
+    pub polys_inner: Vec<u8>,   // (log2(max num_vars) + 1) x 3 x 32 B
+    pub evals_w: Vec<u8>,       // n x 32 B
+    pub polys_batch: Vec<u8>,   // log2(N) x 3 x 32 B
+    pub evals_batch: Vec<u8>,   // 2 n x 32 B
+    pub ipa_l: Vec<u8>,         // log2(N) x 96 B Jacobians
+    pub ipa_r: Vec<u8>,
+    pub ipa_a: [u8; 32],
+}
+/// # Safety
+/// Every instance's pointers obey the contract of [`spartan_prove`]; `key` holds at least max(`num_cons`, `num_vars`) points over all instances.
+pub unsafe fn spartan_prove_batch(instances: &[lurk_hip_spartan_instance], key: *mut lurk_hip_msm_ctx, ck_c: &[u8; 96], label: &[u8], stream: *mut c_void)
+                                  -> Result<SpartanBatchProof, Error> {
+    let log2 = |n: usize| n.trailing_zeros() as usize;
+    let n = instances.len();
+    let max_nc = instances.iter().map(|i| i.num_cons).max().unwrap_or(2);
+    let max_nv = instances.iter().map(|i| i.num_vars).max().unwrap_or(2);
+    let (ell_x, ell_y, ell) = (log2(max_nc), log2(max_nv) + 1, log2(max_nc.max(max_nv)));
+    let mut p = SpartanBatchProof {
+        polys_outer: vec![0; ell_x * 128], claims_outer: vec![0; n * 96], evals_e: vec![0; n * 32], polys_inner: vec![0; ell_y * 96], evals_w: vec![0; n * 32],
+        polys_batch: vec![0; ell.max(1) * 96], evals_batch: vec![0; 2 * n * 32], ipa_l: vec![0; ell.max(1) * 96], ipa_r: vec![0; ell.max(1) * 96], ipa_a: [0; 32],
+    };
+    let mut out = lurk_hip_spartan_batch_proof {
+        polys_outer: p.polys_outer.as_mut_ptr().cast(), claims_outer: p.claims_outer.as_mut_ptr().cast(), evals_e: p.evals_e.as_mut_ptr().cast(),
+        polys_inner: p.polys_inner.as_mut_ptr().cast(), evals_w: p.evals_w.as_mut_ptr().cast(), polys_batch: p.polys_batch.as_mut_ptr().cast(),
+        evals_batch: p.evals_batch.as_mut_ptr().cast(), ipa_l: p.ipa_l.as_mut_ptr().cast(), ipa_r: p.ipa_r.as_mut_ptr().cast(), ipa_a: p.ipa_a.as_mut_ptr().cast(),
+    };
+    check(lurk_hip_spartan_prove_batch_dev(instances.as_ptr(), n, key, ck_c.as_ptr().cast(), label.as_ptr().cast(), label.len(), &mut out, stream))?;
     Ok(p)
 }
 

@@ -119,6 +119,7 @@ def test_batched_device_prover_matches_the_oracle(hip, cn, c, dims):
     got = bp.prove(dev_insts, _dev(B))
     assert got == want
     assert bp.prove(dev_insts, _dev(B), key=key) == want
+    assert bp.prove(dev_insts, _dev(B), key=key, in_library=True) == want   # lurk_hip_spartan_prove_batch_dev: the batched prover as one library call
     pub = [{k: v for k, v in it.items() if k not in ("W", "E")} for it in insts]
     assert SF.verify_batched(c, pub, B, got)
     pub[0]["X"] = [(pub[0]["X"][0] + 1) % q] + pub[0]["X"][1:]
@@ -152,6 +153,7 @@ def test_batched_device_prover_at_2_12_and_2_14(hip):
     want = SF.prove_batched(c, insts, B)
     got = BatchedSpartanProver(provers).prove(dev_insts, _dev(B), key=key)
     assert got == want
+    assert BatchedSpartanProver(provers).prove(dev_insts, _dev(B), key=key, in_library=True) == want
     assert SF.verify_batched(c, [{k: v for k, v in it.items() if k not in ("W", "E")} for it in insts], B, got)
     key.close()
     for p in provers:

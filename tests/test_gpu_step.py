@@ -656,3 +656,37 @@ def test_steps_with_a_multi_device_key(hip, devices):
     assert np.array_equal(C.from_mont(f, gz), C.axpy(f, z1, z2, 7))
     for x in (mctx, sctx, mkey, skey, shape):
         x.close()
+
+
+@pytest.mark.parametrize("encoding", [0, 1])
+def test_step_from_dump_files(hip, tmp_path, encoding):
+    """`bench.py --workload fold_step --shape-file .. --witness-file .. --key-file .. --verify`: the step driven from LURKDUMP files (what a Rust
+    host writes from arecibo's R1CSShape / witnesses / key: rust/lurk-hip-sys/src/dump.rs) - canonical and Montgomery encodings - folds
+    the dumped witnesses in turn, and one more step has every output equal to the oracle's (bench_workloads/fold_step.py: verify_fold_step)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    from lurk_beta_amd import dump
+
+    f, curve, m, nfree, nio = 1, 0, 3000, 1400, 2
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=21)
+    enc = (lambda a: C.to_mont(f, a)) if encoding == dump.ENC_MONTGOMERY else (lambda a: a)
+    steps = []
+    for k in range(3):
+        z, x2 = _fresh(f, A, B, m, nfree, nio, 300 + 2 * k)
+        steps.append((enc(z[:nv]), enc(x2)))
+    ps, pw, pk = (str(tmp_path / n) for n in ("shape.lurkdump", "wit.lurkdump", "key.lurkdump"))
+    dump.write_shape(ps, f, m, nv, nio, [(ip, ix, enc(d)) for ip, ix, d in (A, B, Cm)], encoding)
+    dump.write_witnesses(pw, f, 0x1234ABCD, steps, encoding)
+    bases = C.synth_bases(curve, max(m, nv) + 5)  # Montgomery affine, as the library's synthetic key: the file may hold more points than needed
+    if encoding == dump.ENC_CANONICAL:
+        bases = C.from_mont(0, bases.reshape(-1, 4)).reshape(-1, 8)
+    dump.write_key(pk, curve, bases, encoding)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "fold_step", "--shape-file", ps, "--witness-file", pw, "--key-file", pk,
+                          "--steps", "4", "--warmup", "1", "--verify", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["data"] == "dumped" and line["config"]["verified"]["ok"] is True and line["ms_per_step"] > 0
