@@ -130,9 +130,9 @@ class SpartanProver:
         if in_library is None:
             in_library = os.environ.get("LURK_SPARTAN_PROVER", "python") == "library"
         if key is not None and in_library:
-            # the whole prover as ONE call (lurk_hip_spartan_prove_dev: what a Rust caller binds): this method then only marshals.  The default
-            # stays the same sequence of library calls driven from here: 32.1-32.9 ms per 2^20 proof against 34.3-34.8 on one box (the library
-            # form takes its scratch from the stream-ordered pool, this one from torch's cached blocks)
+            # the whole prover as ONE call (lurk_hip_spartan_prove_dev: what a Rust caller binds): this method then only marshals.  Since the
+            # library takes its scratch from one arena per stream (round 5) it is the faster form - 30.5 against 30.8 ms per 2^20 proof on one
+            # box - and bench.py's default; the sequence below stays as the mirror the tests compare it with
             return self._prove_lib(X, u, d_W, d_E, d_ck, comm_W_jac, comm_E_jac, key, b"lurk-hip spartan v2" + curve_name)
         tr = Transcript(curve_name, self.curve)
         tr.absorb_point(b"comm_W", point_to_affine(self.curve, comm_W_jac))
@@ -364,7 +364,7 @@ class BatchedSpartanProver:
                                                 d_e.data_ptr(), cw.ctypes.data, ce.ctypes.data)
         ck_c = d_ck[N].cpu().numpy().view(np.uint64).reshape(8)
         ck_c_jac = np.concatenate([ck_c, _mont_one(0 if self.curve == 0 else 1)])
-        label = (b"pallas" if self.curve == 0 else b"vesta") + b"/batched"
+        label = b"lurk-hip spartan v2" + (b"pallas" if self.curve == 0 else b"vesta") + b"/batched"  # (what Transcript prepends)
         s = torch.cuda.current_stream().cuda_stream
         _lib.check(_lib.load().lurk_hip_spartan_prove_batch_dev(ctypes.cast(arr, ctypes.c_void_p), n, key._ctx, _lib.ptr(ck_c_jac), label, len(label), ctypes.byref(out),
                                                                 _lib.ptr(s)))
