@@ -3,11 +3,11 @@
 
 A "step" is one commitment  C = sum_i s_i * ck_i  over Pallas: scalars and the commitment key are
 already resident in HBM when the timed region starts (the PCIe-inclusive rate is noted in
-DESIGN.md, never here).  By default three commitments are in flight (`--pipeline 3`, a context's three async slots:
-the sort of the third runs under the two resident accumulations; 8 of 8 paired runs at K = 20 were faster and steadier
-than two in flight, 958-971 against 900-959 Mscalar-mul/s): every step is still one complete MSM and all K results
+DESIGN.md, never here).  By default four commitments are in flight (`--pipeline 4`, four of a context's async slots: two
+accumulate, one is in its tail, one sorts; alternating runs on one box, K = 20: 3 / 4 / 5 / 6 in flight = 994 / 1 010 / 910 / 952
+Mscalar-mul/s): every step is still one complete MSM and all K results
 are produced inside the timed region, which starts and ends with an empty pipeline (so a small K pays the fill and
-drain: K = 20 / 40 measure about 4.35 / 4.25 ms per step); `--pipeline 1` is the fully synchronous form, and
+drain: K = 20 / 40 / 80 measure about 4.15 / 4.11 / 4.07 ms per step); `--pipeline 1` is the fully synchronous form, and
 the default line also carries `sync_ms_per_commit`, the plain-key synchronous sub-record and the one-shot
 host-pointer sub-record.  The resident key
 carries the precomputed per-window table by default (`--precompute 0` = plain 64 B/point key).  N = 1: n = 2^log_n points on one GPU (default 2^22, the size the metric
@@ -51,8 +51,9 @@ def main():
     ap.add_argument("--dist", choices=["uniform", "witness"], default="uniform")
     ap.add_argument("--precompute", type=int, default=1,
                     help="1 = resident key with the per-window precomputed table (13 x 64 B per point, 20-bit windows); 0 = plain key")
-    ap.add_argument("--pipeline", type=int, default=3,
-                    help="commitments in flight (1 = synchronous; 2..3 = async slots: the tail of one overlaps the accumulation of the next)")
+    ap.add_argument("--pipeline", type=int, default=4,
+                    help="commitments in flight (1 = synchronous; 2..6 = async slots: the tail of one overlaps the accumulation of the next).  4 since round 5: "
+                         "two accumulate, one is in its tail, one sorts (profiles/r05_pipeline_depth.txt: 3 / 4 / 5 / 6 in flight = 994 / 1 010 / 910 / 952)")
     ap.add_argument("--stage-ahead", type=int, default=0,
                     help="fold_step: 1 = the next step's witness is traced and its commitment started one step ahead (lurk_hip_fold_step_prefetch); "
                          "2 = the same from inside begin (the submit hook calls prefetch: the staged commitment runs in the background class beside commit(T)); "
@@ -89,6 +90,8 @@ def main():
     ap.add_argument("--devices", default="",
                     help="fold_step: comma-separated device list, e.g. 0,0 or 0,1,2,3: the commitment key is cut across these devices inside ONE process "
                          "(lurk_hip_msm_multi_* + lurk_hip_fold_ctx_create_multi); a repeated id puts several slices on one GPU (functional and overhead check)")
+    ap.add_argument("--auto-slices", type=int, default=0,
+                    help="fold_step --devices: 1 = LURK_MSM_FLAG_AUTO_SLICES (use only as many of the listed devices as leave every slice >= 2^20 points)")
     ap.add_argument("--helper-devices", default="",
                     help="fold_step with --stage-ahead 1: comma-separated devices that each hold a copy of the commitment key and commit the instances staged "
                          "ahead in turn (lurk_hip_fold_ctx_add_helper: staging ahead across GPUs); e.g. 1,2,3 on a node, 0 on a one-GPU box (functional)")

@@ -148,8 +148,29 @@ def mix(out_json, *listings):
     print(json.dumps(out, indent=1))
 
 
+def poseidon(path, needle, dyn_valu_per_wave_hash=None, measured_mhps=None):
+    """`issue_model.py poseidon <listing.s> <kernel substring> [SQ_INSTS_VALU per wave and hash] [measured M hashes/s]`: the kernel's round
+    loops nest (rounds x rows), so a static census cannot weight them; the issue cost per VALU instruction comes from the static mix of the
+    whole body (the loops' mixes agree to 1 %), the instruction COUNT from the PMC pass (SQ_INSTS_VALU of a poseidon_tree run / waves /
+    hashes per lane) - their product is the issue budget of one hash."""
+    lines = open(path).read().split("\n")
+    n, c = census_of(lines, needle, "whole")
+    mads = sum(1 for l in lines[next(i for i, l in enumerate(lines) if "Begin function" in l and needle in l):] if l.strip().startswith("v_mad_u64_u32"))
+    cpi = c / n
+    print(f"kernel *{needle}*: {n} VALU instructions in the body, mean issue cost {cpi:.3f} cycles per instruction")
+    if dyn_valu_per_wave_hash:
+        d = float(dyn_valu_per_wave_hash)
+        cycles = d * cpi
+        bound = SIMDS * CLOCK_GHZ * 1e9 * LANES / cycles
+        print(f"  dynamic: {d:.0f} VALU wave-instructions per hash -> {cycles:.0f} issue cycles per wave-hash -> bound {bound / 1e6:.1f} M hashes/s on {SIMDS} SIMDs at {CLOCK_GHZ} GHz")
+        if measured_mhps:
+            print(f"  measured {float(measured_mhps):.1f} M hashes/s = {float(measured_mhps) * 1e6 / bound:.1%} of the issue bound")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "mix":
+    if len(sys.argv) > 1 and sys.argv[1] == "poseidon":
+        poseidon(*sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "mix":
         mix(*sys.argv[2:])
     else:
         main(*sys.argv[1:])

@@ -114,7 +114,8 @@ def fold_step_workload(args, lib, world, rank):
     devices = [int(x) for x in args.devices.split(",")] if args.devices else None
     if devices:  # the key cut across a device list inside this process: slices commit concurrently, 96-byte partials summed on the host
         assert not args.stage_ahead, "--devices: staging ahead is not available with a multi-device key"
-        ck = L.MultiCommitmentKey(L.CURVE_PALLAS, d_bases.cpu().numpy().view(np.uint64), devices, precompute=bool(args.precompute), window_bits=args.window_bits)
+        ck = L.MultiCommitmentKey(L.CURVE_PALLAS, d_bases.cpu().numpy().view(np.uint64), devices, precompute=bool(args.precompute), window_bits=args.window_bits,
+                                  auto_slices=bool(args.auto_slices))
     else:
         ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n_key, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     ctx = L.FoldingContext(L.CURVE_PALLAS, shape, ck)
@@ -260,6 +261,7 @@ def fold_step_workload(args, lib, world, rank):
             "dtype": "u32x8 (255-bit Montgomery, integer VALU)", "data": "synthetic",
             "config": {"staged_ahead": args.stage_ahead, "witness_ahead": 0 if args.stage_ahead else args.witness_ahead,
                        "devices": devices, "distinct_devices": len(set(devices)) if devices else 1,
+                       "slices": len(ck.shards()) if devices else 1, "auto_slices": bool(args.auto_slices) if devices else None,
                        "helper_devices": args.helper_devices or None,
                        "workload": f"fold-step stand-in rc={rc} through lurk_hip_fold_step_{'prefetch/begin_prefetched' if args.stage_ahead else 'begin'}/finish: W2 ({n_w} aux: {21 * rc} Poseidon + {3 * rc} bit-decomposition "
                                    f"slot blocks traced on the device + {rc} x 1311 body aux over PCIe) -> MSM(W2) + cross term over {n_t} rows ({nnz} non-zeros, "

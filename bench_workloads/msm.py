@@ -313,7 +313,7 @@ def msm_workload(args, lib, world, rank):
     d_scalars = synth.scalars(L.FIELD_PALLAS_FQ, 1, dist_id, n, first=first, mont=True)
     torch.cuda.synchronize()
     t_setup = time.perf_counter()
-    depth = max(1, min(4, args.pipeline))
+    depth = max(1, min(6, args.pipeline))  # LURK_MSM_SLOTS
     ck = L.CommitmentKey(L.CURVE_PALLAS, d_bases, n=n, device=True, precompute=bool(args.precompute), window_bits=args.window_bits)
     ck.reserve(n, depth)  # every slot's workspace is part of the once-per-key setup, not of whichever step touches the slot first
     torch.cuda.synchronize()

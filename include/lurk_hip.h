@@ -115,6 +115,10 @@ typedef struct lurk_hip_msm_ctx lurk_hip_msm_ctx;
 #define LURK_MSM_FLAG_WINDOW_BITS(c) (((c) & 0xff) << 8)
 #define LURK_MSM_FLAG_SMALL_FORM (1 << 16)
 #define LURK_MSM_FLAG_NO_SMALL_FORM (1 << 17)
+/* lurk_hip_msm_multi_create only: cut the key over as many of the listed devices as leave every slice at least 2^20 points (the first k
+ * of the list; LURK_MSM_MULTI_MIN_SLICE_LOG in the environment moves the threshold).  A slice pays a whole commitment's latency-bound
+ * chain (~0.64 ms) around 0.83 ms of accumulation per 2^20 points: smaller slices cost more than they take off. */
+#define LURK_MSM_FLAG_AUTO_SLICES (1 << 18)
 int lurk_hip_msm_ctx_create(lurk_hip_msm_ctx** ctx, int curve, const void* bases_affine64,
                             size_t npoints, int flags);
 /* same, bases already in device memory (borrowed for the lifetime of the ctx unless precomputed) */
@@ -133,7 +137,7 @@ int lurk_hip_msm_ctx_run_dev(lurk_hip_msm_ctx* ctx, void* out_jacobian96, const 
  * consecutive steps - so that the latency-bound tail of one overlaps the throughput-bound bucket
  * accumulation of the next.  submit enqueues (ordered after `stream`, the stream that produced the
  * scalars) and returns; wait blocks for that slot and writes the 96-byte result to host memory. */
-#define LURK_MSM_SLOTS 4
+#define LURK_MSM_SLOTS 6
 int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars32,
                                 size_t nscalars, int is_mont, void* stream);
 /* The same with a scheduling class.  Commitments in flight share the integer VALU; a prover knows which one its next step

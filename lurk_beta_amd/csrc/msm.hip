@@ -44,7 +44,7 @@ __device__ __forceinline__ void msm_set_wave_prio(int /*cls: 0 sort kernels, 1 p
 // ---- 3. task planning ------------------------------------------------------------------------
 // block g (group of MSM_GRP keys), 1024 threads x 32 keys: task starts inside the group + group total
 __global__ __launch_bounds__(1024) void msm_taskscan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ task_start,
-                                                              uint32_t* __restrict__ group_tasks) {
+                                                              uint32_t* __restrict__ group_tasks, uint32_t S) {
     msm_set_wave_prio(1);
     __shared__ uint32_t sh[1024];
     const int g = blockIdx.x, t = threadIdx.x;
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(1024) void msm_taskscan_kernel(const uint32_t* __re
 #pragma unroll
     for (int j = 0; j < PER / 4; j++) {
         uint4 v = src[j];
-        c[4 * j] = (v.x + MSM_S - 1) / MSM_S;
-        c[4 * j + 1] = (v.y + MSM_S - 1) / MSM_S;
-        c[4 * j + 2] = (v.z + MSM_S - 1) / MSM_S;
-        c[4 * j + 3] = (v.w + MSM_S - 1) / MSM_S;
+        c[4 * j] = (v.x + S - 1) / S;
+        c[4 * j + 1] = (v.y + S - 1) / S;
+        c[4 * j + 2] = (v.z + S - 1) / S;
+        c[4 * j + 3] = (v.w + S - 1) / S;
         tot += c[4 * j] + c[4 * j + 1] + c[4 * j + 2] + c[4 * j + 3];
     }
     sh[t] = tot;
@@ -96,7 +96,7 @@ __global__ void msm_task_base_kernel(const uint32_t* __restrict__ group_tasks, u
 // task table: task t -> [first, last) of the sorted list (<= MSM_S entries of one bucket)
 __global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bucket_start,
                                                           const uint32_t* __restrict__ task_start,
-                                                          const uint32_t* __restrict__ group_task_base, int NG, uint2* __restrict__ task_info) {
+                                                          const uint32_t* __restrict__ group_task_base, int NG, uint2* __restrict__ task_info, uint32_t S) {
     msm_set_wave_prio(1);
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= group_task_base[NG]) return;
@@ -107,9 +107,9 @@ __global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restri
     uint32_t b = msm_upper_slot(ts, MSM_GRP, tl);
     uint32_t part = tl - ts[b];
     size_t key = (size_t)g * MSM_GRP + b;
-    uint32_t first = bucket_start[key] + part * MSM_S;
+    uint32_t first = bucket_start[key] + part * S;
     uint32_t end = bucket_start[key] + cnt[key];
-    task_info[t] = make_uint2(first, first + MSM_S < end ? first + MSM_S : end);
+    task_info[t] = make_uint2(first, first + S < end ? first + S : end);
 }
 
 // Longest-task-first order: tasks are counting-sorted by length (1..MSM_S) in descending order, so
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restri
 // short tasks fill the tail of the launch.  Full tasks (length MSM_S, the bulk at large n) are
 // counted per wave with one ballot instead of one LDS atomic each.
 __global__ __launch_bounds__(1024) void msm_len_hist_kernel(const uint2* __restrict__ task_info, const uint32_t* __restrict__ group_task_base,
-                                                              int NG, uint32_t* __restrict__ len_hist) {
+                                                              int NG, uint32_t* __restrict__ len_hist, uint32_t S) {
     msm_set_wave_prio(1);
     __shared__ uint32_t sh[MSM_S + 1];
     if (threadIdx.x <= MSM_S) sh[threadIdx.x] = 0;
@@ -132,20 +132,20 @@ __global__ __launch_bounds__(1024) void msm_len_hist_kernel(const uint2* __restr
                 uint2 ti = task_info[t];
                 len = ti.y - ti.x;
             }
-            unsigned long long full = __ballot(len == MSM_S);
-            if (full && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)full) - 1)) atomicAdd(&sh[MSM_S], (uint32_t)__popcll(full));
-            if (len != 0 && len != MSM_S) atomicAdd(&sh[len], 1u);
+            unsigned long long full = __ballot(len == S);
+            if (full && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)full) - 1)) atomicAdd(&sh[S], (uint32_t)__popcll(full));
+            if (len != 0 && len != S) atomicAdd(&sh[len], 1u);
         }
     }
     __syncthreads();
     if (threadIdx.x <= MSM_S && sh[threadIdx.x]) atomicAdd(&len_hist[threadIdx.x], sh[threadIdx.x]);
 }
 // len_hist -> start offset of each length class, longest first (single small block)
-__global__ void msm_len_scan_kernel(uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor) {
+__global__ void msm_len_scan_kernel(uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor, int S) {
     msm_set_wave_prio(1);
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         uint32_t run = 0;
-        for (int l = MSM_S; l >= 0; l--) {
+        for (int l = S; l >= 0; l--) {
             len_cursor[l] = run;
             run += len_hist[l];
         }
@@ -153,7 +153,7 @@ __global__ void msm_len_scan_kernel(uint32_t* __restrict__ len_hist, uint32_t* _
 }
 __global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __restrict__ task_info,
                                                                  const uint32_t* __restrict__ group_task_base, int NG,
-                                                                 uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+                                                                 uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order, uint32_t S) {
     msm_set_wave_prio(1);
     __shared__ uint32_t sh_cnt[MSM_S + 1], sh_base[MSM_S + 1];
     const uint32_t ntasks = group_task_base[NG];
@@ -166,11 +166,11 @@ __global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __re
             uint2 ti = task_info[t];
             len = ti.y - ti.x;
         }
-        unsigned long long full = __ballot(len == MSM_S);
-        if (len == MSM_S) {
+        unsigned long long full = __ballot(len == S);
+        if (len == S) {
             int lane = threadIdx.x & 63, leader = __ffsll((long long)full) - 1;
             uint32_t wbase = 0;
-            if (lane == leader) wbase = atomicAdd(&sh_cnt[MSM_S], (uint32_t)__popcll(full));
+            if (lane == leader) wbase = atomicAdd(&sh_cnt[S], (uint32_t)__popcll(full));
             wbase = __shfl(wbase, leader);
             rank = wbase + (uint32_t)__popcll(full & ((1ull << lane) - 1ull));
         } else if (len != 0) {
@@ -238,12 +238,12 @@ __global__ __launch_bounds__(256) void msm_finalize_kernel(const Xyzz<P>* __rest
                                                              const uint32_t* __restrict__ task_start,
                                                              const uint32_t* __restrict__ group_task_base, uint32_t NB,
                                                              Xyzz<P>* __restrict__ buckets, uint32_t* __restrict__ big_list,
-                                                             uint32_t* __restrict__ big_count) {
+                                                             uint32_t* __restrict__ big_count, uint32_t S) {
     msm_set_wave_prio(1);
     size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (key >= NB) return;
     uint32_t g = (uint32_t)(key / MSM_GRP), b = (uint32_t)(key % MSM_GRP);
-    uint32_t nt = (cnt[key] + MSM_S - 1) / MSM_S;
+    uint32_t nt = (cnt[key] + S - 1) / S;
     uint32_t first = group_task_base[g] + task_start[(size_t)g * (MSM_GRP + 1) + b];
     if (nt > MSM_SMALL) {
         big_list[atomicAdd(big_count, 1u)] = (uint32_t)key;
@@ -273,7 +273,7 @@ template <class P>
 __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __restrict__ partials, const uint32_t* __restrict__ cnt,
                                                                const uint32_t* __restrict__ task_start,
                                                                const uint32_t* __restrict__ group_task_base, Xyzz<P>* __restrict__ buckets,
-                                                               const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count) {
+                                                               const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count, uint32_t S) {
     msm_set_wave_prio(1);
     extern __shared__ uint4 lds_raw[];
     Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __re
     for (uint32_t i = blockIdx.x; i < nbig; i += gridDim.x) {
         uint32_t key = big_list[i];
         uint32_t g = key / MSM_GRP, b = key % MSM_GRP;
-        uint32_t nt = (cnt[key] + MSM_S - 1) / MSM_S;
+        uint32_t nt = (cnt[key] + S - 1) / S;
         uint32_t first = group_task_base[g] + task_start[(size_t)g * (MSM_GRP + 1) + b];
         Xyzz<P> acc = xyzz_identity<P>();
         for (uint32_t j = threadIdx.x; j < nt; j += 256) xyzz_add<P>(acc, partials[first + j]);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void msm_precompute_kernel(const Affine<P>* __
 }
 
 // ---- context -------------------------------------------------------------------------------
-constexpr int MSM_SLOTS = 4;  // commitments in flight per context (independent workspaces + streams)
+constexpr int MSM_SLOTS = LURK_MSM_SLOTS;  // commitments in flight per context (independent workspaces + streams)
 
 struct MsmCtxBase {
     int curve = 0;
@@ -620,7 +620,7 @@ struct MsmCtx : MsmCtxBase {
         wk.small_ready = true;
     }
 
-    size_t ntask_max(const MsmShape& sh) const { return (size_t)sh.NB + (size_t)sh.W * sh.n / MSM_S + 1; }
+    size_t ntask_max(const MsmShape& sh) const { return (size_t)sh.NB + (size_t)sh.W * sh.n / sh.S + 1; }
 
     void ensure_workspace(Work& wk, const MsmShape& sh) {
         // the buffer sizes depend on (W n, NB), not on n alone: a context rebound from a table key (c = 20: 13 n entries, 2^19
@@ -690,17 +690,17 @@ struct MsmCtx : MsmCtxBase {
             ProfScope ps("msm_tasks", s);
             uint32_t* lh = wk.len_hist.template as<uint32_t>();
             hipLaunchKernelGGL(msm_taskscan_kernel, dim3(sh.NG), dim3(1024), 0, s, wk.cnt.template as<uint32_t>(),
-                               wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>());
+                               wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>(), (uint32_t)sh.S);
             hipLaunchKernelGGL(msm_task_base_kernel, dim3(1), dim3(64), 0, s, wk.group_tasks.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), sh.NG);
             hipLaunchKernelGGL(msm_tasks_kernel, dim3(div_up(nt, 256)), dim3(256), 0, s, wk.cnt.template as<uint32_t>(),
                                wk.bucket_start.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NG, wk.task_info.template as<uint2>());
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, wk.task_info.template as<uint2>(), (uint32_t)sh.S);
             hipLaunchKernelGGL(msm_len_hist_kernel, dim3(256), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh);
-            hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, s, lh, lh + MSM_S + 1);
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh, (uint32_t)sh.S);
+            hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, s, lh, lh + MSM_S + 1, sh.S);
             hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh + MSM_S + 1, wk.task_order.template as<uint32_t>());
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh + MSM_S + 1, wk.task_order.template as<uint32_t>(), (uint32_t)sh.S);
         }
         if (before_accumulate) (*before_accumulate)();  // the one-shot entry point uploads the bases here, behind the sort
         const MsmTuning& tn = msm_tuning();
@@ -747,11 +747,11 @@ struct MsmCtx : MsmCtxBase {
             hipLaunchKernelGGL((msm_finalize_kernel<P>), dim3(div_up((size_t)sh.NB, 256)), dim3(256), 0, s, wk.partials.template as<Xyzz<P>>(),
                                wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), sh.NB, wk.buckets.template as<Xyzz<P>>(),
-                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>());
+                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S);
             hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(128), dim3(256), 256 * sizeof(Xyzz<P>), s, wk.partials.template as<Xyzz<P>>(),
                                wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), wk.buckets.template as<Xyzz<P>>(),
-                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>());
+                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S);
         }
         {
             // the c - 1 levels of the bit-plane merge tree; the last one stores the G x c plane sums into the slot's pinned buffer: the
@@ -1012,8 +1012,8 @@ struct lurk_hip_msm_multi {
     size_t npoints = 0;
     std::vector<std::unique_ptr<Shard>> shards;
     std::mutex mu;  // one commitment at a time per multi-context
-    size_t pending_n[MSM_SLOTS] = {0, 0, 0, 0};  // asynchronous form: scalars of the commitment in flight on each slot
-    bool pending[MSM_SLOTS] = {false, false, false, false};
+    size_t pending_n[MSM_SLOTS] = {};  // asynchronous form: scalars of the commitment in flight on each slot
+    bool pending[MSM_SLOTS] = {};
 
     // f(shard, count) on every shard that owns some of the first n scalars; waits for all of them
     template <class F>
@@ -1407,6 +1407,19 @@ int lurk_hip_msm_multi_create(lurk_hip_msm_multi** out, int curve, const void* b
         auto m = std::make_unique<lurk_hip_msm_multi>();
         m->curve = curve;
         m->npoints = n;
+        if (flags & LURK_MSM_FLAG_AUTO_SLICES) {
+            // Every slice is a whole commitment: its own sort, plan and c - 1 reduction levels - ~0.64 ms of latency-bound chain on
+            // one MI355X whatever its size - around 0.83 ms of accumulation per 2^20 points.  Below ~2^20 points
+            // per slice the chain outweighs what another device takes off the accumulation (and on a list that repeats a device it is
+            // pure overhead: +35 % for [0,0] at the rc = 100 step).  Use the first k devices of the list with k = max(1, n >> min_log).
+            const char* e = getenv("LURK_MSM_MULTI_MIN_SLICE_LOG");
+            int min_log = e ? atoi(e) : 20;
+            if (min_log < 0) min_log = 0;
+            if (min_log > 40) min_log = 40;
+            size_t k = n >> min_log;
+            if (k < 1) k = 1;
+            if ((size_t)n_dev > k) n_dev = (int)k;
+        }
         const size_t base = n / n_dev, extra = n % n_dev;  // the first n % n_dev shards hold one more point
         for (int i = 0; i < n_dev; i++) {
             auto sh = std::make_unique<lurk_hip_msm_multi::Shard>();

@@ -31,6 +31,12 @@ MsmShape msm_make_shape(int c, bool precomputed, size_t npoints, size_t n, int s
     LURK_REQUIRE(sh.LB <= MSM_LB_MAX, "sort shape: more than 8 low key bits per partition");
     sh.tile = MSM_SORT_BLOCK;
     while (sh.tile > 64 && msm_scatter1_lds(sh.P, sh.W, sh.tile) > MSM_LDS_BYTES) sh.tile /= 2;
+    // Task length.  A task is a chain of dependent mixed additions (4.5 us each on a lane): 64-entry tasks suit commitments whose
+    // W n / 64 tasks fill the chip's ~131 072 lanes; a 65 536-point commitment under a 16-bit window table has 2^20 entries - 16 384
+    // tasks of 64 would leave seven lanes in eight idle behind chains of 32-64 additions.  Halve S until the tasks fill the lanes: the
+    // per-bucket partials (<= 16 by one lane, more by a workgroup tree) absorb the rest.
+    sh.S = MSM_S;
+    while (sh.S > MSM_S_MIN && (size_t)sh.W * n / sh.S < MSM_TASK_TARGET) sh.S /= 2;
     sh.NG = (int)(sh.NB / MSM_GRP);
     sh.n = n;
     sh.stride = precomputed ? npoints : 0;

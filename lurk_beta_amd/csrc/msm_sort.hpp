@@ -21,10 +21,15 @@ namespace lurk {
 
 constexpr int MSM_P_MIN = 2048;    // coarse partitions of the key space (pass 1 of the sort): 2048 up to n = 2^22, then
 constexpr int MSM_P_MAX = 8192;    // doubled until a partition fits the LDS stage of pass 2 (msm_make_shape)
-constexpr int MSM_P_PER_MAX = MSM_P_MAX / 1024;
-constexpr int MSM_NB1 = 256;       // workgroups of pass 1 (one per CU)
-constexpr int MSM_SORT_BLOCK = 1024;
-constexpr int MSM_S = 64;          // sorted entries per accumulation task
+#ifndef LURK_SORT_BLOCK
+#define LURK_SORT_BLOCK 1024       // threads per sort workgroup (A/B builds: make SORT_DEFS=-DLURK_SORT_BLOCK=512)
+#endif
+constexpr int MSM_SORT_BLOCK = LURK_SORT_BLOCK;
+constexpr int MSM_P_PER_MAX = MSM_P_MAX / MSM_SORT_BLOCK;
+constexpr int MSM_NB1 = 256 * (1024 / MSM_SORT_BLOCK);  // workgroups of pass 1 (one per CU at 1024 threads, two at 512)
+constexpr int MSM_S = 64;          // sorted entries per accumulation task (the most: MsmShape::S is what a commitment uses)
+constexpr int MSM_S_MIN = 8;
+constexpr size_t MSM_TASK_TARGET = 131072;  // tasks that fill the chip: 256 CUs x 4 SIMDs x 64 lanes x 2 waves
 constexpr size_t MSM_LDS_BYTES = 160 * 1024;  // per workgroup on gfx950
 constexpr int MSM_LB_MAX = 8;      // low key bits sorted in pass 2: they travel as one byte per entry
 
@@ -36,6 +41,7 @@ struct MsmShape {
     int LB;                // low key bits sorted in pass 2 (NB >> LB == P), <= MSM_LB_MAX
     int NG;                // scan groups of MSM_GRP keys
     size_t n, stride;      // scalars in this call; table stride per window (0 in plain mode)
+    int S;                 // sorted entries per accumulation task: MSM_S, less when that would leave lanes idle (small commitments)
     int sel;               // >= 0: TWO key spaces chosen by bit `sel` of the scalar's index (a pair of commitments with disjoint supports
                            // in one pass: the two halves of an inner-product-argument round); -1: off
 };

@@ -21,6 +21,20 @@ from .msm import CommitmentKey, point_sum
 
 
 _GATHER_BUFS: dict = {}
+_SIDE_GROUPS: dict = {}
+
+
+def _host_side_group(group):
+    """A gloo group over the same ranks (created collectively at the first exchange): LURK_PARTIALS_EXCHANGE=host sends the 96-byte partials
+    through it instead of host -> device -> RCCL -> host (the collective then costs no device round trip; the
+    default stays the RCCL exchange the path is specified with)."""
+    import torch.distributed as dist
+
+    key = id(group)
+    if key not in _SIDE_GROUPS:
+        ranks = dist.get_process_group_ranks(group) if group is not None else None
+        _SIDE_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _SIDE_GROUPS[key]
 
 
 def shard_range(n_total: int, world: int, rank: int) -> tuple[int, int]:
@@ -35,8 +49,12 @@ def gather_partials(partial: np.ndarray, group=None) -> np.ndarray:
     import torch
     import torch.distributed as dist
 
+    import os
+
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
+    if os.environ.get("LURK_PARTIALS_EXCHANGE", "rccl") == "host":
+        group, backend = _host_side_group(group), "gloo"
     if backend == "nccl":
         # RCCL moves device buffers: one pinned staging row in, ONE collective into a resident (world, 12) tensor, one copy out -
         # the buffers are kept per (group, world) so that a commitment allocates nothing (a step makes two of these exchanges)

@@ -191,14 +191,14 @@ class MultiCommitmentKey:
     prover binds (/root/reference/src/proof/nova.rs:304-326); ``distributed.ShardedCommitmentKey`` is the
     one-process-per-GPU form of the same sharding."""
 
-    def __init__(self, curve: int, bases: np.ndarray, devices, precompute: bool = False, window_bits: int = 0):
+    def __init__(self, curve: int, bases: np.ndarray, devices, precompute: bool = False, window_bits: int = 0, auto_slices: bool = False):
         lib = _lib.load()
         self.curve = curve
         bases = np.ascontiguousarray(bases, dtype=np.uint64)
         self.n = bases.size // 8
         self.devices = list(devices)
         devs = (ctypes.c_int * len(self.devices))(*self.devices)
-        flags = (1 if precompute else 0) | ((window_bits & 0xFF) << 8)
+        flags = (1 if precompute else 0) | ((window_bits & 0xFF) << 8) | ((1 << 18) if auto_slices else 0)  # LURK_MSM_FLAG_AUTO_SLICES
         self._ctx = ctypes.c_void_p()
         _lib.check(lib.lurk_hip_msm_multi_create(ctypes.byref(self._ctx), curve, _lib.ptr(bases), self.n, devs, len(self.devices), flags))
 

@@ -19,8 +19,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, q):
+def _worker(rank, world, port, n, q, exchange="rccl"):
     try:
+        os.environ["LURK_PARTIALS_EXCHANGE"] = exchange  # "host": the 96-byte partials go through a gloo side group (distributed.py)
         _worker_body(rank, world, port, n, q)
     except Exception as e:  # surface failures instead of hanging the parent
         q.put((rank, repr(e)))
@@ -45,15 +46,15 @@ def _worker_body(rank, world, port, n, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [1001, 4096])
-def test_sharded_commitment_world2_gloo(n):
+@pytest.mark.parametrize("n,exchange", [(1001, "rccl"), (4096, "rccl"), (1001, "host")])
+def test_sharded_commitment_world2_gloo(n, exchange):
     from oracle import coracle as C
 
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))

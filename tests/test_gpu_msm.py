@@ -203,7 +203,7 @@ def test_submit_scheduling_classes_and_four_slots(hip, log_n):
         with pytest.raises(LurkHipError):
             ck.submit_device(0, scal[0], n, is_mont=True, stream=s, mode=3)  # unknown class
         with pytest.raises(LurkHipError):
-            ck.submit_device(4, scal[0], n, is_mont=True, stream=s)  # only four slots
+            ck.submit_device(6, scal[0], n, is_mont=True, stream=s)  # LURK_MSM_SLOTS = 6 slots
         ck.close()
 
 
@@ -388,6 +388,21 @@ def test_multi_device_key_one_process(hip, cn, c):
         mk.close()
     with pytest.raises(LurkHipError):
         MultiCommitmentKey(c, B, [0, 4096])
+    # LURK_MSM_FLAG_AUTO_SLICES: only as many of the listed devices as leave every slice the threshold's points (2^20 by default: one
+    # slice here; 2^12 from the environment: the first two of the three), same commitment
+    import os
+
+    want = C.jac_to_affine(c, C.msm_pippenger(c, B, S))
+    mk = MultiCommitmentKey(c, B, [0, 0, 0], auto_slices=True)
+    assert len(mk.shards()) == 1 and point_to_affine(c, mk.commit(S)) == want
+    mk.close()
+    os.environ["LURK_MSM_MULTI_MIN_SLICE_LOG"] = "12"
+    try:
+        mk = MultiCommitmentKey(c, B, [0, 0, 0], auto_slices=True)
+        assert len(mk.shards()) == 2 and sum(cnt for _, _, cnt in mk.shards()) == n and point_to_affine(c, mk.commit(S)) == want
+        mk.close()
+    finally:
+        del os.environ["LURK_MSM_MULTI_MIN_SLICE_LOG"]
 
 
 def test_multi_device_key_commitments_in_flight(hip):
