@@ -51,53 +51,15 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_kernel(const uin
     msm_accumulate_task<P>(i, sorted, table, task_info, order, partials);
 }
 
-// (XCC, SE, CU) of the running wave as one index < 512 (HW_ID: CU_ID [11:8], SE_ID [14:13]; XCC_ID [3:0])
-__device__ __forceinline__ uint32_t msm_cu_index() {
-    const uint32_t hw = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
-    const uint32_t xcc = __builtin_amdgcn_s_getreg((20 /*XCC_ID*/) | (0 << 6) | (3 << 11));
-    return (xcc & 7u) * 64u + ((hw >> 13) & 3u) * 16u + ((hw >> 8) & 15u);
-}
-
-// Persistent form for commitments in flight: a fixed number of waves per SIMD (the launch grid), each wave pulls the next
-// 64 tasks of the longest-first order from a global cursor.  The kernel then never holds more than its share of every
-// SIMD's registers and wave slots, so the latency / HBM-bound kernels of the NEXT commitment (sort, plan, bucket
-// reduction: other stream, higher priority) find room on every CU while this one keeps the integer VALU busy.
-template <class P>
-__global__ __launch_bounds__(MSM_ACC_BLOCK) void msm_accumulate_persistent_kernel(const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
-                                                                                    const uint2* __restrict__ task_info,
-                                                                                    const uint32_t* __restrict__ order,
-                                                                                    const uint32_t* __restrict__ group_task_base, int NG,
-                                                                                    Xyzz<P>* __restrict__ partials, uint32_t* __restrict__ cursor) {
-    const uint32_t ntasks = group_task_base[NG];
-    const uint32_t lane = threadIdx.x & 63u;
-    if (threadIdx.x == 0) atomicAdd(&cursor[MSM_PLACEMENT_BASE + msm_cu_index()], 1u);  // diagnostic: workgroups per CU
-    for (;;) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(cursor, 64u);
-        base = __builtin_amdgcn_readfirstlane(base);  // wave-uniform: the loop control stays scalar
-        if (base >= ntasks) break;
-        if (base + lane < ntasks) msm_accumulate_task<P>(base + lane, sorted, table, task_info, order, partials);
-    }
-}
-
 template <class P>
 void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
                            const uint32_t* group_task_base, int NG, Xyzz<P>* partials, size_t nt, hipStream_t s) {
     hipLaunchKernelGGL((msm_accumulate_kernel<P>), dim3(div_up(nt, MSM_ACC_BLOCK)), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
                        group_task_base, NG, partials);
 }
-// one workgroup of 4 waves per CU (one wave per SIMD); cursor must be zero when the kernel starts
-template <class P>
-void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
-                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, hipStream_t s) {
-    hipLaunchKernelGGL((msm_accumulate_persistent_kernel<P>), dim3((unsigned)num_cus()), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
-                       group_task_base, NG, partials, cursor);
-}
 #define LURK_ACC_INSTANTIATE(P)                                                                                                             \
     template void msm_launch_accumulate<P>(const uint32_t*, const Affine<P>*, const uint2*, const uint32_t*, const uint32_t*, int, Xyzz<P>*, \
-                                           size_t, hipStream_t);                                                                            \
-    template void msm_launch_accumulate_persistent<P>(const uint32_t*, const Affine<P>*, const uint2*, const uint32_t*, const uint32_t*, int, \
-                                                      Xyzz<P>*, uint32_t*, hipStream_t);
+                                           size_t, hipStream_t);
 LURK_ACC_INSTANTIATE(PallasFp)
 LURK_ACC_INSTANTIATE(PallasFq)
 

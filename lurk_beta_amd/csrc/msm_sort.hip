@@ -182,8 +182,11 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part_start_kernel(const ui
 // partition leave as one run instead of as isolated stores (which cost a 32-byte sector each: rocprof showed 3.9x write
 // amplification for the direct scatter).  Out: inter_e[slot] = table index | sign, inter_k[slot] = the key's low LB bits.
 // C != 0: the tile's counting and placement sweeps share ONE recoding held in W registers.
+#ifndef LURK_SORT_MIN_BLOCKS
+#define LURK_SORT_MIN_BLOCKS 1  // (HIP: minimum WAVES per SIMD) 8: the compiler holds the kernel to 64 registers
+#endif
 template <int C>
-__global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint4* __restrict__ scalars, const uint32_t* __restrict__ block_off,
+__global__ __launch_bounds__(MSM_SORT_BLOCK, LURK_SORT_MIN_BLOCKS) void msm_scatter1_kernel(const uint4* __restrict__ scalars, const uint32_t* __restrict__ block_off,
                                                                         const uint32_t* __restrict__ part_start, uint32_t* __restrict__ inter_e,
                                                                         uint8_t* __restrict__ inter_k, MsmShape sh, size_t chunk) {
     msm_sort_wave_prio();
@@ -234,13 +237,16 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
             }
         }
         __syncthreads();
-        uint32_t c[MSM_P_PER_MAX], sum = 0, total;
+        uint32_t total;
+        {
+            uint32_t c[MSM_P_PER_MAX], sum = 0;
 #pragma unroll
-        for (int j = 0; j < MSM_P_PER_MAX; j++) { c[j] = j < PER ? cnt[t * PER + j] : 0u; sum += c[j]; }
-        uint32_t run = msm_block_scan(sum, scr, &total);
+            for (int j = 0; j < MSM_P_PER_MAX; j++) { c[j] = j < PER ? cnt[t * PER + j] : 0u; sum += c[j]; }
+            uint32_t run = msm_block_scan(sum, scr, &total);
 #pragma unroll
-        for (int j = 0; j < MSM_P_PER_MAX; j++)
-            if (j < PER) { start[t * PER + j] = run; run += c[j]; cnt[t * PER + j] = 0; }
+            for (int j = 0; j < MSM_P_PER_MAX; j++)
+                if (j < PER) { start[t * PER + j] = run; run += c[j]; cnt[t * PER + j] = 0; }
+        }
         __syncthreads();
         if (live) {
             if constexpr (C != 0) {
@@ -280,9 +286,12 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_scatter1_kernel(const uint
             inter_k[dst] = (uint8_t)(e.x & low_mask);
         }
         __syncthreads();
-#pragma unroll
-        for (int j = 0; j < MSM_P_PER_MAX; j++)
-            if (j < PER) { goff[t * PER + j] += c[j]; cnt[t * PER + j] = 0; }
+        // (the placement cursors have counted the tile's entries back up: the counts are read from them rather than kept in registers
+        // across the tile - the kernel has to fit 56 registers to be placed beside two resident accumulations, msm_acc_persistent.hip)
+        for (int j = 0; j < PER; j++) {
+            goff[t * PER + j] += cnt[t * PER + j];
+            cnt[t * PER + j] = 0;
+        }
         __syncthreads();
     }
 }

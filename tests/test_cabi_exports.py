@@ -125,7 +125,7 @@ def test_sort_kernels_fit_beside_a_resident_accumulation(tmp_path):
         return out
 
     granule = lambda v: -(-v // 8) * 8
-    acc = usage("msm_acc.hip")
+    acc = usage("msm_acc_persistent.hip")
     persistent = max(v for k, v in acc.items() if "persistent" in k)
     assert persistent <= 256
     sort = usage("msm_sort.hip")
