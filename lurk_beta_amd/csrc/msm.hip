@@ -81,23 +81,26 @@ __global__ __launch_bounds__(1024) void msm_taskscan_kernel(const uint32_t* __re
         group_tasks[g] = run;
     }
 }
-// exclusive scan of the per-group task totals (NG <= 16) -> group_task_base[0..NG]
-__global__ void msm_task_base_kernel(const uint32_t* __restrict__ group_tasks, uint32_t* __restrict__ group_task_base, int NG) {
+// task table: task t -> [first, last) of the sorted list (<= S entries of one bucket).  Every workgroup first scans the per-group task
+// totals itself (NG <= 32 values: group_task_base[0..NG], which workgroup 0 also stores for the kernels that follow) - a launch of its
+// own for that scan was one more link in a chain of dependent launches that costs 5-60 us per link beside resident accumulations.
+constexpr int MSM_NG_MAX = 64;
+__global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bucket_start,
+                                                          const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ group_tasks,
+                                                          uint32_t* __restrict__ group_task_base_out, int NG, uint2* __restrict__ task_info, uint32_t S) {
     msm_set_wave_prio(1);
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __shared__ uint32_t group_task_base[MSM_NG_MAX + 1];
+    if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (int g = 0; g < NG; g++) {
             group_task_base[g] = run;
             run += group_tasks[g];
         }
         group_task_base[NG] = run;
+        if (blockIdx.x == 0)
+            for (int g = 0; g <= NG; g++) group_task_base_out[g] = group_task_base[g];
     }
-}
-// task table: task t -> [first, last) of the sorted list (<= MSM_S entries of one bucket)
-__global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bucket_start,
-                                                          const uint32_t* __restrict__ task_start,
-                                                          const uint32_t* __restrict__ group_task_base, int NG, uint2* __restrict__ task_info, uint32_t S) {
-    msm_set_wave_prio(1);
+    __syncthreads();
     uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= group_task_base[NG]) return;
     int g = 0;
@@ -140,22 +143,22 @@ __global__ __launch_bounds__(1024) void msm_len_hist_kernel(const uint2* __restr
     __syncthreads();
     if (threadIdx.x <= MSM_S && sh[threadIdx.x]) atomicAdd(&len_hist[threadIdx.x], sh[threadIdx.x]);
 }
-// len_hist -> start offset of each length class, longest first (single small block)
-__global__ void msm_len_scan_kernel(uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor, int S) {
+// (the start offset of each length class, longest first, is scanned from len_hist by every workgroup of the scatter below: the class
+// cursors count from zero - they are cleared with the other small counters by the sort's single-block launch)
+__global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __restrict__ task_info,
+                                                                 const uint32_t* __restrict__ group_task_base, int NG,
+                                                                 const uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor,
+                                                                 uint32_t* __restrict__ order, uint32_t S) {
     msm_set_wave_prio(1);
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    __shared__ uint32_t sh_cnt[MSM_S + 1], sh_base[MSM_S + 1], sh_class[MSM_S + 1];
+    if (threadIdx.x == 0) {
         uint32_t run = 0;
-        for (int l = S; l >= 0; l--) {
-            len_cursor[l] = run;
+        for (int l = (int)S; l >= 0; l--) {
+            sh_class[l] = run;
             run += len_hist[l];
         }
     }
-}
-__global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __restrict__ task_info,
-                                                                 const uint32_t* __restrict__ group_task_base, int NG,
-                                                                 uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order, uint32_t S) {
-    msm_set_wave_prio(1);
-    __shared__ uint32_t sh_cnt[MSM_S + 1], sh_base[MSM_S + 1];
+    __syncthreads();
     const uint32_t ntasks = group_task_base[NG];
     for (uint32_t base = blockIdx.x * 1024u; base < ntasks; base += gridDim.x * 1024u) {
         if (threadIdx.x <= MSM_S) sh_cnt[threadIdx.x] = 0;
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __re
             rank = atomicAdd(&sh_cnt[len], 1u);
         }
         __syncthreads();
-        if (threadIdx.x <= MSM_S && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = atomicAdd(&len_cursor[threadIdx.x], sh_cnt[threadIdx.x]);
+        if (threadIdx.x <= MSM_S && sh_cnt[threadIdx.x]) sh_base[threadIdx.x] = sh_class[threadIdx.x] + atomicAdd(&len_cursor[threadIdx.x], sh_cnt[threadIdx.x]);
         __syncthreads();
         if (len != 0) order[sh_base[len] + rank] = t;
         __syncthreads();
@@ -691,16 +694,13 @@ struct MsmCtx : MsmCtxBase {
             uint32_t* lh = wk.len_hist.template as<uint32_t>();
             hipLaunchKernelGGL(msm_taskscan_kernel, dim3(sh.NG), dim3(1024), 0, s, wk.cnt.template as<uint32_t>(),
                                wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>(), (uint32_t)sh.S);
-            hipLaunchKernelGGL(msm_task_base_kernel, dim3(1), dim3(64), 0, s, wk.group_tasks.template as<uint32_t>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NG);
             hipLaunchKernelGGL(msm_tasks_kernel, dim3(div_up(nt, 256)), dim3(256), 0, s, wk.cnt.template as<uint32_t>(),
-                               wk.bucket_start.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
+                               wk.bucket_start.template as<uint32_t>(), wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), sh.NG, wk.task_info.template as<uint2>(), (uint32_t)sh.S);
             hipLaunchKernelGGL(msm_len_hist_kernel, dim3(256), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
                                wk.group_task_base.template as<uint32_t>(), sh.NG, lh, (uint32_t)sh.S);
-            hipLaunchKernelGGL(msm_len_scan_kernel, dim3(1), dim3(64), 0, s, lh, lh + MSM_S + 1, sh.S);
             hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh + MSM_S + 1, wk.task_order.template as<uint32_t>(), (uint32_t)sh.S);
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh, lh + MSM_S + 1, wk.task_order.template as<uint32_t>(), (uint32_t)sh.S);
         }
         if (before_accumulate) (*before_accumulate)();  // the one-shot entry point uploads the bases here, behind the sort
         const MsmTuning& tn = msm_tuning();
