@@ -222,9 +222,15 @@ void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, i
 // replay, background-behind-sort off) lost its measurement and is gone: the winning setting is now the only code path.
 struct MsmTuning {
     int persistent, max_acc, placement_log;
+    size_t persistent_min;
     MsmTuning() {
         auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
-        persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // DEFAULT-class commitments in flight: 0 = plain launch, 1 = persistent from 2^22 entries, 2 = always
+        persistent = geti("LURK_MSM_ACC_PERSISTENT", 1);  // DEFAULT-class commitments in flight: 0 = plain launch, 1 = persistent from persistent_min entries, 2 = always
+        // W n entries (in 2^20) from which a commitment in flight takes the persistent form.  A one-wave-per-SIMD accumulation runs at
+        // ~55 % of the plain launch's rate; two of them resident pay that back only when the accumulation is long against the sort and
+        // tail around it: 2^21 scalars x 13 windows (27 M entries) break even, 2^20 (13.6 M) is 4 % faster with the plain launch
+        // (853-858 against 821-825 Mscalar-mul/s, two in flight; profiles/r05_persistent_threshold.txt).
+        persistent_min = (size_t)geti("LURK_MSM_PERSISTENT_MIN_MENTRIES", 24) << 20;
         max_acc = geti("LURK_MSM_MAX_ACC", 2);            // persistent accumulations resident at once (0 = no limit)
         placement_log = geti("LURK_MSM_PLACEMENT_LOG", 0);  // diagnostic: persistent workgroups per CU, on stderr
         if (max_acc > 2) max_acc = 0;
@@ -704,9 +710,9 @@ struct MsmCtx : MsmCtxBase {
         }
         if (before_accumulate) (*before_accumulate)();  // the one-shot entry point uploads the bases here, behind the sort
         const MsmTuning& tn = msm_tuning();
-        // commitments in flight take the persistent form on the slot's low-priority accumulate stream (tiny ones excepted: their
-        // accumulation is over before a second kernel could share the chip); synchronous calls keep the plain launch
-        const bool persistent = s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= ((size_t)1 << 22) : tn.persistent != 0));
+        // large commitments in flight take the persistent form on the slot's low-priority accumulate stream (below persistent_min
+        // entries the plain launch: see msm_tuning); synchronous calls keep the plain launch
+        const bool persistent = s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= tn.persistent_min : tn.persistent != 0));
         if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));  // sort and plan are enqueued: a background commitment may start behind this point
         if (persistent) {
             wk.placement_valid = true;  // (the cursor block was zeroed by msm_part_start_kernel)

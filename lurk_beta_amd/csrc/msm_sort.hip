@@ -36,7 +36,8 @@ MsmShape msm_make_shape(int c, bool precomputed, size_t npoints, size_t n, int s
     // tasks of 64 would leave seven lanes in eight idle behind chains of 32-64 additions.  Halve S until the tasks fill the lanes: the
     // per-bucket partials (<= 16 by one lane, more by a workgroup tree) absorb the rest.
     sh.S = MSM_S;
-    while (sh.S > MSM_S_MIN && (size_t)sh.W * n / sh.S < MSM_TASK_TARGET) sh.S /= 2;
+    static const size_t task_target = [] { const char* e = getenv("LURK_MSM_TASK_TARGET"); long v = e ? atol(e) : 0; return v > 0 ? (size_t)v : MSM_TASK_TARGET; }();
+    while (sh.S > MSM_S_MIN && (size_t)sh.W * n / sh.S < task_target) sh.S /= 2;
     sh.NG = (int)(sh.NB / MSM_GRP);
     sh.n = n;
     sh.stride = precomputed ? npoints : 0;

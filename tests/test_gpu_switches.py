@@ -43,7 +43,10 @@ print("child ok")
 @pytest.mark.parametrize("env,expect_stderr", [
     ({}, None),
     ({"LURK_MSM_ACC_PERSISTENT": "0"}, None),                     # never the persistent accumulation
-    ({"LURK_MSM_ACC_PERSISTENT": "2"}, None),                     # always (the default picks it from 2^22 sorted entries on)
+    ({"LURK_MSM_ACC_PERSISTENT": "2"}, None),                     # always (the default picks it from 24 x 2^20 sorted entries on)
+    ({"LURK_MSM_PERSISTENT_MIN_MENTRIES": "1"}, None),            # the default rule with its threshold at 2^20 entries
+    ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_PERSIST_WGS": "2", "LURK_MSM_MAX_ACC": "1"}, None),   # one two-wave accumulation at a time
+    ({"LURK_MSM_TASK_TARGET": "1048576"}, None),                  # shorter accumulation tasks than the shape rule picks
     ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_MAX_ACC": "0"}, None),   # no limit on resident accumulations
     ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_PLACEMENT_LOG": "1"}, "accumulate placement"),
     ({"LURK_STEP_TRACE": "1"}, "[step]"),
