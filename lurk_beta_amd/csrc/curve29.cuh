@@ -206,6 +206,28 @@ LURK_HD void xyzz29_madd(Xyzz29<P>& acc, bool& acc_id, const Affine<P>& q, bool 
     }
 }
 
+// Doubling of an R-bounded XYZZ29 point that is not the identity (dbl-2008-s-1, a = 0: 6 M + 3 S), result R-bounded: the link of
+// the doubling chains that build a window table (msm_precompute.hip).  The bounds are xyzz29_double_affine's with the two
+// products by zz / zzz of xyzz29_madd; a prime-order curve has no point with y = 0.
+template <class P>
+LURK_HD Xyzz29<P> xyzz29_dbl(const Xyzz29<P>& a) {
+    const F29<P> u = f29_dbl<P>(a.y);                            // limbs < 2^30, value < 2^260
+    const F29<P> v = f29_mul<P>(u, u);                           // < 2^259 + p
+    const F29<P> w = f29_mul<P>(u, v);
+    const F29<P> s = f29_mul<P>(a.x, v);
+    const F29<P> xx = f29_sqr<P>(a.x);
+    const F29<P> m = f29_carry<P>(f29_add<P>(f29_dbl<P>(xx), xx));  // 3 x^2, tight
+    const F29<P> m2 = f29_sqr<P>(m);
+    Xyzz29<P> r;
+    r.x = f29_reduce<P>(f29_carry<P>(f29_sub<P>(m2, f29_dbl<P>(s))));
+    const F29<P> t1 = f29_mul<P>(m, f29_sub<P>(s, r.x));
+    const F29<P> t2 = f29_mul<P>(w, a.y);
+    r.y = f29_reduce<P>(f29_carry<P>(f29_sub<P>(t1, t2)));
+    r.zz = f29_mul<P>(v, a.zz);
+    r.zzz = f29_mul<P>(w, a.zzz);
+    return r;
+}
+
 // Doubling of a general XYZZ29 point: only reached when two equal partial sums meet in a reduction tree - rare, so it goes
 // through the 32-bit-limb group law (out of line; arguments and result by value, see xyzz29_double_affine).
 template <class P>
@@ -274,6 +296,22 @@ LURK_HD void xyzz29_add(Xyzz29<P>& acc, bool& acc_id, const Xyzz29<P>& q, bool q
 }
 
 // One accumulation task on the radix-2^29 layer; returns an ordinary XYZZ point.
+// Sum of nt XYZZ points held in the 8 x 32 form (a bucket's task partials: msm_finalize.hip).  One point is copied, more go through
+// the radix-2^29 general addition (6.4 us per dependent addition on a lane where the 8 x 32 group law takes ~20).
+template <class P>
+LURK_HD Xyzz<P> xyzz_sum_via29(const Xyzz<P>* pts, uint32_t nt) {
+    if (nt == 0) return xyzz_identity<P>();
+    if (nt == 1) return pts[0];
+    Xyzz29<P> acc, q;
+    bool acc_id, q_id;
+    xyzz29_from_xyzz<P>(pts[0], acc, acc_id);
+    for (uint32_t i = 1; i < nt; i++) {
+        xyzz29_from_xyzz<P>(pts[i], q, q_id);
+        xyzz29_add<P>(acc, acc_id, q, q_id);
+    }
+    return xyzz29_to_xyzz<P>(acc, acc_id);
+}
+
 template <class P>
 LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, uint32_t last, const Affine<P>* table) {
     Xyzz29<P> acc;

@@ -30,7 +30,7 @@ namespace lurk {
 
 void keygen_from_label_device(int curve, const void* label, size_t label_len, size_t n, void* d_out, hipStream_t s);  // keygen.hip
 
-constexpr int MSM_SMALL = 16;      // buckets with <= this many task partials are summed by one lane
+constexpr int MSM_SMALL = 16;      // buckets with <= this many task partials are summed by one lane (msm_finalize.hip: MSM_FIN_SMALL)
 constexpr int MSM_ACC_BLOCK = 256;
 
 // Every kernel of a commitment except the bucket accumulation is short and bound by latency, LDS atomics or HBM; with
@@ -241,27 +241,10 @@ static const MsmTuning& msm_tuning() {
     return t;
 }
 
-// ---- 5. finalize ---------------------------------------------------------------------------
+// ---- 5. finalize: buckets of <= MSM_SMALL task partials, one lane each (msm_finalize.hip) ----------------------------------
 template <class P>
-__global__ __launch_bounds__(256) void msm_finalize_kernel(const Xyzz<P>* __restrict__ partials, const uint32_t* __restrict__ cnt,
-                                                             const uint32_t* __restrict__ task_start,
-                                                             const uint32_t* __restrict__ group_task_base, uint32_t NB,
-                                                             Xyzz<P>* __restrict__ buckets, uint32_t* __restrict__ big_list,
-                                                             uint32_t* __restrict__ big_count, uint32_t S) {
-    msm_set_wave_prio(1);
-    size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (key >= NB) return;
-    uint32_t g = (uint32_t)(key / MSM_GRP), b = (uint32_t)(key % MSM_GRP);
-    uint32_t nt = (cnt[key] + S - 1) / S;
-    uint32_t first = group_task_base[g] + task_start[(size_t)g * (MSM_GRP + 1) + b];
-    if (nt > MSM_SMALL) {
-        big_list[atomicAdd(big_count, 1u)] = (uint32_t)key;
-        return;
-    }
-    Xyzz<P> acc = xyzz_identity<P>();
-    for (uint32_t i = 0; i < nt; i++) xyzz_add<P>(acc, partials[first + i]);
-    buckets[key] = acc;
-}
+void msm_launch_finalize(const Xyzz<P>* partials, const uint32_t* cnt, const uint32_t* task_start, const uint32_t* group_task_base, uint32_t NB,
+                         Xyzz<P>* buckets, uint32_t* big_list, uint32_t* big_count, uint32_t S, hipStream_t s);
 
 template <class P, int BLOCK>
 __device__ void block_tree_sum(Xyzz<P>& acc, Xyzz<P>* sh) {
@@ -301,46 +284,10 @@ __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __re
 }
 
 // ---- 6. bucket reduction: msm_reduce.hip ------------------------------------------------------------------------------------
-// ---- precomputed table: T[w*n + i] = 2^(c w) * P_i ----------------------------------------------
-// One inversion per POINT, not per table entry: the W-1 multiples are carried in XYZZ form, their (X, Y) parked in the table,
-// ZZ, ZZZ and the running product of the ZZZ parked in a scratch buffer, then one field inversion and Montgomery's trick walk
-// back over the windows (x = X / ZZ, y = Y / ZZZ, 1/ZZ = (ZZ / ZZZ)^2).  The per-entry inversion (285 dependent products each)
-// was 2/3 of the 189 ms a 2^22-point table took.
+// ---- precomputed table: T[w*n + i] = 2^(c w) * P_i: msm_precompute.hip ---------------------------
+size_t msm_precompute_scratch_bytes(size_t n, int W);
 template <class P>
-__global__ __launch_bounds__(256) void msm_precompute_kernel(const Affine<P>* __restrict__ bases, size_t n, Affine<P>* __restrict__ table, int c,
-                                                               int W, Fe<P>* __restrict__ scratch) {
-    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const Affine<P> a = bases[i];
-    table[i] = a;
-    if (affine_is_identity<P>(a)) {
-        for (int w = 1; w < W; w++) table[(size_t)w * n + i] = a;
-        return;
-    }
-    auto slot = [&](int w, int k) -> Fe<P>& { return scratch[((size_t)(w - 1) * 3 + k) * n + i]; };  // k: 0 = ZZ, 1 = ZZZ, 2 = product of ZZZ_1..w
-    Xyzz<P> p = xyzz_from_affine<P>(a);
-    Fe<P> prod = fe_one<P>();
-    for (int w = 1; w < W; w++) {
-        p = xyzz_dbl_n<P>(p, c);
-        table[(size_t)w * n + i] = Affine<P>{p.x, p.y};
-        prod = fe_mul<P>(prod, p.zzz);
-        slot(w, 0) = p.zz;
-        slot(w, 1) = p.zzz;
-        slot(w, 2) = prod;
-    }
-    Fe<P> inv = fe_inv<P>(prod);  // 1 / (ZZZ_1 ... ZZZ_{W-1})
-    for (int w = W - 1; w >= 1; w--) {
-        const Fe<P> zzz = slot(w, 1);
-        const Fe<P> zzz_inv = w > 1 ? fe_mul<P>(inv, slot(w - 1, 2)) : inv;
-        inv = fe_mul<P>(inv, zzz);
-        const Fe<P> t = fe_mul<P>(slot(w, 0), zzz_inv);
-        const Fe<P> zz_inv = fe_sqr<P>(t);
-        Affine<P> q = table[(size_t)w * n + i];
-        q.x = fe_mul<P>(q.x, zz_inv);
-        q.y = fe_mul<P>(q.y, zzz_inv);
-        table[(size_t)w * n + i] = q;
-    }
-}
+void msm_launch_precompute(const Affine<P>* bases, size_t n, Affine<P>* table, int c, int W, void* scratch, hipStream_t s);
 
 // ---- context -------------------------------------------------------------------------------
 constexpr int MSM_SLOTS = LURK_MSM_SLOTS;  // commitments in flight per context (independent workspaces + streams)
@@ -451,12 +398,10 @@ struct MsmCtx : MsmCtxBase {
             LURK_HIP_CHECK(hipMemcpyAsync(own_bases.p, d_bases, n * sizeof(Affine<P>), hipMemcpyDeviceToDevice, s));
             table = own_bases.as<Affine<P>>();
             {
-                DevBuf wbases((size_t)Ws * n * sizeof(Affine<P>)), scratch((size_t)(Ws - 1) * 3 * n * sizeof(Fe<P>));
+                DevBuf wbases((size_t)Ws * n * sizeof(Affine<P>)), scratch(msm_precompute_scratch_bytes(n, Ws));
                 {
                     ProfScope ps("msm_precompute", s);
-                    hipLaunchKernelGGL((msm_precompute_kernel<P>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Affine<P>*)d_bases, n,
-                                       wbases.as<Affine<P>>(), c, Ws, scratch.as<Fe<P>>());
-                    LURK_HIP_CHECK(hipGetLastError());
+                    msm_launch_precompute<P>((const Affine<P>*)d_bases, n, wbases.as<Affine<P>>(), c, Ws, scratch.p, s);
                 }
                 small_table.alloc(msm_small_table_entries(n, c) * sizeof(Affine<P>));
                 msm_small_build_table<P>(wbases.as<Affine<P>>(), n, c, small_table.as<Affine<P>>(), s);  // synchronises s
@@ -481,12 +426,10 @@ struct MsmCtx : MsmCtxBase {
             if (n) {
                 DevBuf once;
                 DevBuf& scratch = keep_buffers ? pre_scratch : once;
-                scratch.ensure((size_t)(W - 1) * 3 * n * sizeof(Fe<P>));
+                scratch.ensure(msm_precompute_scratch_bytes(n, W));
                 {
                     ProfScope ps("msm_precompute", s);
-                    hipLaunchKernelGGL((msm_precompute_kernel<P>), dim3(div_up(n, 256)), dim3(256), 0, s, (const Affine<P>*)d_bases, n,
-                                       own_bases.as<Affine<P>>(), c, W, scratch.as<Fe<P>>());
-                    LURK_HIP_CHECK(hipGetLastError());
+                    msm_launch_precompute<P>((const Affine<P>*)d_bases, n, own_bases.as<Affine<P>>(), c, W, scratch.p, s);
                 }
                 LURK_HIP_CHECK(hipStreamSynchronize(s));  // the scratch buffer is released here
             }
@@ -750,10 +693,9 @@ struct MsmCtx : MsmCtxBase {
         }
         {
             ProfScope ps("msm_finalize", s);
-            hipLaunchKernelGGL((msm_finalize_kernel<P>), dim3(div_up((size_t)sh.NB, 256)), dim3(256), 0, s, wk.partials.template as<Xyzz<P>>(),
-                               wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NB, wk.buckets.template as<Xyzz<P>>(),
-                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S);
+            msm_launch_finalize<P>(wk.partials.template as<Xyzz<P>>(), wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
+                                   wk.group_task_base.template as<uint32_t>(), sh.NB, wk.buckets.template as<Xyzz<P>>(),
+                                   wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S, s);
             hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(128), dim3(256), 256 * sizeof(Xyzz<P>), s, wk.partials.template as<Xyzz<P>>(),
                                wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), wk.buckets.template as<Xyzz<P>>(),

@@ -175,13 +175,25 @@ extern "C" int hh_poseidon_params(int field, int arity, int* rf, int* rp, uint32
 // mode 0: acc = sum (+/-) P_i with xyzz_madd; mode 1: pairwise xyzz_add of xyzz_from_affine;
 // mode 2: sum k_i * P_i with xyzz_mul_small (k_i = signs[i] as small integer); mode 3: as mode 0 on the
 // radix-2^29 layer (xyzz29_madd, bound assertions enabled; the second base goes through the affine-accumulator
-// specialisation exactly as in msm_task_accumulate29); mode 4: radix-2^29, general addition only.  Output: affine Montgomery.
+// specialisation exactly as in msm_task_accumulate29); mode 4: radix-2^29, general addition only; mode 5: partial sums of three
+// bases each (8 x 32) summed by xyzz_sum_via29 (msm_finalize.hip).  Output: affine Montgomery.
 template <class P>
 static void curve_sum(int mode, const uint32_t* bases, const uint32_t* signs, size_t n, uint32_t* out) {
     Xyzz<P> acc = xyzz_identity<P>();
     Xyzz29<P> acc29;
     acc29.x = acc29.y = acc29.zz = acc29.zzz = f29_zero<P>();
     bool acc29_id = true;
+    if (mode == 5) {  // the finalize stage: task partials (8 x 32 XYZZ sums of 3 bases each) summed by xyzz_sum_via29
+        std::vector<Xyzz<P>> partials;
+        for (size_t i = 0; i < n; i++) {
+            Affine<P> a;
+            for (int k = 0; k < 8; k++) { a.x.l[k] = bases[i * 16 + k]; a.y.l[k] = bases[i * 16 + 8 + k]; }
+            if (i % 3 == 0) partials.push_back(xyzz_identity<P>());
+            xyzz_madd<P>(partials.back(), a, signs[i] != 0);
+        }
+        acc = xyzz_sum_via29<P>(partials.data(), (uint32_t)partials.size());
+        n = 0;
+    }
     for (size_t i = 0; i < n; i++) {
         Affine<P> a;
         for (int k = 0; k < 8; k++) { a.x.l[k] = bases[i * 16 + k]; a.y.l[k] = bases[i * 16 + 8 + k]; }
@@ -319,6 +331,36 @@ extern "C" int hh_msm_digits_ct(const uint32_t* scalar8, int c, uint32_t* out) {
         case 20: return hh_digits_ct<20>(scalar8, out);
         default: return 0;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// One point's row of a window table (msm_precompute.cuh: the body of msm_precompute_kernel, doubling chain + Montgomery's trick on the
+// radix-2^29 layer, bound assertions on): out = W affine Montgomery records, 2^(c w) P for w < W.  Also f29_invert against fe_inv.
+#include "../../lurk_beta_amd/csrc/msm_precompute.cuh"
+template <class P>
+static void precompute_row(const uint32_t* base16, int c, int W, uint32_t* out) {
+    Affine<P> a;
+    for (int k = 0; k < 8; k++) { a.x.l[k] = base16[k]; a.y.l[k] = base16[8 + k]; }
+    std::vector<Affine<P>> table(W);
+    std::vector<F29<P>> scratch((size_t)(W > 1 ? W - 1 : 1) * MSM_PRE_SLOTS);
+    msm_precompute_point<P>(a, 0, 1, c, W, table.data(), scratch.data());
+    for (int w = 0; w < W; w++)
+        for (int k = 0; k < 8; k++) { out[16 * w + k] = table[w].x.l[k]; out[16 * w + 8 + k] = table[w].y.l[k]; }
+}
+extern "C" void hh_msm_precompute_row(int curve, const uint32_t* base16, int c, int W, uint32_t* out) {
+    if (curve == 0) precompute_row<PallasFp>(base16, c, W, out);
+    else precompute_row<PallasFq>(base16, c, W, out);
+}
+template <class P>
+static void f29_invert_vs_fe(const uint32_t* a8, uint32_t* out29, uint32_t* out32) {
+    Fe<P> x;
+    for (int k = 0; k < 8; k++) x.l[k] = a8[k];
+    const Fe<P> r29 = f29_to_mont256<P>(f29_invert<P>(f29_from_mont256<P>(x))), r32 = fe_inv<P>(x);
+    for (int k = 0; k < 8; k++) { out29[k] = r29.l[k]; out32[k] = r32.l[k]; }
+}
+extern "C" void hh_f29_invert(int field, const uint32_t* a8, uint32_t* out29, uint32_t* out32) {
+    if (field == 0) f29_invert_vs_fe<PallasFp>(a8, out29, out32);
+    else f29_invert_vs_fe<PallasFq>(a8, out29, out32);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -72,16 +72,23 @@ def test_xyzz_group_law_with_exceptional_cases(cn, c):
     want = None
     for pt, s in zip(pts, signs):
         want = R.ec_add(cn, want, R.ec_neg(cn, pt) if s else pt)
-    for mode in (0, 1, 3, 4):  # 3 = radix-2^29 accumulator (the bucket-accumulation kernel's inner loop)
+    for mode in (0, 1, 3, 4, 5):  # 3 = radix-2^29 accumulator (the bucket-accumulation kernel's inner loop); 5 = the finalize stage's sum of partials
         out = np.zeros(8, dtype=np.uint64)
         L.hh_curve_sum(c, mode, vp(B), vp(signs), ctypes.c_size_t(12), vp(out))
         assert C.affine_to_ints(c, out)[0] == want, mode
     # chain that ends on the identity
     B2 = np.concatenate([B[:1], B[:1]])
-    for mode in (0, 3, 4):
+    for mode in (0, 3, 4, 5):
         out = np.zeros(8, dtype=np.uint64)
         L.hh_curve_sum(c, mode, vp(B2), vp(np.array([0, 1], dtype=np.uint32)), ctypes.c_size_t(2), vp(out))
         assert C.affine_to_ints(c, out)[0] == (0, 0)
+    # partials that are equal (the doubling branch of the general addition), opposite (the identity mid-sum) and the identity itself
+    B6 = np.concatenate([B[:3], B[:3], B[8:11], B[8:11], B[:3], B[5:6], B[5:6], B[5:6]])
+    s6 = np.array([0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0, 1, 1, 1, 1, 0, 0, 0], dtype=np.uint32)
+    o0, o5 = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    L.hh_curve_sum(c, 0, vp(B6), vp(s6), ctypes.c_size_t(18), vp(o0))
+    L.hh_curve_sum(c, 5, vp(B6), vp(s6), ctypes.c_size_t(18), vp(o5))
+    assert (o0 == o5).all() and o0.any()
     # starts with a negated point, then doubles it, then keeps going
     B3 = np.concatenate([B[:1], B[:1], B[1:4]])
     s3 = np.array([1, 1, 0, 1, 1], dtype=np.uint32)
@@ -285,6 +292,40 @@ def test_signed_digits_register_walk_equals_indexed_recoding(c):
             assert mag <= 1 << (c - 1)
             total += (-mag if neg else mag) << (c * w)
         assert total == k, (c, hex(k))
+
+
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+def test_window_table_row_on_the_radix29_layer(cn, c):
+    """msm_precompute_point (the body of msm_precompute_kernel: a chain of xyzz29_dbl, f29_invert, Montgomery's trick) with the bound
+    assertions on: row w of a point's table is 2^(c w) P for the three shapes the library builds (16 x 16, 20 x 13, 8 x 32), the
+    identity stays the identity, and f29_invert = fe_inv."""
+    L = H.lib()
+    assert L.hh_f29_checks_active() == 1
+    B = C.synth_bases(c, 3)
+    pts = C.affine_to_ints(c, B)
+    for cw, W in ((16, 16), (20, 13), (8, 32), (6, 43)):
+        for i in range(2 if cw in (16, 20) else 1):
+            out = np.zeros((W, 8), dtype=np.uint64)
+            L.hh_msm_precompute_row(c, vp(B[i:i + 1].copy()), cw, W, vp(out))
+            got = C.affine_to_ints(c, out)
+            want = pts[i]
+            for w in range(W):
+                assert got[w] == want, (cw, w)
+                if w + 1 < W:
+                    want = R.ec_mul(cn, 1 << cw, want)
+    ident = np.zeros((1, 8), dtype=np.uint64)
+    out = np.ones((16, 8), dtype=np.uint64)
+    L.hh_msm_precompute_row(c, vp(ident), 16, 16, vp(out))
+    assert not out.any()
+    f = c  # the curve's base field: Pallas points have F_p coordinates (field id 0), Vesta points F_q (1)
+    q = R.modulus(f)
+    vals = [1, 2, q - 1, (1 << 254) - 1, 12345] + [R.uniform_fe(77, k, q) for k in range(6)]
+    for v in vals:
+        a = C.to_mont(f, C.ints_to_limbs([v]))
+        o29, o32 = np.zeros(4, dtype=np.uint64), np.zeros(4, dtype=np.uint64)
+        L.hh_f29_invert(f, vp(a), vp(o29), vp(o32))
+        assert (o29 == o32).all(), hex(v)
+        assert C.limbs_to_ints(C.from_mont(f, o29.reshape(1, 4)))[0] == pow(v, -1, q)
 
 
 @pytest.mark.parametrize("kb,Wt", [(20, 13), (16, 16)])
