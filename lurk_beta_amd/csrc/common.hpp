@@ -190,6 +190,9 @@ struct MsmTableView {
     int curve = 0, window_bits = 0, windows = 1, form = 0, device = 0;
 };
 MsmTableView msm_ctx_table_view(const lurk_hip_msm_ctx* ctx);
+// lurk_hip_msm_ctx_wait_pair without the normalisation: the two commitments as XYZZ points (4 x 32 B each, Montgomery limbs) - the caller
+// adds to them and normalises both with one field inversion (ipa.hip: ~17 us of host time per inversion, five per round before)
+void msm_ctx_wait_pair_xyzz(lurk_hip_msm_ctx* ctx, int slot, void* out_lo_xyzz128, void* out_hi_xyzz128);
 // the parent key's folded-key context with its points replaced by d_points (m affine records on the device): msm.hip
 struct FoldedKeyLease {
     lurk_hip_msm_ctx* ctx = nullptr;

@@ -178,6 +178,22 @@ LURK_HD Affine<P> xyzz_to_affine(const Xyzz<P>& p) {
     a.y = fe_mul<P>(p.y, izzz);
     return a;
 }
+// two points with ONE field inversion (Montgomery's trick over ZZ ZZZ of both); the same affine coordinates as xyzz_to_affine
+template <class P>
+LURK_HD void xyzz_pair_to_affine(const Xyzz<P>& p, const Xyzz<P>& q, Affine<P>& ap, Affine<P>& aq) {
+    if (xyzz_is_identity<P>(p) || xyzz_is_identity<P>(q)) {
+        ap = xyzz_to_affine<P>(p);
+        aq = xyzz_to_affine<P>(q);
+        return;
+    }
+    const Fe<P> dp = fe_mul<P>(p.zz, p.zzz), dq = fe_mul<P>(q.zz, q.zzz);
+    const Fe<P> t = fe_inv<P>(fe_mul<P>(dp, dq));
+    const Fe<P> tp = fe_mul<P>(t, dq), tq = fe_mul<P>(t, dp);  // 1 / (ZZ ZZZ) of p, of q
+    ap.x = fe_mul<P>(p.x, fe_mul<P>(tp, p.zzz));
+    ap.y = fe_mul<P>(p.y, fe_mul<P>(tp, p.zz));
+    aq.x = fe_mul<P>(q.x, fe_mul<P>(tq, q.zzz));
+    aq.y = fe_mul<P>(q.y, fe_mul<P>(tq, q.zz));
+}
 template <class P>
 LURK_HD Xyzz<P> xyzz_from_jacobian(const Jacobian<P>& j) {
     if (fe_is_zero<P>(j.z)) return xyzz_identity<P>();

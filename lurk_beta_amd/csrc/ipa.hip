@@ -360,7 +360,12 @@ static void key_fold(const MsmTableView& v, size_t n, const void* weights32_mont
 // a window-table key of >= 2^ipa_fold_min_log() points the key IS folded - once, by the product weights of those rounds (key_fold: about
 // two commitments' worth of additions) - into a window-table key of n / 2^IPA_FOLD_ROUNDS points, and the argument continues under that
 // one (which folds again if it is still long).  2^20: 4 rounds at 1.9 ms + the fold instead of 20 rounds at 1.9 ms.
-constexpr int IPA_FOLD_ROUNDS = 4;
+constexpr int IPA_FOLD_ROUNDS_DEFAULT = 4;
+static int ipa_fold_rounds() {
+    const char* e = getenv("LURK_IPA_FOLD_ROUNDS");  // rounds under the long key before it is folded (1 .. 12); read per call (tests move it)
+    const int v = e ? atoi(e) : IPA_FOLD_ROUNDS_DEFAULT;
+    return v < 1 ? 1 : v > 12 ? 12 : v;
+}
 static int ipa_fold_min_log() {
     const char* e = getenv("LURK_IPA_FOLD_MIN_LOG");  // 0 = never fold the key (the round-3 form); default 2^18 points; read per call (tests move it)
     return e ? atoi(e) : 18;
@@ -394,6 +399,7 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
     size_t m = n0;
     int j = 0;
     const int fold_log = ipa_fold_min_log();
+    const int IPA_FOLD_ROUNDS = ipa_fold_rounds();
     const bool will_fold = pairs && fold_log > 0 && n0 >= ((size_t)1 << fold_log) && n0 >= ((size_t)1 << (IPA_FOLD_ROUNDS + 1));
     while (m > 1) {
         if (will_fold && j == IPA_FOLD_ROUNDS) {
@@ -453,20 +459,35 @@ static void ipa_prove_resident(lurk_hip_msm_ctx* key, int curve, int field_id, v
         ok(lurk_hip_point_mul(curve, tl, ck_c_jac96, cl.l, 1));  // two 255-bit host scalar multiples, under the commitment
         ok(lurk_hip_point_mul(curve, tr, ck_c_jac96, cr.l, 1));
         if (pairs) {
+            // the commitments arrive as XYZZ points, take the multiples of the extra base and leave normalised through ONE inversion
             drain.pending = 0;
-            ok(lurk_hip_msm_ctx_wait_pair(key, 0, c_r, c_l));
+            Xyzz<P> xl, xr;
+            msm_ctx_wait_pair_xyzz(key, 0, &xr, &xl);
+            Jacobian<P> jl, jr;
+            memcpy(&jl, tl, 96);
+            memcpy(&jr, tr, 96);
+            xyzz_add<P>(xl, xyzz_from_jacobian<P>(jl));
+            xyzz_add<P>(xr, xyzz_from_jacobian<P>(jr));
+            Affine<P> al, ar;
+            xyzz_pair_to_affine<P>(xl, xr, al, ar);
+            jl = jacobian_from_affine<P>(al);
+            jr = jacobian_from_affine<P>(ar);
+            memcpy(L, &jl, 96);
+            memcpy(R, &jr, 96);
         } else {
             drain.pending = 0;
             const int rc0 = lurk_hip_msm_ctx_wait(key, 0, c_l), rc1 = lurk_hip_msm_ctx_wait(key, 1, c_r);
             ok(rc0);
             ok(rc1);
         }
-        memcpy(two, c_l, 96);
-        memcpy(two + 12, tl, 96);
-        ok(lurk_hip_point_sum(curve, L, two, 2));
-        memcpy(two, c_r, 96);
-        memcpy(two + 12, tr, 96);
-        ok(lurk_hip_point_sum(curve, R, two, 2));
+        if (!pairs) {
+            memcpy(two, c_l, 96);
+            memcpy(two + 12, tl, 96);
+            ok(lurk_hip_point_sum(curve, L, two, 2));
+            memcpy(two, c_r, 96);
+            memcpy(two + 12, tr, 96);
+            ok(lurk_hip_point_sum(curve, R, two, 2));
+        }
         uint64_t r_can[4] = {0, 0, 0, 0};
         LURK_REQUIRE(challenge(user, round0 + j, L, R, r_can) == 0, "the transcript callback failed");
         Fe<F> r;

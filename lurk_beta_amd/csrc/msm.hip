@@ -310,6 +310,7 @@ struct MsmCtxBase {
     // two commitments with disjoint supports in one pass: scalars whose index has bit sel_bit clear -> out_lo, set -> out_hi
     virtual void submit_pair(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int sel_bit) = 0;
     virtual void wait_pair(int slot, void* out_lo_jac96_host, void* out_hi_jac96_host) = 0;
+    virtual void wait_pair_xyzz(int slot, void* out_lo_xyzz128_host, void* out_hi_xyzz128_host) = 0;  // not normalised: no field inversion
     // pasta-msm's calling convention: everything in host memory, nothing resident (buffers and workspaces are kept for the next call)
     virtual void run_oneshot(const void* bases, const void* scalars, size_t n, int is_mont, void* out_jac96_host) = 0;
     virtual void rebind(const void* d_bases, size_t n) = 0;  // plain key over other (borrowed) device bases, workspaces kept
@@ -766,6 +767,20 @@ struct MsmCtx : MsmCtxBase {
         wk.pending = false;
         LURK_HIP_CHECK(hipStreamSynchronize(wk.pending_stream ? wk.pending_stream : wk.stream));
         host_tail_pair(wk, out_lo, out_hi);
+        wk.sel = -1;
+    }
+    void wait_pair_xyzz(int slot, void* out_lo, void* out_hi) override {
+        LURK_REQUIRE(slot >= 0 && slot < MSM_SLOTS, "slot out of range");
+        Work& wk = work[slot];
+        std::lock_guard<std::mutex> lk(wk.mu);
+        LURK_REQUIRE(wk.pending && wk.sel >= 0, "no pair was submitted on this slot");
+        wk.pending = false;
+        LURK_HIP_CHECK(hipStreamSynchronize(wk.pending_stream ? wk.pending_stream : wk.stream));
+        void* outs[2] = {out_lo, out_hi};
+        for (int g = 0; g < 2; g++) {
+            const Xyzz<P> t = msm_planes_horner_windows<P>(wk.host_pts + (size_t)g * c, 1, c);
+            memcpy(outs[g], &t, sizeof(t));
+        }
         wk.sel = -1;
     }
     void submit(int slot, const void* d_scalars, size_t n, int is_mont, hipStream_t after, int mode) override {
@@ -1324,6 +1339,11 @@ void msm_ctx_drop_folded_child(const lurk_hip_msm_ctx* parent) {
         msm_ctx_drop_folded_child(dead->ctx.get());  // (a folded key long enough to have been folded again)
         dead->ctx.reset();
     }
+}
+void msm_ctx_wait_pair_xyzz(lurk_hip_msm_ctx* ctx, int slot, void* out_lo_xyzz128, void* out_hi_xyzz128) {
+    LURK_REQUIRE(ctx && out_lo_xyzz128 && out_hi_xyzz128, "null argument");
+    DeviceGuard dg(ctx->impl->device);
+    ctx->impl->wait_pair_xyzz(slot, out_lo_xyzz128, out_hi_xyzz128);
 }
 MsmTableView msm_ctx_table_view(const lurk_hip_msm_ctx* ctx) {
     LURK_REQUIRE(ctx, "null ctx");

@@ -49,7 +49,8 @@ def _aff(curve_id, jac):
 
 @pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
 @pytest.mark.parametrize("log_n", [1, 4, 7, 9])
-@pytest.mark.parametrize("form", ["folded_key", "resident_plain_key", "resident_table_key", "resident_window_table_key", "window_table_key_folded_after_4_rounds"])
+@pytest.mark.parametrize("form", ["folded_key", "resident_plain_key", "resident_table_key", "resident_window_table_key", "window_table_key_folded_after_4_rounds",
+                                  "window_table_key_folded_after_3_rounds", "window_table_key_folded_after_2_rounds"])
 def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n, form, monkeypatch):
     """resident_table_key: the small-commitment form at these sizes (two commitments per round); resident_window_table_key: the bucket
     pipeline with the window table (L and R as one pair commitment), the key never folded; ..._folded_after_4_rounds: the same with the
@@ -59,7 +60,11 @@ def test_ipa_rounds_match_the_oracle_and_verify(hip, cn, c, log_n, form, monkeyp
 
     if log_n == 9 and form in ("folded_key", "resident_plain_key"):
         pytest.skip("covered at the smaller sizes")
-    monkeypatch.setenv("LURK_IPA_FOLD_MIN_LOG", "5" if form == "window_table_key_folded_after_4_rounds" else "0")
+    monkeypatch.setenv("LURK_IPA_FOLD_MIN_LOG", "5" if "_folded_after_" in form else "0")
+    if "_folded_after_" in form:  # LURK_IPA_FOLD_ROUNDS: rounds under the long key before the fold (the default is 4)
+        monkeypatch.setenv("LURK_IPA_FOLD_ROUNDS", form.split("_folded_after_")[1][0])
+        if log_n < 7 and form[-8] != "4":
+            pytest.skip("covered by the 4-round form at these sizes")
 
     sf = 1 if c == 0 else 0
     bf = 0 if c == 0 else 1
