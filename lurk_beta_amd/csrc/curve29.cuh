@@ -295,7 +295,6 @@ LURK_HD void xyzz29_add(Xyzz29<P>& acc, bool& acc_id, const Xyzz29<P>& q, bool q
     acc.zzz = f29_mul<P>(zzz12, ppp);
 }
 
-// One accumulation task on the radix-2^29 layer; returns an ordinary XYZZ point.
 // Sum of nt XYZZ points held in the 8 x 32 form (a bucket's task partials: msm_finalize.hip).  One point is copied, more go through
 // the radix-2^29 general addition (6.4 us per dependent addition on a lane where the 8 x 32 group law takes ~20).
 template <class P>
@@ -312,11 +311,12 @@ LURK_HD Xyzz<P> xyzz_sum_via29(const Xyzz<P>* pts, uint32_t nt) {
     return xyzz29_to_xyzz<P>(acc, acc_id);
 }
 
+// One accumulation task on the radix-2^29 layer: the signed table records sorted[first .. last) summed into (acc, acc_id), which
+// leave R-bounded (msm_task_accumulate29 returns them as an ordinary XYZZ point; msm_bucket_direct.hip keeps them on this layer).
 template <class P>
-LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, uint32_t last, const Affine<P>* table) {
-    Xyzz29<P> acc;
+LURK_HD void msm_task_accumulate29_raw(const uint32_t* sorted, uint32_t first, uint32_t last, const Affine<P>* table, Xyzz29<P>& acc, bool& acc_id) {
     acc.x = acc.y = acc.zz = acc.zzz = f29_zero<P>();
-    bool acc_id = true;
+    acc_id = true;
     // (gathering the next base ahead of the current addition was measured: no gain, the other waves of the SIMD
     // already cover the load; so was requesting one dword of it ahead - a one-VGPR "touch" for L2 and the TLB - 3.6 against
     // 3.5 ms, although confining every gather to a 64 MB window of the 3.25 GiB table does make the kernel 8 % faster)
@@ -351,6 +351,12 @@ LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, ui
         xyzz29_madd<P>(acc, acc_id, q, (e & 0x80000000u) != 0);
     }
 #endif
+}
+template <class P>
+LURK_HD Xyzz<P> msm_task_accumulate29(const uint32_t* sorted, uint32_t first, uint32_t last, const Affine<P>* table) {
+    Xyzz29<P> acc;
+    bool acc_id;
+    msm_task_accumulate29_raw<P>(sorted, first, last, table, acc, acc_id);
     return xyzz29_to_xyzz<P>(acc, acc_id);
 }
 

@@ -221,7 +221,7 @@ void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, i
 // Everything else that round 2 kept for A/B runs (stream / wave priorities off, more waves per SIMD, a 128-VGPR build, hipGraph
 // replay, background-behind-sort off) lost its measurement and is gone: the winning setting is now the only code path.
 struct MsmTuning {
-    int persistent, max_acc, placement_log;
+    int persistent, max_acc, placement_log, bucket_direct;
     size_t persistent_min;
     MsmTuning() {
         auto geti = [](const char* k, int d) { const char* v = getenv(k); return v ? atoi(v) : d; };
@@ -232,6 +232,7 @@ struct MsmTuning {
         // (853-858 against 821-825 Mscalar-mul/s, two in flight; profiles/r05_persistent_threshold.txt).
         persistent_min = (size_t)geti("LURK_MSM_PERSISTENT_MIN_MENTRIES", 24) << 20;
         max_acc = geti("LURK_MSM_MAX_ACC", 2);            // persistent accumulations resident at once (0 = no limit)
+        bucket_direct = geti("LURK_MSM_BUCKET_DIRECT", 1);  // 0: short commitments keep the planned-task stages (A/B runs, parity test)
         placement_log = geti("LURK_MSM_PLACEMENT_LOG", 0);  // diagnostic: persistent workgroups per CU, on stderr
         if (max_acc > 2) max_acc = 0;
     }
@@ -240,6 +241,13 @@ static const MsmTuning& msm_tuning() {
     static const MsmTuning t;
     return t;
 }
+
+// ---- 3-5 in one launch for commitments with few buckets (msm_bucket_direct.hip) ---------------------------------------------------
+constexpr uint32_t MSM_DIRECT_MAX_BUCKETS = 131072;          // two key spaces of 16-bit windows
+constexpr size_t MSM_DIRECT_MAX_ENTRIES = (size_t)1 << 21;   // W n: 2^16 points x 16 windows, or a pair over 2^17 composed scalars
+template <class P>
+void msm_launch_bucket_direct(const uint32_t* sorted, const Affine<P>* table, const uint32_t* bucket_start, const uint32_t* cnt, uint32_t NB, size_t entries,
+                              Xyzz<P>* buckets, uint32_t* big_list, uint32_t* big_count, hipStream_t s);
 
 // ---- 5. finalize: buckets of <= MSM_SMALL task partials, one lane each (msm_finalize.hip) ----------------------------------
 template <class P>
@@ -639,6 +647,26 @@ struct MsmCtx : MsmCtxBase {
             sb.zero[2] = wk.cursor.template as<uint32_t>(); sb.zero_n[2] = MSM_PLACEMENT_BASE + 512;
             msm_launch_sort<SF>(sh, d_scalars, is_mont, sb, s);
         }
+        const MsmTuning& tn = msm_tuning();
+        // few buckets, few entries (a key of <= 2^16 points under 16-bit windows): plan, accumulate and finalize as ONE launch, a few
+        // lanes per bucket (msm_bucket_direct.hip)
+        const bool direct = tn.bucket_direct && !wk.force_persistent && sh.NB <= MSM_DIRECT_MAX_BUCKETS && (size_t)sh.W * sh.n <= MSM_DIRECT_MAX_ENTRIES;
+        if (direct) {
+            if (before_accumulate) (*before_accumulate)();
+            if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
+            {
+                ProfScope ps("msm_accumulate_direct", s);
+                msm_launch_bucket_direct<P>(wk.sorted.template as<uint32_t>(), table, wk.bucket_start.template as<uint32_t>(), wk.cnt.template as<uint32_t>(),
+                                            sh.NB, (size_t)sh.W * sh.n, wk.buckets.template as<Xyzz<P>>(), wk.big_list.template as<uint32_t>(),
+                                            wk.big_count.template as<uint32_t>(), s);
+            }
+            {
+                ProfScope ps("msm_reduce", s);
+                msm_launch_reduce<P>(wk.buckets.template as<Xyzz<P>>(), wk.planes_a.p, wk.planes_b.p, sh.c, sh.G, sh.B, wk.host_pts, s);
+            }
+            LURK_HIP_CHECK(hipGetLastError());
+            return;
+        }
         {
             ProfScope ps("msm_tasks", s);
             uint32_t* lh = wk.len_hist.template as<uint32_t>();
@@ -653,7 +681,6 @@ struct MsmCtx : MsmCtxBase {
                                wk.group_task_base.template as<uint32_t>(), sh.NG, lh, lh + MSM_S + 1, wk.task_order.template as<uint32_t>(), (uint32_t)sh.S);
         }
         if (before_accumulate) (*before_accumulate)();  // the one-shot entry point uploads the bases here, behind the sort
-        const MsmTuning& tn = msm_tuning();
         // large commitments in flight take the persistent form on the slot's low-priority accumulate stream (below persistent_min
         // entries the plain launch: see msm_tuning); synchronous calls keep the plain launch
         const bool persistent = s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= tn.persistent_min : tn.persistent != 0));

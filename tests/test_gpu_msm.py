@@ -588,3 +588,75 @@ def test_pair_of_commitments_in_one_pass(hip, cn, c):
     with pytest.raises(LurkHipError):
         small.submit_pair_device(0, d_s, 5000, 1, is_mont=True)
     small.close()
+
+
+DIRECT_CHILD = r'''
+import sys
+import numpy as np
+sys.path.insert(0, %r)
+import torch
+import lurk_beta_amd as L
+from oracle import coracle as C
+c = int(sys.argv[1])
+sf = 1 if c == 0 else 0
+q = (1 << 255)
+outs = []
+for log_n, plain in ((16, False), (14, False), (11, False), (6, False), (12, True)):
+    n = 1 << log_n
+    B = C.synth_bases(c, n).copy()
+    B[3] = 0                                   # an identity base
+    key = L.CommitmentKey(c, B, precompute=not plain, window_bits=0 if plain else 16)   # 16-bit windows: 32 768 buckets per key space
+    assert key.info()["form"] == ("plain" if plain else "table")
+    S = C.synth_scalars(sf, 90 + log_n, 0, n)
+    S[: n // 3] = S[0]                         # a third of the scalars equal: every window has one bucket far above the per-lane cap
+    S[n // 3] = 0
+    S[n // 3 + 1 : n // 3 + 5] = C.ints_to_limbs([1, 2, (1 << 16) - 1, 1 << 15])
+    want = C.jac_to_affine(c, C.msm_fast(c, B, S))
+    got = L.point_to_affine(c, key.commit(S))
+    assert got == want, (log_n, plain)
+    outs.append(got)
+    if not plain and log_n >= 11:
+        d_s = torch.from_numpy(C.to_mont(sf, S).view(np.int64)).cuda()
+        idx = np.arange(n)
+        for bit in (0, log_n - 1):
+            m = ((idx >> bit) & 1).astype(bool)
+            lo_v, hi_v = S.copy(), S.copy()
+            lo_v[m] = 0
+            hi_v[~m] = 0
+            key.submit_pair_device(0, d_s, n, bit, is_mont=True)
+            lo, hi = key.wait_pair(0)
+            assert L.point_to_affine(c, lo) == C.jac_to_affine(c, C.msm_fast(c, B, lo_v)), (log_n, bit)
+            assert L.point_to_affine(c, hi) == C.jac_to_affine(c, C.msm_fast(c, B, hi_v)), (log_n, bit)
+            outs.append(L.point_to_affine(c, lo))
+        for k in range(3):                     # in flight on three slots
+            key.submit_device(k, d_s, n - k, is_mont=True)
+        for k in range(3):
+            assert L.point_to_affine(c, key.wait(k)) == C.jac_to_affine(c, C.msm_fast(c, B[: n - k], S[: n - k])), (log_n, k)
+    key.close()
+print("digest", hash(tuple(outs)) & 0xffffffff)
+print("child ok")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cn,c", CURVES)
+def test_few_bucket_commitments_take_the_direct_path(hip, cn, c):
+    """msm_bucket_direct.hip: commitments with <= 2^17 buckets and <= 2^21 entries (a key of <= 2^16 points under 16-bit windows: the
+    opening argument's folded key) sum each bucket with 1-8 adjacent lanes in one launch instead of plan + accumulate + finalize.  Against
+    the oracle: 4 / 2 / 1 lanes per bucket (2^16 .. 2^6 points; pairs: 2), a third of the scalars equal (buckets handed to the workgroup
+    kernel), zero / identity entries, pairs and commitments in flight, and a plain-form key (2^19 buckets: the planned-task stages);
+    LURK_MSM_BUCKET_DIRECT=0 (the planned-task stages everywhere) must print the same points."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for sw in ("1", "0"):
+        e = dict(os.environ)
+        e["LURK_MSM_BUCKET_DIRECT"] = sw
+        p = subprocess.run([sys.executable, "-c", DIRECT_CHILD % root, str(c)], env=e, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert "child ok" in p.stdout
+        digests.append([l for l in p.stdout.splitlines() if l.startswith("digest")][0])
+    assert digests[0] == digests[1]
