@@ -650,7 +650,9 @@ struct MsmCtx : MsmCtxBase {
         const MsmTuning& tn = msm_tuning();
         // few buckets, few entries (a key of <= 2^16 points under 16-bit windows): plan, accumulate and finalize as ONE launch, a few
         // lanes per bucket (msm_bucket_direct.hip)
-        const bool direct = tn.bucket_direct && !wk.force_persistent && sh.NB <= MSM_DIRECT_MAX_BUCKETS && (size_t)sh.W * sh.n <= MSM_DIRECT_MAX_ENTRIES;
+        // (LURK_MSM_ACC_PERSISTENT=2 - "always the persistent form" - and background submissions keep the planned stages)
+        const bool direct = tn.bucket_direct && !wk.force_persistent && !(s_acc && tn.persistent == 2) && sh.NB <= MSM_DIRECT_MAX_BUCKETS &&
+                            (size_t)sh.W * sh.n <= MSM_DIRECT_MAX_ENTRIES;
         if (direct) {
             if (before_accumulate) (*before_accumulate)();
             if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));

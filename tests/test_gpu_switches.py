@@ -1,5 +1,5 @@
-"""The library's four environment switches (everything else round 2 kept for A/B runs was pruned): each one is read
-once per process, so each setting runs in its own interpreter; whatever the setting, the commitments must be the oracle's."""
+"""The library's environment switches: each one is read once per process, so each setting runs in its own
+interpreter; whatever the setting, the commitments must be the oracle's."""
 import os
 import subprocess
 import sys
@@ -46,8 +46,8 @@ print("child ok")
     ({"LURK_MSM_ACC_PERSISTENT": "2"}, None),                     # always (the default picks it from 24 x 2^20 sorted entries on)
     ({"LURK_MSM_PERSISTENT_MIN_MENTRIES": "1"}, None),            # the default rule with its threshold at 2^20 entries
     ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_PERSIST_WGS": "2", "LURK_MSM_MAX_ACC": "1"}, None),   # one two-wave accumulation at a time
-    ({"LURK_MSM_TASK_TARGET": "1048576"}, None),
-    ({"LURK_MSM_BUCKET_DIRECT": "0"}, None),                      # short commitments through the planned-task stages                  # shorter accumulation tasks than the shape rule picks
+    ({"LURK_MSM_TASK_TARGET": "1048576"}, None),                  # shorter accumulation tasks than the shape rule picks
+    ({"LURK_MSM_BUCKET_DIRECT": "0"}, None),                      # short commitments (these: 2^21 entries) through the planned-task stages
     ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_MAX_ACC": "0"}, None),   # no limit on resident accumulations
     ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_PLACEMENT_LOG": "1"}, "accumulate placement"),
     ({"LURK_STEP_TRACE": "1"}, "[step]"),
