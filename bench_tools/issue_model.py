@@ -142,7 +142,8 @@ def mix(out_json, *listings):
         if n:
             out[stage] = {"valu_instructions_static": n, "cycles_per_valu": round(c / n, 3)}
     out["_source"] = {"listings": [os.path.basename(p) for p in listings], "rates": COST,
-                      "note": "hipcc -O3 --offload-arch=gfx950 -S --cuda-device-only of msm_acc.hip, msm_sort.hip, msm.hip, msm_reduce.hip"}
+                      "note": "hipcc -O3 -std=c++17 --offload-arch=gfx950 -S --cuda-device-only of the listed translation units of lurk_beta_amd/csrc "
+                              "(msm_acc, msm_acc_persistent, msm_sort, msm, msm_reduce, msm_finalize)"}
     with open(out_json, "w") as fh:
         json.dump(out, fh, indent=1)
     print(json.dumps(out, indent=1))
