@@ -20,11 +20,11 @@ namespace lurk {
 constexpr int SC_BLOCK = 256;
 
 template <class F>
-__device__ __forceinline__ Fe<F> sc_bind(const Fe<F>& lo, const Fe<F>& hi, const Fe<F>& r) {
+LURK_HD Fe<F> sc_bind(const Fe<F>& lo, const Fe<F>& hi, const Fe<F>& r) {
     return fe_add<F>(lo, fe_mul<F>(r, fe_sub<F>(hi, lo)));
 }
 template <class F>
-__device__ __forceinline__ Fe<F> sc_comb_cubic(const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, const Fe<F>& d) {
+LURK_HD Fe<F> sc_comb_cubic(const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, const Fe<F>& d) {
     return fe_mul<F>(a, fe_sub<F>(fe_mul<F>(b, c), d));  // comb_func_outer: a * (b * c - d)
 }
 
@@ -246,6 +246,51 @@ static void sumcheck_round(int np, void* const* d_polys, size_t len, const void*
 }
 
 
+// ---- the last rounds on the host -------------------------------------------------------------------------------------------------
+// A round over short tables is all latency on the device: one launch, ~14 dependent 8 x 32 products on a lane (21 us), the last
+// workgroup's sums, one synchronisation - ~45 us per round whatever the length, and the three sum-checks of a proof run 85 rounds.  A
+// host core does a field product in ~45 ns: from SC_HOST_TAIL elements per table on, the tables come to the host once (one copy per
+// table, one synchronisation) and the remaining rounds - the same bind, the same evaluation sums, in the same exact arithmetic - cost
+// 70, 35, 17, ... us.  The device tables are left as they were at that point (sumcheck_prove consumes them).
+static size_t sumcheck_host_tail_len() {
+    const char* e = getenv("LURK_SUMCHECK_HOST_TAIL_LOG");  // log2 of the table length from which the rounds run on the host; 0 = never; read per call
+    const int v = e ? atoi(e) : 8;
+    return v <= 0 ? 0 : (size_t)1 << (v > 16 ? 16 : v);
+}
+// one round on host tables P[0 .. np) of `len` elements: bind (r != NULL: len -> len / 2, in place) then the evaluation sums at
+// 0, 2 (, 3) over the bound tables - sumcheck_round_kernel's arithmetic, element for element
+template <class F>
+static void sumcheck_host_round(int np, std::vector<Fe<F>>* P, size_t& len, const Fe<F>* r, Fe<F>* ev) {
+    if (r) {
+        const size_t m = len / 2;
+        for (int k = 0; k < np; k++) {
+            for (size_t i = 0; i < m; i++) P[k][i] = sc_bind<F>(P[k][i], P[k][m + i], *r);
+            P[k].resize(m);
+        }
+        len = m;
+    }
+    const int nv = np == 4 ? 3 : 2;
+    for (int k = 0; k < nv; k++) ev[k] = fe_zero<F>();
+    const size_t h = len / 2;
+    for (size_t i = 0; i < h; i++) {
+        Fe<F> lo[4], b2[4], b3[4];
+        for (int k = 0; k < np; k++) {
+            lo[k] = P[k][i];
+            const Fe<F> hi = P[k][h + i], d = fe_sub<F>(hi, lo[k]);
+            b2[k] = fe_add<F>(hi, d);
+            b3[k] = fe_add<F>(b2[k], d);
+        }
+        if (np == 4) {
+            ev[0] = fe_add<F>(ev[0], sc_comb_cubic<F>(lo[0], lo[1], lo[2], lo[3]));
+            ev[1] = fe_add<F>(ev[1], sc_comb_cubic<F>(b2[0], b2[1], b2[2], b2[3]));
+            ev[2] = fe_add<F>(ev[2], sc_comb_cubic<F>(b3[0], b3[1], b3[2], b3[3]));
+        } else {
+            ev[0] = fe_add<F>(ev[0], fe_mul<F>(lo[0], lo[1]));
+            ev[1] = fe_add<F>(ev[1], fe_mul<F>(b2[0], b2[1]));
+        }
+    }
+}
+
 // ---- a whole sum-check as host code of the library (arecibo SumcheckProof::prove_quad / prove_cubic_with_additive_term behind
 // /root/reference/src/proof/nova.rs:341-356): the round loop of lurk_beta_amd/sumcheck.py: prove - one launch per round, the round
 // polynomial interpolated from its evaluations at 0, 2 (, 3) and the running claim, the transcript's challenge from a callback.
@@ -277,11 +322,24 @@ static void sumcheck_prove(int np, size_t ninst, void* const* d_polys, size_t n,
     // the (device, stream)'s scratch, made once and kept: a proof runs three of these loops
     std::unique_lock<std::mutex> scratch_lk;
     SumcheckScratch& scratch = *sumcheck_cached_scratch(s, scratch_lk);
+    const size_t host_tail = sumcheck_host_tail_len();
+    std::vector<std::vector<Fe<F>>> host_tabs;  // ninst x np tables once the rounds have moved to the host (sumcheck_host_round)
+    std::vector<size_t> host_len;
     for (size_t m = n; m > 1; m /= 2, j++) {
         Fe<F> ev[3] = {fe_zero<F>(), fe_zero<F>(), fe_zero<F>()};
+        if (host_tabs.empty() && host_tail && length <= host_tail) {
+            host_tabs.resize(ninst * (size_t)np);
+            host_len.assign(ninst, length);
+            for (size_t k = 0; k < ninst * (size_t)np; k++) {
+                host_tabs[k].resize(length);
+                LURK_HIP_CHECK(hipMemcpyAsync(host_tabs[k].data(), d_polys[k], length * 32, hipMemcpyDeviceToHost, s));
+            }
+            LURK_HIP_CHECK(hipStreamSynchronize(s));
+        }
         for (size_t i = 0; i < ninst; i++) {
             Fe<F> one_ev[3];
-            sumcheck_round<F>(np, d_polys + i * np, length, have_r ? (const void*)r.l : nullptr, one_ev, s, &scratch);  // Montgomery images of the evaluations at 0, 2 (, 3)
+            if (!host_tabs.empty()) sumcheck_host_round<F>(np, host_tabs.data() + i * np, host_len[i], have_r ? &r : nullptr, one_ev);
+            else sumcheck_round<F>(np, d_polys + i * np, length, have_r ? (const void*)r.l : nullptr, one_ev, s, &scratch);  // Montgomery images of the evaluations at 0, 2 (, 3)
             for (int k = 0; k < nv; k++) ev[k] = ninst == 1 && !coeffs32_canonical ? one_ev[k] : fe_add<F>(ev[k], fe_mul<F>(coeff[i], one_ev[k]));
         }
         if (have_r) length /= 2;
@@ -317,13 +375,22 @@ static void sumcheck_prove(int np, size_t ninst, void* const* d_polys, size_t n,
         for (int k = ncoef - 1; k >= 0; k--) acc = fe_add<F>(fe_mul<F>(acc, r), poly[k]);
         claim = acc;
     }
-    for (size_t i = 0; have_r && i < ninst; i++) sumcheck_round<F>(np, d_polys + i * np, length, r.l, nullptr, s, &scratch);  // the last bind: every table is down to one element
-    for (size_t k = 0; k < ninst * (size_t)np; k++) {
-        Fe<F> v;
-        LURK_HIP_CHECK(hipMemcpyAsync(v.l, d_polys[k], 32, hipMemcpyDeviceToHost, s));
-        LURK_HIP_CHECK(hipStreamSynchronize(s));
-        v = fe_from_mont<F>(v);
-        memcpy(out_finals + 4 * k, v.l, 32);
+    if (!host_tabs.empty()) {
+        // the last bind and the final evaluations, on the host tables
+        for (size_t k = 0; k < ninst * (size_t)np; k++) {
+            const std::vector<Fe<F>>& t = host_tabs[k];
+            const Fe<F> v = fe_from_mont<F>(have_r && t.size() >= 2 ? sc_bind<F>(t[0], t[1], r) : t[0]);
+            memcpy(out_finals + 4 * k, v.l, 32);
+        }
+    } else {
+        for (size_t i = 0; have_r && i < ninst; i++) sumcheck_round<F>(np, d_polys + i * np, length, r.l, nullptr, s, &scratch);  // the last bind: every table is down to one element
+        for (size_t k = 0; k < ninst * (size_t)np; k++) {
+            Fe<F> v;
+            LURK_HIP_CHECK(hipMemcpyAsync(v.l, d_polys[k], 32, hipMemcpyDeviceToHost, s));
+            LURK_HIP_CHECK(hipStreamSynchronize(s));
+            v = fe_from_mont<F>(v);
+            memcpy(out_finals + 4 * k, v.l, 32);
+        }
     }
     claim = fe_from_mont<F>(claim);
     memcpy(out_claim32, claim.l, 32);

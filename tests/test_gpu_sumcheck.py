@@ -17,10 +17,14 @@ def _dev(a):
 
 
 @pytest.mark.parametrize("f", [0, 1, 2])
-@pytest.mark.parametrize("ell", [1, 2, 5, 11])
-def test_rounds_match_the_oracle(hip, f, ell):
+@pytest.mark.parametrize("ell,tail", [(1, None), (2, None), (5, None), (11, None), (1, "0"), (5, "0"), (11, "0"), (5, "3"), (11, "11"), (11, "1")])
+def test_rounds_match_the_oracle(hip, f, ell, tail, monkeypatch):
+    """tail: LURK_SUMCHECK_HOST_TAIL_LOG - the rounds move to the host once the tables are down to 2^tail elements (default 2^8; "0":
+    every round on the device; 2^11 here: every round on the host) - the proof must not depend on where that is."""
     from lurk_beta_amd import sumcheck as S
 
+    if tail is not None:
+        monkeypatch.setenv("LURK_SUMCHECK_HOST_TAIL_LOG", tail)
     p = R.modulus(f)
     n = 1 << ell
     for ntab in (4, 2):
