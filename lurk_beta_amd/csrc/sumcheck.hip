@@ -14,19 +14,12 @@
 
 #include "common.hpp"
 #include "field.cuh"
+#include "sumcheck_host.hpp"
 
 namespace lurk {
 
 constexpr int SC_BLOCK = 256;
 
-template <class F>
-LURK_HD Fe<F> sc_bind(const Fe<F>& lo, const Fe<F>& hi, const Fe<F>& r) {
-    return fe_add<F>(lo, fe_mul<F>(r, fe_sub<F>(hi, lo)));
-}
-template <class F>
-LURK_HD Fe<F> sc_comb_cubic(const Fe<F>& a, const Fe<F>& b, const Fe<F>& c, const Fe<F>& d) {
-    return fe_mul<F>(a, fe_sub<F>(fe_mul<F>(b, c), d));  // comb_func_outer: a * (b * c - d)
-}
 
 // workgroup tree sum of NV values per thread; thread 0 writes the block's partial sums.  With a ticket counter (final != nullptr) the
 // LAST workgroup to arrive (agent-scope ticket: release before, acquire after - cdna_hip_programming.md guideline 16) sums every
@@ -257,40 +250,6 @@ static size_t sumcheck_host_tail_len() {
     const int v = e ? atoi(e) : 8;
     return v <= 0 ? 0 : (size_t)1 << (v > 16 ? 16 : v);
 }
-// one round on host tables P[0 .. np) of `len` elements: bind (r != NULL: len -> len / 2, in place) then the evaluation sums at
-// 0, 2 (, 3) over the bound tables - sumcheck_round_kernel's arithmetic, element for element
-template <class F>
-static void sumcheck_host_round(int np, std::vector<Fe<F>>* P, size_t& len, const Fe<F>* r, Fe<F>* ev) {
-    if (r) {
-        const size_t m = len / 2;
-        for (int k = 0; k < np; k++) {
-            for (size_t i = 0; i < m; i++) P[k][i] = sc_bind<F>(P[k][i], P[k][m + i], *r);
-            P[k].resize(m);
-        }
-        len = m;
-    }
-    const int nv = np == 4 ? 3 : 2;
-    for (int k = 0; k < nv; k++) ev[k] = fe_zero<F>();
-    const size_t h = len / 2;
-    for (size_t i = 0; i < h; i++) {
-        Fe<F> lo[4], b2[4], b3[4];
-        for (int k = 0; k < np; k++) {
-            lo[k] = P[k][i];
-            const Fe<F> hi = P[k][h + i], d = fe_sub<F>(hi, lo[k]);
-            b2[k] = fe_add<F>(hi, d);
-            b3[k] = fe_add<F>(b2[k], d);
-        }
-        if (np == 4) {
-            ev[0] = fe_add<F>(ev[0], sc_comb_cubic<F>(lo[0], lo[1], lo[2], lo[3]));
-            ev[1] = fe_add<F>(ev[1], sc_comb_cubic<F>(b2[0], b2[1], b2[2], b2[3]));
-            ev[2] = fe_add<F>(ev[2], sc_comb_cubic<F>(b3[0], b3[1], b3[2], b3[3]));
-        } else {
-            ev[0] = fe_add<F>(ev[0], fe_mul<F>(lo[0], lo[1]));
-            ev[1] = fe_add<F>(ev[1], fe_mul<F>(b2[0], b2[1]));
-        }
-    }
-}
-
 // ---- a whole sum-check as host code of the library (arecibo SumcheckProof::prove_quad / prove_cubic_with_additive_term behind
 // /root/reference/src/proof/nova.rs:341-356): the round loop of lurk_beta_amd/sumcheck.py: prove - one launch per round, the round
 // polynomial interpolated from its evaluations at 0, 2 (, 3) and the running claim, the transcript's challenge from a callback.

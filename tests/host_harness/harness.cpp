@@ -334,6 +334,63 @@ extern "C" int hh_msm_digits_ct(const uint32_t* scalar8, int c, uint32_t* out) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// One sum-check round on host tables (sumcheck_host.hpp: what lurk_hip_sumcheck_prove_dev runs once the tables are short, and the
+// arithmetic of the round kernel): tabs = np tables of len Montgomery elements, bound in place when r8 != NULL (the first len / 2
+// elements of each are the new tables); ev = the evaluation sums at 0, 2 (, 3); returns the new length.
+#include "../../lurk_beta_amd/csrc/sumcheck_host.hpp"
+template <class F>
+static size_t sumcheck_round_host(int np, uint32_t* tabs, size_t len, const uint32_t* r8, uint32_t* ev24) {
+    std::vector<Fe<F>> P[4];
+    for (int k = 0; k < np; k++) {
+        P[k].resize(len);
+        for (size_t i = 0; i < len; i++)
+            for (int w = 0; w < 8; w++) P[k][i].l[w] = tabs[((size_t)k * len + i) * 8 + w];
+    }
+    Fe<F> r, ev[3];
+    if (r8)
+        for (int w = 0; w < 8; w++) r.l[w] = r8[w];
+    size_t n = len;
+    sumcheck_host_round<F>(np, P, n, r8 ? &r : nullptr, ev);
+    for (int k = 0; k < np; k++)
+        for (size_t i = 0; i < n; i++)
+            for (int w = 0; w < 8; w++) tabs[((size_t)k * len + i) * 8 + w] = P[k][i].l[w];
+    for (int k = 0; k < (np == 4 ? 3 : 2); k++)
+        for (int w = 0; w < 8; w++) ev24[8 * k + w] = ev[k].l[w];
+    return n;
+}
+extern "C" size_t hh_sumcheck_round(int field, int np, uint32_t* tabs, size_t len, const uint32_t* r8, uint32_t* ev24) {
+    if (field == 0) return sumcheck_round_host<PallasFp>(np, tabs, len, r8, ev24);
+    if (field == 1) return sumcheck_round_host<PallasFq>(np, tabs, len, r8, ev24);
+    return sumcheck_round_host<Bn254Fr>(np, tabs, len, r8, ev24);
+}
+
+// two signed sums of bases normalised with ONE inversion (curve.cuh: xyzz_pair_to_affine, the opening argument's L and R) and one by
+// one (xyzz_to_affine): out = 4 affine Montgomery records (pair: A, B; single: A, B)
+template <class P>
+static void pair_to_affine(const uint32_t* ba, const uint32_t* sa, size_t na, const uint32_t* bb, const uint32_t* sb, size_t nb, uint32_t* out) {
+    auto sum = [](const uint32_t* bases, const uint32_t* signs, size_t n) {
+        Xyzz<P> acc = xyzz_identity<P>();
+        for (size_t i = 0; i < n; i++) {
+            Affine<P> a;
+            for (int k = 0; k < 8; k++) { a.x.l[k] = bases[i * 16 + k]; a.y.l[k] = bases[i * 16 + 8 + k]; }
+            xyzz_madd<P>(acc, a, signs[i] != 0);
+        }
+        return acc;
+    };
+    const Xyzz<P> A = sum(ba, sa, na), B = sum(bb, sb, nb);
+    Affine<P> r[4];
+    xyzz_pair_to_affine<P>(A, B, r[0], r[1]);
+    r[2] = xyzz_to_affine<P>(A);
+    r[3] = xyzz_to_affine<P>(B);
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 8; k++) { out[16 * j + k] = r[j].x.l[k]; out[16 * j + 8 + k] = r[j].y.l[k]; }
+}
+extern "C" void hh_pair_to_affine(int curve, const uint32_t* ba, const uint32_t* sa, size_t na, const uint32_t* bb, const uint32_t* sb, size_t nb, uint32_t* out) {
+    if (curve == 0) pair_to_affine<PallasFp>(ba, sa, na, bb, sb, nb, out);
+    else pair_to_affine<PallasFq>(ba, sa, na, bb, sb, nb, out);
+}
+
+// ---------------------------------------------------------------------------------------------
 // One point's row of a window table (msm_precompute.cuh: the body of msm_precompute_kernel, doubling chain + Montgomery's trick on the
 // radix-2^29 layer, bound assertions on): out = W affine Montgomery records, 2^(c w) P for w < W.  Also f29_invert against fe_inv.
 #include "../../lurk_beta_amd/csrc/msm_precompute.cuh"

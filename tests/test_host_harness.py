@@ -294,6 +294,70 @@ def test_signed_digits_register_walk_equals_indexed_recoding(c):
         assert total == k, (c, hex(k))
 
 
+@pytest.mark.parametrize("f", [0, 1, 2])
+@pytest.mark.parametrize("np_", [4, 2])
+def test_sumcheck_rounds_on_the_host(f, np_):
+    """sumcheck_host.hpp: the rounds lurk_hip_sumcheck_prove_dev runs on the host once the tables are short (and the arithmetic of the
+    round kernel): from 32 elements down to 2, every round's evaluation sums at 0, 2 (, 3) and every bound table against the
+    definition in Python integers - e_t = sum_i comb((1 - t) P[i] + t P[h + i]), P[i] <- P[i] + r (P[h + i] - P[i])."""
+    import ctypes
+
+    L = H.lib()
+    L.hh_sumcheck_round.restype = ctypes.c_size_t
+    p = R.modulus(f)
+    n = 32
+    tabs = [[R.uniform_fe(300 + f + k, i, p) for i in range(n)] for k in range(np_)]
+    tabs[0][3] = 0
+    tabs[1][n - 1] = p - 1
+    comb = (lambda a, b, c, d: a * (b * c - d)) if np_ == 4 else (lambda a, b: a * b)
+    buf = np.concatenate([C.to_mont(f, C.ints_to_limbs(t)) for t in tabs]).reshape(np_, n, 4).copy()
+    r = None
+    length = n
+    for rnd in range(6):
+        if r is not None:   # what the round is expected to do first: bind the top variable to r
+            h = length // 2
+            tabs = [[(t[i] + r * (t[h + i] - t[i])) % p for i in range(h)] for t in tabs]
+        h = len(tabs[0]) // 2
+        want = [sum(comb(*[((1 - t) * tab[i] + t * tab[h + i]) % p for tab in tabs]) for i in range(h)) % p for t in ((0, 2, 3) if np_ == 4 else (0, 2))]
+        ev = np.zeros((3, 4), dtype=np.uint64)
+        cur = np.ascontiguousarray(buf[:, :length, :]).copy()
+        r_l = None if r is None else C.to_mont(f, C.ints_to_limbs([r]))
+        new_len = L.hh_sumcheck_round(f, np_, vp(cur), ctypes.c_size_t(length), None if r is None else vp(r_l), vp(ev))
+        assert new_len == len(tabs[0]), rnd
+        got_tabs = [C.limbs_to_ints(C.from_mont(f, np.ascontiguousarray(cur[k, :new_len, :]))) for k in range(np_)]
+        assert got_tabs == tabs, rnd
+        assert C.limbs_to_ints(C.from_mont(f, ev))[: len(want)] == want, rnd
+        buf = np.ascontiguousarray(cur[:, :new_len, :]).copy()
+        length = new_len
+        if length < 2:
+            break
+        r = R.uniform_fe(310 + f, rnd, p)
+    assert length == 1   # the sixth call bound the last variable: nothing left to sum, the tables are the final evaluations
+
+
+@pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
+def test_pair_normalised_with_one_inversion(cn, c):
+    """xyzz_pair_to_affine (the opening argument's L and R leave through one field inversion) = xyzz_to_affine of each, for two
+    ordinary sums, with either or both the identity, and against the oracle's group law."""
+    L = H.lib()
+    B = C.synth_bases(c, 8)
+    pts = C.affine_to_ints(c, B)
+    z = np.zeros(0, dtype=np.uint32)
+    cases = [((0, 5), (5, 8)), ((0, 3), (0, 0)), ((0, 0), (2, 6)), ((0, 0), (0, 0)), ((1, 2), (1, 2))]
+    for (a0, a1), (b0, b1) in cases:
+        out = np.zeros((4, 8), dtype=np.uint64)
+        sa, sb = np.zeros(max(a1 - a0, 1), dtype=np.uint32), np.ones(max(b1 - b0, 1), dtype=np.uint32)
+        L.hh_pair_to_affine(c, vp(B[a0:max(a1, a0 + 1)].copy()), vp(sa), ctypes.c_size_t(a1 - a0), vp(B[b0:max(b1, b0 + 1)].copy()), vp(sb), ctypes.c_size_t(b1 - b0), vp(out))
+        got = C.affine_to_ints(c, out)
+        assert got[0] == got[2] and got[1] == got[3], ((a0, a1), (b0, b1))
+        wa = wb = None
+        for pt in pts[a0:a1]:
+            wa = R.ec_add(cn, wa, pt)
+        for pt in pts[b0:b1]:
+            wb = R.ec_add(cn, wb, R.ec_neg(cn, pt))
+        assert got[0] == (wa or (0, 0)) and got[1] == (wb or (0, 0))
+
+
 @pytest.mark.parametrize("cn,c", [("pallas", 0), ("vesta", 1)])
 def test_window_table_row_on_the_radix29_layer(cn, c):
     """msm_precompute_point (the body of msm_precompute_kernel: a chain of xyzz29_dbl, f29_invert, Montgomery's trick) with the bound
