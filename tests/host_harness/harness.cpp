@@ -50,6 +50,22 @@ extern "C" void hh_fe_dot(int field, int T, const uint32_t* a, const uint32_t* b
     else dot_t<P, 9>(a, b, o);
     if (field == 0) { DOT_CASE(PallasFp) } else if (field == 1) { DOT_CASE(PallasFq) } else { DOT_CASE(Bn254Fr) }
 }
+// the host's inverse (binary extended Euclid, field.cuh: host_inv) against the exponentiation the device uses; n Montgomery elements
+template <class F>
+static void fe_inv_both(const uint32_t* a, uint32_t* o_host, uint32_t* o_pow, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        Fe<F> x;
+        for (int k = 0; k < 8; k++) x.l[k] = a[8 * i + k];
+        const Fe<F> h = fe_inv<F>(x), q = fe_inv_pow<F>(x);
+        for (int k = 0; k < 8; k++) { o_host[8 * i + k] = h.l[k]; o_pow[8 * i + k] = q.l[k]; }
+    }
+}
+extern "C" void hh_fe_inv_both(int field, const uint32_t* a, uint32_t* o_host, uint32_t* o_pow, size_t n) {
+    if (field == 0) fe_inv_both<PallasFp>(a, o_host, o_pow, n);
+    else if (field == 1) fe_inv_both<PallasFq>(a, o_host, o_pow, n);
+    else fe_inv_both<Bn254Fr>(a, o_host, o_pow, n);
+}
+
 extern "C" void hh_fe_op(int field, int op, const uint32_t* a, const uint32_t* b, uint32_t* o, size_t n) {
     if (field == 0) mul_n<PallasFp>(a, b, o, n, op);
     else if (field == 1) mul_n<PallasFq>(a, b, o, n, op);

@@ -295,6 +295,25 @@ def test_signed_digits_register_walk_equals_indexed_recoding(c):
 
 
 @pytest.mark.parametrize("f", [0, 1, 2])
+def test_host_inverse_equals_the_exponentiation(f):
+    """field.cuh: on the host fe_inv is the binary extended Euclidean algorithm (the device keeps a^(p-2)); both on 0, 1, 2, p - 1, the
+    powers of two, values around the limb boundaries, (p +- 1) / 2, and 6 000 uniform elements - and x * x^-1 = 1 in Python integers."""
+    L = H.lib()
+    p = R.modulus(f)
+    vals = [0, 1, 2, 3, p - 1, p - 2, (p - 1) // 2, (p + 1) // 2, (1 << 64) - 1, 1 << 64, (1 << 128) - 1, 1 << 128, (1 << 192) + 1, (1 << 253) - 1, (1 << 253) + 12345]
+    vals += [1 << k for k in range(1, 254)] + [(p - (1 << k)) % p for k in range(0, 254, 7)]
+    vals += [R.uniform_fe(400 + f, i, p) for i in range(6000)]
+    vals = [v % p for v in vals]
+    a = C.to_mont(f, C.ints_to_limbs(vals))
+    oh, op_ = np.zeros_like(a), np.zeros_like(a)
+    L.hh_fe_inv_both(f, vp(a), vp(oh), vp(op_), ctypes.c_size_t(len(vals)))
+    assert (oh == op_).all()
+    inv = C.limbs_to_ints(C.from_mont(f, oh))
+    for v, w in zip(vals[:400], inv[:400]):
+        assert (v * w) % p == (1 if v else 0)
+
+
+@pytest.mark.parametrize("f", [0, 1, 2])
 @pytest.mark.parametrize("np_", [4, 2])
 def test_sumcheck_rounds_on_the_host(f, np_):
     """sumcheck_host.hpp: the rounds lurk_hip_sumcheck_prove_dev runs on the host once the tables are short (and the arithmetic of the
