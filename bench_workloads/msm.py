@@ -71,9 +71,9 @@ def oneshot_leg(d_bases, d_scalars, n):
 
 
 KERNEL_GROUPS = {  # kernels of one commitment, by pipeline stage (name substrings of the rocprofv3 kernel names)
-    "accumulate": ("msm_accumulate",),
+    "accumulate": ("msm_accumulate", "msm_bucket_direct"),   # (the direct bucket launch: short commitments only, none at the headline size)
     "sort": ("msm_canon", "msm_hist1", "msm_scan1", "msm_part_start", "msm_scatter1", "msm_part2"),
-    "plan": ("msm_taskscan", "msm_task_base", "msm_tasks_kernel", "msm_len_"),
+    "plan": ("msm_taskscan", "msm_tasks_kernel", "msm_len_"),
     "finalize": ("msm_finalize", "msm_big_bucket"),
     "reduce": ("msm_planes29", "msm_reduce"),
 }
