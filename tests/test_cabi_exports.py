@@ -135,6 +135,11 @@ def test_sort_kernels_fit_beside_a_resident_accumulation(tmp_path):
             assert 4 * granule(v) + granule(persistent) <= 512, (k, v, persistent)
             checked += 1
     assert checked >= 5
+    # the latency-bound tail kernels (finalize, the bit-plane levels) run one 256-thread workgroup's wave per SIMD beside TWO resident
+    # accumulations: held to 128 registers (__launch_bounds__(256, 4)) - with 183 every level waited for an accumulation to end
+    for src, needle in (("msm_finalize.hip", "msm_finalize_kernel"), ("msm_reduce.hip", "msm_planes29_kernel")):
+        tail = {k: v for k, v in usage(src).items() if needle in k}
+        assert tail and all(granule(v) + 2 * granule(persistent) <= 512 for v in tail.values()), tail
 
 
 def test_rust_ffi_matches_the_header():
