@@ -597,8 +597,12 @@ inline void sub_mod(U256& x, const U256& y, const U256& p) {  // x = x - y mod p
         add(x, t);  // < p: no carry
     }
 }
-// a^-1 mod p for 0 < a < p, p odd
+inline bool is_zero(const U256& a) { return (a.w[0] | a.w[1] | a.w[2] | a.w[3]) == 0; }
+// a^-1 mod p for any 256-bit a (reduced first; a multiple of p gives 0), p an odd prime: total - it returns on every input, whatever a
+// caller of the C ABI put into a point's coordinates
 inline U256 inverse(U256 u, const U256& p) {
+    while (ge(u, p)) sub(u, p);  // < 2^256 / p <= 5 rounds for the moduli here
+    if (is_zero(u)) return u;
     U256 v = p, x1 = {{1, 0, 0, 0}}, x2 = {{0, 0, 0, 0}};
     while (!is_one(u) && !is_one(v)) {
         while (!(u.w[0] & 1)) {
@@ -625,7 +629,6 @@ inline U256 inverse(U256 u, const U256& p) {
 template <class P>
 LURK_HD Fe<P> fe_inv(const Fe<P>& a) {  // a^(p-2); 0 -> 0
 #if !defined(__HIP_DEVICE_COMPILE__)
-    if (fe_is_zero<P>(a)) return a;
     host_inv::U256 u, p;
     for (int i = 0; i < 4; i++) {
         u.w[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);

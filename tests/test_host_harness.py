@@ -311,6 +311,15 @@ def test_host_inverse_equals_the_exponentiation(f):
     inv = C.limbs_to_ints(C.from_mont(f, oh))
     for v, w in zip(vals[:400], inv[:400]):
         assert (v * w) % p == (1 if v else 0)
+    # raw 256-bit patterns that are NOT canonical (a caller's garbage in a point's coordinates): the host inverse must return - the
+    # inverse of the residue, 0 for a multiple of p - and never loop
+    raw = [p, 2 * p, 3 * p, p + 5, 2 * p + 7, (1 << 256) - 1, (1 << 255) + 3]
+    raw = [v for v in raw if v < 1 << 256]
+    a = C.ints_to_limbs(raw)
+    oh, op_ = np.zeros_like(a), np.zeros_like(a)
+    L.hh_fe_inv_both(f, vp(a), vp(oh), vp(op_), ctypes.c_size_t(len(raw)))
+    R2 = pow(2, 512, p)
+    assert C.limbs_to_ints(oh) == [(pow(v % p, -1, p) * R2) % p if v % p else 0 for v in raw]
 
 
 @pytest.mark.parametrize("f", [0, 1, 2])
