@@ -56,3 +56,24 @@ def test_script_globals_resolve(fname):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)  # both files only define functions at import time (main() is guarded)
     _check(mod)
+
+
+def test_every_run_time_switch_is_documented():
+    """INTEGRATION.md section 10 lists the library's and the mirror's LURK_* environment switches: every one the sources read must be
+    in that table, and the table must not name one nobody reads."""
+    import re
+
+    read = set()
+    csrc = os.path.join(ROOT, "lurk_beta_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".hip", ".hpp", ".cuh")):
+            read |= set(re.findall(r'(?:getenv|geti)\("(LURK_[A-Z0-9_]+)"', open(os.path.join(csrc, f)).read()))
+    for f in sorted(os.listdir(os.path.join(ROOT, "lurk_beta_amd"))):
+        if f.endswith(".py"):
+            read |= set(re.findall(r'environ(?:\.get)?[\(\[]\s*"(LURK_[A-Z0-9_]+)"', open(os.path.join(ROOT, "lurk_beta_amd", f)).read()))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = doc[doc.index("## 10. Run-time switches"):]
+    listed = set(re.findall(r"`(LURK_[A-Z0-9_]+)`", section)) - {"LURK_MSM_FLAG_AUTO_SLICES"}   # (a flag of the C ABI, named in a row's text)
+    assert read, "no switch found: the patterns above no longer match the sources"
+    assert read - listed == set(), f"read by the sources, missing from INTEGRATION.md section 10: {sorted(read - listed)}"
+    assert listed - read == set(), f"listed in INTEGRATION.md section 10, read by nobody: {sorted(listed - read)}"
