@@ -94,7 +94,7 @@ def fold_step_workload(args, lib, world, rank):
     bodies_host = torch.empty((rc, mf.body_len, 4), dtype=torch.int64).pin_memory()
     bodies_host.copy_(synth.scalars(F, 8, 1, rc * mf.body_len, mont=True).reshape(rc, mf.body_len, 4).cpu())
     bodies_np = bodies_host.numpy().view(np.uint64)
-    d_w2s = [torch.zeros((n_w, 4), dtype=torch.int64, device="cuda") for _ in range(2)]
+    d_w2s = [torch.zeros((n_w, 4), dtype=torch.int64, device="cuda") for _ in range(3 if args.stage_ahead == 3 else 2)]
     d_w2 = d_w2s[0]
     x2 = synth.scalars(F, 9, 0, n_io, mont=True).cpu().numpy().view(np.uint64)
     t_setup = time.perf_counter()
@@ -158,6 +158,24 @@ def fold_step_workload(args, lib, world, rank):
         mf.assemble(buf, pre, globals_host, bodies_np, mont=True, stream=stream)     # W2 in HBM (slot traces on the device)
         ctx.prefetch(buf[lo:hi], lo, stream=stream)                                  # commit(step circuit's range) starts now
 
+    # --stage-ahead 3: the witness producer runs TWO steps ahead (lurk-beta's producer thread synthesizes frames independently of the
+    # folding loop, nova.rs:304-326).  Witness k + 2 is traced from step k's submit hook; instance k + 1 (traced during step k - 1, so
+    # complete) is staged when step k starts, and step k's begin submits its commitment behind commit(T) in the FOLLOW class: its sort and
+    # plan run beside the cross term and commit(T)'s sort, its accumulation starts when commit(T)'s has ended and fills the window that the
+    # step's serial chain leaves idle (T's bucket reduction, the transcript, the folds).
+    trace_k = [0]
+    tstreams = [torch.cuda.Stream() for _ in range(3)] if args.stage_ahead == 3 else []
+
+    def trace_next():
+        k = trace_k[0]
+        trace_k[0] += 1
+        mf.assemble(d_w2s[k % 3], pre, globals_host, bodies_np, mont=True, stream=tstreams[k % 3].cuda_stream)
+
+    def stage_traced():
+        k = staged_k[0]
+        staged_k[0] += 1
+        ctx.prefetch(d_w2s[k % 3][lo:hi], lo, stream=tstreams[k % 3].cuda_stream)
+
     phase = {"assemble_and_stage": 0.0, "begin": 0.0, "transcript": 0.0, "finish": 0.0}  # host wall time per call site (begin blocks on the commitments)
 
     def step():
@@ -165,6 +183,8 @@ def fold_step_workload(args, lib, world, rank):
         if args.stage_ahead:
             if args.stage_ahead == 1:
                 stage()                                                               # the next step's, under this step's work
+            elif args.stage_ahead == 3:
+                stage_traced()                                                        # instance k + 1 (traced a step ago): committed behind this step's commit(T)
             t_b = time.perf_counter()
             cw, ct = ctx.begin_prefetched(x2, patches)                               # late ranges + cross term + commit(T) (2: + stage() from the submit hook)
         elif args.witness_ahead:
@@ -197,7 +217,13 @@ def fold_step_workload(args, lib, world, rank):
         phase["finish"] += t_d - t_r
         return cw, ct
 
-    if args.stage_ahead:
+    if args.stage_ahead == 3:
+        trace_next()
+        trace_next()
+        torch.cuda.synchronize()
+        stage_traced()
+        ctx.set_submit_hook(trace_next)
+    elif args.stage_ahead:
         stage()
         if args.stage_ahead == 2:  # the next instance is traced, staged and its commitment started from inside begin (the submit hook)
             ctx.set_submit_hook(stage)
@@ -226,7 +252,7 @@ def fold_step_workload(args, lib, world, rank):
     elapsed = time.perf_counter() - t0
     gc.enable()
     lib.lurk_hip_profile_enable(0)
-    if args.stage_ahead == 2 or (not args.stage_ahead and args.witness_ahead == 3):
+    if args.stage_ahead >= 2 or (not args.stage_ahead and args.witness_ahead == 3):
         ctx.set_submit_hook(None)
     if args.stage_ahead:  # drain the instance staged by the last timed step (one was staged before the region: K stagings inside it)
         ctx.begin_prefetched(x2, patches)

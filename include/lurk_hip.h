@@ -144,10 +144,15 @@ int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_s
  * waits for.  FOREGROUND: the accumulation is the plain launch (three waves per SIMD, raised wave priority) - the commitment
  * the host is about to wait for (commit(T) of the open folding step).  BACKGROUND: the persistent one-wave-per-SIMD
  * accumulation at the lowest priority whatever the size - work staged ahead (commit(W2) of the next step), which fills the
- * issue slots the foreground commitment leaves during its sort and its bucket reduction.  DEFAULT = submit_dev (by size). */
+ * issue slots the foreground commitment leaves during its sort and its bucket reduction.  DEFAULT = submit_dev (by size).
+ * FOLLOW (round 6): the plain full-rate launch of FOREGROUND, but the whole commitment starts behind the ACCUMULATION of the
+ * latest FOREGROUND commitment in flight on this context: commit(W2 of the next step) then sorts and accumulates in the window the
+ * open step leaves idle - commit(T)'s bucket reduction, the host's transcript, the folds and the next cross term - instead of
+ * sharing the VALU with commit(T)'s accumulation, which the host waits for. */
 #define LURK_MSM_SUBMIT_DEFAULT 0
 #define LURK_MSM_SUBMIT_FOREGROUND 1
 #define LURK_MSM_SUBMIT_BACKGROUND 2
+#define LURK_MSM_SUBMIT_FOLLOW 3
 int lurk_hip_msm_ctx_submit_dev_mode(lurk_hip_msm_ctx* ctx, int slot, const void* d_scalars32, size_t nscalars, int is_mont,
                                      void* stream, int mode);
 int lurk_hip_msm_ctx_wait(lurk_hip_msm_ctx* ctx, int slot, void* out_jacobian96);
@@ -181,6 +186,28 @@ int lurk_hip_msm_ctx_device(const lurk_hip_msm_ctx* ctx, int* device); /* the de
  * from_label_dev writes npoints x 64 B to device memory (synchronises `stream`); ctx_from_label builds the resident context in
  * place, no host copy of the key ever exists; hash_to_curve_dev is the per-point map on caller-supplied 32-byte strings. */
 int lurk_hip_shake256(const void* in, size_t in_len, void* out, size_t out_len); /* host-only helper (the XOF above) */
+/* Run-time parameters of the restatement above (round 6): arecibo's from_label and pasta_curves' hash_to_curve are un-vendored
+ * (/root/reference/Cargo.toml:128,131) and /root/reference holds no key bytes, so what was recalled from memory is a FIELD, not a
+ * literal: the XOF, the bytes squeezed per point, and the three parts of the hash_to_curve domain-separation tag
+ * DST = domain_prefix "-" curve_name suite.  Process-wide, set(NULL) restores the defaults (in brackets); from_label_dev /
+ * ctx_from_label / from_label_host read them per call.  hash_to_curve_dev takes its own domain prefix and uses the rest.
+ * from_label_host is the same map on the host (no device; <= 2^16 points, ~0.3 ms each): the first points of a key for a LURKDUMP
+ * probe record (`python -m lurk_beta_amd.dump probe FILE`) or a CPU test. */
+#define LURK_CK_XOF_SHAKE256 0
+#define LURK_CK_XOF_SHAKE128 1
+typedef struct lurk_hip_ck_params {
+    uint32_t struct_size;       /* sizeof(lurk_hip_ck_params): get() fills it, set() checks it */
+    uint32_t xof;               /* LURK_CK_XOF_* over the label [SHAKE256] */
+    uint32_t bytes_per_point;   /* XOF bytes handed to hash_to_curve per point, 1..64 [32] */
+    uint32_t reserved;          /* 0 */
+    char domain_prefix[32];     /* hash_to_curve's domain prefix, NUL-terminated ["from_uniform_bytes"] */
+    char curve_name_pallas[16]; /* CURVE_ID of Pallas in the tag ["pallas"] */
+    char curve_name_vesta[16];  /* ["vesta"] */
+    char suite[32];             /* the tag's tail ["_XMD:BLAKE2b_SSWU_RO_"] */
+} lurk_hip_ck_params;
+int lurk_hip_ck_params_get(lurk_hip_ck_params* out);
+int lurk_hip_ck_params_set(const lurk_hip_ck_params* params);
+int lurk_hip_ck_from_label_host(int curve, const void* label, size_t label_len, size_t npoints, void* out_affine64);
 int lurk_hip_ck_hash_to_curve_dev(int curve, const char* domain_prefix, const void* d_uniform32, size_t n, void* d_out_affine64,
                                   void* stream);
 int lurk_hip_ck_from_label_dev(int curve, const void* label, size_t label_len, size_t npoints, void* d_out_affine64,
@@ -452,6 +479,46 @@ int lurk_hip_fold_step(lurk_hip_fold_ctx* ctx, const void* w2, int w2_on_device,
  *   nifs_challenge      the absorb list of NIFS::prove on `curve`: pp_digest, U1 = (comm_W1, comm_E1, u1, X1 as 4 x 64-bit limbs
  *                       each), U2 = (comm_W2, X2), comm_T - commitments as (x, y, is_infinity), scalars through scalar_as_base -
  *                       then r = squeeze(NUM_CHALLENGE_BITS = 128) in Montgomery form of the curve's scalar field. */
+/* Run-time parameters of the restatement above (round 6).  arecibo and neptune are un-vendored dependencies of the reference
+ * (/root/reference/Cargo.toml:127-128) and /root/reference holds no transcript value, so every constant of the sponge and of the
+ * absorb list that was recalled from memory is a FIELD here instead of a compiled-in literal: the first Rust-side run that gets
+ * another r than arecibo's NIFS::prove (caller: /root/reference/src/proof/nova.rs:282-295) can move one field at a time - or hand a
+ * LURKDUMP probe record (lurk_beta_amd/dump.py, rust/lurk-hip-sys/src/dump.rs) to `python -m lurk_beta_amd.dump probe FILE`, which
+ * searches them - with no rebuild.  Process-wide; set(NULL) restores the defaults (the values of rounds 1-5, in brackets); a folding
+ * context reads them when a step's transcript begins.  nova_ro_squeeze / nova_ro_pattern_tag use arity, domain_separator (squeeze
+ * only), absorb_tag_bit, pattern_absorbs and squeeze_element; nifs_challenge and the folding contexts use all of them. */
+#define LURK_RO_ITEM_PP_DIGEST 0
+#define LURK_RO_ITEM_U1 1
+#define LURK_RO_ITEM_U2 2
+#define LURK_RO_ITEM_COMM_T 3
+#define LURK_RO_PART_COMM_W 0
+#define LURK_RO_PART_COMM_E 1
+#define LURK_RO_PART_U 2
+#define LURK_RO_PART_X 3
+typedef struct lurk_hip_ro_params {
+    uint32_t struct_size;        /* sizeof(lurk_hip_ro_params): get() fills it, set() checks it */
+    uint32_t arity;              /* rate of the sponge = neptune arity, width arity + 1 [24] */
+    uint32_t domain_separator;   /* IOPattern::value(domain_separator) [0] */
+    uint32_t absorb_tag_bit;     /* SpongeOp::Absorb(n).value() = n + 2^absorb_tag_bit [31] */
+    uint32_t num_challenge_bits; /* NUM_CHALLENGE_BITS: low bits of the squeezed element kept as r [128] */
+    uint32_t item_order[4];      /* NIFS::prove absorbs LURK_RO_ITEM_* in this order [pp_digest, U1, U2, comm_T] */
+    uint32_t relaxed_order[4];   /* RelaxedR1CSInstance::absorb_in_ro: LURK_RO_PART_* in this order [comm_W, comm_E, u, X] */
+    uint32_t fresh_order[2];     /* R1CSInstance::absorb_in_ro: 0 = comm_W, 1 = X [comm_W, X] */
+    uint32_t point_elements;     /* a commitment is (x, y, is_infinity) = 3 elements, or (x, y) = 2 [3] */
+    uint32_t relaxed_x_limbs;    /* every X_i of a relaxed instance as this many limbs (BN_N_LIMBS); 0 = one element through scalar_as_base [4] */
+    uint32_t fresh_x_limbs;      /* the same for a fresh instance [0] */
+    uint32_t limb_bits;          /* BN_LIMB_WIDTH [64] */
+    uint32_t pattern_absorbs;    /* 0 = the IO pattern declares the number of elements really absorbed; else this constant (NUM_FE_FOR_RO) [0] */
+    uint32_t squeeze_element;    /* which rate element squeeze reads [0] */
+} lurk_hip_ro_params;
+int lurk_hip_ro_params_get(lurk_hip_ro_params* out);
+int lurk_hip_ro_params_set(const lurk_hip_ro_params* params);
+/* Diagnostic twin of nifs_challenge: the elements it absorbs, in order, canonical 32-byte integers of the RO's field (the other
+ * field of the cycle) - what a probe record's `absorbed` list is compared with, element by element.  *count = the number of
+ * elements; out_elems32 (cap elements) may be NULL to ask for the count only. */
+int lurk_hip_nifs_absorb_list(int curve, const void* pp_digest32, const void* comm_w1_jacobian96, const void* comm_e1_jacobian96,
+                              const void* u1_mont, const void* x1_mont, const void* comm_w2_jacobian96, const void* x2_mont, size_t num_io,
+                              const void* comm_t_jacobian96, void* out_elems32, size_t cap, size_t* count);
 int lurk_hip_nova_ro_squeeze(int field_id, const void* elems32, size_t n, unsigned num_bits, void* out32);
 int lurk_hip_nova_ro_pattern_tag(uint32_t absorbs, uint32_t squeezes, uint32_t domain_separator, void* out16);
 int lurk_hip_nifs_challenge(int curve, const void* pp_digest32, const void* comm_w1_jacobian96, const void* comm_e1_jacobian96,

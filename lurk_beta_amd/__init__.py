@@ -16,6 +16,7 @@ from .ntt import ntt  # noqa: E402
 from .fold import R1CSShape, fold_vec  # noqa: E402
 from .step import FoldingContext, NivcFoldingContext, nifs_challenge, nova_ro_squeeze, point_mul, public_io  # noqa: E402
 from . import sumcheck, ipa, spartan  # noqa: E402,F401
+from . import params  # noqa: E402,F401
 from .witness import MultiFrameWitness, slot_witness, slot_witness_size  # noqa: E402
 
 __all__ = [

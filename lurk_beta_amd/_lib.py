@@ -27,6 +27,21 @@ class RustError(ctypes.Structure):
     _fields_ = [("code", c_int), ("message", ctypes.c_void_p)]
 
 
+class RoParamsStruct(ctypes.Structure):
+    """lurk_hip_ro_params"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("arity", ctypes.c_uint32), ("domain_separator", ctypes.c_uint32), ("absorb_tag_bit", ctypes.c_uint32),
+                ("num_challenge_bits", ctypes.c_uint32), ("item_order", ctypes.c_uint32 * 4), ("relaxed_order", ctypes.c_uint32 * 4),
+                ("fresh_order", ctypes.c_uint32 * 2), ("point_elements", ctypes.c_uint32), ("relaxed_x_limbs", ctypes.c_uint32),
+                ("fresh_x_limbs", ctypes.c_uint32), ("limb_bits", ctypes.c_uint32), ("pattern_absorbs", ctypes.c_uint32), ("squeeze_element", ctypes.c_uint32)]
+
+
+class CkParamsStruct(ctypes.Structure):
+    """lurk_hip_ck_params"""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("xof", ctypes.c_uint32), ("bytes_per_point", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("domain_prefix", ctypes.c_char * 32), ("curve_name_pallas", ctypes.c_char * 16), ("curve_name_vesta", ctypes.c_char * 16),
+                ("suite", ctypes.c_char * 32)]
+
+
 # every symbol include/lurk_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "lurk_hip_device_count": (c_int, []),
@@ -56,6 +71,9 @@ SIGNATURES = {
     "lurk_hip_msm_ctx_rebind_dev": (c_int, [c_void_p, c_void_p, c_size_t]),
     "lurk_hip_msm_ctx_reserve": (c_int, [c_void_p, c_size_t, c_int]),
     "lurk_hip_shake256": (c_int, [ctypes.c_char_p, c_size_t, c_void_p, c_size_t]),
+    "lurk_hip_ck_params_get": (c_int, [ctypes.POINTER(CkParamsStruct)]),
+    "lurk_hip_ck_params_set": (c_int, [ctypes.POINTER(CkParamsStruct)]),
+    "lurk_hip_ck_from_label_host": (c_int, [c_int, ctypes.c_char_p, c_size_t, c_size_t, c_void_p]),
     "lurk_hip_ck_hash_to_curve_dev": (c_int, [c_int, ctypes.c_char_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_ck_from_label_dev": (c_int, [c_int, ctypes.c_char_p, c_size_t, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_msm_ctx_from_label": (c_int, [ctypes.POINTER(c_void_p), c_int, ctypes.c_char_p, c_size_t, c_size_t, c_int]),
@@ -119,6 +137,10 @@ SIGNATURES = {
     "lurk_hip_fold_ctx_set_instance": (c_int, [c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_ctx_instance": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "lurk_hip_fold_step": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "lurk_hip_ro_params_get": (c_int, [ctypes.POINTER(RoParamsStruct)]),
+    "lurk_hip_ro_params_set": (c_int, [ctypes.POINTER(RoParamsStruct)]),
+    "lurk_hip_nifs_absorb_list": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t,
+                                          ctypes.POINTER(c_size_t)]),
     "lurk_hip_nova_ro_squeeze": (c_int, [c_int, c_void_p, c_size_t, c_uint, c_void_p]),
     "lurk_hip_nova_ro_pattern_tag": (c_int, [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, c_void_p]),
     "lurk_hip_nifs_challenge": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

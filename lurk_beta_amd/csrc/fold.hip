@@ -30,6 +30,13 @@ namespace lurk {
 
 constexpr int FOLD_BLOCK = 256;
 
+// The cross term and the two folds are links of the step's serial chain (cross term -> commit(T) -> r -> folds -> next cross term) and
+// are bound by HBM latency, not by issue slots; what shares the device with them is an accumulation of the NEXT step's commit(W2)
+// (step.hip: LURK_MSM_SUBMIT_FOLLOW), whose waves are older and - at equal priority - served first by the instruction arbiter:
+// measured round 6, a 60 us fold took 320 us and the cross term 590 instead of 410.  Raised wave priority lets these waves issue when
+// their loads come back (2: above both forms of the accumulation, below the commitments' own short kernels at 3).
+__device__ __forceinline__ void fold_wave_prio() { __builtin_amdgcn_s_setprio(2); }
+
 struct CsrDev {
     DevBuf rowptr;  // u32 x (rows + 1)
     DevBuf ent;     // uint2 {col, coefficient id} x nnz
@@ -290,6 +297,7 @@ __device__ __forceinline__ void r1cs_cross_term_body(const R1csDev& s, const Fe<
 template <class P>
 __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2,
                                                                        size_t u_index, Fe<P>* __restrict__ t, unsigned long_blocks) {
+    fold_wave_prio();
     if (blockIdx.x < long_blocks) r1cs_cross_term_body<P, true>(s, z1, z2, u_index, t, blockIdx.x, long_blocks);
     else r1cs_cross_term_body<P, false>(s, z1, z2, u_index, t, blockIdx.x - long_blocks, gridDim.x - long_blocks);
 }
@@ -302,6 +310,7 @@ constexpr int FOLD_VEC_E = 2;
 template <class P>
 __global__ __launch_bounds__(FOLD_BLOCK) void fold_vec_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, Fe<P> r, size_t n,
                                                                 uint4* __restrict__ out) {
+    fold_wave_prio();
     const size_t base = (size_t)blockIdx.x * (FOLD_BLOCK * FOLD_VEC_E) + threadIdx.x;
     uint4 al[FOLD_VEC_E], ah[FOLD_VEC_E], bl[FOLD_VEC_E], bh[FOLD_VEC_E];
 #pragma unroll

@@ -10,6 +10,8 @@
 // The XOF stream is inherently sequential: the host squeezes it (Keccak-f[1600]); everything per point - three BLAKE2b hashes, two
 // Legendre symbols, two square roots (Tonelli-Shanks, 2-adicity 32), three inversions - runs one point per lane.
 #include <memory>
+#include <mutex>
+#include <string>
 
 #include "common.hpp"
 #include "curve.cuh"
@@ -18,8 +20,7 @@
 namespace lurk {
 
 // ---- SHAKE256 (host): Keccak-f from keccak.hpp ----------------------------------------------------------------------------------
-void shake256(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len) {
-    constexpr size_t RATE = 136;
+static void shake_xof(size_t RATE, const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len) {
     uint64_t st[25] = {0};
     uint8_t* sb = reinterpret_cast<uint8_t*>(st);  // little-endian host
     size_t pos = 0;
@@ -38,21 +39,36 @@ void shake256(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len) {
         if (got < out_len) keccak_f(st);
     }
 }
+void shake256(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_len) { shake_xof(136, in, in_len, out, out_len); }
 
 // ---- BLAKE2b-512 (device), unkeyed, 64-byte digest ------------------------------------------------------------
-__device__ __constant__ uint64_t B2B_IV[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
-                                              0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
-__device__ __constant__ uint8_t B2B_SIGMA[12][16] = {
-    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
-    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
-    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
-    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
-    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
-    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+// (one copy for each side: the per-point map below is __host__ __device__ - the device builds keys, the host maps the handful of points
+// a probe record or a CPU test asks for, lurk_hip_ck_from_label_host)
+#define KG_HD __host__ __device__
+#define B2B_IV_INIT {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL, \
+                     0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL}
+__device__ __constant__ uint64_t B2B_IV_DEV[8] = B2B_IV_INIT;
+static const uint64_t B2B_IV_HOST[8] = B2B_IV_INIT;
+#define B2B_SIGMA_INIT { \
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}, \
+    {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8}, \
+    {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9}, \
+    {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10}, \
+    {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}, \
+    {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}}
+__device__ __constant__ uint8_t B2B_SIGMA_DEV[12][16] = B2B_SIGMA_INIT;
+static const uint8_t B2B_SIGMA_HOST[12][16] = B2B_SIGMA_INIT;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define B2B_IV B2B_IV_DEV
+#define B2B_SIGMA B2B_SIGMA_DEV
+#else
+#define B2B_IV B2B_IV_HOST
+#define B2B_SIGMA B2B_SIGMA_HOST
+#endif
 
-__device__ __forceinline__ uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
+KG_HD inline uint64_t rotr64(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 // h: chaining value; m: 16 message words (little-endian); t: bytes so far including this block
-__device__ void b2b_compress(uint64_t* h, const uint64_t* m, uint64_t t, bool last) {
+KG_HD inline void b2b_compress(uint64_t* h, const uint64_t* m, uint64_t t, bool last) {
     uint64_t v[16];
     for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = B2B_IV[i]; }
     v[12] ^= t;
@@ -75,12 +91,12 @@ __device__ void b2b_compress(uint64_t* h, const uint64_t* m, uint64_t t, bool la
 #undef B2B_G
     for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
 }
-__device__ __forceinline__ void b2b_init(uint64_t* h) {
+KG_HD inline void b2b_init(uint64_t* h) {
     for (int i = 0; i < 8; i++) h[i] = B2B_IV[i];
     h[0] ^= 0x01010040ULL;  // digest length 64, no key, fanout 1, depth 1
 }
 // hash of a message of len <= 256 bytes held as bytes in `buf` (zero padded to a multiple of 128)
-__device__ void b2b_hash(const uint8_t* buf, unsigned len, uint8_t* out64) {
+KG_HD inline void b2b_hash(const uint8_t* buf, unsigned len, uint8_t* out64) {
     uint64_t h[8];
     b2b_init(h);
     const unsigned nblocks = len <= 128 ? 1 : 2;
@@ -108,10 +124,11 @@ struct KeygenConsts {
     uint32_t legendre_exp[8];    // (p - 1) / 2
     uint8_t dst_prime[64];       // DST || len(DST)
     uint32_t dst_len;
+    uint32_t msg_len;            // bytes of XOF output per point (lurk_hip_ck_params::bytes_per_point)
 };
 
 template <class P>
-__device__ Fe<P> kg_from_be64(const uint8_t* b64, const Fe<P>& r3) {  // big-endian 512-bit integer mod p, Montgomery
+KG_HD inline Fe<P> kg_from_be64(const uint8_t* b64, const Fe<P>& r3) {  // big-endian 512-bit integer mod p, Montgomery
     Fe<P> lo, hi;
     for (int i = 0; i < 8; i++) {
         uint32_t wl = 0, wh = 0;
@@ -128,13 +145,13 @@ __device__ Fe<P> kg_from_be64(const uint8_t* b64, const Fe<P>& r3) {  // big-end
 }
 
 template <class P>
-__device__ bool kg_is_square(const Fe<P>& a, const KeygenConsts<P>& K) {
+KG_HD inline bool kg_is_square(const Fe<P>& a, const KeygenConsts<P>& K) {
     if (fe_is_zero<P>(a)) return true;
     return fe_eq<P>(fe_pow<P>(a, K.legendre_exp), fe_one<P>());
 }
 // a square root of a square a (Tonelli-Shanks; per-lane loop counts differ, the wave runs the longest)
 template <class P>
-__device__ Fe<P> kg_sqrt(const Fe<P>& a, const KeygenConsts<P>& K) {
+KG_HD inline Fe<P> kg_sqrt(const Fe<P>& a, const KeygenConsts<P>& K) {
     if (fe_is_zero<P>(a)) return a;
     const Fe<P> one = fe_one<P>();
     const Fe<P> w = fe_pow<P>(a, K.ts_exp);  // a^((T-1)/2)
@@ -157,25 +174,25 @@ __device__ Fe<P> kg_sqrt(const Fe<P>& a, const KeygenConsts<P>& K) {
     return x;
 }
 template <class P>
-__device__ __forceinline__ bool kg_is_odd(const Fe<P>& mont) { return fe_from_mont<P>(mont).l[0] & 1u; }
+KG_HD inline bool kg_is_odd(const Fe<P>& mont) { return fe_from_mont<P>(mont).l[0] & 1u; }
 
 // g(x) = x^3 + a x + b on the isogenous curve
 template <class P>
-__device__ __forceinline__ Fe<P> kg_g(const Fe<P>& x, const KeygenConsts<P>& K) {
+KG_HD inline Fe<P> kg_g(const Fe<P>& x, const KeygenConsts<P>& K) {
     return fe_add<P>(fe_mul<P>(fe_add<P>(fe_sqr<P>(x), K.a), x), K.b);
 }
 
+// one point: hash_to_curve(domain)(msg), msg = K.msg_len bytes (128 + msg_len + 3 + dst_len <= 256: checked where K is built)
 template <class P>
-__global__ __launch_bounds__(128) void keygen_kernel(const uint8_t* __restrict__ uniform32, size_t n, KeygenConsts<P> K, Affine<P>* __restrict__ out) {
-    const size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
-    if (i >= n) return;
+KG_HD inline Affine<P> keygen_point(const uint8_t* msg, const KeygenConsts<P>& K) {
     // ---- hash_to_field: b0 = H(0^128 || msg || 0,128,0 || DST'), b1 = H(b0 || 1 || DST'), b2 = H(b0 ^ b1 || 2 || DST')
     uint8_t buf[256], b0[64], b1[64], b2[64];
     for (int k = 0; k < 256; k++) buf[k] = 0;
-    for (int k = 0; k < 32; k++) buf[128 + k] = uniform32[i * 32 + k];
-    buf[160] = 0; buf[161] = 128; buf[162] = 0;
-    for (unsigned k = 0; k < K.dst_len; k++) buf[163 + k] = K.dst_prime[k];
-    b2b_hash(buf, 163 + K.dst_len, b0);
+    const unsigned ml = K.msg_len;
+    for (unsigned k = 0; k < ml; k++) buf[128 + k] = msg[k];
+    buf[128 + ml] = 0; buf[129 + ml] = 128; buf[130 + ml] = 0;
+    for (unsigned k = 0; k < K.dst_len; k++) buf[131 + ml + k] = K.dst_prime[k];
+    b2b_hash(buf, 131 + ml + K.dst_len, b0);
     for (int k = 0; k < 128; k++) buf[k] = 0;
     for (int k = 0; k < 64; k++) buf[k] = b0[k];
     buf[64] = 1;
@@ -243,7 +260,14 @@ __global__ __launch_bounds__(128) void keygen_kernel(const uint8_t* __restrict__
             res.y = fe_mul<P>(ny, fe_mul<P>(inv, dx));
         }
     }
-    out[i] = res;
+    return res;
+}
+
+template <class P>
+__global__ __launch_bounds__(128) void keygen_kernel(const uint8_t* __restrict__ uniform, size_t n, KeygenConsts<P> K, Affine<P>* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 128 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = keygen_point<P>(uniform + i * K.msg_len, K);
 }
 
 // pasta_curves 0.5.0 constants (canonical integers, 4 x u64 little-endian): the isogenous curves' A, B = 1265, Z = -13 and the
@@ -284,8 +308,45 @@ static Fe<P> kg_const(const uint64_t* c) {
     for (int i = 0; i < 4; i++) { x.l[2 * i] = (uint32_t)c[i]; x.l[2 * i + 1] = (uint32_t)(c[i] >> 32); }
     return fe_to_mont<P>(x);
 }
+// ---- run-time parameters of from_label (round 6; include/lurk_hip.h: lurk_hip_ck_params) ----------------------------------------
+// Like the random oracle's (transcript.hip): every constant of DlogGroup::from_label / hash_to_curve that was recalled from memory is a
+// field, process-wide, defaults = what rounds 1-5 compiled in.
+static lurk_hip_ck_params ck_params_default() {
+    lurk_hip_ck_params p;
+    memset(&p, 0, sizeof(p));
+    p.struct_size = (uint32_t)sizeof(p);
+    p.xof = LURK_CK_XOF_SHAKE256;
+    p.bytes_per_point = 32;
+    strcpy(p.domain_prefix, "from_uniform_bytes");
+    strcpy(p.curve_name_pallas, "pallas");
+    strcpy(p.curve_name_vesta, "vesta");
+    strcpy(p.suite, "_XMD:BLAKE2b_SSWU_RO_");
+    return p;
+}
+static std::mutex g_ck_mu;
+static lurk_hip_ck_params g_ck = ck_params_default();
+static lurk_hip_ck_params ck_params() {
+    std::lock_guard<std::mutex> lk(g_ck_mu);
+    return g_ck;
+}
+static bool c_string_within(const char* s, size_t cap) { return memchr(s, 0, cap) != nullptr; }
+static std::string ck_dst(const lurk_hip_ck_params& p, int curve, const char* domain_prefix) {
+    return std::string(domain_prefix) + "-" + (curve == 0 ? p.curve_name_pallas : p.curve_name_vesta) + p.suite;
+}
+static void ck_params_validate(const lurk_hip_ck_params& p) {
+    LURK_REQUIRE(p.struct_size == sizeof(lurk_hip_ck_params), "lurk_hip_ck_params: struct_size does not match this library's layout");
+    LURK_REQUIRE(p.xof == LURK_CK_XOF_SHAKE256 || p.xof == LURK_CK_XOF_SHAKE128, "lurk_hip_ck_params: unknown xof");
+    LURK_REQUIRE(p.bytes_per_point >= 1 && p.bytes_per_point <= 64, "lurk_hip_ck_params: bytes_per_point must be in 1..64");
+    LURK_REQUIRE(c_string_within(p.domain_prefix, sizeof(p.domain_prefix)) && c_string_within(p.curve_name_pallas, sizeof(p.curve_name_pallas)) &&
+                     c_string_within(p.curve_name_vesta, sizeof(p.curve_name_vesta)) && c_string_within(p.suite, sizeof(p.suite)),
+                 "lurk_hip_ck_params: a string is not NUL-terminated");
+    for (int curve = 0; curve < 2; curve++)
+        LURK_REQUIRE(131 + p.bytes_per_point + ck_dst(p, curve, p.domain_prefix).size() + 1 <= 256 && ck_dst(p, curve, p.domain_prefix).size() < 63,
+                     "lurk_hip_ck_params: message + domain-separation tag do not fit two BLAKE2b blocks");
+}
+
 template <class P>
-static KeygenConsts<P> make_keygen_consts(int curve, const char* domain_prefix) {
+static KeygenConsts<P> make_keygen_consts(int curve, const char* domain_prefix, const lurk_hip_ck_params& prm) {
     KeygenConsts<P> K;
     K.a = kg_const<P>(KG_A[curve]);
     K.b = fe_from_u64<P>(1265);
@@ -305,12 +366,14 @@ static KeygenConsts<P> make_keygen_consts(int curve, const char* domain_prefix) 
         if (!fe_eq<P>(fe_pow<P>(g, K.legendre_exp), fe_one<P>())) break;
     }
     K.ts_c = fe_pow<P>(g, T);
-    std::string dst = std::string(domain_prefix) + "-" + (curve == 0 ? "pallas" : "vesta") + "_XMD:BLAKE2b_SSWU_RO_";
+    const std::string dst = ck_dst(prm, curve, domain_prefix);
     LURK_REQUIRE(dst.size() < 63, "domain prefix too long");
+    LURK_REQUIRE(131 + prm.bytes_per_point + dst.size() + 1 <= 256, "message + domain-separation tag do not fit two BLAKE2b blocks");
     memset(K.dst_prime, 0, sizeof(K.dst_prime));
     memcpy(K.dst_prime, dst.data(), dst.size());
     K.dst_prime[dst.size()] = (uint8_t)dst.size();
     K.dst_len = (uint32_t)dst.size() + 1;
+    K.msg_len = prm.bytes_per_point;
     return K;
 }
 
@@ -319,20 +382,38 @@ static void keygen_device(int curve, const char* domain, const void* d_uniform, 
     if (n == 0) return;
     static_assert(P::ID != 2, "Pasta only");
     LURK_REQUIRE(P::mod(0) == 1u, "unexpected modulus");  // the low 32 bits of p - 1 are zero: 2-adicity 32
-    const KeygenConsts<P> K = make_keygen_consts<P>(curve, domain);
+    const KeygenConsts<P> K = make_keygen_consts<P>(curve, domain, ck_params());
     ProfScope ps("keygen", s);
     hipLaunchKernelGGL((keygen_kernel<P>), dim3(div_up(n, 128)), dim3(128), 0, s, (const uint8_t*)d_uniform, n, K, (Affine<P>*)d_out);
     LURK_HIP_CHECK(hipGetLastError());
 }
 
+static std::vector<uint8_t> ck_xof_stream(const lurk_hip_ck_params& prm, const void* label, size_t label_len, size_t n) {
+    std::vector<uint8_t> stream(n * prm.bytes_per_point);
+    shake_xof(prm.xof == LURK_CK_XOF_SHAKE128 ? 168 : 136, (const uint8_t*)label, label_len, stream.data(), stream.size());
+    return stream;
+}
+
 void keygen_from_label_device(int curve, const void* label, size_t label_len, size_t n, void* d_out, hipStream_t s) {
-    std::vector<uint8_t> stream(n * 32);
-    shake256((const uint8_t*)label, label_len, stream.data(), stream.size());
-    DevBuf d_u(n * 32);
-    if (n) LURK_HIP_CHECK(hipMemcpyAsync(d_u.p, stream.data(), n * 32, hipMemcpyHostToDevice, s));
-    if (curve == LURK_CURVE_PALLAS) keygen_device<PallasFp>(curve, "from_uniform_bytes", d_u.p, n, d_out, s);
-    else keygen_device<PallasFq>(curve, "from_uniform_bytes", d_u.p, n, d_out, s);
+    const lurk_hip_ck_params prm = ck_params();
+    const std::vector<uint8_t> stream = ck_xof_stream(prm, label, label_len, n);
+    DevBuf d_u(stream.size());
+    if (n) LURK_HIP_CHECK(hipMemcpyAsync(d_u.p, stream.data(), stream.size(), hipMemcpyHostToDevice, s));
+    if (curve == LURK_CURVE_PALLAS) keygen_device<PallasFp>(curve, prm.domain_prefix, d_u.p, n, d_out, s);
+    else keygen_device<PallasFq>(curve, prm.domain_prefix, d_u.p, n, d_out, s);
     LURK_HIP_CHECK(hipStreamSynchronize(s));  // the staging buffers go out of scope
+}
+
+// the same map on the host, one point after the other (~0.3 ms each): the first points of a key for a probe record or a CPU test
+template <class P>
+static void keygen_from_label_host(int curve, const void* label, size_t label_len, size_t n, void* out) {
+    const lurk_hip_ck_params prm = ck_params();
+    const std::vector<uint8_t> stream = ck_xof_stream(prm, label, label_len, n);
+    const KeygenConsts<P> K = make_keygen_consts<P>(curve, prm.domain_prefix, prm);
+    for (size_t i = 0; i < n; i++) {
+        const Affine<P> pt = keygen_point<P>(stream.data() + i * prm.bytes_per_point, K);
+        memcpy((char*)out + 64 * i, &pt, 64);
+    }
 }
 
 }  // namespace lurk
@@ -346,6 +427,47 @@ int lurk_hip_shake256(const void* in, size_t in_len, void* out, size_t out_len) 
     try {
         LURK_REQUIRE((in || in_len == 0) && (out || out_len == 0), "null buffer");
         shake256((const uint8_t*)in, in_len, (uint8_t*)out, out_len);
+        set_error(0, "");
+        return 0;
+    } catch (const HipFailure& e) {
+        set_error(e.code, e.msg);
+        return e.code;
+    }
+}
+
+int lurk_hip_ck_params_get(lurk_hip_ck_params* out) {
+    try {
+        LURK_REQUIRE(out, "null argument");
+        *out = ck_params();
+        set_error(0, "");
+        return 0;
+    } catch (const HipFailure& e) {
+        set_error(e.code, e.msg);
+        return e.code;
+    }
+}
+int lurk_hip_ck_params_set(const lurk_hip_ck_params* params) {
+    try {
+        const lurk_hip_ck_params p = params ? *params : ck_params_default();  // NULL: back to the defaults
+        ck_params_validate(p);
+        std::lock_guard<std::mutex> lk(g_ck_mu);
+        g_ck = p;
+        set_error(0, "");
+        return 0;
+    } catch (const HipFailure& e) {
+        set_error(e.code, e.msg);
+        return e.code;
+    }
+}
+
+int lurk_hip_ck_from_label_host(int curve, const void* label, size_t label_len, size_t npoints, void* out_affine64) {
+    // pure host computation: no device is needed
+    try {
+        LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
+        LURK_REQUIRE((label || label_len == 0) && (npoints == 0 || out_affine64), "null argument");
+        LURK_REQUIRE(npoints <= ((size_t)1 << 16), "the host form maps at most 2^16 points: build keys with lurk_hip_ck_from_label_dev / lurk_hip_msm_ctx_from_label");
+        if (curve == LURK_CURVE_PALLAS) keygen_from_label_host<PallasFp>(curve, label, label_len, npoints, out_affine64);
+        else keygen_from_label_host<PallasFq>(curve, label, label_len, npoints, out_affine64);
         set_error(0, "");
         return 0;
     } catch (const HipFailure& e) {

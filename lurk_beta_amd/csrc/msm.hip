@@ -37,15 +37,21 @@ constexpr int MSM_ACC_BLOCK = 256;
 // commitments in flight they share the SIMDs with the (older, VALU-saturating) accumulate waves of the previous
 // commitment, and the instruction arbiter serves the oldest wave first: measured 15-18x slowdowns of these kernels.
 // Raising their wave priority lets them issue when they are ready; they need a few percent of the VALU.
-__device__ __forceinline__ void msm_set_wave_prio(int /*cls: 0 sort kernels, 1 plan / finalize / reduce kernels*/) { __builtin_amdgcn_s_setprio(3); }
+// `low`: the commitment was submitted with LURK_MSM_SUBMIT_FOLLOW - work staged ahead that must only take what the open step's serial
+// chain (cross term, commit(T), folds: wave priority 2-3) leaves; its short kernels then run at the lowest wave priority like its
+// accumulation (measured round 6 with everything at 3: commit(T)'s sort + plan 0.34 -> 0.70 ms beside the staged commitment's bucket reduction).
+__device__ __forceinline__ void msm_set_wave_prio(int low) {
+    if (low) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(3);
+}
 
 // ---- 1-2. digits and sort: msm_sort.hip (msm_launch_sort) ---------------------------------------------
 
 // ---- 3. task planning ------------------------------------------------------------------------
 // block g (group of MSM_GRP keys), 1024 threads x 32 keys: task starts inside the group + group total
 __global__ __launch_bounds__(1024) void msm_taskscan_kernel(const uint32_t* __restrict__ cnt, uint32_t* __restrict__ task_start,
-                                                              uint32_t* __restrict__ group_tasks, uint32_t S) {
-    msm_set_wave_prio(1);
+                                                              uint32_t* __restrict__ group_tasks, uint32_t S, int low) {
+    msm_set_wave_prio(low);
     __shared__ uint32_t sh[1024];
     const int g = blockIdx.x, t = threadIdx.x;
     constexpr int PER = MSM_GRP / 1024;
@@ -87,8 +93,8 @@ __global__ __launch_bounds__(1024) void msm_taskscan_kernel(const uint32_t* __re
 constexpr int MSM_NG_MAX = 64;
 __global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ bucket_start,
                                                           const uint32_t* __restrict__ task_start, const uint32_t* __restrict__ group_tasks,
-                                                          uint32_t* __restrict__ group_task_base_out, int NG, uint2* __restrict__ task_info, uint32_t S) {
-    msm_set_wave_prio(1);
+                                                          uint32_t* __restrict__ group_task_base_out, int NG, uint2* __restrict__ task_info, uint32_t S, int low) {
+    msm_set_wave_prio(low);
     __shared__ uint32_t group_task_base[MSM_NG_MAX + 1];
     if (threadIdx.x == 0) {
         uint32_t run = 0;
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(256) void msm_tasks_kernel(const uint32_t* __restri
 // short tasks fill the tail of the launch.  Full tasks (length MSM_S, the bulk at large n) are
 // counted per wave with one ballot instead of one LDS atomic each.
 __global__ __launch_bounds__(1024) void msm_len_hist_kernel(const uint2* __restrict__ task_info, const uint32_t* __restrict__ group_task_base,
-                                                              int NG, uint32_t* __restrict__ len_hist, uint32_t S) {
-    msm_set_wave_prio(1);
+                                                              int NG, uint32_t* __restrict__ len_hist, uint32_t S, int low) {
+    msm_set_wave_prio(low);
     __shared__ uint32_t sh[MSM_S + 1];
     if (threadIdx.x <= MSM_S) sh[threadIdx.x] = 0;
     __syncthreads();
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(1024) void msm_len_hist_kernel(const uint2* __restr
 __global__ __launch_bounds__(1024) void msm_len_scatter_kernel(const uint2* __restrict__ task_info,
                                                                  const uint32_t* __restrict__ group_task_base, int NG,
                                                                  const uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor,
-                                                                 uint32_t* __restrict__ order, uint32_t S) {
-    msm_set_wave_prio(1);
+                                                                 uint32_t* __restrict__ order, uint32_t S, int low) {
+    msm_set_wave_prio(low);
     __shared__ uint32_t sh_cnt[MSM_S + 1], sh_base[MSM_S + 1], sh_class[MSM_S + 1];
     if (threadIdx.x == 0) {
         uint32_t run = 0;
@@ -196,7 +202,7 @@ void msm_launch_accumulate(const uint32_t* sorted, const Affine<P>* table, const
                            const uint32_t* group_task_base, int NG, Xyzz<P>* partials, size_t nt, hipStream_t s);
 template <class P>
 void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
-                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, hipStream_t s);
+                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, hipStream_t s, unsigned wgs_per_cu = 0);
 
 // ---- 4b. the small-commitment path (msm_small.hip): a resident key of <= 2^16 points keeps every multiple of every window base ----
 constexpr size_t MSM_SMALL_MAX_POINTS = (size_t)1 << 16;
@@ -215,7 +221,7 @@ size_t msm_small_scratch_bytes();
 // ---- 6'. the bucket reduction (msm_reduce.hip): one launch per level of the bit-plane merge tree, radix-2^29 points ----
 size_t msm_reduce_plane_bytes(size_t nb);
 template <class P>
-void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s);
+void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s, int low_prio = 0);
 
 // Switches of the commitments-in-flight path (read once per process; the defaults are the measured best).
 // Everything else that round 2 kept for A/B runs (stream / wave priorities off, more waves per SIMD, a 128-VGPR build, hipGraph
@@ -252,7 +258,7 @@ void msm_launch_bucket_direct(const uint32_t* sorted, const Affine<P>* table, co
 // ---- 5. finalize: buckets of <= MSM_SMALL task partials, one lane each (msm_finalize.hip) ----------------------------------
 template <class P>
 void msm_launch_finalize(const Xyzz<P>* partials, const uint32_t* cnt, const uint32_t* task_start, const uint32_t* group_task_base, uint32_t NB,
-                         Xyzz<P>* buckets, uint32_t* big_list, uint32_t* big_count, uint32_t S, hipStream_t s);
+                         Xyzz<P>* buckets, uint32_t* big_list, uint32_t* big_count, uint32_t S, hipStream_t s, int low_prio = 0);
 
 template <class P, int BLOCK>
 __device__ void block_tree_sum(Xyzz<P>& acc, Xyzz<P>* sh) {
@@ -273,8 +279,8 @@ template <class P>
 __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __restrict__ partials, const uint32_t* __restrict__ cnt,
                                                                const uint32_t* __restrict__ task_start,
                                                                const uint32_t* __restrict__ group_task_base, Xyzz<P>* __restrict__ buckets,
-                                                               const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count, uint32_t S) {
-    msm_set_wave_prio(1);
+                                                               const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count, uint32_t S, int low) {
+    msm_set_wave_prio(low);
     extern __shared__ uint4 lds_raw[];
     Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
     const uint32_t nbig = *big_count;
@@ -353,7 +359,10 @@ struct MsmCtx : MsmCtxBase {
         uint32_t ws_NB = 0;                          // keys
         hipStream_t stream = nullptr;      // slot stream: sort, plan, finalize, reduce (high priority)
         hipStream_t acc_stream = nullptr;  // the accumulate kernel alone (low priority)
-        hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
+        hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr, done = nullptr;
+        hipEvent_t acc_gate = nullptr;     // LURK_MSM_SUBMIT_FOLLOW: the accumulation also waits for this event (the followed commitment's end)
+        int follow_wgs = 0;                // LURK_MSM_SUBMIT_FOLLOW: persistent accumulation with this many waves per SIMD (0: the plain launch)
+        bool follow_low = false;           // LURK_MSM_SUBMIT_FOLLOW: the commitment's short kernels at the lowest wave priority
         DevBuf cursor;                     // task cursor of the persistent accumulate kernel (+ its per-CU placement counters)
         bool placement_valid = false;
         int sel = -1;                      // the pending commitment is a PAIR split by this bit of the scalar index (submit_pair)
@@ -370,6 +379,7 @@ struct MsmCtx : MsmCtxBase {
             if (ready) (void)hipEventDestroy(ready);
             if (planned) (void)hipEventDestroy(planned);
             if (accumulated) (void)hipEventDestroy(accumulated);
+            if (done) (void)hipEventDestroy(done);
         }
     };
     Work work[MSM_SLOTS];
@@ -626,7 +636,15 @@ struct MsmCtx : MsmCtxBase {
             if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
             return;
         }
-        const MsmShape sh = shape(n, wk.sel);
+        MsmShape sh = shape(n, wk.sel);
+        // LURK_MSM_SUBMIT_FOLLOW: the sort, the plan and the accumulation at the lowest wave priority - they only have to be through when
+        // the followed accumulation ends / the next step's begin asks for the result.  The TAIL (finalize, bucket reduction) keeps the
+        // raised priority: the next step's begin waits for this commitment as well as for its own commit(T), and 19 dependent levels at
+        // the lowest priority were served last of everything (measured: 2.5 ms, ending after commit(T)'s own reduction).
+        const int low = wk.follow_low ? 1 : 0;
+        static const int low_tail_env = [] { const char* v = getenv("LURK_MSM_FOLLOW_LOW_TAIL"); return v ? atoi(v) : 0; }();
+        const int low_tail = low && low_tail_env;
+        sh.low_prio = low;
         ensure_workspace(wk, sh);
         const size_t nt = ntask_max(sh);
         {
@@ -666,6 +684,7 @@ struct MsmCtx : MsmCtxBase {
                 ProfScope ps("msm_reduce", s);
                 msm_launch_reduce<P>(wk.buckets.template as<Xyzz<P>>(), wk.planes_a.p, wk.planes_b.p, sh.c, sh.G, sh.B, wk.host_pts, s);
             }
+            if (wk.done) LURK_HIP_CHECK(hipEventRecord(wk.done, s));
             LURK_HIP_CHECK(hipGetLastError());
             return;
         }
@@ -673,21 +692,35 @@ struct MsmCtx : MsmCtxBase {
             ProfScope ps("msm_tasks", s);
             uint32_t* lh = wk.len_hist.template as<uint32_t>();
             hipLaunchKernelGGL(msm_taskscan_kernel, dim3(sh.NG), dim3(1024), 0, s, wk.cnt.template as<uint32_t>(),
-                               wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>(), (uint32_t)sh.S);
+                               wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>(), (uint32_t)sh.S, low);
             hipLaunchKernelGGL(msm_tasks_kernel, dim3(div_up(nt, 256)), dim3(256), 0, s, wk.cnt.template as<uint32_t>(),
                                wk.bucket_start.template as<uint32_t>(), wk.task_start.template as<uint32_t>(), wk.group_tasks.template as<uint32_t>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NG, wk.task_info.template as<uint2>(), (uint32_t)sh.S);
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, wk.task_info.template as<uint2>(), (uint32_t)sh.S, low);
             hipLaunchKernelGGL(msm_len_hist_kernel, dim3(256), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh, (uint32_t)sh.S);
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh, (uint32_t)sh.S, low);
             hipLaunchKernelGGL(msm_len_scatter_kernel, dim3(512), dim3(1024), 0, s, wk.task_info.template as<uint2>(),
-                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh, lh + MSM_S + 1, wk.task_order.template as<uint32_t>(), (uint32_t)sh.S);
+                               wk.group_task_base.template as<uint32_t>(), sh.NG, lh, lh + MSM_S + 1, wk.task_order.template as<uint32_t>(), (uint32_t)sh.S, low);
         }
         if (before_accumulate) (*before_accumulate)();  // the one-shot entry point uploads the bases here, behind the sort
         // large commitments in flight take the persistent form on the slot's low-priority accumulate stream (below persistent_min
         // entries the plain launch: see msm_tuning); synchronous calls keep the plain launch
-        const bool persistent = s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= tn.persistent_min : tn.persistent != 0));
+        const bool follow_persistent = wk.follow_wgs > 0;  // LURK_MSM_SUBMIT_FOLLOW: a persistent accumulation of follow_wgs waves per SIMD on the slot stream
+        const bool persistent = follow_persistent || (s_acc && (wk.force_persistent || (tn.persistent == 1 ? (size_t)sh.W * sh.n >= tn.persistent_min : tn.persistent != 0)));
         if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));  // sort and plan are enqueued: a background commitment may start behind this point
-        if (persistent) {
+        if (wk.acc_gate) LURK_HIP_CHECK(hipStreamWaitEvent(s, wk.acc_gate, 0));
+        if (follow_persistent) {
+            // the registers two waves per SIMD leave (512 - 2 x 176) hold the waves of what the open step's serial chain launches
+            // meanwhile - the reduction levels of commit(T), the folds, the next cross term - where a plain launch (three waves, 504
+            // registers) made every one of them queue for an accumulate wave to retire
+            wk.placement_valid = true;
+            {
+                ProfScope ps("msm_accumulate_persistent", s);
+                msm_launch_accumulate_persistent<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
+                                                    wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
+                                                    wk.partials.template as<Xyzz<P>>(), wk.cursor.template as<uint32_t>(), s, (unsigned)wk.follow_wgs);
+            }
+            LURK_HIP_CHECK(hipEventRecord(wk.accumulated, s));
+        } else if (persistent) {
             wk.placement_valid = true;  // (the cursor block was zeroed by msm_part_start_kernel)
             LURK_HIP_CHECK(hipEventRecord(wk.planned, s));
             LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, wk.planned, 0));
@@ -697,12 +730,10 @@ struct MsmCtx : MsmCtxBase {
                 // workgroup of the NEXT commitment needs; a third would take them (measured: the sort then waits for an
                 // accumulation to end and the remaining one runs alone at half speed).
                 std::lock_guard<std::mutex> lk(acc_ring_mu);
-                Work* old = acc_ring[acc_ring_pos % MSM_SLOTS];
                 if (acc_ring_count >= tn.max_acc) {
                     Work* gate = acc_ring[(acc_ring_pos + MSM_SLOTS - tn.max_acc) % MSM_SLOTS];
                     if (gate && gate != &wk && gate->accumulated) LURK_HIP_CHECK(hipStreamWaitEvent(s_acc, gate->accumulated, 0));
                 }
-                (void)old;
                 acc_ring[acc_ring_pos % MSM_SLOTS] = &wk;
                 acc_ring_pos++;
                 if (acc_ring_count < MSM_SLOTS) acc_ring_count++;
@@ -716,27 +747,31 @@ struct MsmCtx : MsmCtxBase {
             LURK_HIP_CHECK(hipEventRecord(wk.accumulated, s_acc));
             LURK_HIP_CHECK(hipStreamWaitEvent(s, wk.accumulated, 0));
         } else {
-            ProfScope ps("msm_accumulate", s);
-            msm_launch_accumulate<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
-                                     wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
-                                     wk.partials.template as<Xyzz<P>>(), nt, s);
+            {
+                ProfScope ps("msm_accumulate", s);
+                msm_launch_accumulate<P>(wk.sorted.template as<uint32_t>(), table, wk.task_info.template as<uint2>(),
+                                         wk.task_order.template as<uint32_t>(), wk.group_task_base.template as<uint32_t>(), sh.NG,
+                                         wk.partials.template as<Xyzz<P>>(), nt, s);
+            }
+            if (wk.accumulated) LURK_HIP_CHECK(hipEventRecord(wk.accumulated, s));  // what a LURK_MSM_SUBMIT_FOLLOW commitment starts behind
         }
         {
             ProfScope ps("msm_finalize", s);
             msm_launch_finalize<P>(wk.partials.template as<Xyzz<P>>(), wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                    wk.group_task_base.template as<uint32_t>(), sh.NB, wk.buckets.template as<Xyzz<P>>(),
-                                   wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S, s);
+                                   wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S, s, low_tail);
             hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(128), dim3(256), 256 * sizeof(Xyzz<P>), s, wk.partials.template as<Xyzz<P>>(),
                                wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), wk.buckets.template as<Xyzz<P>>(),
-                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S);
+                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S, low_tail);
         }
         {
             // the c - 1 levels of the bit-plane merge tree; the last one stores the G x c plane sums into the slot's pinned buffer: the
             // host's Horner over them (G c doublings and as many additions) is cheaper than a 20-deep dependent chain on one lane
             ProfScope ps("msm_reduce", s);
-            msm_launch_reduce<P>(wk.buckets.template as<Xyzz<P>>(), wk.planes_a.p, wk.planes_b.p, sh.c, sh.G, sh.B, wk.host_pts, s);
+            msm_launch_reduce<P>(wk.buckets.template as<Xyzz<P>>(), wk.planes_a.p, wk.planes_b.p, sh.c, sh.G, sh.B, wk.host_pts, s, low_tail);
         }
+        if (wk.done) LURK_HIP_CHECK(hipEventRecord(wk.done, s));
         LURK_HIP_CHECK(hipGetLastError());
     }
 
@@ -829,8 +864,8 @@ struct MsmCtx : MsmCtxBase {
             // background: persistent one-wave accumulation whatever the size, started behind the foreground commitment's sort.
             // (Its short kernels stay on the high-priority stream: on the low-priority queue every one of the ~45 dependent
             // launches of a commitment was dispatched 40 us late - 50-60 us per bit-plane level instead of 13 - even on an idle chip.)
-            const bool bg = mode == LURK_MSM_SUBMIT_BACKGROUND;
-            wk.foreground = mode == LURK_MSM_SUBMIT_FOREGROUND;
+            const bool bg = mode == LURK_MSM_SUBMIT_BACKGROUND, follow = mode == LURK_MSM_SUBMIT_FOLLOW;
+            wk.foreground = mode == LURK_MSM_SUBMIT_FOREGROUND || follow;
             wk.force_persistent = bg;
             wk.pending_stream = wk.stream;
             LURK_HIP_CHECK(hipEventRecord(wk.ready, after));
@@ -841,11 +876,38 @@ struct MsmCtx : MsmCtxBase {
                 std::lock_guard<std::mutex> lk2(fg_mu);
                 if (bg && last_fg && last_fg != &wk && last_fg->planned)
                     LURK_HIP_CHECK(hipStreamWaitEvent(wk.pending_stream, last_fg->planned, 0));
-                if (mode == LURK_MSM_SUBMIT_FOREGROUND) last_fg = &wk;
+                // follow: behind the foreground commitment's ACCUMULATION (recorded by its enqueue, which the caller's thread has
+                // already returned from; an event of an earlier, finished commitment - or one never recorded - orders nothing)
+                // Its own accumulation waits for the END of that commitment (the last level of its bucket reduction): a plain
+                // accumulate launch fills every SIMD's registers, and the followed commitment's 19 dependent reduction levels - what
+                // the host is waiting for - would each queue for a wave slot (measured: the reduction 0.35 -> 0.70 ms).  The sort and
+                // the plan (LDS atomics, short workgroups) do run beside that reduction.
+                wk.acc_gate = nullptr;
+                wk.follow_wgs = 0;
+                wk.follow_low = false;
+                if (follow) {
+                    static const int lowp = [] { const char* v = getenv("LURK_MSM_FOLLOW_LOW_PRIO"); return v ? atoi(v) : 1; }();
+                    wk.follow_low = lowp != 0;
+                    static const int wgs = [] { const char* v = getenv("LURK_MSM_FOLLOW_WGS"); const int x = v ? atoi(v) : 2; return x < 0 ? 0 : x > 3 ? 3 : x; }();
+                    wk.follow_wgs = wgs;
+                }
+                if (follow && last_fg && last_fg != &wk && last_fg->accumulated) {
+                    // LURK_MSM_FOLLOW_SORT: 1 = the sort and the plan run at once (beside the followed commitment's own sort and the
+                    // cross term: LDS- and HBM-bound neighbours) and only the ACCUMULATION waits for the followed accumulation's end;
+                    // 0 = the whole commitment waits for it.  LURK_MSM_FOLLOW_ACC_GATE=1: the accumulation waits for the followed
+                    // commitment's END (the last level of its bucket reduction) instead.
+                    static const int sort_now = [] { const char* v = getenv("LURK_MSM_FOLLOW_SORT"); return v ? atoi(v) : 1; }();
+                    static const int gate = [] { const char* v = getenv("LURK_MSM_FOLLOW_ACC_GATE"); return v ? atoi(v) : 0; }();
+                    if (!sort_now) LURK_HIP_CHECK(hipStreamWaitEvent(wk.pending_stream, last_fg->accumulated, 0));
+                    wk.acc_gate = gate && last_fg->done ? last_fg->done : last_fg->accumulated;
+                }
             }
             // foreground: everything on the (high-priority) slot stream
             hipStream_t acc_s = wk.foreground ? nullptr : wk.acc_stream;
             enqueue(wk, d_scalars, n, is_mont, wk.pending_stream, acc_s);
+            wk.acc_gate = nullptr;
+            wk.follow_wgs = 0;
+            wk.follow_low = false;
         }
         wk.pending = true;
         wk.pending_n = n;
@@ -862,6 +924,7 @@ struct MsmCtx : MsmCtxBase {
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.ready, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.planned, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.accumulated, hipEventDisableTiming));
+            LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.done, hipEventDisableTiming));
         }
     }
 
@@ -1143,7 +1206,7 @@ int lurk_hip_msm_ctx_submit_dev_mode(lurk_hip_msm_ctx* ctx, int slot, const void
     return guarded([&] {
         LURK_REQUIRE(ctx, "null ctx");
         LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
-        LURK_REQUIRE(mode >= LURK_MSM_SUBMIT_DEFAULT && mode <= LURK_MSM_SUBMIT_BACKGROUND, "unknown submit mode");
+        LURK_REQUIRE(mode >= LURK_MSM_SUBMIT_DEFAULT && mode <= LURK_MSM_SUBMIT_FOLLOW, "unknown submit mode");
         DeviceGuard dg(ctx->impl->device);
         ctx->impl->submit(slot, d_scalars, n, is_mont, (hipStream_t)stream, mode);
     });
@@ -1491,7 +1554,7 @@ int lurk_hip_msm_multi_submit_dev(lurk_hip_msm_multi* m, int slot, const void* c
         LURK_REQUIRE(n_slices == m->shards.size(), "one device pointer per shard is required (n_slices != number of shards)");
         LURK_REQUIRE(n <= m->npoints, "more scalars than bases in the context");
         LURK_REQUIRE(n == 0 || d_scalars, "null scalars");
-        LURK_REQUIRE(mode >= LURK_MSM_SUBMIT_DEFAULT && mode <= LURK_MSM_SUBMIT_BACKGROUND, "unknown submit mode");
+        LURK_REQUIRE(mode >= LURK_MSM_SUBMIT_DEFAULT && mode <= LURK_MSM_SUBMIT_FOLLOW, "unknown submit mode");
         std::lock_guard<std::mutex> lk(m->mu);
         LURK_REQUIRE(!m->pending[slot], "slot is busy: wait for it first");
         for (size_t i = 0; i < m->shards.size(); i++)

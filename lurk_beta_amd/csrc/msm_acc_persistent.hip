@@ -73,16 +73,17 @@ __global__ __launch_bounds__(MSM_ACC_BLOCK, LURK_PERSIST_MIN_BLOCKS) void msm_ac
 // one workgroup of 4 waves per CU (one wave per SIMD); cursor must be zero when the kernel starts
 template <class P>
 void msm_launch_accumulate_persistent(const uint32_t* sorted, const Affine<P>* table, const uint2* task_info, const uint32_t* order,
-                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, hipStream_t s) {
+                                      const uint32_t* group_task_base, int NG, Xyzz<P>* partials, uint32_t* cursor, hipStream_t s, unsigned wgs_per_cu) {
     // LURK_MSM_PERSIST_WGS workgroups per CU (1: one wave per SIMD, the form two of which are resident at once; 2: two waves per SIMD - a
     // single accumulation at the multiplier's full rate, for LURK_MSM_MAX_ACC=1)
     static const unsigned wgs = [] { const char* e = getenv("LURK_MSM_PERSIST_WGS"); int v = e ? atoi(e) : 1; return (unsigned)(v < 1 ? 1 : v > 4 ? 4 : v); }();
-    hipLaunchKernelGGL((msm_accumulate_persistent_kernel<P>), dim3((unsigned)num_cus() * wgs), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
+    // wgs_per_cu != 0: the caller's choice for this launch (a LURK_MSM_SUBMIT_FOLLOW commitment: msm.hip)
+    hipLaunchKernelGGL((msm_accumulate_persistent_kernel<P>), dim3((unsigned)num_cus() * (wgs_per_cu ? wgs_per_cu : wgs)), dim3(MSM_ACC_BLOCK), 0, s, sorted, table, task_info, order,
                        group_task_base, NG, partials, cursor);
 }
 #define LURK_ACC_PERSISTENT_INSTANTIATE(P)                                                                                                    \
     template void msm_launch_accumulate_persistent<P>(const uint32_t*, const Affine<P>*, const uint2*, const uint32_t*, const uint32_t*, int, \
-                                                      Xyzz<P>*, uint32_t*, hipStream_t);
+                                                      Xyzz<P>*, uint32_t*, hipStream_t, unsigned);
 LURK_ACC_PERSISTENT_INSTANTIATE(PallasFp)
 LURK_ACC_PERSISTENT_INSTANTIATE(PallasFq)
 

@@ -13,6 +13,7 @@ MsmShape msm_make_shape(int c, bool precomputed, size_t npoints, size_t n, int s
     sh.c = c;
     sh.W = msm_num_windows(c);
     sh.sel = precomputed ? sel : -1;
+    sh.low_prio = 0;
     sh.G = precomputed ? (sh.sel >= 0 ? 2 : 1) : sh.W;
     sh.B = 1u << (c - 1);
     sh.NB = (uint32_t)sh.G * sh.B;
@@ -48,7 +49,10 @@ MsmShape msm_make_shape(int c, bool precomputed, size_t npoints, size_t n, int s
 // commitments in flight they share the SIMDs with the (older, VALU-saturating) accumulate waves of the previous
 // commitment, and the instruction arbiter serves the oldest wave first: measured 15-18x slowdowns of these kernels.
 // Raising their wave priority lets them issue when they are ready; they need a few percent of the VALU.
-__device__ __forceinline__ void msm_sort_wave_prio() { __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void msm_sort_wave_prio(int low = 0) {
+    if (low) __builtin_amdgcn_s_setprio(0);
+    else __builtin_amdgcn_s_setprio(3);
+}
 
 // entry (w, i) -> key = space * B + |d| - 1 (space = w in plain mode, 0 with the table)
 __device__ __forceinline__ uint32_t msm_key(const MsmShape& sh, uint32_t w, uint32_t mag, size_t i) {
@@ -64,7 +68,7 @@ constexpr int msm_ct_windows(int C) { return C ? (256 + C - 1) / C : 1; }
 template <class SF, int C, bool MONT>
 __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_hist1_kernel(const uint4* __restrict__ scalars, uint4* __restrict__ canon,
                                                                      uint32_t* __restrict__ block_hist, MsmShape sh, size_t chunk) {
-    msm_sort_wave_prio();
+    msm_sort_wave_prio(sh.low_prio);
     extern __shared__ uint32_t h[];  // [P]
     for (int p = threadIdx.x; p < sh.P; p += MSM_SORT_BLOCK) h[p] = 0;
     __syncthreads();
@@ -190,7 +194,7 @@ template <int C>
 __global__ __launch_bounds__(MSM_SORT_BLOCK, LURK_SORT_MIN_BLOCKS) void msm_scatter1_kernel(const uint4* __restrict__ scalars, const uint32_t* __restrict__ block_off,
                                                                         const uint32_t* __restrict__ part_start, uint32_t* __restrict__ inter_e,
                                                                         uint8_t* __restrict__ inter_k, MsmShape sh, size_t chunk) {
-    msm_sort_wave_prio();
+    msm_sort_wave_prio(sh.low_prio);
     extern __shared__ uint32_t lds[];
     const int P = sh.P, PER = P / MSM_SORT_BLOCK;
     uint32_t* goff = lds;          // [P] where this block's next entry of partition p goes
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(MSM_SORT_BLOCK) void msm_part2_kernel(const uint32_
                                                                      const uint32_t* __restrict__ part_start, uint32_t* __restrict__ sorted,
                                                                      uint32_t* __restrict__ cnt, uint32_t* __restrict__ bucket_start, MsmShape sh,
                                                                      uint32_t cap) {
-    msm_sort_wave_prio();
+    msm_sort_wave_prio(sh.low_prio);
     extern __shared__ uint32_t lds[];  // [2^LB] counters, [32] scan scratch, [cap] staged output
     const int p = blockIdx.x, t = threadIdx.x;
     const uint32_t nbins = 1u << sh.LB;

@@ -44,6 +44,7 @@ struct MsmShape {
     int S;                 // sorted entries per accumulation task: MSM_S, less when that would leave lanes idle (small commitments)
     int sel;               // >= 0: TWO key spaces chosen by bit `sel` of the scalar's index (a pair of commitments with disjoint supports
                            // in one pass: the two halves of an inner-product-argument round); -1: off
+    int low_prio;          // 1: the sort's kernels run at the lowest wave priority (a LURK_MSM_SUBMIT_FOLLOW commitment, msm.hip); 0: raised
 };
 
 inline size_t msm_scatter1_lds(int P, int W, int tile) { return (size_t)(3 * P + 32) * 4 + (size_t)W * tile * 8; }

@@ -201,6 +201,20 @@ static void fold_challenge_finish(lurk_hip_fold_ctx* c, void* r32_mont) {
 // the key and the slot the staged commitment of buffer b runs on
 static lurk_hip_msm_ctx* fold_staged_key(lurk_hip_fold_ctx* c, int b) { return c->helper_of[b] >= 0 ? c->helpers[c->helper_of[b]]->key : c->key; }
 
+// The scheduling class of a commitment staged AHEAD of its step (the next step's commit(W2) while a step is open).  Default
+// LURK_MSM_SUBMIT_FOLLOW (round 6): full-rate launches that start when the open step's commit(T) has left the accumulate stage, so that
+// the staged commitment fills the window the step's serial chain leaves idle (T's bucket reduction, the transcript, the folds, the next
+// cross term) and commit(T)'s accumulation keeps the VALU to itself.  LURK_FOLD_STAGED_MODE=2: the round-2..5 behaviour
+// (LURK_MSM_SUBMIT_BACKGROUND: persistent one-wave accumulation beside commit(T)'s).
+static int fold_staged_mode() {
+    static const int m = [] {
+        const char* v = getenv("LURK_FOLD_STAGED_MODE");
+        const int x = v ? atoi(v) : LURK_MSM_SUBMIT_FOLLOW;
+        return x == LURK_MSM_SUBMIT_BACKGROUND || x == LURK_MSM_SUBMIT_DEFAULT || x == LURK_MSM_SUBMIT_FOREGROUND ? x : LURK_MSM_SUBMIT_FOLLOW;
+    }();
+    return m;
+}
+
 static void fold_submit_staged(lurk_hip_fold_ctx* c, int b, int mode) {
     if (c->submitted[b]) return;
     // (an instance staged whole is read in place: begin refuses late ranges for it, and what begin does write - u2 and X2 - lies
@@ -256,7 +270,7 @@ static void fold_stage(lurk_hip_fold_ctx* c, const void* w2, size_t offset, size
     // Between begin and finish nothing the host waits for is in flight: the commitment starts now, in the background class.
     // Otherwise it is submitted by the begin that comes next, BEHIND that step's commit(T): the device serves its queues
     // roughly in submission order, and T is what the host waits for.
-    if (c->begun || c->in_hook) fold_submit_staged(c, b, LURK_MSM_SUBMIT_BACKGROUND);
+    if (c->begun || c->in_hook) fold_submit_staged(c, b, fold_staged_mode());
 }
 
 constexpr size_t FOLD_LATE_KEY_MAX = (size_t)1 << 16;  // late positions a key of their own is built for (the small-commitment form's limit)
@@ -412,7 +426,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
         rollback.late_in_flight = true;
     }
     tt[2] = now();
-    if (ahead) fold_submit_staged(c, c->staged[0], LURK_MSM_SUBMIT_BACKGROUND);  // commit(next W2) fills what T leaves
+    if (ahead) fold_submit_staged(c, c->staged[0], fold_staged_mode());  // commit(next W2) fills what T leaves
     tt[3] = now();
     fold_run_submit_hook(c);  // the caller's device work beside the step (the next witness's traces)
     fold_instance_settle(c);  // the previous step's instance fold, while the device works on this step

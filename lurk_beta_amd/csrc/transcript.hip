@@ -28,23 +28,73 @@
 
 namespace lurk {
 
-constexpr int RO_ARITY = 24;  // neptune U24: rate of the sponge arecibo's PoseidonRO is built on
+// ---- the run-time parameters of this restatement (round 6) -----------------------------------------------------------------------
+// Everything above that is recalled from memory [MEM] and cannot be checked against /root/reference is a FIELD of lurk_hip_ro_params
+// (include/lurk_hip.h), process-wide, defaults = what rounds 1-5 compiled in: a Rust host whose first r differs from arecibo's can
+// move one field at a time (or let lurk_beta_amd/dump.py search them against a LURKDUMP probe record) instead of rebuilding the
+// library.  A folding context snapshots the parameters when a step's transcript begins.
+static lurk_hip_ro_params ro_params_default() {
+    lurk_hip_ro_params p;
+    memset(&p, 0, sizeof(p));
+    p.struct_size = (uint32_t)sizeof(p);
+    p.arity = 24;               // neptune U24: rate of the sponge arecibo's PoseidonRO is built on
+    p.domain_separator = 0;
+    p.absorb_tag_bit = 31;      // SpongeOp::Absorb(n).value() = n + 2^31
+    p.num_challenge_bits = 128; // NUM_CHALLENGE_BITS
+    for (uint32_t i = 0; i < 4; i++) p.item_order[i] = i;     // pp_digest, U1, U2, comm_T
+    for (uint32_t i = 0; i < 4; i++) p.relaxed_order[i] = i;  // comm_W, comm_E, u, X
+    for (uint32_t i = 0; i < 2; i++) p.fresh_order[i] = i;    // comm_W, X
+    p.point_elements = 3;       // (x, y, is_infinity)
+    p.relaxed_x_limbs = 4;      // BN_N_LIMBS
+    p.fresh_x_limbs = 0;        // one element through scalar_as_base
+    p.limb_bits = 64;           // BN_LIMB_WIDTH
+    p.pattern_absorbs = 0;      // the IO pattern declares what is absorbed
+    p.squeeze_element = 0;
+    return p;
+}
+static std::mutex g_ro_mu;
+static lurk_hip_ro_params g_ro = ro_params_default();
+static lurk_hip_ro_params ro_params() {
+    std::lock_guard<std::mutex> lk(g_ro_mu);
+    return g_ro;
+}
+static bool is_permutation(const uint32_t* v, uint32_t n) {
+    uint32_t seen = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (v[i] >= n || (seen >> v[i] & 1)) return false;
+        seen |= 1u << v[i];
+    }
+    return true;
+}
+static void ro_params_validate(const lurk_hip_ro_params& p) {
+    LURK_REQUIRE(p.struct_size == sizeof(lurk_hip_ro_params), "lurk_hip_ro_params: struct_size does not match this library's layout");
+    LURK_REQUIRE(p.arity >= 2 && p.arity <= 36, "lurk_hip_ro_params: arity must be in 2..36");
+    LURK_REQUIRE(p.absorb_tag_bit <= 31, "lurk_hip_ro_params: absorb_tag_bit must be in 0..31");
+    LURK_REQUIRE(p.num_challenge_bits >= 1 && p.num_challenge_bits <= 250, "lurk_hip_ro_params: num_challenge_bits must be in 1..250");
+    LURK_REQUIRE(is_permutation(p.item_order, 4), "lurk_hip_ro_params: item_order is not a permutation of 0..3");
+    LURK_REQUIRE(is_permutation(p.relaxed_order, 4), "lurk_hip_ro_params: relaxed_order is not a permutation of 0..3");
+    LURK_REQUIRE(is_permutation(p.fresh_order, 2), "lurk_hip_ro_params: fresh_order is not a permutation of 0..1");
+    LURK_REQUIRE(p.point_elements == 2 || p.point_elements == 3, "lurk_hip_ro_params: point_elements must be 2 or 3");
+    LURK_REQUIRE(p.relaxed_x_limbs <= 16 && p.fresh_x_limbs <= 16, "lurk_hip_ro_params: at most 16 limbs per element");
+    LURK_REQUIRE(p.limb_bits >= 1 && p.limb_bits <= 250, "lurk_hip_ro_params: limb_bits must be in 1..250");
+    LURK_REQUIRE(p.pattern_absorbs < (1u << 31), "lurk_hip_ro_params: pattern_absorbs out of range");
+    LURK_REQUIRE(p.squeeze_element < p.arity, "lurk_hip_ro_params: squeeze_element must be below the arity");
+}
 
 template <class P>
-static const RoHost& ro_host() {
-    static const RoHost& h = poseidon_host<P>(RO_ARITY);
-    return h;
+static const RoHost& ro_host(uint32_t arity) {
+    return poseidon_host<P>((int)arity);  // one table per (field, arity), built on first use
 }
 
 // neptune sponge/api.rs: IOPattern::value
-static unsigned __int128 io_pattern_tag(uint32_t absorbs, uint32_t squeezes, uint32_t domain_separator) {
+static unsigned __int128 io_pattern_tag(uint32_t absorbs, uint32_t squeezes, uint32_t domain_separator, uint32_t absorb_tag_bit = 31) {
     const unsigned __int128 x = (unsigned __int128)0 - 159;
     unsigned __int128 xi = 1, st = 0;
     auto update = [&](uint32_t a) {
         xi *= x;
         st += xi * a;
     };
-    if (absorbs) update(absorbs + (1u << 31));
+    if (absorbs) update(absorbs + (1u << absorb_tag_bit));
     if (squeezes) update(squeezes);
     update(domain_separator);
     return st;
@@ -59,11 +109,13 @@ struct RoSponge {
     std::vector<H4> s;
     int pos = 0;
     size_t total = 0, absorbed = 0;
-    void begin(size_t n) {
-        R = &ro_host<P>();
+    uint32_t squeeze_element = 0;
+    void begin(size_t n, const lurk_hip_ro_params& prm) {
+        R = &ro_host<P>(prm.arity);
+        squeeze_element = prm.squeeze_element;
         const H4 zero = {{0, 0, 0, 0}};
         s.assign(R->t, zero);
-        const unsigned __int128 tag = io_pattern_tag((uint32_t)n, 1, 0);
+        const unsigned __int128 tag = io_pattern_tag(prm.pattern_absorbs ? prm.pattern_absorbs : (uint32_t)n, 1, prm.domain_separator, prm.absorb_tag_bit);
         H4 c = {{(uint64_t)tag, (uint64_t)(tag >> 64), 0, 0}};
         s[0] = h4_mul(R->F, c, R->r2);
         pos = 0;
@@ -97,7 +149,7 @@ struct RoSponge {
         LURK_REQUIRE(absorbed == total, "random oracle: fewer elements than the declared IO pattern");
         const H4 one = {{1, 0, 0, 0}};
         permute_host(*R, s);
-        return h4_to<P>(h4_mul(R->F, s[1], one));
+        return h4_to<P>(h4_mul(R->F, s[1 + squeeze_element], one));
     }
 };
 
@@ -105,7 +157,7 @@ struct RoSponge {
 template <class P>
 static Fe<P> ro_squeeze_host(const uint64_t* elems, size_t n) {
     RoSponge<P> sp;
-    sp.begin(n);
+    sp.begin(n, ro_params());
     sp.absorb(elems, n);
     return sp.squeeze();
 }
@@ -136,43 +188,70 @@ static void scalar_as_base(const void* x_mont, uint64_t* out4) {
     }
     memcpy(out4, w, 32);
 }
+// n_limbs limbs of limb_bits bits of the canonical integer, low limb first (BN_N_LIMBS = 4 limbs of BN_LIMB_WIDTH = 64 bits by default)
 template <class F>
-static void scalar_limbs(const void* x_mont, std::vector<uint64_t>& out) {  // BN_N_LIMBS = 4 limbs of BN_LIMB_WIDTH = 64 bits
+static void scalar_limbs(const void* x_mont, uint32_t n_limbs, uint32_t limb_bits, std::vector<uint64_t>& out) {
     Fe<F> x;
     memcpy(x.l, x_mont, 32);
     x = fe_from_mont<F>(x);
-    for (int k = 0; k < 4; k++) {
-        out.push_back((uint64_t)x.l[2 * k] | (uint64_t)x.l[2 * k + 1] << 32);
-        out.push_back(0);
-        out.push_back(0);
-        out.push_back(0);
+    auto bit = [&](uint32_t b) -> uint64_t { return b < 256 ? (x.l[b >> 5] >> (b & 31)) & 1u : 0u; };
+    for (uint32_t k = 0; k < n_limbs; k++) {
+        uint64_t w[4] = {0, 0, 0, 0};
+        for (uint32_t b = 0; b < limb_bits; b++) w[b >> 6] |= bit(k * limb_bits + b) << (b & 63);
+        out.insert(out.end(), w, w + 4);
     }
 }
-static void absorb_commitment(int curve, const void* jac96, std::vector<uint64_t>& out) {
+static void absorb_commitment(int curve, const void* jac96, uint32_t point_elements, std::vector<uint64_t>& out) {
     uint64_t xy[8];
     if (lurk_hip_point_to_affine_canonical(curve, xy, jac96) != 0) throw HipFailure{LURK_HIP_ERR_INVALID_ARG, lurk_hip_last_error()};
     bool inf = true;
     for (int i = 0; i < 8; i++) inf = inf && xy[i] == 0;
     out.insert(out.end(), xy, xy + 8);
-    out.push_back(inf ? 1 : 0);
-    out.push_back(0);
-    out.push_back(0);
-    out.push_back(0);
+    if (point_elements == 3) {
+        out.push_back(inf ? 1 : 0);
+        out.push_back(0);
+        out.push_back(0);
+        out.push_back(0);
+    }
 }
 
 // F = scalar field of `curve`, B = its base field (the RO's field).  In three stages, so that a folding context can run the first two
-// while the device is still busy with the step (nifs_pre.hpp): `begin` absorbs pp_digest and U1 - for a Lurk step (num_io = 6: 44
-// elements in all) that fills the first rate of 24 and its permutation runs at once -, `fresh` absorbs U2 = (comm_W2, X2), `finish`
-// absorbs comm_T and squeezes: one permutation and one affine conversion are all that is left behind commit(T).
+// while the device is still busy with the step (nifs_pre.hpp): `begin` brings pp_digest and U1, `fresh` U2 = (comm_W2, X2), `finish`
+// comm_T and squeezes.  The four items are absorbed in lurk_hip_ro_params::item_order as soon as every item before them has arrived:
+// in the default order a Lurk step (num_io = 6: 44 elements in all) fills the first rate of 24 inside `begin` and its permutation runs
+// at once; one permutation and one affine conversion are all that is left behind commit(T).
 template <class F, class B>
 struct NifsStages {
     RoSponge<B> sp;
+    lurk_hip_ro_params prm;
     int curve = 0;
     size_t num_io = 0;
+    std::vector<uint64_t> item[4];
+    bool have[4] = {false, false, false, false};
+    int next = 0;
+    void drain() {
+        while (next < 4 && have[prm.item_order[next]]) {
+            std::vector<uint64_t>& el = item[prm.item_order[next]];
+            sp.absorb(el.data(), el.size() / 4);
+            sp.permute_if_full();
+            next++;
+        }
+    }
+    void x_elements(const void* x_mont, uint32_t limbs, std::vector<uint64_t>& el) {
+        uint64_t tmp[4];
+        for (size_t i = 0; i < num_io; i++) {
+            if (limbs) {
+                scalar_limbs<F>((const char*)x_mont + 32 * i, limbs, prm.limb_bits, el);
+            } else {
+                scalar_as_base<F, B>((const char*)x_mont + 32 * i, tmp);
+                el.insert(el.end(), tmp, tmp + 4);
+            }
+        }
+    }
     void begin(int curve_, const void* pp_digest32, const void* comm_w1, const void* comm_e1, const void* u1_mont, const void* x1_mont, size_t num_io_) {
+        prm = ro_params();
         curve = curve_;
         num_io = num_io_;
-        std::vector<uint64_t> el;
         {
             // the digest is a scalar's canonical bytes: scalar_as_base through a Montgomery round trip is not needed, reduce directly
             uint32_t w[8];
@@ -184,41 +263,63 @@ struct NifsStages {
             }
             uint64_t d[4];
             memcpy(d, w, 32);
-            el.insert(el.end(), d, d + 4);
+            item[LURK_RO_ITEM_PP_DIGEST].assign(d, d + 4);
+            have[LURK_RO_ITEM_PP_DIGEST] = true;
         }
-        absorb_commitment(curve, comm_w1, el);   // U1: RelaxedR1CSInstance::absorb_in_ro
-        absorb_commitment(curve, comm_e1, el);
-        uint64_t tmp[4];
-        scalar_as_base<F, B>(u1_mont, tmp);
-        el.insert(el.end(), tmp, tmp + 4);
-        for (size_t i = 0; i < num_io; i++) scalar_limbs<F>((const char*)x1_mont + 32 * i, el);
-        sp.begin(1 + 3 + 3 + 1 + 4 * num_io + 3 + num_io + 3);
-        sp.absorb(el.data(), el.size() / 4);
-        sp.permute_if_full();
+        std::vector<uint64_t>& el = item[LURK_RO_ITEM_U1];  // U1: RelaxedR1CSInstance::absorb_in_ro
+        el.clear();
+        for (int k = 0; k < 4; k++) {
+            switch (prm.relaxed_order[k]) {
+                case LURK_RO_PART_COMM_W: absorb_commitment(curve, comm_w1, prm.point_elements, el); break;
+                case LURK_RO_PART_COMM_E: absorb_commitment(curve, comm_e1, prm.point_elements, el); break;
+                case LURK_RO_PART_U: {
+                    uint64_t tmp[4];
+                    scalar_as_base<F, B>(u1_mont, tmp);
+                    el.insert(el.end(), tmp, tmp + 4);
+                    break;
+                }
+                default: x_elements(x1_mont, prm.relaxed_x_limbs, el); break;
+            }
+        }
+        have[LURK_RO_ITEM_U1] = true;
+        const size_t pt = prm.point_elements;
+        sp.begin(1 + (2 * pt + 1 + num_io * (prm.relaxed_x_limbs ? prm.relaxed_x_limbs : 1)) + (pt + num_io * (prm.fresh_x_limbs ? prm.fresh_x_limbs : 1)) + pt, prm);
+        drain();
     }
     void fresh(const void* comm_w2, const void* x2_mont) {
-        std::vector<uint64_t> el;
-        uint64_t tmp[4];
-        absorb_commitment(curve, comm_w2, el);   // U2: R1CSInstance::absorb_in_ro
-        for (size_t i = 0; i < num_io; i++) {
-            scalar_as_base<F, B>((const char*)x2_mont + 32 * i, tmp);
-            el.insert(el.end(), tmp, tmp + 4);
+        std::vector<uint64_t>& el = item[LURK_RO_ITEM_U2];  // U2: R1CSInstance::absorb_in_ro
+        el.clear();
+        for (int k = 0; k < 2; k++) {
+            if (prm.fresh_order[k] == 0) absorb_commitment(curve, comm_w2, prm.point_elements, el);
+            else x_elements(x2_mont, prm.fresh_x_limbs, el);
         }
-        sp.absorb(el.data(), el.size() / 4);
-        sp.permute_if_full();
+        have[LURK_RO_ITEM_U2] = true;
+        drain();
     }
     void finish(const void* comm_t, void* r32_mont) {
-        std::vector<uint64_t> el;
-        absorb_commitment(curve, comm_t, el);
-        sp.absorb(el.data(), el.size() / 4);
+        item[LURK_RO_ITEM_COMM_T].clear();
+        absorb_commitment(curve, comm_t, prm.point_elements, item[LURK_RO_ITEM_COMM_T]);
+        have[LURK_RO_ITEM_COMM_T] = true;
+        drain();
+        LURK_REQUIRE(next == 4, "the transcript is missing an item (begin / fresh / finish out of order)");
         Fe<B> sq = sp.squeeze();
         uint32_t w[8];
         memcpy(w, sq.l, 32);
-        for (unsigned b = 128; b < 256; b++) w[b >> 5] &= ~(1u << (b & 31));  // NUM_CHALLENGE_BITS
+        for (unsigned b = prm.num_challenge_bits; b < 256; b++) w[b >> 5] &= ~(1u << (b & 31));  // NUM_CHALLENGE_BITS
         Fe<F> rf;
         memcpy(rf.l, w, 32);
+        while (fe_canonical_ge_mod<F>(rf.l)) {  // only with more than 253 challenge bits: the integer is read as a scalar
+            uint32_t borrow = 0;
+            for (int i = 0; i < 8; i++) rf.l[i] = subb32(rf.l[i], F::mod(i), borrow);
+        }
         rf = fe_to_mont<F>(rf);
         memcpy(r32_mont, rf.l, 32);
+    }
+    // the elements in absorb order (diagnostics: lurk_hip_nifs_absorb_list); valid once all four items are present
+    std::vector<uint64_t> absorb_list() const {
+        std::vector<uint64_t> out;
+        for (int k = 0; k < 4; k++) out.insert(out.end(), item[prm.item_order[k]].begin(), item[prm.item_order[k]].end());
+        return out;
     }
 };
 template <class F, class B>
@@ -325,8 +426,53 @@ int lurk_hip_nova_ro_squeeze(int field_id, const void* elems32, size_t n, unsign
 int lurk_hip_nova_ro_pattern_tag(uint32_t absorbs, uint32_t squeezes, uint32_t domain_separator, void* out16) {
     return host_guarded([&] {
         LURK_REQUIRE(out16, "null argument");
-        const unsigned __int128 t = io_pattern_tag(absorbs, squeezes, domain_separator);
+        const unsigned __int128 t = io_pattern_tag(absorbs, squeezes, domain_separator, ro_params().absorb_tag_bit);
         memcpy(out16, &t, 16);
+    });
+}
+
+int lurk_hip_ro_params_get(lurk_hip_ro_params* out) {
+    return host_guarded([&] {
+        LURK_REQUIRE(out, "null argument");
+        *out = ro_params();
+    });
+}
+int lurk_hip_ro_params_set(const lurk_hip_ro_params* params) {
+    return host_guarded([&] {
+        const lurk_hip_ro_params p = params ? *params : ro_params_default();  // NULL: back to the defaults
+        ro_params_validate(p);
+        std::lock_guard<std::mutex> lk(g_ro_mu);
+        g_ro = p;
+    });
+}
+
+int lurk_hip_nifs_absorb_list(int curve, const void* pp_digest32, const void* comm_w1_jac96, const void* comm_e1_jac96, const void* u1_mont,
+                              const void* x1_mont, const void* comm_w2_jac96, const void* x2_mont, size_t num_io, const void* comm_t_jac96,
+                              void* out_elems32, size_t cap, size_t* count) {
+    return host_guarded([&] {
+        LURK_REQUIRE(curve == LURK_CURVE_PALLAS || curve == LURK_CURVE_VESTA, "unknown curve id");
+        LURK_REQUIRE(pp_digest32 && comm_w1_jac96 && comm_e1_jac96 && u1_mont && comm_w2_jac96 && comm_t_jac96 && count, "null argument");
+        LURK_REQUIRE(num_io == 0 || (x1_mont && x2_mont), "null public IO");
+        std::vector<uint64_t> el;
+        uint64_t r[4];
+        if (curve == LURK_CURVE_PALLAS) {
+            NifsStages<PallasFq, PallasFp> st;
+            st.begin(curve, pp_digest32, comm_w1_jac96, comm_e1_jac96, u1_mont, x1_mont, num_io);
+            st.fresh(comm_w2_jac96, x2_mont);
+            st.finish(comm_t_jac96, r);
+            el = st.absorb_list();
+        } else {
+            NifsStages<PallasFp, PallasFq> st;
+            st.begin(curve, pp_digest32, comm_w1_jac96, comm_e1_jac96, u1_mont, x1_mont, num_io);
+            st.fresh(comm_w2_jac96, x2_mont);
+            st.finish(comm_t_jac96, r);
+            el = st.absorb_list();
+        }
+        *count = el.size() / 4;
+        if (out_elems32) {
+            LURK_REQUIRE(cap >= *count, "the output buffer is shorter than the absorb list");
+            memcpy(out_elems32, el.data(), el.size() * 8);
+        }
     });
 }
 

@@ -90,10 +90,17 @@ def sqrt_mod(a: int, p: int):
     return r
 
 
-def hash_to_field(curve: str, domain_prefix: bytes, msg: bytes) -> tuple[int, int]:
+# The recalled-from-memory constants of from_label as a parameter block (the oracle's mirror of include/lurk_hip.h:
+# lurk_hip_ck_params; the defaults are what the product defaults to).  Tests move one field in BOTH and expect the same new key.
+CK_DEFAULTS = dict(xof=0, bytes_per_point=32, domain_prefix="from_uniform_bytes", curve_name_pallas="pallas", curve_name_vesta="vesta",
+                   suite="_XMD:BLAKE2b_SSWU_RO_")
+
+
+def hash_to_field(curve: str, domain_prefix: bytes, msg: bytes, params: dict | None = None) -> tuple[int, int]:
     """pasta_curves hashtocurve::hash_to_field: expand_message_xmd(BLAKE2b-512), two elements."""
     c = CURVE[curve]
-    dst = domain_prefix + b"-" + c["id"] + b"_XMD:BLAKE2b_SSWU_RO_"
+    prm = {**CK_DEFAULTS, **(params or {})}
+    dst = domain_prefix + b"-" + prm["curve_name_" + curve].encode() + prm["suite"].encode()
     dst_prime = dst + bytes([len(dst)])
     H = lambda data: hashlib.blake2b(data, digest_size=64).digest()
     b0 = H(bytes(128) + msg + bytes([0, 128, 0]) + dst_prime)
@@ -158,13 +165,15 @@ def iso_map(curve: str, Pt):
     return nx * pow(dx, p - 2, p) % p, ny * pow(dy, p - 2, p) % p
 
 
-def hash_to_curve(curve: str, domain_prefix: bytes, msg: bytes):
-    u0, u1 = hash_to_field(curve, domain_prefix, msg)
+def hash_to_curve(curve: str, domain_prefix: bytes, msg: bytes, params: dict | None = None):
+    u0, u1 = hash_to_field(curve, domain_prefix, msg, params)
     q0, q1 = map_to_curve_simple_swu(curve, u0), map_to_curve_simple_swu(curve, u1)
     return iso_map(curve, iso_add(curve, q0, q1))
 
 
-def from_label(curve: str, label: bytes, n: int) -> list:
+def from_label(curve: str, label: bytes, n: int, params: dict | None = None) -> list:
     """arecibo DlogGroup::from_label: n affine points (None = identity, encoded (0,0) at the ABI)."""
-    stream = hashlib.shake_256(label).digest(32 * n)
-    return [hash_to_curve(curve, b"from_uniform_bytes", stream[32 * i:32 * (i + 1)]) for i in range(n)]
+    prm = {**CK_DEFAULTS, **(params or {})}
+    k = prm["bytes_per_point"]
+    stream = (hashlib.shake_128 if prm["xof"] == 1 else hashlib.shake_256)(label).digest(k * n)
+    return [hash_to_curve(curve, prm["domain_prefix"].encode(), stream[k * i:k * (i + 1)], prm) for i in range(n)]

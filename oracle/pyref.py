@@ -490,55 +490,68 @@ def axpy(p, a, b, r):
 RO_ARITY = 24
 NUM_CHALLENGE_BITS = 128
 BN_LIMB_WIDTH, BN_N_LIMBS = 64, 4
+# Everything above that is recalled from memory, as a parameter block: the oracle's mirror of include/lurk_hip.h: lurk_hip_ro_params
+# (same field names, same defaults).  Tests move one field in BOTH the product and here and expect the same new r.
+RO_DEFAULTS = dict(arity=RO_ARITY, domain_separator=0, absorb_tag_bit=31, num_challenge_bits=NUM_CHALLENGE_BITS, item_order=[0, 1, 2, 3],
+                   relaxed_order=[0, 1, 2, 3], fresh_order=[0, 1], point_elements=3, relaxed_x_limbs=BN_N_LIMBS, fresh_x_limbs=0,
+                   limb_bits=BN_LIMB_WIDTH, pattern_absorbs=0, squeeze_element=0)
 
 
-def nova_ro_pattern_tag(absorbs: int, squeezes: int, domain_separator: int = 0) -> int:
+def nova_ro_pattern_tag(absorbs: int, squeezes: int, domain_separator: int = 0, absorb_tag_bit: int = 31) -> int:
     """neptune sponge/api.rs ``IOPattern([Absorb(a), Squeeze(s)]).value(domain_separator)``: a polynomial hash mod 2^128
     with base 2^128 - 159 over the op values (absorb: n + 2^31, squeeze: n), the domain separator last."""
     m = 1 << 128
     x, xi, st = m - 159, 1, 0
-    for op in ([absorbs + (1 << 31)] if absorbs else []) + ([squeezes] if squeezes else []) + [domain_separator]:
+    for op in ([absorbs + (1 << absorb_tag_bit)] if absorbs else []) + ([squeezes] if squeezes else []) + [domain_separator]:
         xi = xi * x % m
         st = (st + xi * op) % m
     return st
 
 
-def nova_ro_squeeze(field_id: int, elems: list[int], num_bits: int) -> int:
+def nova_ro_squeeze(field_id: int, elems: list[int], num_bits: int, params: dict | None = None) -> int:
     """``PoseidonRO::squeeze``: a simplex sponge of rate 24 (capacity element = the IO-pattern tag) absorbs ``elems`` - a
     permutation whenever the rate is full -, permutes, reads rate element 0 and keeps its low ``num_bits`` bits."""
-    p = modulus(field_id)
-    state = [nova_ro_pattern_tag(len(elems), 1) % p] + [0] * RO_ARITY
+    prm = {**RO_DEFAULTS, **(params or {})}
+    p, rate = modulus(field_id), prm["arity"]
+    state = [nova_ro_pattern_tag(prm["pattern_absorbs"] or len(elems), 1, prm["domain_separator"], prm["absorb_tag_bit"]) % p] + [0] * rate
     pos = 0
     for e in elems:
         assert 0 <= e < p
-        if pos == RO_ARITY:
+        if pos == rate:
             state = poseidon_permute(field_id, state)
             pos = 0
         state[1 + pos] = (state[1 + pos] + e) % p
         pos += 1
     state = poseidon_permute(field_id, state)
-    return state[1] & ((1 << num_bits) - 1)
+    return state[1 + prm["squeeze_element"]] & ((1 << num_bits) - 1)
 
 
-def nifs_absorb_list(base_p: int, pp_digest: int, comm_w1, comm_e1, u1: int, x1: list[int], comm_w2, x2: list[int], comm_t) -> list[int]:
+def nifs_absorb_list(base_p: int, pp_digest: int, comm_w1, comm_e1, u1: int, x1: list[int], comm_w2, x2: list[int], comm_t,
+                     params: dict | None = None) -> list[int]:
     """The elements NIFS::prove feeds the oracle, in order.  Commitments are affine points or IDENTITY (None):
     ``to_coordinates`` gives (x, y, is_infinity) with (0, 0, 1) for the identity; a relaxed instance absorbs comm_W, comm_E,
     u and every X_i as 4 limbs of 64 bits; a fresh instance comm_W and every X_i; scalars enter the base field through their
     canonical integer (scalar_as_base)."""
-    pt = lambda c: [0, 0, 1] if c is None else [c[0], c[1], 0]
-    limbs = lambda v: [(v >> (BN_LIMB_WIDTH * k)) & ((1 << BN_LIMB_WIDTH) - 1) for k in range(BN_N_LIMBS)]
-    out = [pp_digest % base_p] + pt(comm_w1) + pt(comm_e1) + [u1 % base_p]
-    for x in x1:
-        out += limbs(x)
-    out += pt(comm_w2) + [x % base_p for x in x2] + pt(comm_t)
-    return out
+    prm = {**RO_DEFAULTS, **(params or {})}
+    pe = prm["point_elements"]
+    pt = lambda c: ([0, 0, 1] if c is None else [c[0], c[1], 0])[:pe]
+    lb = prm["limb_bits"]
+    limbs = lambda v, n: [(v >> (lb * k)) & ((1 << lb) - 1) for k in range(n)]
+    xs = lambda x, n: [e for v in x for e in (limbs(v, n) if n else [v % base_p])]
+    relaxed = {0: pt(comm_w1), 1: pt(comm_e1), 2: [u1 % base_p], 3: xs(x1, prm["relaxed_x_limbs"])}
+    fresh = {0: pt(comm_w2), 1: xs(x2, prm["fresh_x_limbs"])}
+    items = {0: [pp_digest % base_p], 1: [e for k in prm["relaxed_order"] for e in relaxed[k]], 2: [e for k in prm["fresh_order"] for e in fresh[k]],
+             3: pt(comm_t)}
+    return [e for k in prm["item_order"] for e in items[k]]
 
 
-def nifs_challenge(curve: str, pp_digest: int, comm_w1, comm_e1, u1: int, x1: list[int], comm_w2, x2: list[int], comm_t) -> int:
+def nifs_challenge(curve: str, pp_digest: int, comm_w1, comm_e1, u1: int, x1: list[int], comm_w2, x2: list[int], comm_t,
+                   params: dict | None = None) -> int:
     """r of one NIFS::prove on ``curve`` ("pallas": scalars in Fq, the oracle runs over Fp; "vesta": the other way round)."""
+    prm = {**RO_DEFAULTS, **(params or {})}
     base_field = 0 if curve == "pallas" else 1
-    els = nifs_absorb_list(modulus(base_field), pp_digest, comm_w1, comm_e1, u1, x1, comm_w2, x2, comm_t)
-    return nova_ro_squeeze(base_field, els, NUM_CHALLENGE_BITS)
+    els = nifs_absorb_list(modulus(base_field), pp_digest, comm_w1, comm_e1, u1, x1, comm_w2, x2, comm_t, prm)
+    return nova_ro_squeeze(base_field, els, prm["num_challenge_bits"], prm) % modulus(1 - base_field)
 
 
 # --------------------------------------------------------------------------------------------

@@ -9,6 +9,9 @@
 //! * [`store`]: `HipPoseidonCache` (the shape of `PoseidonCache<F>`), `HipStoreHasher` (the shape of `StoreHasher`,
 //!   `/root/reference/src/lem/store_core.rs:10-14`, layouts of `/root/reference/src/lem/store.rs:29-78`) and `hydrate`
 //!   (`hydrate_z_cache`, `store_core.rs:256-269`, as one level-batched call);
+//! * [`params`]: the run-time parameter blocks of the two restatements written from memory - Nova's random oracle
+//!   (`lurk_hip_ro_params`) and `from_label` (`lurk_hip_ck_params`) - so that the first run beside arecibo can move one field at a time
+//!   without rebuilding the library (callers: `/root/reference/src/proof/nova.rs:196-216, 282-295`);
 //! * [`dump`]: LURKDUMP writers - `R1CSShape`, the fresh witnesses of consecutive steps and the `CommitmentKey` as the files
 //!   `bench.py --workload fold_step --shape-file .. --witness-file ..` measures (`/root/reference/benches/fibonacci.rs:98-122`).
 //!
@@ -16,6 +19,7 @@
 //! (see `rust/gen_sys.py`), the wrappers are a reading aid for the maintainer who wires the feature in.
 pub mod dump;
 pub mod ffi;
+pub mod params;
 pub mod store;
 pub use ffi::*;
 

@@ -207,3 +207,30 @@ def test_rust_ffi_matches_the_header():
     store_rs = open(os.path.join(src_dir, "store.rs")).read()
     for hook in ("fn hash_ptrs", "fn hash_compact", "fn hash_commitment", "fn hash3", "fn hash4", "fn hash6", "fn hash8", "pub fn hydrate"):
         assert hook in store_rs, hook
+
+
+def test_parameter_blocks_have_one_layout_in_c_ctypes_and_rust(tmp_path):
+    """lurk_hip_ro_params / lurk_hip_ck_params (round 6) cross the ABI by pointer: their size and every field's offset as the header
+    compiles must be what lurk_beta_amd/_lib.py declares to ctypes, and rust/lurk-hip-sys/src/ffi.rs must list the same fields."""
+    import ctypes
+    import shutil
+    import subprocess
+
+    from lurk_beta_amd import _lib
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    rs = open(os.path.join(ROOT, "rust", "lurk-hip-sys", "src", "ffi.rs")).read()
+    for cname, st in (("lurk_hip_ro_params", _lib.RoParamsStruct), ("lurk_hip_ck_params", _lib.CkParamsStruct)):
+        fields = [f[0] for f in st._fields_]
+        prog = '#include <stdio.h>\n#include <stddef.h>\n#include "lurk_hip.h"\nint main(void) {\n' + f'  printf("%zu", sizeof({cname}));\n' + \
+            "".join(f'  printf(" %zu", offsetof({cname}, {f}));\n' for f in fields) + "  return 0;\n}\n"
+        src, exe = tmp_path / f"{cname}.c", tmp_path / cname
+        src.write_text(prog)
+        subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+        nums = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+        assert nums[0] == ctypes.sizeof(st), cname
+        assert nums[1:] == [getattr(st, f).offset for f in fields], cname
+        block = rs[rs.index(f"pub struct {cname} {{"):]
+        block = block[:block.index("}")]
+        assert re.findall(r"pub (\w+):", block) == fields, cname
