@@ -54,10 +54,12 @@ def main():
     ap.add_argument("--pipeline", type=int, default=4,
                     help="commitments in flight (1 = synchronous; 2..6 = async slots: the tail of one overlaps the accumulation of the next).  4 since round 5: "
                          "two accumulate, one is in its tail, one sorts (profiles/r05_pipeline_depth.txt: 3 / 4 / 5 / 6 in flight = 994 / 1 010 / 910 / 952)")
-    ap.add_argument("--stage-ahead", type=int, default=0,
-                    help="fold_step: 1 = the next step's witness is traced and its commitment started one step ahead (lurk_hip_fold_step_prefetch); "
-                         "2 = the same from inside begin (the submit hook calls prefetch: the staged commitment runs in the background class beside commit(T)); "
-                         "0 = plain begin (default: measured 4.4 ms against 4.05 ms staged whole / 5.1 ms staged with late ranges at rc = 100, DESIGN.md)")
+    ap.add_argument("--stage-ahead", type=int, default=None,
+                    help="fold_step: 3 (default since round 6) = the witness producer runs TWO steps ahead: witness k+2 is traced from step k's submit hook, instance k+1 "
+                         "(complete) is staged when step k starts and step k's begin submits its commitment behind commit(T) in the FOLLOW class "
+                         "(LURK_MSM_SUBMIT_FOLLOW: low-priority sort + plan at once, persistent accumulation once commit(T)'s has ended); "
+                         "1 = traced and staged one step ahead at the top of the step; 2 = the same from inside begin (the submit hook); "
+                         "0 = plain begin, W2 of step k committed inside step k (rounds 1-5; the default with --devices, where nothing is staged ahead)")
     ap.add_argument("--witness-ahead", type=int, default=3,
                     help="fold_step: the witness of step k+1 is traced while step k is in progress (the reference's producer thread): 3 = enqueued from the step's submit hook "
                          "(lurk_hip_fold_ctx_set_submit_hook: behind the step's opening kernels, beside its commitments; default: 3.5 ms at rc = 100); 2 = enqueued after begin "
@@ -103,6 +105,15 @@ def main():
                     help="auto = the default msm line at N = 1 also carries the other workloads of the path as verified sub-records "
                          "(fold_step_rc100, poseidon_tree_2_24, ntt_2_24, compress_2_20: each a child run of this file with --verify, same --steps / --warmup)")
     args = ap.parse_args()
+    if args.stage_ahead is None:
+        args.stage_ahead = 0 if (args.devices or args.shape_file) else 3
+    if args.workload == "fold_step":
+        # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues PER PRIORITY LEVEL (default 4); the step keeps ~25 streams busy in three
+        # priority classes (commitment slots, their accumulate streams, the folding contexts of both curves, the witness producer), and
+        # two streams that share a queue serialise.  6 is the measured best for the step (round 6: 4 / 6 / 8 = 3.44 / 3.20 / 8.9 ms for a
+        # both-curve step - at 8 the 24+ queues of one process exceed what the device keeps mapped at once and it time-slices them);
+        # the msm workload does not care (1 016 / 1 011 Mscalar-mul/s at 4 / 8).  Must be set before the HIP runtime initialises.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
 
     # N > 1 without a launcher: become the launcher (one rank per GPU, the same command line the driver uses)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -33,3 +33,23 @@ def cpu_quota_cores():
         return None if q <= 0 else q / per
     except Exception:
         return None
+
+
+def cpu_leg_threads():
+    """The thread count a cpu_baseline leg runs with, and the three numbers every leg reports beside its value (round 6: one helper
+    for the headline and every sub-record).  A cgroup CPU quota caps the useful thread count whatever the host has (the GPU boxes
+    show 256 logical CPUs under a 16-CPU quota): the OpenMP legs run with ceil(quota) threads, or every logical CPU without a quota.
+    -> (threads, {"threads_used", "cpu_quota_cores", "host_cores"})"""
+    import math
+
+    quota = cpu_quota_cores()
+    logical = os.cpu_count() or 1
+    threads = max(1, min(logical, math.ceil(quota))) if quota else logical
+    return threads, {"threads_used": threads, "cpu_quota_cores": quota, "host_cores": logical}
+
+
+def cpu_leg_omp(threads):
+    """Pin the oracle's OpenMP regions (oracle/oracle.c) to `threads` for a cpu_baseline leg."""
+    from oracle import coracle as C
+
+    C.lib().orc_set_num_threads(int(threads))

@@ -7,17 +7,17 @@ import os
 import sys
 import time
 
-from .common import BENCH, ROOT
+from .common import BENCH, ROOT, cpu_leg_omp, cpu_leg_threads
 
 
 def poseidon_mads_per_hash(arity):
     """v_mad_u64_u32 per hash of the kernels' schedule (poseidon29.cuh), radix-2^29 layer: product 135, squaring 99, one lazy row
     of k terms 81 k + 54.  Full round: t S-boxes (2 squarings + 1 product) + t rows of t terms; partial round: 1 S-box + one
     row of t terms + t - 1 products; canonical in (arity products) and out (1)."""
-    from oracle import pyref as R
+    import lurk_beta_amd as L
 
     t = arity + 1
-    rf, rp = R.round_numbers(arity)
+    rf, rp = L.poseidon_constants(L.FIELD_PALLAS_FQ, arity)[:2]  # the product's own round numbers (lurk_hip_poseidon_constants: host code)
     sbox, row = 2 * 99 + 135, 81 * t + 54
     return rf * (t * sbox + t * row) + rp * (sbox + row + (t - 1) * 135) + (arity + 1) * 135
 
@@ -37,6 +37,10 @@ def other_workloads(args, lib, world, rank):
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    cpu_threads, cpu_info = cpu_leg_threads()
+    if rank == 0 and (args.verify or not args.no_cpu_baseline):
+        cpu_leg_omp(cpu_threads)  # every CPU leg below (the --verify run doubles as the baseline) with the thread count it reports
 
     import lurk_beta_amd as L
     from lurk_beta_amd import _lib, synth
@@ -200,6 +204,6 @@ def other_workloads(args, lib, world, rank):
                     C.ntt(1, sample)
                 dt = time.perf_counter() - t1
                 sample_desc = f"first 2^18 {what} of the same workload"
-            out["cpu_baseline"] = {"value": round(m / dt / 1e6, 4), "unit": unit, "cores": C.lib().orc_num_threads(), "kind": "port",
-                                   "sample": f"{sample_desc}, {dt:.2f} s (oracle/oracle.c, OpenMP)"}
+            out["cpu_baseline"] = {"value": round(m / dt / 1e6, 4), "unit": unit, "cores": cpu_threads, **cpu_info, "kind": "port",
+                                   "sample": f"{sample_desc}, {dt:.2f} s (oracle/oracle.c, OpenMP, {cpu_threads} threads)"}
         print(json.dumps(out), flush=True)

@@ -7,7 +7,7 @@ import os
 import sys
 import time
 
-from .common import BENCH, ROOT
+from .common import BENCH, ROOT, cpu_leg_omp, cpu_leg_threads
 
 
 def store_hydrate_workload(args, lib, world, rank):
@@ -23,6 +23,8 @@ def store_hydrate_workload(args, lib, world, rank):
 
     F = 1
     out = None
+    cpu_threads, cpu_info = cpu_leg_threads()
+    cpu_leg_omp(cpu_threads)  # the CPU leg below runs with the thread count it reports
     for name, dag in (("deep", SH.list_dag(400)), ("wide", SH.wide_dag(12000))):
         rec, vals = SH.encode(dag)
         hashed = int((rec[:, 0] != 0).sum())
@@ -40,7 +42,7 @@ def store_hydrate_workload(args, lib, world, rank):
             t1 = time.perf_counter()
             want, _ = C.store_hydrate(F, rec, vals)
             dt = time.perf_counter() - t1
-            r["cpu_baseline"] = {"value": round(hashed / dt / 1e6, 4), "unit": "M hashed nodes/s", "ms": round(dt * 1e3, 2), "cores": C.lib().orc_num_threads(), "kind": "port",
+            r["cpu_baseline"] = {"value": round(hashed / dt / 1e6, 4), "unit": "M hashed nodes/s", "ms": round(dt * 1e3, 2), "cores": cpu_threads, **cpu_info, "kind": "port",
                                  "sample": "the same DAG, whole, oracle/oracle.c: orc_store_hydrate (level by level, OpenMP inside a level, plain-schedule Poseidon)"}
             r["speedup_vs_cpu_leg"] = round(dt * 1e3 / ms, 2)
         if args.verify:

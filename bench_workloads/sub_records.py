@@ -37,6 +37,11 @@ def sub_records(args):
     common = ["--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--sub-records", "off", "--pmc", "off", "--verify"]
     legs = {
         "fold_step_rc100": ["--workload", "fold_step", "--rc", "100"],
+        # BASELINE.json configs[1] (the standalone 2^20 MSM) synchronous and with two commitments in flight, and configs[3] (the rc = 900
+        # step), on the driver's clock since round 6: --verify = the discrete-log checksum / every output of one more step vs the oracle
+        "msm_2_20_sync": ["--workload", "msm", "--log-n", "20", "--pipeline", "1", "--no-plain-leg", "--cpu-sample-log-n", "20"],
+        "msm_2_20_inflight2": ["--workload", "msm", "--log-n", "20", "--pipeline", "2", "--no-plain-leg", "--no-cpu-baseline"],
+        "fold_step_rc900": ["--workload", "fold_step", "--rc", "900", "--secondary", "0"],
         "poseidon_tree_2_24": ["--workload", "poseidon_tree", "--log-n", "24"],
         "ntt_2_24": ["--workload", "ntt", "--log-n", "24"],
         "compress_2_20": ["--workload", "compress", "--log-n", "20"],  # the compressing proof of a 2^20 x 2^20 instance; --verify = the oracle's verifier
@@ -47,7 +52,8 @@ def sub_records(args):
     for name, extra in legs.items():
         t0 = time.perf_counter()
         try:
-            r = subprocess.run([sys.executable, BENCH] + extra + common, capture_output=True, text=True, timeout=240)
+            r = subprocess.run([sys.executable, BENCH] + extra + [a for a in common if not (a == "--no-cpu-baseline" and a in extra)], capture_output=True, text=True,
+                               timeout=420)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
             if r.returncode != 0 or not lines:
                 out[name] = {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
@@ -68,8 +74,16 @@ def summarize(subs):
             out[name] = [None, False, str(r["error"])[-120:]]
             continue
         v = (r.get("config") or {}).get("verified")
+        if v is None:
+            v = r.get("verified")  # the msm workload reports its discrete-log checksum at the top level
         ok = bool(v.get("ok")) if isinstance(v, dict) else (bool(v) if v is not None else None)
+        if ok and (r.get("cpu_baseline") or {}).get("matches_gpu_result") is False:
+            ok = False
+        if ok and isinstance((r.get("secondary_curve_step") or {}).get("verified"), dict) and not r["secondary_curve_step"]["verified"].get("ok"):
+            ok = False
         out[name] = [r.get("ms_per_step"), ok]
+        if "both_curves_ms_per_step" in r:
+            out[name].append({"both_curves_ms_per_step": r["both_curves_ms_per_step"]})
     return out
 
 

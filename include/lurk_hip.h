@@ -52,6 +52,18 @@ extern "C" {
 int lurk_hip_device_count(void);
 const char* lurk_hip_last_error(void);
 const char* lurk_hip_version(void);
+/* The ABI revision this header describes; lurk_hip_abi_version() is what the loaded library was built from (a binding compares the
+ * two at start-up).  2 (round 6): lurk_hip_msm_ctx_info's *precomputed is a boolean (the key's form comes from lurk_hip_msm_ctx_form),
+ * LURK_MSM_SLOTS is 6, LURK_MSM_SUBMIT_FOLLOW, the parameter blocks lurk_hip_ro_params / lurk_hip_ck_params, lurk_hip_scratch_trim.
+ * 1: rounds 1-4 (*precomputed returned the form 0 / 1 / 2, four slots). */
+#define LURK_HIP_ABI_VERSION 2
+int lurk_hip_abi_version(void);
+/* Prover scratch (the compressing SNARK's sum-check tables, eq tables, opening-argument halves) comes from one stack arena per
+ * (device, stream) that grows by blocks of >= 256 MiB and is KEPT between proofs: about 2 GB per stream that has run a 2^20-row proof,
+ * for the life of the process.  trim releases every arena no prover is using right now (nothing is live in it) back to the driver;
+ * *released_bytes (may be NULL) = what went back.  The next proof on that stream re-allocates (a device-wide synchronisation the first
+ * time a size is seen): call it when a process stops proving, not between proofs. */
+int lurk_hip_scratch_trim(size_t* released_bytes);
 /* bind the calling thread to a device (one process per GPU; the multi-GPU layer calls this) */
 int lurk_hip_set_device(int device);
 /* per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) */
@@ -252,6 +264,13 @@ int lurk_hip_msm_multi_destroy(lurk_hip_msm_multi* ctx);
 /* Group helpers used by the multi-GPU gather (sum of per-rank partial commitments) and by tests:
  * out = sum of `count` Jacobian points (host memory, 96 B each). */
 int lurk_hip_point_sum(int curve, void* out_jacobian96, const void* points_jacobian96, size_t count);
+/* One process per GPU (a Rust host under MPI / its own launcher instead of one process with a device list): every rank commits its
+ * slice of the vector under its slice of the key (lurk_hip_msm_ctx_*), the ranks all-gather the 96-byte partial commitments with
+ * whatever transport they have (RCCL ncclAllGather on bytes, MPI_Allgather, a socket) into `gathered` (world x 96 B, rank order), and
+ * THIS is the only library call the exchange needs: out = the commitment of the whole vector.  Host memory, no device touched; the
+ * identity partial of a rank with an empty slice is handled.  (lurk_beta_amd/distributed.py drives exactly this from Python for the
+ * tests and bench.py --gpus N: test plumbing, not a second ABI.) */
+int lurk_hip_point_sum_gathered(int curve, void* out_jacobian96, const void* gathered_jacobian96, size_t world);
 /* out = [scalar] point on the host (the transcript-side folding of commitments: comm_W1 + r comm_W2, comm_E1 + r comm_T) */
 int lurk_hip_point_mul(int curve, void* out_jacobian96, const void* point_jacobian96, const void* scalar32, int is_mont);
 /* Jacobian (Montgomery) -> canonical affine bytes (x, y), 64 B; identity -> all zero */
@@ -375,9 +394,20 @@ int lurk_hip_r1cs_multiply_vec_dev(const lurk_hip_r1cs* shape, const void* d_z, 
 /* R1CSShape::commit_T's vector: T = AZ1 o BZ2 + AZ2 o BZ1 - u1 CZ2 - u2 CZ1 (u_i = z_i[num_vars]) */
 int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const void* d_z2, void* d_t,
                                  void* stream);
+/* The same vector with the running instance's products CACHED (round 6): A z1, B z1, C z1 fold linearly with the running pair
+ * (A (z1 + r z2) = A z1 + r A z2), so a prover that keeps them resident gathers from z2 alone - half the gather chains of the call
+ * above.  d_u1: the running u (one 32-byte Montgomery element in device memory, i.e. z1 + num_vars); outputs T and (A z2, B z2,
+ * C z2), which the caller folds into its cache with the step's r (lurk_hip_fold_vecs_dev).  A folding context does all of this
+ * itself (lurk_hip_fold_step_*; LURK_FOLD_CACHED_PRODUCTS=0 keeps it on the call above). */
+int lurk_hip_r1cs_cross_term_cached_dev(lurk_hip_r1cs* shape, const void* d_z2, const void* d_az1, const void* d_bz1, const void* d_cz1,
+                                        const void* d_u1, void* d_t, void* d_az2, void* d_bz2, void* d_cz2, void* stream);
 /* RelaxedR1CSWitness::fold: out = a + r b over n elements (W1 + r W2, E1 + r T); r: 32 B Montgomery, host */
 int lurk_hip_fold_vec_dev(int field_id, const void* d_a, const void* d_b, const void* r32_mont, size_t n,
                           void* d_out, void* stream);
+/* count (<= 8) such folds under one r in ONE launch: d_a / d_b / d_out / n are host arrays of count device pointers / lengths
+ * (out_k may be a_k: the fold is elementwise) - the step's finish(r) folds [W | u | X], E and the three cached products this way. */
+int lurk_hip_fold_vecs_dev(int field_id, int count, const void* const* d_a, const void* const* d_b, const size_t* n, void* const* d_out,
+                           const void* r32_mont, void* stream);
 /* host-pointer forms of the three calls above (copy in, run, copy out): small inputs and tests */
 int lurk_hip_r1cs_multiply_vec(const lurk_hip_r1cs* shape, const void* z, void* az, void* bz, void* cz);
 int lurk_hip_r1cs_cross_term(lurk_hip_r1cs* shape, const void* z1, const void* z2, void* t);
@@ -585,7 +615,9 @@ int lurk_hip_sumcheck_round_dev(int field_id, int degree, void* const* d_polys, 
  * /root/reference/src/proof/nova.rs:341-356) with the tables resident: log2(len) rounds of lurk_hip_sumcheck_round_dev, the round
  * polynomial interpolated on the host, the transcript behind a callback: `challenge` receives the round and the polynomial's
  * degree + 1 canonical coefficients (low to high) and writes r as a canonical 32-byte value (return 0; anything else aborts the call).
- * The tables are consumed (bound in place).  Outputs, all canonical: the round polynomials (rounds x (degree + 1) x 32 bytes), the
+ * The tables are consumed: their contents are UNSPECIFIED after the call (the first rounds bind them in place; once they are down to
+ * 2^LURK_SUMCHECK_HOST_TAIL_LOG elements the remaining rounds run on a host copy, so d_polys[k][0] is NOT the final evaluation) -
+ * out_finals is the only place the final evaluations are returned.  Outputs, all canonical: the round polynomials (rounds x (degree + 1) x 32 bytes), the
  * tables' final evaluations (2 or 4 x 32 bytes) and the final claim. */
 typedef int (*lurk_hip_sumcheck_challenge_fn)(void* user, int round, const void* coefficients32_canonical, void* out_r32_canonical);
 int lurk_hip_sumcheck_prove_dev(int field_id, int degree, void* const* d_polys, size_t len, const void* claim32_canonical,

@@ -47,6 +47,8 @@ SIGNATURES = {
     "lurk_hip_device_count": (c_int, []),
     "lurk_hip_last_error": (ctypes.c_char_p, []),
     "lurk_hip_version": (ctypes.c_char_p, []),
+    "lurk_hip_abi_version": (c_int, []),
+    "lurk_hip_scratch_trim": (c_int, [ctypes.POINTER(c_size_t)]),
     "lurk_hip_set_device": (c_int, [c_int]),
     "lurk_hip_profile_enable": (c_int, [c_int]),
     "lurk_hip_profile_reset": (c_int, []),
@@ -91,6 +93,7 @@ SIGNATURES = {
     "lurk_hip_msm_multi_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "lurk_hip_msm_multi_destroy": (c_int, [c_void_p]),
     "lurk_hip_point_sum": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
+    "lurk_hip_point_sum_gathered": (c_int, [c_int, c_void_p, c_void_p, c_size_t]),
     "lurk_hip_point_mul": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int]),
     "lurk_hip_point_to_affine_canonical": (c_int, [c_int, c_void_p, c_void_p]),
     "lurk_hip_poseidon_batch": (c_int, [c_int, c_int, c_void_p, c_size_t, c_void_p]),
@@ -114,6 +117,8 @@ SIGNATURES = {
     "lurk_hip_r1cs_device": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "lurk_hip_r1cs_multiply_vec_dev": (c_int, [c_void_p] * 6),
     "lurk_hip_r1cs_cross_term_dev": (c_int, [c_void_p] * 5),
+    "lurk_hip_r1cs_cross_term_cached_dev": (c_int, [c_void_p] * 11),
+    "lurk_hip_fold_vecs_dev": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "lurk_hip_fold_vec_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_r1cs_multiply_vec": (c_int, [c_void_p] * 5),
     "lurk_hip_r1cs_cross_term": (c_int, [c_void_p] * 4),

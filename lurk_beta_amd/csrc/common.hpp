@@ -33,6 +33,7 @@ struct HipFailure {
     do {                                                                                                  \
         hipError_t _e = (expr);                                                                           \
         if (_e != hipSuccess) {                                                                           \
+            (void)hipGetLastError(); /* the failure becomes an exception: the thread's sticky last-error must not resurface in a later hipGetLastError() check */ \
             throw ::lurk::HipFailure{_e == hipErrorOutOfMemory ? LURK_HIP_ERR_OOM : LURK_HIP_ERR_HIP,     \
                                      std::string(#expr) + ": " + hipGetErrorString(_e)};                 \
         }                                                                                                 \
@@ -218,6 +219,7 @@ void msm_ctx_drop_folded_child(const lurk_hip_msm_ctx* parent);
 class ScratchArena {
   public:
     static ScratchArena& of(hipStream_t s);  // the arena of (current device, s)
+    static size_t trim_all();                // lurk_hip_scratch_trim: hipFree every block of every arena with nothing live; bytes released
     void* push(size_t bytes);
     void pop(void* p);
     std::recursive_mutex mu;

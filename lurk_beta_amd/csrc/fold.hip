@@ -34,8 +34,8 @@ constexpr int FOLD_BLOCK = 256;
 // are bound by HBM latency, not by issue slots; what shares the device with them is an accumulation of the NEXT step's commit(W2)
 // (step.hip: LURK_MSM_SUBMIT_FOLLOW), whose waves are older and - at equal priority - served first by the instruction arbiter:
 // measured round 6, a 60 us fold took 320 us and the cross term 590 instead of 410.  Raised wave priority lets these waves issue when
-// their loads come back (2: above both forms of the accumulation, below the commitments' own short kernels at 3).
-__device__ __forceinline__ void fold_wave_prio() { __builtin_amdgcn_s_setprio(2); }
+// their loads come back (3: the class of commit(T)'s own short kernels; a followed commitment's tail runs at 2, accumulations at 0-1).
+__device__ __forceinline__ void fold_wave_prio() { __builtin_amdgcn_s_setprio(3); }
 
 struct CsrDev {
     DevBuf rowptr;  // u32 x (rows + 1)
@@ -302,6 +302,61 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
     else r1cs_cross_term_body<P, false>(s, z1, z2, u_index, t, blockIdx.x - long_blocks, gridDim.x - long_blocks);
 }
 
+// ---- the cross term with the running products cached (round 6) ---------------------------------------------------------------------
+// A z1, B z1, C z1 fold linearly with the running instance (A (z1 + r z2) = A z1 + r A z2), so a folding context keeps them resident
+// beside z1 and E (step.hip) and a step gathers from z2 ALONE: three inner products per row instead of six, half the dependent
+// 32-byte gather chains and half the Montgomery conversions of r1cs_cross_term_kernel - the kernel is bound by exactly those (L1 tag
+// path 55 %, VALU 47 %: profiles/r04_cross_term_pmc.txt).  The cached rows arrive as three coalesced 32-byte reads per lane; A z2, B z2,
+// C z2 leave the same way for finish(r), which folds them into the cache in the launch that folds z and E (fold_vecs_kernel).
+template <class P, bool LONG>
+__device__ __forceinline__ void r1cs_cross_term_cached_body(const R1csDev& s, const Fe<P>* __restrict__ z2, const Fe<P>* __restrict__ az1,
+                                                            const Fe<P>* __restrict__ bz1, const Fe<P>* __restrict__ cz1, const Fe<P>* __restrict__ u1,
+                                                            size_t u_index, Fe<P>* __restrict__ t, Fe<P>* __restrict__ az2, Fe<P>* __restrict__ bz2,
+                                                            Fe<P>* __restrict__ cz2, unsigned bid, unsigned nb) {
+    const uint32_t* one29 = s.dict + s.dict_size * P29_STRIDE;
+    const Fe<P>* zs[1] = {z2};
+    uint32_t lo[3], hi[3];
+    F29<P> a2, b2, c2;
+    size_t row;
+    if (!LONG) {
+        row = fold_row_block(bid, nb) * FOLD_BLOCK + threadIdx.x;
+        if (row >= s.rows || fold_is_long(s, row, lo, hi)) return;
+        fold_row_lane<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &a2);
+        fold_row_lane<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &b2);
+        fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &c2);
+    } else {
+        size_t w = ((size_t)bid * FOLD_BLOCK + threadIdx.x) / FOLD_GROUP;
+        const bool live = w < s.n_long;  // a group without a row shadows the last one (the shuffles need every lane)
+        row = s.long_rows[live ? w : s.n_long - 1];
+        fold_is_long(s, row, lo, hi);
+        fold_row_wave<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &a2);
+        fold_row_wave<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &b2);
+        fold_row_wave<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &c2);
+        if (!live || (threadIdx.x & (FOLD_GROUP - 1))) return;
+    }
+    const Fe<P> a1 = az1[row], b1 = bz1[row], c1 = cz1[row];
+    Dot29<P> acc;
+    dot29_init<P>(acc);
+    dot29_mac<P>(acc, f29_from_mont256<P>(a1), b2);
+    dot29_mac<P>(acc, a2, f29_from_mont256<P>(b1));
+    dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(*u1)), c2);
+    dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(z2[u_index])), f29_from_mont256<P>(c1));
+    fold_store<P>(t + row, dot29_finish<P>(acc));
+    fold_store<P>(az2 + row, a2);
+    fold_store<P>(bz2 + row, b2);
+    fold_store<P>(cz2 + row, c2);
+}
+template <class P>
+__global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_cached_kernel(R1csDev s, const Fe<P>* __restrict__ z2, const Fe<P>* __restrict__ az1,
+                                                                              const Fe<P>* __restrict__ bz1, const Fe<P>* __restrict__ cz1,
+                                                                              const Fe<P>* __restrict__ u1, size_t u_index, Fe<P>* __restrict__ t,
+                                                                              Fe<P>* __restrict__ az2, Fe<P>* __restrict__ bz2, Fe<P>* __restrict__ cz2,
+                                                                              unsigned long_blocks) {
+    fold_wave_prio();
+    if (blockIdx.x < long_blocks) r1cs_cross_term_cached_body<P, true>(s, z2, az1, bz1, cz1, u1, u_index, t, az2, bz2, cz2, blockIdx.x, long_blocks);
+    else r1cs_cross_term_cached_body<P, false>(s, z2, az1, bz1, cz1, u1, u_index, t, az2, bz2, cz2, blockIdx.x - long_blocks, gridDim.x - long_blocks);
+}
+
 // out = a + r b (r: Montgomery 2^256, broadcast).  A pure 96 B / element stream (two reads, one write): a lane takes FOLD_VEC_E
 // elements FOLD_BLOCK apart, issues all of their 128-bit loads before the first product (8 loads in flight per lane; with one
 // element per trip of a grid-stride loop the kernel sat at 45-53 % of HBM, waiting on each pair of loads in turn), and the grid
@@ -312,6 +367,54 @@ __global__ __launch_bounds__(FOLD_BLOCK) void fold_vec_kernel(const uint4* __res
                                                                 uint4* __restrict__ out) {
     fold_wave_prio();
     const size_t base = (size_t)blockIdx.x * (FOLD_BLOCK * FOLD_VEC_E) + threadIdx.x;
+    uint4 al[FOLD_VEC_E], ah[FOLD_VEC_E], bl[FOLD_VEC_E], bh[FOLD_VEC_E];
+#pragma unroll
+    for (int e = 0; e < FOLD_VEC_E; e++) {
+        const size_t i = base + (size_t)e * FOLD_BLOCK;
+        if (i < n) {
+            al[e] = a[2 * i];
+            ah[e] = a[2 * i + 1];
+            bl[e] = b[2 * i];
+            bh[e] = b[2 * i + 1];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < FOLD_VEC_E; e++) {
+        const size_t i = base + (size_t)e * FOLD_BLOCK;
+        if (i >= n) continue;
+        Fe<P> x, y;
+        x.l[0] = al[e].x; x.l[1] = al[e].y; x.l[2] = al[e].z; x.l[3] = al[e].w; x.l[4] = ah[e].x; x.l[5] = ah[e].y; x.l[6] = ah[e].z; x.l[7] = ah[e].w;
+        y.l[0] = bl[e].x; y.l[1] = bl[e].y; y.l[2] = bl[e].z; y.l[3] = bl[e].w; y.l[4] = bh[e].x; y.l[5] = bh[e].y; y.l[6] = bh[e].z; y.l[7] = bh[e].w;
+        x = fe_add<P>(x, fe_mul<P>(r, y));
+        out[2 * i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]);
+        out[2 * i + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]);
+    }
+}
+
+// Up to FOLD_VECS_MAX folds out_k = a_k + r b_k in ONE launch (the step's finish(r): [W | u | X], E and the three cached products): a
+// workgroup belongs to one vector (first_block[k] <= blockIdx.x < first_block[k + 1]) and does what fold_vec_kernel does for it.  Five
+// launches of 30 MB each are each bound by their own ramp-up (fold_vec at rc = 100: 49 % of HBM); one launch of 150 MB is not.
+constexpr int FOLD_VECS_MAX = 8;
+struct FoldVecs {
+    const uint4* a[FOLD_VECS_MAX];
+    const uint4* b[FOLD_VECS_MAX];
+    uint4* out[FOLD_VECS_MAX];
+    size_t n[FOLD_VECS_MAX];
+    unsigned first_block[FOLD_VECS_MAX + 1];
+    int count;
+};
+template <class P>
+__global__ __launch_bounds__(FOLD_BLOCK) void fold_vecs_kernel(FoldVecs v, Fe<P> r) {
+    fold_wave_prio();
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < FOLD_VECS_MAX; j++)
+        if (j < v.count && blockIdx.x >= v.first_block[j]) k = j;
+    const uint4* __restrict__ a = v.a[k];
+    const uint4* __restrict__ b = v.b[k];
+    uint4* __restrict__ out = v.out[k];
+    const size_t n = v.n[k];
+    const size_t base = (size_t)(blockIdx.x - v.first_block[k]) * (FOLD_BLOCK * FOLD_VEC_E) + threadIdx.x;
     uint4 al[FOLD_VEC_E], ah[FOLD_VEC_E], bl[FOLD_VEC_E], bh[FOLD_VEC_E];
 #pragma unroll
     for (int e = 0; e < FOLD_VEC_E; e++) {
@@ -439,6 +542,41 @@ static void cross_term(const R1csShape& sh, const void* d_z1, const void* d_z2, 
     LURK_HIP_CHECK(hipGetLastError());
 }
 template <class P>
+static void cross_term_cached(const R1csShape& sh, const void* d_z2, const void* az1, const void* bz1, const void* cz1, const void* d_u1, void* d_t, void* az2,
+                              void* bz2, void* cz2, hipStream_t s) {
+    if (!sh.num_cons) return;
+    ProfScope ps("r1cs_cross_term", s);
+    const R1csDev d = dev_view(sh);
+    const unsigned long_blocks = sh.n_long ? div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK) : 0;
+    hipLaunchKernelGGL((r1cs_cross_term_cached_kernel<P>), dim3(long_blocks + fold_grid(sh.num_cons)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z2,
+                       (const Fe<P>*)az1, (const Fe<P>*)bz1, (const Fe<P>*)cz1, (const Fe<P>*)d_u1, sh.num_vars, (Fe<P>*)d_t, (Fe<P>*)az2, (Fe<P>*)bz2,
+                       (Fe<P>*)cz2, long_blocks);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+template <class P>
+static void fold_vecs(int count, const void* const* a, const void* const* b, const size_t* n, void* const* out, const void* r32, hipStream_t s) {
+    FoldVecs v;
+    memset(&v, 0, sizeof(v));
+    unsigned blocks = 0;
+    for (int k = 0; k < count; k++) {
+        if (!n[k]) continue;
+        v.a[v.count] = (const uint4*)a[k];
+        v.b[v.count] = (const uint4*)b[k];
+        v.out[v.count] = (uint4*)out[k];
+        v.n[v.count] = n[k];
+        v.first_block[v.count] = blocks;
+        blocks += div_up(n[k], (size_t)FOLD_BLOCK * FOLD_VEC_E);
+        v.count++;
+    }
+    if (!v.count) return;
+    v.first_block[v.count] = blocks;
+    Fe<P> r;
+    memcpy(r.l, r32, 32);
+    ProfScope ps("fold_vec", s);
+    hipLaunchKernelGGL((fold_vecs_kernel<P>), dim3(blocks), dim3(FOLD_BLOCK), 0, s, v, r);
+    LURK_HIP_CHECK(hipGetLastError());
+}
+template <class P>
 static void fold_vec(const void* a, const void* b, const void* r32, size_t n, void* out, hipStream_t s) {
     if (!n) return;
     Fe<P> r;
@@ -558,6 +696,37 @@ int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const v
         if (sh.field_id == 0) cross_term<PallasFp>(sh, d_z1, d_z2, d_t, (hipStream_t)stream);
         else if (sh.field_id == 1) cross_term<PallasFq>(sh, d_z1, d_z2, d_t, (hipStream_t)stream);
         else cross_term<Bn254Fr>(sh, d_z1, d_z2, d_t, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_r1cs_cross_term_cached_dev(lurk_hip_r1cs* shape, const void* d_z2, const void* d_az1, const void* d_bz1, const void* d_cz1, const void* d_u1,
+                                        void* d_t, void* d_az2, void* d_bz2, void* d_cz2, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(shape && d_z2 && d_az1 && d_bz1 && d_cz1 && d_u1 && d_t && d_az2 && d_bz2 && d_cz2, "null argument");
+        DeviceGuard dg(shape->sh.device);
+        const R1csShape& sh = shape->sh;
+        if (sh.field_id == 0) cross_term_cached<PallasFp>(sh, d_z2, d_az1, d_bz1, d_cz1, d_u1, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
+        else if (sh.field_id == 1) cross_term_cached<PallasFq>(sh, d_z2, d_az1, d_bz1, d_cz1, d_u1, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
+        else cross_term_cached<Bn254Fr>(sh, d_z2, d_az1, d_bz1, d_cz1, d_u1, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
+    });
+}
+
+int lurk_hip_fold_vecs_dev(int field_id, int count, const void* const* d_a, const void* const* d_b, const size_t* n, void* const* d_out,
+                           const void* r32_mont, void* stream) {
+    return guarded([&] {
+        LURK_REQUIRE(field_id >= 0 && field_id <= 2, "unknown field id");
+        LURK_REQUIRE(count >= 0 && count <= FOLD_VECS_MAX, "at most 8 vectors per launch");
+        LURK_REQUIRE(count == 0 || (d_a && d_b && n && d_out), "null argument");
+        LURK_REQUIRE(r32_mont, "null challenge");
+        size_t blocks = 0;
+        for (int k = 0; k < count; k++) {
+            LURK_REQUIRE(n[k] == 0 || (d_a[k] && d_b[k] && d_out[k]), "null buffer");
+            blocks += div_up(n[k], (size_t)FOLD_BLOCK * FOLD_VEC_E);
+        }
+        LURK_REQUIRE(blocks < ((size_t)1 << 31), "too many elements for one launch");
+        if (field_id == 0) fold_vecs<PallasFp>(count, d_a, d_b, n, d_out, r32_mont, (hipStream_t)stream);
+        else if (field_id == 1) fold_vecs<PallasFq>(count, d_a, d_b, n, d_out, r32_mont, (hipStream_t)stream);
+        else fold_vecs<Bn254Fr>(count, d_a, d_b, n, d_out, r32_mont, (hipStream_t)stream);
     });
 }
 

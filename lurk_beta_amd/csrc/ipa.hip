@@ -571,9 +571,9 @@ int lurk_hip_ipa_prove_dev(lurk_hip_msm_ctx* key, void* d_a, void* d_b, size_t n
         LURK_REQUIRE(key && d_a && d_b && ck_c_jacobian96 && challenge && out_a_hat32 && out_ck_hat_affine64, "null argument");
         LURK_REQUIRE(n >= 1 && (n & (n - 1)) == 0, "the vector length must be a power of two");
         LURK_REQUIRE(n == 1 || (out_l_jacobian96 && out_r_jacobian96), "null argument");
-        int curve = 0, bits = 0, table = 0, device = 0;
+        int curve = 0, bits = 0, device = 0;
         size_t points = 0;
-        if (lurk_hip_msm_ctx_info(key, &curve, &points, &bits, &table) != 0 || lurk_hip_msm_ctx_device(key, &device) != 0)
+        if (lurk_hip_msm_ctx_info(key, &curve, &points, &bits, nullptr) != 0 || lurk_hip_msm_ctx_device(key, &device) != 0)
             throw HipFailure{LURK_HIP_ERR_INVALID_ARG, lurk_hip_last_error()};
         DeviceGuard dg(device);
         if (curve == LURK_CURVE_PALLAS)

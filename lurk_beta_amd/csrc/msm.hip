@@ -38,8 +38,8 @@ constexpr int MSM_ACC_BLOCK = 256;
 // commitment, and the instruction arbiter serves the oldest wave first: measured 15-18x slowdowns of these kernels.
 // Raising their wave priority lets them issue when they are ready; they need a few percent of the VALU.
 // `low`: the commitment was submitted with LURK_MSM_SUBMIT_FOLLOW - work staged ahead that must only take what the open step's serial
-// chain (cross term, commit(T), folds: wave priority 2-3) leaves; its short kernels then run at the lowest wave priority like its
-// accumulation (measured round 6 with everything at 3: commit(T)'s sort + plan 0.34 -> 0.70 ms beside the staged commitment's bucket reduction).
+// chain (cross term, commit(T), folds: wave priority 3) leaves; its sort and plan kernels then run at the lowest wave priority like its
+// accumulation (the tail kernels - finalize, bucket reduction - always run at 3: see submit_impl).
 __device__ __forceinline__ void msm_set_wave_prio(int low) {
     if (low) __builtin_amdgcn_s_setprio(0);
     else __builtin_amdgcn_s_setprio(3);
@@ -221,7 +221,7 @@ size_t msm_small_scratch_bytes();
 // ---- 6'. the bucket reduction (msm_reduce.hip): one launch per level of the bit-plane merge tree, radix-2^29 points ----
 size_t msm_reduce_plane_bytes(size_t nb);
 template <class P>
-void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s, int low_prio = 0);
+void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s);
 
 // Switches of the commitments-in-flight path (read once per process; the defaults are the measured best).
 // Everything else that round 2 kept for A/B runs (stream / wave priorities off, more waves per SIMD, a 128-VGPR build, hipGraph
@@ -258,7 +258,7 @@ void msm_launch_bucket_direct(const uint32_t* sorted, const Affine<P>* table, co
 // ---- 5. finalize: buckets of <= MSM_SMALL task partials, one lane each (msm_finalize.hip) ----------------------------------
 template <class P>
 void msm_launch_finalize(const Xyzz<P>* partials, const uint32_t* cnt, const uint32_t* task_start, const uint32_t* group_task_base, uint32_t NB,
-                         Xyzz<P>* buckets, uint32_t* big_list, uint32_t* big_count, uint32_t S, hipStream_t s, int low_prio = 0);
+                         Xyzz<P>* buckets, uint32_t* big_list, uint32_t* big_count, uint32_t S, hipStream_t s);
 
 template <class P, int BLOCK>
 __device__ void block_tree_sum(Xyzz<P>& acc, Xyzz<P>* sh) {
@@ -279,8 +279,8 @@ template <class P>
 __global__ __launch_bounds__(256) void msm_big_bucket_kernel(const Xyzz<P>* __restrict__ partials, const uint32_t* __restrict__ cnt,
                                                                const uint32_t* __restrict__ task_start,
                                                                const uint32_t* __restrict__ group_task_base, Xyzz<P>* __restrict__ buckets,
-                                                               const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count, uint32_t S, int low) {
-    msm_set_wave_prio(low);
+                                                               const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count, uint32_t S) {
+    msm_set_wave_prio(0);
     extern __shared__ uint4 lds_raw[];
     Xyzz<P>* sh = reinterpret_cast<Xyzz<P>*>(lds_raw);
     const uint32_t nbig = *big_count;
@@ -359,8 +359,8 @@ struct MsmCtx : MsmCtxBase {
         uint32_t ws_NB = 0;                          // keys
         hipStream_t stream = nullptr;      // slot stream: sort, plan, finalize, reduce (high priority)
         hipStream_t acc_stream = nullptr;  // the accumulate kernel alone (low priority)
-        hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr, done = nullptr;
-        hipEvent_t acc_gate = nullptr;     // LURK_MSM_SUBMIT_FOLLOW: the accumulation also waits for this event (the followed commitment's end)
+        hipEvent_t ready = nullptr, planned = nullptr, accumulated = nullptr;
+        hipEvent_t acc_gate = nullptr;     // LURK_MSM_SUBMIT_FOLLOW: the accumulation waits for this event (the end of the followed commitment's accumulation)
         int follow_wgs = 0;                // LURK_MSM_SUBMIT_FOLLOW: persistent accumulation with this many waves per SIMD (0: the plain launch)
         bool follow_low = false;           // LURK_MSM_SUBMIT_FOLLOW: the commitment's short kernels at the lowest wave priority
         DevBuf cursor;                     // task cursor of the persistent accumulate kernel (+ its per-CU placement counters)
@@ -379,7 +379,6 @@ struct MsmCtx : MsmCtxBase {
             if (ready) (void)hipEventDestroy(ready);
             if (planned) (void)hipEventDestroy(planned);
             if (accumulated) (void)hipEventDestroy(accumulated);
-            if (done) (void)hipEventDestroy(done);
         }
     };
     Work work[MSM_SLOTS];
@@ -399,6 +398,20 @@ struct MsmCtx : MsmCtxBase {
         small_table.release();
         bool small_form = precompute && !c_override && n > 0 && n <= MSM_SMALL_MAX_POINTS && small_pref >= 0;
         LURK_REQUIRE(small_pref <= 0 || small_form, "LURK_MSM_FLAG_SMALL_FORM: the small form needs the precompute flag, no window override and 1 .. 2^16 points");
+        if (small_form && small_pref > 0) {
+            // the form was asked for by name (LURK_MSM_FLAG_SMALL_FORM): refuse BEFORE allocating gigabytes when the device cannot hold it
+            // (table + build scratch), with the out-of-memory code the caller's fallback tests for.  LURK_MSM_SMALL_FORM_MAX_MB caps what a
+            // small-form key may take (a deployment knob, and the way the test of the refusal path forces it).
+            const int cs = msm_small_window_bits(n);
+            const size_t need = msm_small_table_entries(n, cs) * sizeof(Affine<P>) + msm_small_scratch_bytes() + (size_t)msm_num_windows(cs) * n * 160;
+            size_t free_b = 0, total_b = 0;
+            LURK_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+            const char* cap_env = getenv("LURK_MSM_SMALL_FORM_MAX_MB");  // read per call: a deployment may set it between keys
+            const size_t cap_mb = cap_env ? (size_t)atoll(cap_env) : (size_t)0;
+            if (need > free_b || (cap_mb && need > (cap_mb << 20)))
+                throw HipFailure{LURK_HIP_ERR_OOM, "LURK_MSM_FLAG_SMALL_FORM: the small-commitment form of this key needs " + std::to_string(need >> 20) +
+                                                       " MiB (free: " + std::to_string(free_b >> 20) + " MiB" + (cap_mb ? ", LURK_MSM_SMALL_FORM_MAX_MB=" + std::to_string(cap_mb) : std::string()) + ")"};
+        }
         if (small_form && small_pref == 0) {
             // the small form is a memory-for-latency trade sized for 288 GB: 256 KiB per point resident (4.3 GB at 2^14 points, 5.6 GB
             // at 2^16) + <= 1 GiB of build scratch.  It is taken only when that is at most a quarter of what the device has free
@@ -637,13 +650,9 @@ struct MsmCtx : MsmCtxBase {
             return;
         }
         MsmShape sh = shape(n, wk.sel);
-        // LURK_MSM_SUBMIT_FOLLOW: the sort, the plan and the accumulation at the lowest wave priority - they only have to be through when
-        // the followed accumulation ends / the next step's begin asks for the result.  The TAIL (finalize, bucket reduction) keeps the
-        // raised priority: the next step's begin waits for this commitment as well as for its own commit(T), and 19 dependent levels at
-        // the lowest priority were served last of everything (measured: 2.5 ms, ending after commit(T)'s own reduction).
+        // LURK_MSM_SUBMIT_FOLLOW: the sort, the plan and the accumulation at the lowest wave priority, the tail (finalize, bucket reduction)
+        // at the raised one (see submit_impl)
         const int low = wk.follow_low ? 1 : 0;
-        static const int low_tail_env = [] { const char* v = getenv("LURK_MSM_FOLLOW_LOW_TAIL"); return v ? atoi(v) : 0; }();
-        const int low_tail = low && low_tail_env;
         sh.low_prio = low;
         ensure_workspace(wk, sh);
         const size_t nt = ntask_max(sh);
@@ -684,7 +693,6 @@ struct MsmCtx : MsmCtxBase {
                 ProfScope ps("msm_reduce", s);
                 msm_launch_reduce<P>(wk.buckets.template as<Xyzz<P>>(), wk.planes_a.p, wk.planes_b.p, sh.c, sh.G, sh.B, wk.host_pts, s);
             }
-            if (wk.done) LURK_HIP_CHECK(hipEventRecord(wk.done, s));
             LURK_HIP_CHECK(hipGetLastError());
             return;
         }
@@ -759,19 +767,18 @@ struct MsmCtx : MsmCtxBase {
             ProfScope ps("msm_finalize", s);
             msm_launch_finalize<P>(wk.partials.template as<Xyzz<P>>(), wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                    wk.group_task_base.template as<uint32_t>(), sh.NB, wk.buckets.template as<Xyzz<P>>(),
-                                   wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S, s, low_tail);
+                                   wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S, s);
             hipLaunchKernelGGL((msm_big_bucket_kernel<P>), dim3(128), dim3(256), 256 * sizeof(Xyzz<P>), s, wk.partials.template as<Xyzz<P>>(),
                                wk.cnt.template as<uint32_t>(), wk.task_start.template as<uint32_t>(),
                                wk.group_task_base.template as<uint32_t>(), wk.buckets.template as<Xyzz<P>>(),
-                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S, low_tail);
+                               wk.big_list.template as<uint32_t>(), wk.big_count.template as<uint32_t>(), (uint32_t)sh.S);
         }
         {
             // the c - 1 levels of the bit-plane merge tree; the last one stores the G x c plane sums into the slot's pinned buffer: the
             // host's Horner over them (G c doublings and as many additions) is cheaper than a 20-deep dependent chain on one lane
             ProfScope ps("msm_reduce", s);
-            msm_launch_reduce<P>(wk.buckets.template as<Xyzz<P>>(), wk.planes_a.p, wk.planes_b.p, sh.c, sh.G, sh.B, wk.host_pts, s, low_tail);
+            msm_launch_reduce<P>(wk.buckets.template as<Xyzz<P>>(), wk.planes_a.p, wk.planes_b.p, sh.c, sh.G, sh.B, wk.host_pts, s);
         }
-        if (wk.done) LURK_HIP_CHECK(hipEventRecord(wk.done, s));
         LURK_HIP_CHECK(hipGetLastError());
     }
 
@@ -876,31 +883,25 @@ struct MsmCtx : MsmCtxBase {
                 std::lock_guard<std::mutex> lk2(fg_mu);
                 if (bg && last_fg && last_fg != &wk && last_fg->planned)
                     LURK_HIP_CHECK(hipStreamWaitEvent(wk.pending_stream, last_fg->planned, 0));
-                // follow: behind the foreground commitment's ACCUMULATION (recorded by its enqueue, which the caller's thread has
-                // already returned from; an event of an earlier, finished commitment - or one never recorded - orders nothing)
-                // Its own accumulation waits for the END of that commitment (the last level of its bucket reduction): a plain
-                // accumulate launch fills every SIMD's registers, and the followed commitment's 19 dependent reduction levels - what
-                // the host is waiting for - would each queue for a wave slot (measured: the reduction 0.35 -> 0.70 ms).  The sort and
-                // the plan (LDS atomics, short workgroups) do run beside that reduction.
+                // follow (round 6): work staged ahead that must only take what the open step's serial chain leaves.  Its sort and plan
+                // run at once, at the LOWEST wave priority (beside the cross term and commit(T)'s own sort: they only have to be through
+                // when commit(T)'s accumulation ends); its accumulation waits for the END of the followed commitment's accumulation
+                // (the event that commitment's enqueue recorded: the caller's thread has returned from it; an event of an earlier,
+                // finished commitment - or one never recorded - orders nothing) and is the persistent form with follow_wgs waves per
+                // SIMD, lowest priority: what two waves leave of a SIMD's registers (512 - 2 x 176) holds the waves of commit(T)'s
+                // reduction levels, the folds and the next cross term, where a plain launch (three waves, 504 registers) made each of
+                // them queue for an accumulate wave to retire (measured: a 60 us fold 320 us, the reduction 0.35 -> 0.70 ms).  Its
+                // TAIL keeps the raised priority: the next step's begin waits for this commitment as well as for its own commit(T).
                 wk.acc_gate = nullptr;
                 wk.follow_wgs = 0;
                 wk.follow_low = false;
                 if (follow) {
-                    static const int lowp = [] { const char* v = getenv("LURK_MSM_FOLLOW_LOW_PRIO"); return v ? atoi(v) : 1; }();
-                    wk.follow_low = lowp != 0;
                     static const int wgs = [] { const char* v = getenv("LURK_MSM_FOLLOW_WGS"); const int x = v ? atoi(v) : 2; return x < 0 ? 0 : x > 3 ? 3 : x; }();
-                    wk.follow_wgs = wgs;
+                    wk.follow_wgs = wgs;  // 0: the plain launch (A/B runs)
+                    wk.follow_low = true;
+                    if (last_fg && last_fg != &wk && last_fg->accumulated) wk.acc_gate = last_fg->accumulated;
                 }
-                if (follow && last_fg && last_fg != &wk && last_fg->accumulated) {
-                    // LURK_MSM_FOLLOW_SORT: 1 = the sort and the plan run at once (beside the followed commitment's own sort and the
-                    // cross term: LDS- and HBM-bound neighbours) and only the ACCUMULATION waits for the followed accumulation's end;
-                    // 0 = the whole commitment waits for it.  LURK_MSM_FOLLOW_ACC_GATE=1: the accumulation waits for the followed
-                    // commitment's END (the last level of its bucket reduction) instead.
-                    static const int sort_now = [] { const char* v = getenv("LURK_MSM_FOLLOW_SORT"); return v ? atoi(v) : 1; }();
-                    static const int gate = [] { const char* v = getenv("LURK_MSM_FOLLOW_ACC_GATE"); return v ? atoi(v) : 0; }();
-                    if (!sort_now) LURK_HIP_CHECK(hipStreamWaitEvent(wk.pending_stream, last_fg->accumulated, 0));
-                    wk.acc_gate = gate && last_fg->done ? last_fg->done : last_fg->accumulated;
-                }
+                if (mode == LURK_MSM_SUBMIT_FOREGROUND) last_fg = &wk;
             }
             // foreground: everything on the (high-priority) slot stream
             hipStream_t acc_s = wk.foreground ? nullptr : wk.acc_stream;
@@ -924,7 +925,6 @@ struct MsmCtx : MsmCtxBase {
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.ready, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.planned, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.accumulated, hipEventDisableTiming));
-            LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.done, hipEventDisableTiming));
         }
     }
 
@@ -1617,6 +1617,14 @@ int lurk_hip_msm_multi_destroy(lurk_hip_msm_multi* m) {
 }
 
 // host-side group helpers (a handful of points: partial commitments gathered from the ranks)
+int lurk_hip_point_sum_gathered(int curve, void* out, const void* gathered, size_t world) {
+    if (world == 0) {
+        set_error(LURK_HIP_ERR_INVALID_ARG, "lurk_hip_point_sum_gathered: a world of 0 ranks");
+        return LURK_HIP_ERR_INVALID_ARG;
+    }
+    return lurk_hip_point_sum(curve, out, gathered, world);
+}
+
 int lurk_hip_point_sum(int curve, void* out, const void* points, size_t count) {
     try {
         LURK_REQUIRE(curve == 0 || curve == 1, "unknown curve id");

@@ -1,8 +1,10 @@
-// msm_acc_persistent.hip - the persistent form of the bucket accumulation (commitments in flight), in its own translation unit so that
-// it can be built for a SMALLER register footprint than the plain launch of msm_acc.hip (Makefile: PERSIST_FLAGS).  Two of these kernels
-// are resident at once, one wave per SIMD each, and everything that has to run beside them - the next commitment's sort above all - must
-// fit the registers they leave: at 144 instead of 176 registers the 56-register sort kernels (pass 1a, pass 2)
-// can be placed beside BOTH.  The plain launch (the folding step's commitments, synchronous calls) keeps the faster 162-register build.
+// msm_acc_persistent.hip - the persistent form of the bucket accumulation (commitments in flight; round 6: the accumulation of a
+// LURK_MSM_SUBMIT_FOLLOW commitment), in its own translation unit so that it CAN be built for another register footprint than the
+// plain launch of msm_acc.hip (Makefile: PERSIST_FLAGS / PERSIST_DEFS).  The SHIPPED build sets neither: the kernel takes ~176 VGPRs,
+// the same code as the plain launch (msm_acc_task.cuh).  What has to run beside resident accumulations is sized for THAT footprint and
+// checked on the compiler's own numbers (tests/test_cabi_exports.py::test_sort_kernels_fit_beside_a_resident_accumulation): four waves
+// of a 1024-thread sort workgroup beside ONE 176-register wave, a 128-register tail wave beside TWO.  (A 144-register build - machine
+// LICM off - lets the 56-register sort passes sit beside two; measured in round 4, +1.7 % in flight, -4 % for the folding step: not shipped.)
 #ifndef LURK_ACC_RADIX29
 #define LURK_ACC_RADIX29 1
 #endif
@@ -10,33 +12,9 @@
 #define LURK_MUL_FORCE_INLINE
 #endif
 #include "common.hpp"
-#include "msm_core.cuh"
-#include "curve29.cuh"
+#include "msm_acc_task.cuh"
 
 namespace lurk {
-
-constexpr int MSM_ACC_BLOCK = 256;
-
-#ifndef LURK_ACC_TASK_NOINLINE
-#define LURK_ACC_TASK_NOINLINE 0
-#endif
-#if LURK_ACC_TASK_NOINLINE
-#define LURK_ACC_TASK_ATTR __attribute__((noinline))
-#else
-#define LURK_ACC_TASK_ATTR __forceinline__
-#endif
-template <class P>
-__device__ LURK_ACC_TASK_ATTR void msm_accumulate_task(uint32_t i, const uint32_t* __restrict__ sorted, const Affine<P>* __restrict__ table,
-                                                    const uint2* __restrict__ task_info, const uint32_t* __restrict__ order,
-                                                    Xyzz<P>* __restrict__ partials) {
-    uint32_t t = order[i];
-    uint2 ti = task_info[t];
-#if LURK_ACC_RADIX29
-    partials[t] = msm_task_accumulate29<P>(sorted, ti.x, ti.y, table);
-#else
-    partials[t] = msm_task_accumulate<P>(sorted, ti.x, ti.y, table);
-#endif
-}
 
 // (XCC, SE, CU) of the running wave as one index < 512 (HW_ID: CU_ID [11:8], SE_ID [14:13]; XCC_ID [3:0])
 __device__ __forceinline__ uint32_t msm_cu_index() {

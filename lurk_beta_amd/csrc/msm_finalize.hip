@@ -18,9 +18,8 @@ __global__ __launch_bounds__(256, 4) void msm_finalize_kernel(const Xyzz<P>* __r
                                                              const uint32_t* __restrict__ task_start,
                                                              const uint32_t* __restrict__ group_task_base, uint32_t NB,
                                                              Xyzz<P>* __restrict__ buckets, uint32_t* __restrict__ big_list,
-                                                             uint32_t* __restrict__ big_count, uint32_t S, int low) {
-    if (low) __builtin_amdgcn_s_setprio(0);  // a LURK_MSM_SUBMIT_FOLLOW commitment (msm.hip): whatever the open step's chain leaves
-    else __builtin_amdgcn_s_setprio(3);      // a latency-bound tail kernel: issue ahead of an accumulation sharing the SIMD
+                                                             uint32_t* __restrict__ big_count, uint32_t S) {
+    __builtin_amdgcn_s_setprio(3);  // a latency-bound tail kernel: issue ahead of an accumulation sharing the SIMD
     const size_t key = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (key >= NB) return;
     const uint32_t g = (uint32_t)(key / MSM_GRP), b = (uint32_t)(key % MSM_GRP);
@@ -35,13 +34,13 @@ __global__ __launch_bounds__(256, 4) void msm_finalize_kernel(const Xyzz<P>* __r
 
 template <class P>
 void msm_launch_finalize(const Xyzz<P>* partials, const uint32_t* cnt, const uint32_t* task_start, const uint32_t* group_task_base, uint32_t NB,
-                         Xyzz<P>* buckets, uint32_t* big_list, uint32_t* big_count, uint32_t S, hipStream_t s, int low_prio) {
+                         Xyzz<P>* buckets, uint32_t* big_list, uint32_t* big_count, uint32_t S, hipStream_t s) {
     hipLaunchKernelGGL((msm_finalize_kernel<P>), dim3(div_up((size_t)NB, 256)), dim3(256), 0, s, partials, cnt, task_start, group_task_base, NB, buckets,
-                       big_list, big_count, S, low_prio);
+                       big_list, big_count, S);
 }
 template void msm_launch_finalize<PallasFp>(const Xyzz<PallasFp>*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, Xyzz<PallasFp>*, uint32_t*,
-                                            uint32_t*, uint32_t, hipStream_t, int);
+                                            uint32_t*, uint32_t, hipStream_t);
 template void msm_launch_finalize<PallasFq>(const Xyzz<PallasFq>*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, Xyzz<PallasFq>*, uint32_t*,
-                                            uint32_t*, uint32_t, hipStream_t, int);
+                                            uint32_t*, uint32_t, hipStream_t);
 
 }  // namespace lurk

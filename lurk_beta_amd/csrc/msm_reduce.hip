@@ -51,9 +51,8 @@ __device__ __forceinline__ void plane_load(const Plane29<P>* __restrict__ src, X
 // LAST: the G x c plane sums leave as ordinary XYZZ points (out_host, pinned host memory) instead of plane records
 template <class P, bool FIRST, bool LAST>
 __global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
-                                                                      Plane29<P>* __restrict__ out, Xyzz<P>* __restrict__ out_host, int k, int G, uint32_t B, int low) {
-    if (low) __builtin_amdgcn_s_setprio(0);  // a LURK_MSM_SUBMIT_FOLLOW commitment (msm.hip): whatever the open step's chain leaves
-    else __builtin_amdgcn_s_setprio(3);      // a latency-bound tail kernel: issue ahead of an accumulation sharing the SIMD
+                                                                      Plane29<P>* __restrict__ out, Xyzz<P>* __restrict__ out_host, int k, int G, uint32_t B) {
+    __builtin_amdgcn_s_setprio(3);  // a latency-bound tail kernel: issue ahead of an accumulation sharing the SIMD
     const size_t nseg_out = (size_t)B >> (k + 1);
     const size_t comps_out = (size_t)k + 2, comps_in = (size_t)k + 1;
     const size_t id = (size_t)blockIdx.x * REDUCE_BLOCK + threadIdx.x;
@@ -98,7 +97,7 @@ size_t msm_reduce_plane_bytes(size_t nb) { return nb * 160; }
 
 // planes_a / planes_b: msm_reduce_plane_bytes(G * B) each; out_host: G * c XYZZ points of pinned host memory
 template <class P>
-void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s, int low_prio) {
+void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s) {
     static_assert(sizeof(Plane29<P>) == 160, "plane record");
     Plane29<P>* bufs[2] = {(Plane29<P>*)planes_a, (Plane29<P>*)planes_b};
     for (int k = 0; k < c - 1; k++) {
@@ -107,14 +106,14 @@ void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, i
         const Plane29<P>* in = bufs[(k + 1) & 1];
         Plane29<P>* out = bufs[k & 1];
         const bool last = k == c - 2;
-        if (k == 0 && last) hipLaunchKernelGGL((msm_planes29_kernel<P, true, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B, low_prio);
-        else if (k == 0) hipLaunchKernelGGL((msm_planes29_kernel<P, true, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B, low_prio);
-        else if (last) hipLaunchKernelGGL((msm_planes29_kernel<P, false, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B, low_prio);
-        else hipLaunchKernelGGL((msm_planes29_kernel<P, false, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B, low_prio);
+        if (k == 0 && last) hipLaunchKernelGGL((msm_planes29_kernel<P, true, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+        else if (k == 0) hipLaunchKernelGGL((msm_planes29_kernel<P, true, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+        else if (last) hipLaunchKernelGGL((msm_planes29_kernel<P, false, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+        else hipLaunchKernelGGL((msm_planes29_kernel<P, false, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
     }
     LURK_HIP_CHECK(hipGetLastError());
 }
-template void msm_launch_reduce<PallasFp>(const Xyzz<PallasFp>*, void*, void*, int, int, uint32_t, Xyzz<PallasFp>*, hipStream_t, int);
-template void msm_launch_reduce<PallasFq>(const Xyzz<PallasFq>*, void*, void*, int, int, uint32_t, Xyzz<PallasFq>*, hipStream_t, int);
+template void msm_launch_reduce<PallasFp>(const Xyzz<PallasFp>*, void*, void*, int, int, uint32_t, Xyzz<PallasFp>*, hipStream_t);
+template void msm_launch_reduce<PallasFq>(const Xyzz<PallasFq>*, void*, void*, int, int, uint32_t, Xyzz<PallasFq>*, hipStream_t);
 
 }  // namespace lurk

@@ -6,9 +6,10 @@
 // transform uses omega^-1 and scales by 1/n.
 //
 // Two implementations of the same twisted decimation-in-time:
-//   log_n >= 12  wave-resident passes (ntt_wave_pass_kernel below): <= 8 stages per pass with the butterflies in registers and
-//                across lanes (__shfl_xor), radix-2^29 arithmetic, bit reversal folded into the first pass's tile addressing,
-//                LDS only as the transposing tile and the twiddle table: 3 passes over memory at 2^24
+//   log_n >= 12  wave-resident passes (ntt_wave_pass_kernel below): <= 8 stages per pass, a wave owns 256 elements of a 2048-element
+//                tile and runs radix-4 rounds entirely in registers; between register rounds its 256 elements are transposed through
+//                a swizzled, bank-conflict-free LDS buffer (no lane shuffles, no selects); radix-2^29 arithmetic with a 4p bias, bit
+//                reversal folded into the first pass's tile addressing, LDS also holds the twiddle table: 3 passes over memory at 2^24
 //   smaller      the LDS-stage kernels (sizes below 2^12 only):
 // Shape of the LDS-stage path: decimation-in-time after a bit-reversal permutation, in passes that each fuse several
 // radix-2 stages out of an LDS tile:

@@ -170,14 +170,38 @@ void Profiler::query(const char* prefix, double* total_ms, uint64_t* launches) {
     *launches = cnt;
 }
 
-ScratchArena& ScratchArena::of(hipStream_t s) {
-    static std::mutex map_mu;
+static std::mutex g_arena_map_mu;
+static std::map<std::pair<int, hipStream_t>, ScratchArena*>& arena_map() {
     static auto& arenas = *new std::map<std::pair<int, hipStream_t>, ScratchArena*>();  // never torn down (process lifetime)
-    std::lock_guard<std::mutex> g(map_mu);
+    return arenas;
+}
+ScratchArena& ScratchArena::of(hipStream_t s) {
+    std::lock_guard<std::mutex> g(g_arena_map_mu);
+    auto& arenas = arena_map();
     auto key = std::make_pair(current_device(), s);
     auto it = arenas.find(key);
     if (it == arenas.end()) it = arenas.emplace(key, new ScratchArena()).first;
     return *it->second;
+}
+// An arena that some thread holds (a prover with a buffer alive keeps its recursive lock) is skipped: try_lock, never wait.
+size_t ScratchArena::trim_all() {
+    std::lock_guard<std::mutex> g(g_arena_map_mu);
+    size_t released = 0;
+    for (auto& kv : arena_map()) {
+        ScratchArena& a = *kv.second;
+        if (!a.mu.try_lock()) continue;
+        if (a.live_.empty()) {
+            DeviceGuard dg(kv.first.first);
+            for (auto& b : a.blocks_) {
+                (void)hipFree(b.base);
+                released += b.cap;
+            }
+            a.blocks_.clear();
+            a.cur_ = 0;
+        }
+        a.mu.unlock();
+    }
+    return released;
 }
 void* ScratchArena::push(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
@@ -292,7 +316,15 @@ const char* lurk_hip_last_error(void) {
     copy = std::string("lurk_hip error ") + std::to_string(lurk::last_error_code()) + ": " + lurk::tl_msg;
     return copy.c_str();
 }
-const char* lurk_hip_version(void) { return "lurk-hip 0.1 (gfx950)"; }
+const char* lurk_hip_version(void) { return "lurk-hip 0.2 (gfx950)"; }
+int lurk_hip_abi_version(void) { return LURK_HIP_ABI_VERSION; }
+
+int lurk_hip_scratch_trim(size_t* released_bytes) {
+    return guarded([&] {
+        const size_t n = ScratchArena::trim_all();
+        if (released_bytes) *released_bytes = n;
+    });
+}
 
 int lurk_hip_set_device(int device) {
     return guarded([&] {

@@ -486,9 +486,9 @@ int lurk_hip_spartan_prove_dev(const lurk_hip_r1cs* shape, const lurk_hip_r1cs* 
         LURK_REQUIRE(out->polys_outer && out->claims_outer && out->eval_e && out->polys_inner && out->eval_w && out->polys_batch && out->evals_batch && out->ipa_l &&
                          out->ipa_r && out->ipa_a,
                      "null output buffer");
-        int curve = 0, bits = 0, form = 0, device = 0;
+        int curve = 0, bits = 0, device = 0;
         size_t points = 0;
-        if (lurk_hip_msm_ctx_info(key, &curve, &points, &bits, &form) != 0 || lurk_hip_msm_ctx_device(key, &device) != 0)
+        if (lurk_hip_msm_ctx_info(key, &curve, &points, &bits, nullptr) != 0 || lurk_hip_msm_ctx_device(key, &device) != 0)
             throw HipFailure{LURK_HIP_ERR_INVALID_ARG, lurk_hip_last_error()};
         LURK_REQUIRE(points >= (num_cons > num_vars ? num_cons : num_vars), "the key has fewer points than the padded polynomials have elements");
         // every scratch vector below is sized from (num_cons, num_vars, num_io) while the mat-vecs write what the shapes say: the two must agree

@@ -96,6 +96,10 @@ struct lurk_hip_fold_ctx {
     int helper_of[2] = {-1, -1};       // which helper commits the instance staged in buffer b (-1: this context's own key)
     size_t num_cons = 0, num_vars = 0, num_io = 0, ncols = 0;
     DevBuf z[2], e[2], t;              // running pair ping-pongs between two buffers (cur = index of the live one)
+    // round 6: A z1, B z1, C z1 of the running instance stay resident (they fold linearly: A (z1 + r z2) = A z1 + r A z2), so a step's
+    // cross term gathers from z2 alone (fold.hip: r1cs_cross_term_cached_kernel) and leaves A z2, B z2, C z2 for finish(r) to fold in
+    DevBuf abc1[3], abc2[3];
+    bool cached = false;
     DevBuf z2[2], zstaged[2], zpatch;  // fresh instances [W2 | 1 | X2]: the open step's and the one staged ahead; the staged ranges alone
                                        // (what their commitment reads while late ranges are written into z2); the late ranges alone
     int cur = 0;
@@ -302,12 +306,22 @@ static bool fold_late_key(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches
     if (lurk_hip_msm_ctx_create_dev(&c->late_key, c->curve, pts.p, patched, LURK_MSM_FLAG_PRECOMPUTE | LURK_MSM_FLAG_SMALL_FORM, (void*)s) != 0) {
         c->late_key = nullptr;
         if (last_error_code() != LURK_HIP_ERR_OOM) throw HipFailure{last_error_code(), lurk_hip_last_error()};
+        (void)hipGetLastError();  // the refusal is handled here: nothing of it may resurface in a later launch check on this thread
         c->late_layout.clear();
         c->late_key_refused = true;
         return false;
     }
     c->late_layout = layout;
     return true;
+}
+
+// T of the open step on the context's stream: from the cached products of the running instance (z2's gathers alone) or from (z1, z2)
+static void fold_cross_term(lurk_hip_fold_ctx* c, const void* z2) {
+    if (c->cached)
+        ok(lurk_hip_r1cs_cross_term_cached_dev(c->shape, z2, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p, (const char*)c->z[c->cur].p + c->num_vars * 32, c->t.p,
+                                               c->abc2[0].p, c->abc2[1].p, c->abc2[2].p, c->stream));
+    else
+        ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));
 }
 
 static void fold_run_submit_hook(lurk_hip_fold_ctx* c) {
@@ -415,7 +429,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     // commit(W2)'s accumulation held back until T's sort is through 4.15.  The cross term gathers from HBM while commit(W2) sorts;
     // its successor commit(T) is what the host waits for last.
     const int fg = LURK_MSM_SUBMIT_FOREGROUND;
-    ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));          // T ...
+    fold_cross_term(c, z2);                                                                     // T ...
     fold_submit_staged(c, b, fg);
     tt[1] = now();
     ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t.p, c->num_cons, 1, c->stream, fg));     // ... commit(T): what the host waits for
@@ -547,7 +561,7 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
     LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, need, hipMemcpyHostToDevice, c->stage_stream[0]));
     LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream[0]));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
-    ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));  // beside the slices' copies and commit(W2)'s sorts
+    fold_cross_term(c, z2);  // beside the slices' copies and commit(W2)'s sorts
     LURK_HIP_CHECK(hipEventRecord(c->t_ev, c->stream));
     bool w_in_flight = false, t_in_flight = false;
     try {
@@ -582,8 +596,12 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
 static void fold_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
     const int nx = c->cur ^ 1;
     // z = [W | u | X]: one pass folds the witness, u <- u1 + r * 1 and X <- X1 + r X2
-    ok(lurk_hip_fold_vec_dev(c->field_id, c->z[c->cur].p, c->z2[c->open_buf].p, r32_mont, c->ncols, c->z[nx].p, c->stream));
-    ok(lurk_hip_fold_vec_dev(c->field_id, c->e[c->cur].p, c->t.p, r32_mont, c->num_cons, c->e[nx].p, c->stream));
+    // (with the cached products: those three fold in place, in the same launch)
+    const void* a[5] = {c->z[c->cur].p, c->e[c->cur].p, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p};
+    const void* b[5] = {c->z2[c->open_buf].p, c->t.p, c->abc2[0].p, c->abc2[1].p, c->abc2[2].p};
+    void* o[5] = {c->z[nx].p, c->e[nx].p, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p};
+    const size_t n[5] = {c->ncols, c->num_cons, c->num_cons, c->num_cons, c->num_cons};
+    ok(lurk_hip_fold_vecs_dev(c->field_id, c->cached ? 5 : 2, a, b, n, o, r32_mont, c->stream));
     LURK_HIP_CHECK(hipEventRecord(c->folded_ev[c->open_buf], c->stream));
     c->folded_valid[c->open_buf] = true;
     c->cur = nx;
@@ -644,6 +662,15 @@ static void fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* s
         c->e[k].alloc(c->num_cons * 32);
     }
     c->t.alloc(c->num_cons * 32);
+    {
+        const char* sw = getenv("LURK_FOLD_CACHED_PRODUCTS");  // 0: the six-gather cross term of rounds 1-5 (A/B runs, the parity test of both forms)
+        c->cached = !(sw && atoi(sw) == 0);
+    }
+    if (c->cached)
+        for (int k = 0; k < 3; k++) {
+            c->abc1[k].alloc(c->num_cons * 32);
+            c->abc2[k].alloc(c->num_cons * 32);
+        }
     c->ux.assign(4 * (1 + c->num_io), 0);
     {   // the transcript's width-25 Poseidon constants are generated on first use (~0.15 s): now, not inside the first step
         uint64_t one[4] = {1, 0, 0, 0}, out[4];
@@ -662,6 +689,8 @@ static void fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* s
     // RelaxedR1CSWitness::default / RelaxedR1CSInstance::default: W = 0, E = 0, u = 0, X = 0
     LURK_HIP_CHECK(hipMemsetAsync(c->z[0].p, 0, c->ncols * 32, c->stream));
     LURK_HIP_CHECK(hipMemsetAsync(c->e[0].p, 0, c->num_cons * 32, c->stream));
+    if (c->cached)
+        for (int k = 0; k < 3; k++) LURK_HIP_CHECK(hipMemsetAsync(c->abc1[k].p, 0, c->num_cons * 32, c->stream));  // A 0 = B 0 = C 0 = 0
     LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
     *out = c.release();
 }
@@ -723,6 +752,7 @@ int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* c, const void* z1, const vo
         LURK_REQUIRE(!c->begun, "a step is open: finish it first");
         LURK_HIP_CHECK(hipMemcpyAsync(c->z[c->cur].p, z1, c->ncols * 32, hipMemcpyHostToDevice, c->stream));
         LURK_HIP_CHECK(hipMemcpyAsync(c->e[c->cur].p, e1, c->num_cons * 32, hipMemcpyHostToDevice, c->stream));
+        if (c->cached) ok(lurk_hip_r1cs_multiply_vec_dev(c->shape, c->z[c->cur].p, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p, c->stream));
         LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
         fold_instance_settle(c);  // the commitments of the last step first: only u and X are replaced here
         memcpy(c->ux.data(), (const char*)z1 + c->num_vars * 32, (1 + c->num_io) * 32);

@@ -281,6 +281,9 @@ static void sumcheck_prove(int np, size_t ninst, void* const* d_polys, size_t n,
     // the (device, stream)'s scratch, made once and kept: a proof runs three of these loops
     std::unique_lock<std::mutex> scratch_lk;
     SumcheckScratch& scratch = *sumcheck_cached_scratch(s, scratch_lk);
+    // the scratch is cached per (device, stream): the last-workgroup ticket counter is reset by the workgroup that takes the last ticket,
+    // so a round that faulted midway would leave it non-zero for every later sum-check on this stream - it starts every call at zero
+    LURK_HIP_CHECK(hipMemsetAsync(scratch.counter, 0, 4, s));
     const size_t host_tail = sumcheck_host_tail_len();
     std::vector<std::vector<Fe<F>>> host_tabs;  // ninst x np tables once the rounds have moved to the host (sumcheck_host_round)
     std::vector<size_t> host_len;

@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .msm import CommitmentKey, point_sum
+from .msm import CommitmentKey, point_sum_gathered
 
 
 _GATHER_BUFS: dict = {}
@@ -79,7 +79,7 @@ def gather_partials(partial: np.ndarray, group=None) -> np.ndarray:
 
 def allreduce_commitment(curve: int, partial: np.ndarray, group=None) -> np.ndarray:
     """Group-sum of the per-rank partial commitments; every rank gets the full commitment."""
-    return point_sum(curve, gather_partials(partial, group))
+    return point_sum_gathered(curve, gather_partials(partial, group))  # the ABI's one call for this exchange (INTEGRATION.md section 8)
 
 
 class ShardedCommitmentKey:

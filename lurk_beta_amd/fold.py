@@ -64,6 +64,19 @@ class R1CSShape:
         _lib.check(_lib.load().lurk_hip_r1cs_cross_term_dev(self._h, _lib.ptr(d_z1), _lib.ptr(d_z2), _lib.ptr(out), _lib.ptr(s)))
         return out
 
+    def cross_term_cached(self, d_z2, d_abc1, d_u1, stream=None):
+        """The same T from the running instance's cached products (A z1, B z1, C z1) and z2 alone; d_u1: the running u (one element on
+        the device).  Returns (T, [A z2, B z2, C z2]) - ``lurk_hip_r1cs_cross_term_cached_dev``."""
+        import torch
+
+        assert d_z2.is_cuda and d_z2.shape[0] == self.num_cols and len(d_abc1) == 3
+        t = torch.empty((self.num_cons, 4), dtype=torch.int64, device=d_z2.device)
+        abc2 = [torch.empty_like(t) for _ in range(3)]
+        s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.load().lurk_hip_r1cs_cross_term_cached_dev(self._h, _lib.ptr(d_z2), *[_lib.ptr(x) for x in d_abc1], _lib.ptr(d_u1), _lib.ptr(t),
+                                                                  *[_lib.ptr(x) for x in abc2], _lib.ptr(s)))
+        return t, abc2
+
     def close(self):
         if self._h:
             _lib.check(_lib.load().lurk_hip_r1cs_destroy(self._h))
@@ -88,3 +101,21 @@ def fold_vec(field_id: int, d_a, d_b, r_mont: np.ndarray, out=None, stream=None)
     s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
     _lib.check(_lib.load().lurk_hip_fold_vec_dev(field_id, _lib.ptr(d_a), _lib.ptr(d_b), _lib.ptr(r), n, _lib.ptr(out), _lib.ptr(s)))
     return out
+
+
+def fold_vecs(field_id: int, pairs, r_mont: np.ndarray, outs=None, stream=None):
+    """Several folds a_k + r b_k under one r in ONE launch (``lurk_hip_fold_vecs_dev``, at most 8): pairs = [(d_a, d_b), ...];
+    outs[k] may be d_a (in place).  Returns the outputs."""
+    import torch
+
+    n = len(pairs)
+    if outs is None:
+        outs = [torch.empty_like(a) for a, _ in pairs]
+    r = np.ascontiguousarray(r_mont, dtype=np.uint64).reshape(4)
+    s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    pa = (ctypes.c_void_p * max(n, 1))(*[_lib.ptr(a) for a, _ in pairs])
+    pb = (ctypes.c_void_p * max(n, 1))(*[_lib.ptr(b) for _, b in pairs])
+    po = (ctypes.c_void_p * max(n, 1))(*[_lib.ptr(o) for o in outs])
+    ns = (ctypes.c_size_t * max(n, 1))(*[a.shape[0] for a, _ in pairs])
+    _lib.check(_lib.load().lurk_hip_fold_vecs_dev(field_id, n, pa, pb, ns, po, _lib.ptr(r), _lib.ptr(s)))
+    return outs

@@ -49,6 +49,15 @@ def point_sum(curve: int, points: np.ndarray) -> np.ndarray:
     return out
 
 
+def point_sum_gathered(curve: int, gathered: np.ndarray) -> np.ndarray:
+    """``lurk_hip_point_sum_gathered``: the commitment of a vector from the world x 12 u64 partial commitments of its slices (rank order) -
+    the one library call a one-process-per-GPU host needs after its own all-gather."""
+    gathered = np.ascontiguousarray(gathered, dtype=np.uint64)
+    out = np.zeros(12, dtype=np.uint64)
+    _lib.check(_lib.load().lurk_hip_point_sum_gathered(curve, _lib.ptr(out), _lib.ptr(gathered), gathered.size // 12))
+    return out
+
+
 class CommitmentKey:
     """Resident commitment key (``ck``): n affine bases kept in HBM for the lifetime of the object."""
 
@@ -128,7 +137,8 @@ class CommitmentKey:
 
     def submit_device(self, slot: int, d_scalars, n: int, is_mont: bool = False, stream=None, mode: int = 0) -> None:
         """Asynchronous commit on `slot` (0..3); pair with ``wait(slot)``.  mode: 0 = default, 1 = foreground (the commitment the
-        host waits for next), 2 = background (work staged ahead)."""
+        host waits for next), 2 = background (work staged ahead: persistent one-wave accumulation beside the foreground one), 3 = follow
+        (work staged ahead: low-priority sort and plan at once, accumulation once the latest foreground commitment's has ended)."""
         lib = _lib.load()
         self._keep = getattr(self, "_keep", {})
         self._keep[slot] = d_scalars  # the scalars must stay alive until wait()

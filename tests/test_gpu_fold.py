@@ -155,3 +155,70 @@ def test_folding_identity_at_step_circuit_size(hip, rc):
     assert u == (u1 + r) % p
     assert not C.relaxed_residual(f, az, bz, cz, u, C.from_mont(f, _host(d_e))).any()
     sh.close()
+
+
+@pytest.mark.parametrize("f", [0, 1, 2])
+def test_cached_products_cross_term_and_multi_fold_match_oracle(hip, f):
+    """Round 6: lurk_hip_r1cs_cross_term_cached_dev (T from the cached A z1, B z1, C z1 and the gathers of z2 alone; long rows through
+    the lanes-per-row path) and lurk_hip_fold_vecs_dev (several folds in one launch, in place) against the oracle, and the linearity
+    the cache rests on: folding the cached products with r gives the products of the folded z."""
+    from lurk_beta_amd import fold_vecs
+
+    p = R.modulus(f)
+    m, nv, nio = 3000, 2500, 2
+    A, B, Cm, z2 = C.synth_r1cs(f, m, nv, nio, seed=21)
+    # make a few rows long (more than FOLD_LONG = 32 entries, one beyond the 64-term re-entry period) so that both row paths run
+    rng = np.random.default_rng(5)
+    ip, ix, dv = A
+    cnt = np.diff(ip.astype(np.int64))
+    extra_rows = [7, 1500, 2999]
+    new_ip, new_ix, new_dv = [0], [], []
+    for i in range(m):
+        lo, hi = int(ip[i]), int(ip[i + 1])
+        cols, vals = list(ix[lo:hi]), list(dv[lo:hi])
+        if i in extra_rows:
+            k = 40 if i != 1500 else 200
+            cols += list(rng.integers(0, nv + 1 + nio, k).astype(np.uint64))
+            vals += list(C.synth_scalars(f, 300 + i, 0, k))
+        new_ix += cols
+        new_dv += vals
+        new_ip.append(len(new_ix))
+    A = (np.array(new_ip, dtype=np.uint64), np.array(new_ix, dtype=np.uint64), np.array(new_dv, dtype=np.uint64).reshape(-1, 4))
+    sh = _shape(f, A, B, Cm, m, nv, nio)
+    z1 = C.synth_scalars(f, 18, 0, nv + 1 + nio)
+    d_z1, d_z2 = _dev(C.to_mont(f, z1)), _dev(C.to_mont(f, z2))
+    abc1 = sh.multiply_vec(d_z1)
+    want1 = [C.spmv(f, *M, z1) for M in (A, B, Cm)]
+    want2 = [C.spmv(f, *M, z2) for M in (A, B, Cm)]
+    u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+    u2 = C.limbs_to_ints(z2[nv:nv + 1])[0]
+    t_want = C.cross_term(f, *want1, *want2, u1, u2)
+    d_t, abc2 = sh.cross_term_cached(d_z2, abc1, d_z1[nv:nv + 1])
+    assert np.array_equal(C.from_mont(f, _host(d_t)), t_want)
+    assert np.array_equal(_host(d_t), _host(sh.cross_term(d_z1, d_z2)))  # bit for bit the six-gather kernel's T
+    for g, w in zip(abc2, want2):
+        assert np.array_equal(C.from_mont(f, _host(g)), w)
+    # finish(r): [z, E, A z1, B z1, C z1] fold in one launch; the three products in place
+    r = R.uniform_fe(73, f, p)
+    r_mont = C.to_mont(f, C.ints_to_limbs([r]))
+    e1 = C.synth_scalars(f, 19, 0, m)
+    d_e1 = _dev(C.to_mont(f, e1))
+    outs = fold_vecs(f, [(d_z1, d_z2), (d_e1, d_t)] + list(zip(abc1, abc2)), r_mont)
+    zf, ef = C.axpy(f, z1, z2, r), C.axpy(f, e1, t_want, r)
+    assert np.array_equal(C.from_mont(f, _host(outs[0])), zf) and np.array_equal(C.from_mont(f, _host(outs[1])), ef)
+    import torch
+
+    inplace = [x.clone() for x in abc1]
+    fold_vecs(f, list(zip(inplace, abc2)), r_mont, outs=inplace)
+    torch.cuda.synchronize()
+    for g, M in zip(inplace, (A, B, Cm)):
+        assert np.array_equal(C.from_mont(f, _host(g)), C.spmv(f, *M, zf))  # A (z1 + r z2) = A z1 + r A z2
+    # edge: zero vectors in the list, a single vector, the empty call
+    assert fold_vecs(f, [], r_mont) == []
+    one = fold_vecs(f, [(d_e1, d_t)], r_mont)
+    assert np.array_equal(C.from_mont(f, _host(one[0])), ef)
+    from lurk_beta_amd import LurkHipError
+
+    with pytest.raises(LurkHipError):
+        fold_vecs(f, [(d_e1, d_t)] * 9, r_mont)
+    sh.close()

@@ -690,3 +690,43 @@ def test_step_from_dump_files(hip, tmp_path, encoding):
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["data"] == "dumped" and line["config"]["verified"]["ok"] is True and line["ms_per_step"] > 0
+
+
+def test_late_key_refusal_falls_back_to_slot_3_and_the_steps_still_match(hip, monkeypatch):
+    """Round-5 advisor finding: when the device cannot hold the late ranges' small-form key, fold_late_key must fall back to slot 3 of
+    the commitment key AND leave no sticky HIP error behind (the next launch check on the thread used to fail with a spurious
+    out-of-memory).  The refusal is forced with LURK_MSM_SMALL_FORM_MAX_MB=1 (the table of ~500 late positions needs > 100 MiB):
+    two consecutive staged steps with late ranges still give the oracle's commitments and folds."""
+    from lurk_beta_amd import CommitmentKey, FoldingContext, LurkHipError, R1CSShape, point_to_affine
+
+    monkeypatch.setenv("LURK_MSM_SMALL_FORM_MAX_MB", "1")
+    curve, f, m, nfree, nio = 0, 1, 6000, 2500, 2
+    A, B, Cm, nv = _product_shape(f, m, nfree, nio, seed=79)
+    mont = lambda M: (M[0], M[1], C.to_mont(f, M[2]))
+    shape = R1CSShape(f, m, nv, nio, mont(A), mont(B), mont(Cm))
+    bases = C.synth_bases(curve, max(m, nv))
+    # stated by name, the small form is refused with the out-of-memory code - before anything is allocated
+    with pytest.raises(LurkHipError, match="small-commitment form") as ei:
+        CommitmentKey(curve, bases[:512], precompute=True, small_form=True)
+    assert ei.value.code == 4  # LURK_HIP_ERR_OOM
+    key = CommitmentKey(curve, bases, precompute=True, window_bits=16)
+    key.reserve(max(m, nv), 4)
+    ctx = FoldingContext(curve, shape, key)
+    z1, e1 = np.zeros((nv + 1 + nio, 4), dtype=np.uint64), np.zeros((m, 4), dtype=np.uint64)
+    lo, hi = 300, nv - 200
+    for step, r in enumerate((0xC0FFEE, 0xBEEF)):
+        z2, x2 = _fresh(f, A, B, m, nfree, nio, 930 + step)
+        w2m, x2m = C.to_mont(f, z2[:nv]), C.to_mont(f, x2)
+        ctx.prefetch(w2m[lo:hi], lo)
+        cw, ct = ctx.begin_prefetched(x2m, [(0, w2m[:lo]), (hi, w2m[hi:])])
+        u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
+        t = C.cross_term(f, *[C.spmv(f, *M, z1) for M in (A, B, Cm)], *[C.spmv(f, *M, z2) for M in (A, B, Cm)], u1, 1)
+        assert point_to_affine(curve, cw) == C.jac_to_affine(curve, C.msm_pippenger(curve, bases[:nv], z2[:nv])), step
+        assert point_to_affine(curve, ct) == C.jac_to_affine(curve, C.msm_pippenger(curve, bases[:m], t)), step
+        ctx.finish(C.to_mont(f, C.ints_to_limbs([r])))
+        z1, e1 = C.axpy(f, z1, z2, r), C.axpy(f, e1, t, r)
+        gz, ge = ctx.read()
+        assert np.array_equal(C.from_mont(f, gz), z1) and np.array_equal(C.from_mont(f, ge), e1), step
+    ctx.close()
+    key.close()
+    shape.close()

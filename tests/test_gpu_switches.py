@@ -36,6 +36,41 @@ k2 = L.CommitmentKey(0, B[:3000], precompute=True, window_bits=16)
 ctx = L.FoldingContext(0, shape, k2)
 cw, ct, r = ctx.step(C.to_mont(1, z2[:2500]), C.to_mont(1, z2[2501:]), 12345)
 assert L.point_to_affine(0, cw) == C.jac_to_affine(0, C.msm_fast(0, B[:2500], z2[:2500]))
+# two more steps with the NEXT instance staged ahead (its commitment in the class LURK_FOLD_STAGED_MODE names, FOLLOW by default) and the
+# running products A z1, B z1, C z1 cached or not (LURK_FOLD_CACHED_PRODUCTS): commit(T) of a step depends on every fold before it
+z1m, e1m = ctx.read()
+z1, e1 = C.from_mont(1, z1m), C.from_mont(1, e1m)
+mats = (A, Bm, Cm)
+fresh = [np.concatenate([C.synth_scalars(1, 60 + k, 1, 2500), C.ints_to_limbs([1]), C.synth_scalars(1, 70 + k, 0, 2)]) for k in range(3)]
+ctx.prefetch(C.to_mont(1, fresh[0][:2500]), 0)
+for k in range(2):
+    ctx.prefetch(C.to_mont(1, fresh[k + 1][:2500]), 0) if k == 0 else None
+    cw, ct = ctx.begin_prefetched(C.to_mont(1, fresh[k][2501:]), [])
+    u1 = C.limbs_to_ints(z1[2500:2501])[0]
+    t = C.cross_term(1, *[C.spmv(1, *M, z1) for M in mats], *[C.spmv(1, *M, fresh[k]) for M in mats], u1, 1)
+    assert L.point_to_affine(0, cw) == C.jac_to_affine(0, C.msm_fast(0, B[:2500], fresh[k][:2500])), k
+    assert L.point_to_affine(0, ct) == C.jac_to_affine(0, C.msm_fast(0, B[:3000], t)), k
+    rk = 0xABCDEF + k
+    ctx.finish(C.to_mont(1, C.ints_to_limbs([rk])))
+    z1, e1 = C.axpy(1, z1, fresh[k], rk), C.axpy(1, e1, t, rk)
+gz, ge = ctx.read()
+assert np.array_equal(C.from_mont(1, gz), z1) and np.array_equal(C.from_mont(1, ge), e1)
+# the FOLLOW class on the bucket pipeline (2^22 sorted entries: the planned stages, not the one-launch form): a foreground commitment and
+# one that follows it (sort at once, accumulation behind the first's), and a follower with nothing to follow
+n2 = 1 << 18
+B2 = C.synth_bases(0, n2)
+kf = L.CommitmentKey(0, B2, precompute=True, window_bits=16)
+kf.reserve(n2, 3)
+v2 = [C.synth_scalars(1, 80 + k, 0, n2) for k in range(2)]
+d2 = [torch.from_numpy(C.to_mont(1, v).view(np.int64)).cuda() for v in v2]
+torch.cuda.synchronize()
+want2 = [C.jac_to_affine(0, C.msm_fast(0, B2, v)) for v in v2]
+kf.submit_device(2, d2[1], n2, is_mont=True, mode=3)
+assert L.point_to_affine(0, kf.wait(2)) == want2[1]
+for rep in range(2):
+    kf.submit_device(1, d2[0], n2, is_mont=True, mode=1)
+    kf.submit_device(0, d2[1], n2, is_mont=True, mode=3)
+    assert L.point_to_affine(0, kf.wait(0)) == want2[1] and L.point_to_affine(0, kf.wait(1)) == want2[0], rep
 print("child ok")
 '''
 
@@ -51,6 +86,12 @@ print("child ok")
     ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_MAX_ACC": "0"}, None),   # no limit on resident accumulations
     ({"LURK_MSM_ACC_PERSISTENT": "2", "LURK_MSM_PLACEMENT_LOG": "1"}, "accumulate placement"),
     ({"LURK_STEP_TRACE": "1"}, "[step]"),
+    ({"LURK_FOLD_CACHED_PRODUCTS": "0"}, None),                   # the six-gather cross term of rounds 1-5
+    ({"LURK_FOLD_STAGED_MODE": "2"}, None),                       # staged commitments in the BACKGROUND class (rounds 2-5)
+    ({"LURK_FOLD_STAGED_MODE": "1"}, None),                       # ... in the foreground class
+    ({"LURK_MSM_FOLLOW_WGS": "0"}, None),                         # a FOLLOW commitment's accumulation as the plain launch
+    ({"LURK_MSM_FOLLOW_WGS": "1"}, None),
+    ({"LURK_MSM_FOLLOW_WGS": "3", "LURK_FOLD_CACHED_PRODUCTS": "0"}, None),
 ])
 def test_switch_settings_keep_the_results(hip, env, expect_stderr):
     e = dict(os.environ)
