@@ -108,12 +108,14 @@ def main():
     if args.stage_ahead is None:
         args.stage_ahead = 0 if (args.devices or args.shape_file) else 3
     if args.workload == "fold_step":
-        # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues PER PRIORITY LEVEL (default 4); the step keeps ~25 streams busy in three
-        # priority classes (commitment slots, their accumulate streams, the folding contexts of both curves, the witness producer), and
-        # two streams that share a queue serialise.  6 is the measured best for the step (round 6: 4 / 6 / 8 = 3.44 / 3.20 / 8.9 ms for a
-        # both-curve step - at 8 the 24+ queues of one process exceed what the device keeps mapped at once and it time-slices them);
-        # the msm workload does not care (1 016 / 1 011 Mscalar-mul/s at 4 / 8).  Must be set before the HIP runtime initialises.
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "6")
+        # HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues PER PRIORITY CLASS (default 4), balancing them by use count; the step
+        # keeps ~25 streams busy (commitment slots, the folding contexts of both curves, the witness producer) and two streams that
+        # share a queue serialise.  8 per class is the measured best for the step (round 6, both curves alive, staged flow: 4 / 6 / 8 / 12
+        # = 3.33 / 3.32 / 3.18 / 3.32 ms, and at 12 the queues of one process exceed what the device keeps mapped and it time-slices
+        # them: 17 ms with one more producer).  The library helps by not opening a third class: a slot's low-priority accumulate
+        # stream is only made when a commitment needs it (msm.hip: ensure_acc_stream) - with it open, 8 already over-subscribed (8.9 ms).
+        # The msm workload does not care (1 016 / 1 011 Mscalar-mul/s at 4 / 8).  Must be set before the HIP runtime initialises.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
     # N > 1 without a launcher: become the launcher (one rank per GPU, the same command line the driver uses)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

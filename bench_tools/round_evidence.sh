@@ -1,7 +1,7 @@
 # One GPU call that regenerates the round's measurement evidence (run through gpurun; results land in gpurun_out/evidence_<tag>/ and,
 # for the summaries that are tracked, in gpurun_out/evidence_<tag>/profiles/ - copy those into profiles/ and commit them).
-# usage: bash bench_tools/round_evidence.sh <tag> [notests]        (tag e.g. r05)
-TAG=${1:-r05}
+# usage: bash bench_tools/round_evidence.sh <tag> [notests]        (tag e.g. r06)
+TAG=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 E=gpurun_out/evidence_$TAG
 rm -rf $E; mkdir -p $E/profiles
@@ -27,9 +27,14 @@ Q="--no-cpu-baseline --pmc off --no-plain-leg --sub-records off"
   python bench.py --log-n 22 --precompute 0 --pipeline 1 --steps 10 --warmup 3 $Q
   python bench.py --gpus 2 --backend gloo --scaling strong --log-n 22 --steps 10 --warmup 3 $Q --verify   # two ranks on this box's one GPU: the strong-scaling path, functional
   python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --verify
+  python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --stage-ahead 0 --no-cpu-baseline                      # W2 committed inside its own step (rounds 1-5)
+  LURK_FOLD_CACHED_PRODUCTS=0 python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --stage-ahead 0 --no-cpu-baseline   # ... and the six-gather cross term: round 5's step
+  LURK_FOLD_STAGED_MODE=2 python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --no-cpu-baseline              # staged flow, BACKGROUND class instead of FOLLOW
+  for q in 4 6 12; do GPU_MAX_HW_QUEUES=$q python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --no-cpu-baseline; done   # hardware queues per priority class (default of the workload: 8)
   python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --devices 0,0 --no-cpu-baseline --secondary 0
   python bench.py --workload fold_step --rc 100 --steps 20 --warmup 5 --devices 0,0 --auto-slices 1 --no-cpu-baseline --secondary 0
   python bench.py --workload fold_step --rc 900 --steps 8 --warmup 2 --no-cpu-baseline --secondary 0
+  python bench.py --workload fold_step --rc 900 --steps 8 --warmup 2 --no-cpu-baseline --secondary 0 --stage-ahead 0
   python bench.py --workload store_hydrate --steps 10 --warmup 2 --verify
   python bench.py --workload compress --steps 10 --warmup 3 --verify
   python bench.py --workload compress --steps 10 --warmup 3 --spartan-prover python --no-cpu-baseline
@@ -59,6 +64,10 @@ for k, (v, w, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
     print(k, "launches", n, "SQ_INSTS_VALU %.1f M" % (v / 1e6), "SQ_WAVES %.0f" % w, "VALU wave-instructions per wave %.0f" % (v / max(w, 1)))
 PY
 rm -rf $E/pmc_tree
+# 3c. the fold kernels in isolation (HIP events per launch) and the device-side scope timeline of the default step
+{ python bench_tools/fold_bench.py 100; python bench_tools/fold_bench.py 900; } > $E/profiles/${TAG}_fold_kernels_isolated.txt 2> $E/fold_bench.err
+LURK_PROF_TIMELINE=$E/step_scopes.txt python bench.py --workload fold_step --steps 12 --warmup 4 --no-cpu-baseline --secondary 0 > /dev/null 2> $E/step_tl.err
+{ echo "# device-side scope timeline (LURK_PROF_TIMELINE, bench_tools/scope_timeline.py) of one step of bench.py --workload fold_step (rc = 100, default flow: --stage-ahead 3,"; echo "# GPU_MAX_HW_QUEUES=8, primary curve only); microseconds relative to the step's cross term: start, end, duration, stream, scope"; python bench_tools/scope_timeline.py $E/step_scopes.txt; } > $E/profiles/${TAG}_step_timeline_rc100.txt 2>&1
 ./bench_tools/microbench > $E/profiles/${TAG}_microbench_instr_rates.txt 2>&1
 ./bench_tools/mds_mfma > $E/profiles/${TAG}_mds_mfma_final.txt 2>&1
 tail -c 400 $E/bench_default.json; echo; tail -3 $E/bench_default.err; wc -l $E/profiles/${TAG}_sweep.jsonl

@@ -159,10 +159,11 @@ def fold_step_workload(args, lib, world, rank):
         ctx.prefetch(buf[lo:hi], lo, stream=stream)                                  # commit(step circuit's range) starts now
 
     # --stage-ahead 3: the witness producer runs TWO steps ahead (lurk-beta's producer thread synthesizes frames independently of the
-    # folding loop, nova.rs:304-326).  Witness k + 2 is traced from step k's submit hook; instance k + 1 (traced during step k - 1, so
-    # complete) is staged when step k starts, and step k's begin submits its commitment behind commit(T) in the FOLLOW class: its sort and
-    # plan run beside the cross term and commit(T)'s sort, its accumulation starts when commit(T)'s has ended and fills the window that the
-    # step's serial chain leaves idle (T's bucket reduction, the transcript, the folds).
+    # folding loop, nova.rs:304-326).  Step k's submit hook - called inside begin once the step's own launches are enqueued, so nothing
+    # of it stands between a step's finish and the next cross term - traces witness k + 2 and stages instance k + 1 (traced during step
+    # k - 1, so complete): its commitment is submitted at once, behind commit(T), in the FOLLOW class: sort and plan beside the cross
+    # term's end and commit(T)'s sort, the accumulation once commit(T)'s has ended, in the window the step's serial chain leaves idle
+    # (T's bucket reduction, the transcript, the next cross term).
     trace_k = [0]
     tstreams = [torch.cuda.Stream() for _ in range(3)] if args.stage_ahead == 3 else []
 
@@ -214,8 +215,6 @@ def fold_step_workload(args, lib, world, rank):
         if args.stage_ahead:
             if args.stage_ahead == 1:
                 stage()                                                               # the next step's, under this step's work
-            elif args.stage_ahead == 3:
-                stage_traced()                                                        # instance k + 1 (traced a step ago): committed behind this step's commit(T)
             t_b = time.perf_counter()
             cw, ct = ctx.begin_prefetched(x2, patches)                               # late ranges + cross term + commit(T) (2: + stage() from the submit hook)
         elif args.witness_ahead:
@@ -248,12 +247,16 @@ def fold_step_workload(args, lib, world, rank):
         phase["finish"] += t_d - t_r
         return cw, ct
 
+    def hook_sa3():
+        trace_next()      # witness k + 2
+        stage_traced()    # instance k + 1: staged and its commitment submitted (FOLLOW) from inside step k's begin
+
     if args.stage_ahead == 3:
         trace_next()
         trace_next()
         torch.cuda.synchronize()
         stage_traced()
-        ctx.set_submit_hook(trace_next)
+        ctx.set_submit_hook(hook_sa3)
     elif args.stage_ahead:
         stage()
         if args.stage_ahead == 2:  # the next instance is traced, staged and its commitment started from inside begin (the submit hook)
@@ -282,6 +285,7 @@ def fold_step_workload(args, lib, world, rank):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lib.lurk_hip_profile_enable(0)
+    phase_primary = dict(phase)  # (the both-curve loops below run step() again)
     both = {}
     if sec is not None:
         # (a) the secondary half alone, (b) BOTH halves as ONE timed loop in prove_step's order - secondary NIFS::prove, then the primary
@@ -307,7 +311,7 @@ def fold_step_workload(args, lib, world, rank):
 
         both_serial()
         both["serial_order"] = timed(both_serial, args.steps)
-        hook_before = {2: stage, 3: trace_next}.get(args.stage_ahead) if args.stage_ahead else \
+        hook_before = {2: stage, 3: hook_sa3}.get(args.stage_ahead) if args.stage_ahead else \
             ((lambda: mf.assemble(d_w2s[hook_k[0] & 1], pre, globals_host, bodies_np, mont=True, stream=wstreams[hook_k[0] & 1].cuda_stream)) if args.witness_ahead == 3 else None)
 
         def hook_both():
@@ -367,7 +371,7 @@ def fold_step_workload(args, lib, world, rank):
                        "r1cs_columns": "frame-structured (88 % frame-local, 6 % globals, 4 % previous frame, 2 % u): a builder-chosen model of the step circuit's sparsity, "
                                        "see fold_kernels.r1cs_cross_term_uniform_columns for the structure-free case",
                        "shape_setup_s_once": round(shape_setup_s, 2)},
-            "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase.items()},
+            "host_ms_per_step": {k: round(v / args.steps * 1e3, 3) for k, v in phase_primary.items()},
             # the step's dominant kernel is the bucket accumulation of its two commitments; the cross term (fold_kernels below) is the HBM-side one
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": round(acc_bytes / (acc_ms * 1e-3) / 1e9, 3) if acc_ms else None,
                          "peak": 8000.0, "unit": "GB/s", "frac": round(acc_bytes / (acc_ms * 1e-3) / 8e12, 6) if acc_ms else None, "traffic": None,

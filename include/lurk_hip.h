@@ -157,10 +157,11 @@ int lurk_hip_msm_ctx_submit_dev(lurk_hip_msm_ctx* ctx, int slot, const void* d_s
  * the host is about to wait for (commit(T) of the open folding step).  BACKGROUND: the persistent one-wave-per-SIMD
  * accumulation at the lowest priority whatever the size - work staged ahead (commit(W2) of the next step), which fills the
  * issue slots the foreground commitment leaves during its sort and its bucket reduction.  DEFAULT = submit_dev (by size).
- * FOLLOW (round 6): the plain full-rate launch of FOREGROUND, but the whole commitment starts behind the ACCUMULATION of the
- * latest FOREGROUND commitment in flight on this context: commit(W2 of the next step) then sorts and accumulates in the window the
- * open step leaves idle - commit(T)'s bucket reduction, the host's transcript, the folds and the next cross term - instead of
- * sharing the VALU with commit(T)'s accumulation, which the host waits for. */
+ * FOLLOW (round 6): work staged ahead that must only take what the open step's serial chain leaves - commit(W2 of the next
+ * step).  Sort and plan run at once at the LOWEST wave priority; the accumulation (persistent, two waves per SIMD - LURK_MSM_FOLLOW_WGS -,
+ * lowest priority) starts behind the ACCUMULATION of the latest FOREGROUND commitment in flight on this context and fills the window the
+ * step leaves idle (commit(T)'s bucket reduction, the host's transcript, the folds, the next cross term); the tail (finalize, bucket
+ * reduction) keeps the raised priority: the next step waits for this commitment too. */
 #define LURK_MSM_SUBMIT_DEFAULT 0
 #define LURK_MSM_SUBMIT_FOREGROUND 1
 #define LURK_MSM_SUBMIT_BACKGROUND 2
@@ -396,11 +397,15 @@ int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const v
                                  void* stream);
 /* The same vector with the running instance's products CACHED (round 6): A z1, B z1, C z1 fold linearly with the running pair
  * (A (z1 + r z2) = A z1 + r A z2), so a prover that keeps them resident gathers from z2 alone - half the gather chains of the call
- * above.  d_u1: the running u (one 32-byte Montgomery element in device memory, i.e. z1 + num_vars); outputs T and (A z2, B z2,
- * C z2), which the caller folds into its cache with the step's r (lurk_hip_fold_vecs_dev).  A folding context does all of this
- * itself (lurk_hip_fold_step_*; LURK_FOLD_CACHED_PRODUCTS=0 keeps it on the call above). */
-int lurk_hip_r1cs_cross_term_cached_dev(lurk_hip_r1cs* shape, const void* d_z2, const void* d_az1, const void* d_bz1, const void* d_cz1,
-                                        const void* d_u1, void* d_t, void* d_az2, void* d_bz2, void* d_cz2, void* stream);
+ * above.  u1_32_mont: the running u (32 bytes, HOST memory: the caller folds scalars itself, u <- u + r u2).  Outputs T and (A z2,
+ * B z2, C z2).  The fold of the cache rides in the call: given the PREVIOUS step's products d_*z2_prev and its challenge r_prev32_mont
+ * (host; all four NULL = nothing to fold in), every cached row becomes row + r_prev * previous row - stored back in place - before it
+ * is used, so that nothing stands between a step's transcript and the next cross term (two buffers: the previous products are read
+ * while the new ones are written).  A folding context does all of this itself (lurk_hip_fold_step_*; LURK_FOLD_CACHED_PRODUCTS=0
+ * keeps it on the call above). */
+int lurk_hip_r1cs_cross_term_cached_dev(lurk_hip_r1cs* shape, const void* d_z2, void* d_az1, void* d_bz1, void* d_cz1, const void* u1_32_mont,
+                                        const void* d_az2_prev, const void* d_bz2_prev, const void* d_cz2_prev, const void* r_prev32_mont, void* d_t,
+                                        void* d_az2, void* d_bz2, void* d_cz2, void* stream);
 /* RelaxedR1CSWitness::fold: out = a + r b over n elements (W1 + r W2, E1 + r T); r: 32 B Montgomery, host */
 int lurk_hip_fold_vec_dev(int field_id, const void* d_a, const void* d_b, const void* r32_mont, size_t n,
                           void* d_out, void* stream);

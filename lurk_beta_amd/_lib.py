@@ -117,7 +117,7 @@ SIGNATURES = {
     "lurk_hip_r1cs_device": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "lurk_hip_r1cs_multiply_vec_dev": (c_int, [c_void_p] * 6),
     "lurk_hip_r1cs_cross_term_dev": (c_int, [c_void_p] * 5),
-    "lurk_hip_r1cs_cross_term_cached_dev": (c_int, [c_void_p] * 11),
+    "lurk_hip_r1cs_cross_term_cached_dev": (c_int, [c_void_p] * 15),
     "lurk_hip_fold_vecs_dev": (c_int, [c_int, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_size_t), ctypes.POINTER(c_void_p), c_void_p, c_void_p]),
     "lurk_hip_fold_vec_dev": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "lurk_hip_r1cs_multiply_vec": (c_int, [c_void_p] * 5),

@@ -89,7 +89,16 @@ __device__ __forceinline__ void row_mac(RowAcc<P>& r, const F29<P>& a, const F29
 }
 
 constexpr uint32_t FOLD_LONG = 32;  // rows with more entries (in any of A, B, C) go to the wave-per-row kernel
-constexpr int FOLD_BATCH = 4;       // entries whose loads are issued together by one lane
+// Measured in isolation at rc = 100 (bench_tools/fold_bench.py, round 6): a batch of 4 entries keeps 180-200 registers live (two waves
+// per SIMD), a batch of 2 keeps 144 (three waves): 0.227 -> 0.200 ms for the cached-products kernel, 0.323 -> 0.312 for the six-gather
+// one - the kernels are bound by gather latency that only more resident waves hide (1.6 waves per SIMD on average in round 4's counters).
+#ifndef LURK_FOLD_BATCH
+#define LURK_FOLD_BATCH 2
+#endif
+#ifndef LURK_FOLD_MIN_WAVES
+#define LURK_FOLD_MIN_WAVES 1  // (HIP: minimum waves per SIMD the cross-term kernels are compiled for)
+#endif
+constexpr int FOLD_BATCH = LURK_FOLD_BATCH;  // entries whose loads are issued together by one lane
 
 struct CsrView {
     const uint32_t* rowptr;
@@ -295,7 +304,7 @@ __device__ __forceinline__ void r1cs_cross_term_body(const R1csDev& s, const Fe<
 // 0.14 ms of a 0.42 ms cross term at rc = 100 with the device nearly idle (profiles/r04_step_timeline_rc100.txt), and commit(T) - which
 // waits for T - started that much later.
 template <class P>
-__global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2,
+__global__ __launch_bounds__(FOLD_BLOCK, LURK_FOLD_MIN_WAVES) void r1cs_cross_term_kernel(R1csDev s, const Fe<P>* __restrict__ z1, const Fe<P>* __restrict__ z2,
                                                                        size_t u_index, Fe<P>* __restrict__ t, unsigned long_blocks) {
     fold_wave_prio();
     if (blockIdx.x < long_blocks) r1cs_cross_term_body<P, true>(s, z1, z2, u_index, t, blockIdx.x, long_blocks);
@@ -308,53 +317,81 @@ __global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_kernel(R1csDev s, 
 // 32-byte gather chains and half the Montgomery conversions of r1cs_cross_term_kernel - the kernel is bound by exactly those (L1 tag
 // path 55 %, VALU 47 %: profiles/r04_cross_term_pmc.txt).  The cached rows arrive as three coalesced 32-byte reads per lane; A z2, B z2,
 // C z2 leave the same way for finish(r), which folds them into the cache in the launch that folds z and E (fold_vecs_kernel).
+// The fold of the cache itself rides in the same kernel (prev != nullptr): the products left by the PREVIOUS step and that step's
+// challenge, cached row <- cached row + r_prev * previous row, stored back in place and used at once - the step's finish(r) then has
+// nothing on the chain between the transcript and the next cross term (the folds of z and E, which the cross term does not read, run on
+// a side stream: step.hip), and the three cached vectors are read once per step instead of twice.
+template <class P>
+struct CachedProducts {
+    Fe<P>* a1;  // A z1, B z1, C z1: read, and written back when prev_* are given
+    Fe<P>* b1;
+    Fe<P>* c1;
+    const Fe<P>* prev_a;  // A z2, B z2, C z2 of the previous step (or nullptr: nothing to fold in)
+    const Fe<P>* prev_b;
+    const Fe<P>* prev_c;
+    Fe<P> r_prev;  // the previous step's challenge (Montgomery)
+    Fe<P> u1;      // the running u AFTER that fold (Montgomery): the host folds scalars itself
+};
+template <class P>
+__device__ __forceinline__ Fe<P> cached_row(Fe<P>* cur, const Fe<P>* prev, const Fe<P>& r, size_t row) {
+    Fe<P> v = cur[row];
+    if (prev) {
+        v = fe_add<P>(v, fe_mul<P>(r, prev[row]));
+        cur[row] = v;
+    }
+    return v;
+}
 template <class P, bool LONG>
-__device__ __forceinline__ void r1cs_cross_term_cached_body(const R1csDev& s, const Fe<P>* __restrict__ z2, const Fe<P>* __restrict__ az1,
-                                                            const Fe<P>* __restrict__ bz1, const Fe<P>* __restrict__ cz1, const Fe<P>* __restrict__ u1,
-                                                            size_t u_index, Fe<P>* __restrict__ t, Fe<P>* __restrict__ az2, Fe<P>* __restrict__ bz2,
+__device__ __forceinline__ void r1cs_cross_term_cached_body(const R1csDev& s, const Fe<P>* __restrict__ z2, const CachedProducts<P>& cp, size_t u_index,
+                                                            Fe<P>* __restrict__ t, Fe<P>* __restrict__ az2, Fe<P>* __restrict__ bz2,
                                                             Fe<P>* __restrict__ cz2, unsigned bid, unsigned nb) {
     const uint32_t* one29 = s.dict + s.dict_size * P29_STRIDE;
     const Fe<P>* zs[1] = {z2};
     uint32_t lo[3], hi[3];
-    F29<P> a2, b2, c2;
     size_t row;
+    bool store = true;
     if (!LONG) {
         row = fold_row_block(bid, nb) * FOLD_BLOCK + threadIdx.x;
         if (row >= s.rows || fold_is_long(s, row, lo, hi)) return;
-        fold_row_lane<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &a2);
-        fold_row_lane<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &b2);
-        fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &c2);
     } else {
         size_t w = ((size_t)bid * FOLD_BLOCK + threadIdx.x) / FOLD_GROUP;
         const bool live = w < s.n_long;  // a group without a row shadows the last one (the shuffles need every lane)
         row = s.long_rows[live ? w : s.n_long - 1];
         fold_is_long(s, row, lo, hi);
-        fold_row_wave<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &a2);
-        fold_row_wave<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &b2);
-        fold_row_wave<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &c2);
-        if (!live || (threadIdx.x & (FOLD_GROUP - 1))) return;
+        store = live && (threadIdx.x & (FOLD_GROUP - 1)) == 0;
     }
-    const Fe<P> a1 = az1[row], b1 = bz1[row], c1 = cz1[row];
+    // One product at a time, each folded into T's four-term lazy row and stored as soon as it is complete: only ONE row value is live
+    // beside the accumulator (three of them at once cost the kernel its third wave per SIMD: 200 registers against 168).
     Dot29<P> acc;
     dot29_init<P>(acc);
-    dot29_mac<P>(acc, f29_from_mont256<P>(a1), b2);
-    dot29_mac<P>(acc, a2, f29_from_mont256<P>(b1));
-    dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(*u1)), c2);
-    dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(z2[u_index])), f29_from_mont256<P>(c1));
+    F29<P> v;
+    if (!LONG) fold_row_lane<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &v);
+    else fold_row_wave<P, 1>(s.a, s.dict, one29, lo[0], hi[0], zs, &v);
+    if (store) {
+        dot29_mac<P>(acc, v, f29_from_mont256<P>(cached_row<P>(cp.b1, cp.prev_b, cp.r_prev, row)));  // A z2 o B z1
+        fold_store<P>(az2 + row, v);
+    }
+    if (!LONG) fold_row_lane<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &v);
+    else fold_row_wave<P, 1>(s.b, s.dict, one29, lo[1], hi[1], zs, &v);
+    if (store) {
+        dot29_mac<P>(acc, f29_from_mont256<P>(cached_row<P>(cp.a1, cp.prev_a, cp.r_prev, row)), v);  // A z1 o B z2
+        fold_store<P>(bz2 + row, v);
+    }
+    if (!LONG) fold_row_lane<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &v);
+    else fold_row_wave<P, 1>(s.c, s.dict, one29, lo[2], hi[2], zs, &v);
+    if (!store) return;
+    dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(cp.u1)), v);                                                                          // - u1 C z2
+    dot29_mac<P>(acc, f29_from_mont256<P>(fe_neg<P>(z2[u_index])), f29_from_mont256<P>(cached_row<P>(cp.c1, cp.prev_c, cp.r_prev, row)));  // - u2 C z1
+    fold_store<P>(cz2 + row, v);
     fold_store<P>(t + row, dot29_finish<P>(acc));
-    fold_store<P>(az2 + row, a2);
-    fold_store<P>(bz2 + row, b2);
-    fold_store<P>(cz2 + row, c2);
 }
 template <class P>
-__global__ __launch_bounds__(FOLD_BLOCK) void r1cs_cross_term_cached_kernel(R1csDev s, const Fe<P>* __restrict__ z2, const Fe<P>* __restrict__ az1,
-                                                                              const Fe<P>* __restrict__ bz1, const Fe<P>* __restrict__ cz1,
-                                                                              const Fe<P>* __restrict__ u1, size_t u_index, Fe<P>* __restrict__ t,
-                                                                              Fe<P>* __restrict__ az2, Fe<P>* __restrict__ bz2, Fe<P>* __restrict__ cz2,
-                                                                              unsigned long_blocks) {
+__global__ __launch_bounds__(FOLD_BLOCK, LURK_FOLD_MIN_WAVES) void r1cs_cross_term_cached_kernel(R1csDev s, const Fe<P>* __restrict__ z2, CachedProducts<P> cp,
+                                                                              size_t u_index, Fe<P>* __restrict__ t, Fe<P>* __restrict__ az2,
+                                                                              Fe<P>* __restrict__ bz2, Fe<P>* __restrict__ cz2, unsigned long_blocks) {
     fold_wave_prio();
-    if (blockIdx.x < long_blocks) r1cs_cross_term_cached_body<P, true>(s, z2, az1, bz1, cz1, u1, u_index, t, az2, bz2, cz2, blockIdx.x, long_blocks);
-    else r1cs_cross_term_cached_body<P, false>(s, z2, az1, bz1, cz1, u1, u_index, t, az2, bz2, cz2, blockIdx.x - long_blocks, gridDim.x - long_blocks);
+    if (blockIdx.x < long_blocks) r1cs_cross_term_cached_body<P, true>(s, z2, cp, u_index, t, az2, bz2, cz2, blockIdx.x, long_blocks);
+    else r1cs_cross_term_cached_body<P, false>(s, z2, cp, u_index, t, az2, bz2, cz2, blockIdx.x - long_blocks, gridDim.x - long_blocks);
 }
 
 // out = a + r b (r: Montgomery 2^256, broadcast).  A pure 96 B / element stream (two reads, one write): a lane takes FOLD_VEC_E
@@ -542,15 +579,24 @@ static void cross_term(const R1csShape& sh, const void* d_z1, const void* d_z2, 
     LURK_HIP_CHECK(hipGetLastError());
 }
 template <class P>
-static void cross_term_cached(const R1csShape& sh, const void* d_z2, const void* az1, const void* bz1, const void* cz1, const void* d_u1, void* d_t, void* az2,
-                              void* bz2, void* cz2, hipStream_t s) {
+static void cross_term_cached(const R1csShape& sh, const void* d_z2, void* az1, void* bz1, void* cz1, const void* u1_32, const void* prev_a, const void* prev_b,
+                              const void* prev_c, const void* r_prev32, void* d_t, void* az2, void* bz2, void* cz2, hipStream_t s) {
     if (!sh.num_cons) return;
     ProfScope ps("r1cs_cross_term", s);
     const R1csDev d = dev_view(sh);
     const unsigned long_blocks = sh.n_long ? div_up(sh.n_long * FOLD_GROUP, FOLD_BLOCK) : 0;
-    hipLaunchKernelGGL((r1cs_cross_term_cached_kernel<P>), dim3(long_blocks + fold_grid(sh.num_cons)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z2,
-                       (const Fe<P>*)az1, (const Fe<P>*)bz1, (const Fe<P>*)cz1, (const Fe<P>*)d_u1, sh.num_vars, (Fe<P>*)d_t, (Fe<P>*)az2, (Fe<P>*)bz2,
-                       (Fe<P>*)cz2, long_blocks);
+    CachedProducts<P> cp;
+    cp.a1 = (Fe<P>*)az1;
+    cp.b1 = (Fe<P>*)bz1;
+    cp.c1 = (Fe<P>*)cz1;
+    cp.prev_a = (const Fe<P>*)prev_a;
+    cp.prev_b = (const Fe<P>*)prev_b;
+    cp.prev_c = (const Fe<P>*)prev_c;
+    cp.r_prev = fe_zero<P>();
+    if (r_prev32) memcpy(cp.r_prev.l, r_prev32, 32);
+    memcpy(cp.u1.l, u1_32, 32);
+    hipLaunchKernelGGL((r1cs_cross_term_cached_kernel<P>), dim3(long_blocks + fold_grid(sh.num_cons)), dim3(FOLD_BLOCK), 0, s, d, (const Fe<P>*)d_z2, cp,
+                       sh.num_vars, (Fe<P>*)d_t, (Fe<P>*)az2, (Fe<P>*)bz2, (Fe<P>*)cz2, long_blocks);
     LURK_HIP_CHECK(hipGetLastError());
 }
 template <class P>
@@ -699,15 +745,22 @@ int lurk_hip_r1cs_cross_term_dev(lurk_hip_r1cs* shape, const void* d_z1, const v
     });
 }
 
-int lurk_hip_r1cs_cross_term_cached_dev(lurk_hip_r1cs* shape, const void* d_z2, const void* d_az1, const void* d_bz1, const void* d_cz1, const void* d_u1,
-                                        void* d_t, void* d_az2, void* d_bz2, void* d_cz2, void* stream) {
+int lurk_hip_r1cs_cross_term_cached_dev(lurk_hip_r1cs* shape, const void* d_z2, void* d_az1, void* d_bz1, void* d_cz1, const void* u1_32_mont,
+                                        const void* d_az2_prev, const void* d_bz2_prev, const void* d_cz2_prev, const void* r_prev32_mont, void* d_t,
+                                        void* d_az2, void* d_bz2, void* d_cz2, void* stream) {
     return guarded([&] {
-        LURK_REQUIRE(shape && d_z2 && d_az1 && d_bz1 && d_cz1 && d_u1 && d_t && d_az2 && d_bz2 && d_cz2, "null argument");
+        LURK_REQUIRE(shape && d_z2 && d_az1 && d_bz1 && d_cz1 && u1_32_mont && d_t && d_az2 && d_bz2 && d_cz2, "null argument");
+        const bool prev = d_az2_prev || d_bz2_prev || d_cz2_prev || r_prev32_mont;
+        LURK_REQUIRE(!prev || (d_az2_prev && d_bz2_prev && d_cz2_prev && r_prev32_mont), "the previous step's products and its challenge go together");
+        LURK_REQUIRE(!prev || (d_az2_prev != d_az2 && d_bz2_prev != d_bz2 && d_cz2_prev != d_cz2), "the previous products are read while the new ones are written: two buffers");
         DeviceGuard dg(shape->sh.device);
         const R1csShape& sh = shape->sh;
-        if (sh.field_id == 0) cross_term_cached<PallasFp>(sh, d_z2, d_az1, d_bz1, d_cz1, d_u1, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
-        else if (sh.field_id == 1) cross_term_cached<PallasFq>(sh, d_z2, d_az1, d_bz1, d_cz1, d_u1, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
-        else cross_term_cached<Bn254Fr>(sh, d_z2, d_az1, d_bz1, d_cz1, d_u1, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
+        if (sh.field_id == 0)
+            cross_term_cached<PallasFp>(sh, d_z2, d_az1, d_bz1, d_cz1, u1_32_mont, d_az2_prev, d_bz2_prev, d_cz2_prev, r_prev32_mont, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
+        else if (sh.field_id == 1)
+            cross_term_cached<PallasFq>(sh, d_z2, d_az1, d_bz1, d_cz1, u1_32_mont, d_az2_prev, d_bz2_prev, d_cz2_prev, r_prev32_mont, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
+        else
+            cross_term_cached<Bn254Fr>(sh, d_z2, d_az1, d_bz1, d_cz1, u1_32_mont, d_az2_prev, d_bz2_prev, d_cz2_prev, r_prev32_mont, d_t, d_az2, d_bz2, d_cz2, (hipStream_t)stream);
     });
 }
 

@@ -580,7 +580,7 @@ struct MsmCtx : MsmCtxBase {
             LURK_REQUIRE(!wk.pending, "slot is busy");
             ensure_workspace(wk, sh);
             ensure_streams(wk);
-            enqueue(wk, zeros.p, nz, 0, wk.stream, wk.acc_stream);
+            enqueue(wk, zeros.p, nz, 0, wk.stream, nullptr);  // (the plain launch: a slot's low-priority accumulate stream is made when a commitment first needs it)
             LURK_HIP_CHECK(hipStreamSynchronize(wk.stream));
         }
     }
@@ -904,7 +904,7 @@ struct MsmCtx : MsmCtxBase {
                 if (mode == LURK_MSM_SUBMIT_FOREGROUND) last_fg = &wk;
             }
             // foreground: everything on the (high-priority) slot stream
-            hipStream_t acc_s = wk.foreground ? nullptr : wk.acc_stream;
+            hipStream_t acc_s = wk.foreground ? nullptr : ensure_acc_stream(wk);
             enqueue(wk, d_scalars, n, is_mont, wk.pending_stream, acc_s);
             wk.acc_gate = nullptr;
             wk.follow_wgs = 0;
@@ -914,6 +914,18 @@ struct MsmCtx : MsmCtxBase {
         wk.pending_n = n;
     }
 
+    // The low-priority stream of a slot's persistent accumulation, made on first need (round 6): a stream of a new priority class costs
+    // the process another pool of hardware queues (GPU_MAX_HW_QUEUES per class), and a prover whose commitments are all FOREGROUND /
+    // FOLLOW (the folding step) never launches on it - its streams then share the queues of two classes instead of three.
+    hipStream_t ensure_acc_stream(Work& wk) {
+        if (!wk.acc_stream) {
+            int least = 0, greatest = 0;
+            LURK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.acc_stream, hipStreamNonBlocking, least));
+        }
+        return wk.acc_stream;
+    }
+
     void ensure_streams(Work& wk) {
         if (!wk.stream) {
             // the throughput-bound accumulate kernel runs on its own low-priority stream, everything else of the slot on a
@@ -921,7 +933,6 @@ struct MsmCtx : MsmCtxBase {
             int least = 0, greatest = 0;
             LURK_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
             LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.stream, hipStreamNonBlocking, greatest));
-            LURK_HIP_CHECK(hipStreamCreateWithPriority(&wk.acc_stream, hipStreamNonBlocking, least));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.ready, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.planned, hipEventDisableTiming));
             LURK_HIP_CHECK(hipEventCreateWithFlags(&wk.accumulated, hipEventDisableTiming));

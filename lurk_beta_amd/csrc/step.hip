@@ -25,6 +25,16 @@ static void ok(int rc) {
     if (rc != 0) throw HipFailure{rc, lurk_hip_last_error()};
 }
 
+// acc <- acc + x (Montgomery elements in host memory; r * 1 in Montgomery form is r itself)
+template <class F>
+static void host_add_mont(uint64_t* acc, const void* x) {
+    Fe<F> a, b;
+    memcpy(a.l, acc, 32);
+    memcpy(b.l, x, 32);
+    a = fe_add<F>(a, b);
+    memcpy(acc, a.l, 32);
+}
+
 template <class F>
 static void mont_one(void* out32) {
     Fe<F> o = fe_one<F>();
@@ -95,11 +105,20 @@ struct lurk_hip_fold_ctx {
     size_t helper_next = 0;
     int helper_of[2] = {-1, -1};       // which helper commits the instance staged in buffer b (-1: this context's own key)
     size_t num_cons = 0, num_vars = 0, num_io = 0, ncols = 0;
-    DevBuf z[2], e[2], t;              // running pair ping-pongs between two buffers (cur = index of the live one)
+    DevBuf z[2], e[2], t[2];           // running pair ping-pongs between two buffers (cur = index of the live one); T of the open step = t[tcur]
     // round 6: A z1, B z1, C z1 of the running instance stay resident (they fold linearly: A (z1 + r z2) = A z1 + r A z2), so a step's
     // cross term gathers from z2 alone (fold.hip: r1cs_cross_term_cached_kernel) and leaves A z2, B z2, C z2 for finish(r) to fold in
-    DevBuf abc1[3], abc2[3];
-    bool cached = false;
+    // The fold of the cache rides in the NEXT step's cross-term launch (abc_pending: the previous step's products abc2[abc_buf] and its
+    // challenge abc_r), and the folds of z and E - which the cross term does not read - run on fold_stream: nothing of finish(r) stands
+    // between the transcript and the next cross term.  T and the step's products ping-pong (tcur) so that the side stream's fold of E
+    // may still read T while the next cross term writes the other buffer.
+    DevBuf abc1[3], abc2[2][3];
+    bool cached = false, abc_pending = false;
+    int tcur = 0, abc_buf = 0;
+    uint64_t abc_r[4] = {0}, u_host[4] = {0};  // the pending challenge; the running u (Montgomery) as the host folds it
+    hipStream_t fold_stream = nullptr;
+    hipEvent_t zfold_ev = nullptr, efold_ev[2] = {nullptr, nullptr};  // the last fold of (z, E); the fold that last read t[k]
+    bool efold_valid[2] = {false, false};
     DevBuf z2[2], zstaged[2], zpatch;  // fresh instances [W2 | 1 | X2]: the open step's and the one staged ahead; the staged ranges alone
                                        // (what their commitment reads while late ranges are written into z2); the late ranges alone
     int cur = 0;
@@ -129,6 +148,10 @@ struct lurk_hip_fold_ctx {
         if (pre) nifs_pre_free(pre);
         if (pin) (void)hipHostFree(pin);
         if (stream) (void)hipStreamDestroy(stream);
+        if (fold_stream) (void)hipStreamDestroy(fold_stream);
+        if (zfold_ev) (void)hipEventDestroy(zfold_ev);
+        for (int k = 0; k < 2; k++)
+            if (efold_ev[k]) (void)hipEventDestroy(efold_ev[k]);
         for (int k = 0; k < 2; k++)
             if (stage_stream[k]) (void)hipStreamDestroy(stage_stream[k]);
         if (patch_ev) (void)hipEventDestroy(patch_ev);
@@ -206,10 +229,13 @@ static void fold_challenge_finish(lurk_hip_fold_ctx* c, void* r32_mont) {
 static lurk_hip_msm_ctx* fold_staged_key(lurk_hip_fold_ctx* c, int b) { return c->helper_of[b] >= 0 ? c->helpers[c->helper_of[b]]->key : c->key; }
 
 // The scheduling class of a commitment staged AHEAD of its step (the next step's commit(W2) while a step is open).  Default
-// LURK_MSM_SUBMIT_FOLLOW (round 6): full-rate launches that start when the open step's commit(T) has left the accumulate stage, so that
-// the staged commitment fills the window the step's serial chain leaves idle (T's bucket reduction, the transcript, the folds, the next
-// cross term) and commit(T)'s accumulation keeps the VALU to itself.  LURK_FOLD_STAGED_MODE=2: the round-2..5 behaviour
-// (LURK_MSM_SUBMIT_BACKGROUND: persistent one-wave accumulation beside commit(T)'s).
+// LURK_MSM_SUBMIT_FOLLOW (round 6, msm.hip: submit_impl): its sort and plan run at once at the lowest wave priority, its accumulation -
+// persistent, two waves per SIMD, lowest priority - starts when the open step's commit(T) has left the accumulate stage and fills the
+// window the step's serial chain leaves (T's bucket reduction, the transcript, the folds, the next cross term), its tail keeps the raised
+// priority (the next begin waits for it).  commit(T)'s accumulation keeps the VALU to itself.  Measured at rc = 100 with the witness
+// producer two steps ahead (bench.py --stage-ahead 3): 3.03 ms per step against 3.24 with W2 committed inside its own step, 3.21 against
+// 3.47 for both curves.  LURK_FOLD_STAGED_MODE=2: the round-2..5 behaviour (LURK_MSM_SUBMIT_BACKGROUND: persistent one-wave
+// accumulation beside commit(T)'s: 3.9 ms).
 static int fold_staged_mode() {
     static const int m = [] {
         const char* v = getenv("LURK_FOLD_STAGED_MODE");
@@ -315,13 +341,21 @@ static bool fold_late_key(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches
     return true;
 }
 
-// T of the open step on the context's stream: from the cached products of the running instance (z2's gathers alone) or from (z1, z2)
+// T of the open step on the context's stream: from the cached products of the running instance (z2's gathers alone; the previous
+// step's fold of the cache rides in the same launch) or from (z1, z2)
 static void fold_cross_term(lurk_hip_fold_ctx* c, const void* z2) {
-    if (c->cached)
-        ok(lurk_hip_r1cs_cross_term_cached_dev(c->shape, z2, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p, (const char*)c->z[c->cur].p + c->num_vars * 32, c->t.p,
-                                               c->abc2[0].p, c->abc2[1].p, c->abc2[2].p, c->stream));
-    else
-        ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t.p, c->stream));
+    if (c->cached) {
+        const int k = c->tcur;
+        if (c->efold_valid[k]) LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->efold_ev[k], 0));  // the fold of E two steps back read t[k]
+        const DevBuf* prev = c->abc_pending ? c->abc2[c->abc_buf] : nullptr;
+        ok(lurk_hip_r1cs_cross_term_cached_dev(c->shape, z2, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p, c->u_host, prev ? prev[0].p : nullptr,
+                                               prev ? prev[1].p : nullptr, prev ? prev[2].p : nullptr, prev ? c->abc_r : nullptr, c->t[k].p, c->abc2[k][0].p,
+                                               c->abc2[k][1].p, c->abc2[k][2].p, c->stream));
+        c->abc_pending = false;  // the launch is in the stream: a begin that fails later and is repeated must not fold the cache twice
+    } else {
+        ok(lurk_hip_r1cs_cross_term_dev(c->shape, c->z[c->cur].p, z2, c->t[c->tcur].p, c->stream));
+    }
+    LURK_HIP_CHECK(hipEventRecord(c->t_ev, c->stream));  // T (and the step's products) are complete
 }
 
 static void fold_run_submit_hook(lurk_hip_fold_ctx* c) {
@@ -432,7 +466,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     fold_cross_term(c, z2);                                                                     // T ...
     fold_submit_staged(c, b, fg);
     tt[1] = now();
-    ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t.p, c->num_cons, 1, c->stream, fg));     // ... commit(T): what the host waits for
+    ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t[c->tcur].p, c->num_cons, 1, c->stream, fg));  // ... commit(T): what the host waits for
     rollback.t_in_flight = true;
     if (patched) {  // commitment of the late ranges: under their own key, or as a num_vars-long vector that is zero elsewhere
         if (late_own_key) ok(lurk_hip_msm_ctx_submit_dev_mode(c->late_key, 0, c->late_vals.p, patched, 1, c->stage_stream[b], fg));
@@ -561,13 +595,12 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
     LURK_HIP_CHECK(hipMemcpyAsync(z2 + c->num_vars * 32, c->pin, need, hipMemcpyHostToDevice, c->stage_stream[0]));
     LURK_HIP_CHECK(hipEventRecord(c->staged_ev[b], c->stage_stream[0]));
     LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->staged_ev[b], 0));
-    fold_cross_term(c, z2);  // beside the slices' copies and commit(W2)'s sorts
-    LURK_HIP_CHECK(hipEventRecord(c->t_ev, c->stream));
+    fold_cross_term(c, z2);  // beside the slices' copies and commit(W2)'s sorts (records t_ev)
     bool w_in_flight = false, t_in_flight = false;
     try {
         fold_submit_multi(c, 0, z2, c->num_vars, c->staged_ev[b]);
         w_in_flight = true;
-        fold_submit_multi(c, 1, c->t.p, c->num_cons, c->t_ev);
+        fold_submit_multi(c, 1, c->t[c->tcur].p, c->num_cons, c->t_ev);
         t_in_flight = true;
         fold_run_submit_hook(c);
         fold_instance_settle(c);  // the previous step's instance fold, while the devices work on this step
@@ -596,13 +629,29 @@ static void fold_begin_multi(lurk_hip_fold_ctx* c, const void* w2, int on_device
 static void fold_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
     const int nx = c->cur ^ 1;
     // z = [W | u | X]: one pass folds the witness, u <- u1 + r * 1 and X <- X1 + r X2
-    // (with the cached products: those three fold in place, in the same launch)
-    const void* a[5] = {c->z[c->cur].p, c->e[c->cur].p, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p};
-    const void* b[5] = {c->z2[c->open_buf].p, c->t.p, c->abc2[0].p, c->abc2[1].p, c->abc2[2].p};
-    void* o[5] = {c->z[nx].p, c->e[nx].p, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p};
-    const size_t n[5] = {c->ncols, c->num_cons, c->num_cons, c->num_cons, c->num_cons};
-    ok(lurk_hip_fold_vecs_dev(c->field_id, c->cached ? 5 : 2, a, b, n, o, r32_mont, c->stream));
-    LURK_HIP_CHECK(hipEventRecord(c->folded_ev[c->open_buf], c->stream));
+    const void* a[2] = {c->z[c->cur].p, c->e[c->cur].p};
+    const void* b[2] = {c->z2[c->open_buf].p, c->t[c->tcur].p};
+    void* o[2] = {c->z[nx].p, c->e[nx].p};
+    const size_t n[2] = {c->ncols, c->num_cons};
+    if (c->cached) {
+        // off the chain: the next cross term reads the cached products (folded inside its own launch) and u (a kernel argument), not z or E
+        LURK_HIP_CHECK(hipStreamWaitEvent(c->fold_stream, c->t_ev, 0));  // T of this step is complete (the cross term ran on the context's stream)
+        LURK_HIP_CHECK(hipStreamWaitEvent(c->fold_stream, c->staged_ev[c->open_buf], 0));  // ... and so is z2 (staged on its own stream)
+        ok(lurk_hip_fold_vecs_dev(c->field_id, 2, a, b, n, o, r32_mont, c->fold_stream));
+        LURK_HIP_CHECK(hipEventRecord(c->folded_ev[c->open_buf], c->fold_stream));
+        LURK_HIP_CHECK(hipEventRecord(c->efold_ev[c->tcur], c->fold_stream));
+        LURK_HIP_CHECK(hipEventRecord(c->zfold_ev, c->fold_stream));
+        c->efold_valid[c->tcur] = true;
+        memcpy(c->abc_r, r32_mont, 32);
+        c->abc_buf = c->tcur;
+        c->abc_pending = true;
+        c->tcur ^= 1;
+        if (c->field_id == LURK_FIELD_PALLAS_FQ) host_add_mont<PallasFq>(c->u_host, r32_mont);  // u <- u + r u2, u2 = 1 (a fresh instance is strict)
+        else host_add_mont<PallasFp>(c->u_host, r32_mont);
+    } else {
+        ok(lurk_hip_fold_vecs_dev(c->field_id, 2, a, b, n, o, r32_mont, c->stream));
+        LURK_HIP_CHECK(hipEventRecord(c->folded_ev[c->open_buf], c->stream));
+    }
     c->folded_valid[c->open_buf] = true;
     c->cur = nx;
     c->begun = false;
@@ -661,22 +710,30 @@ static void fold_ctx_create(lurk_hip_fold_ctx** out, int curve, lurk_hip_r1cs* s
         c->z[k].alloc(c->ncols * 32);
         c->e[k].alloc(c->num_cons * 32);
     }
-    c->t.alloc(c->num_cons * 32);
+    c->t[0].alloc(c->num_cons * 32);
     {
         const char* sw = getenv("LURK_FOLD_CACHED_PRODUCTS");  // 0: the six-gather cross term of rounds 1-5 (A/B runs, the parity test of both forms)
         c->cached = !(sw && atoi(sw) == 0);
     }
-    if (c->cached)
+    if (c->cached) {
+        c->t[1].alloc(c->num_cons * 32);
         for (int k = 0; k < 3; k++) {
             c->abc1[k].alloc(c->num_cons * 32);
-            c->abc2[k].alloc(c->num_cons * 32);
+            c->abc2[0][k].alloc(c->num_cons * 32);
+            c->abc2[1][k].alloc(c->num_cons * 32);
         }
+    }
     c->ux.assign(4 * (1 + c->num_io), 0);
     {   // the transcript's width-25 Poseidon constants are generated on first use (~0.15 s): now, not inside the first step
         uint64_t one[4] = {1, 0, 0, 0}, out[4];
         ok(lurk_hip_nova_ro_squeeze(c->field_id == LURK_FIELD_PALLAS_FQ ? LURK_FIELD_PALLAS_FP : LURK_FIELD_PALLAS_FQ, one, 1, 128, out));
     }
     LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (c->cached) {
+        LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->fold_stream, hipStreamNonBlocking));
+        LURK_HIP_CHECK(hipEventCreateWithFlags(&c->zfold_ev, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) LURK_HIP_CHECK(hipEventCreateWithFlags(&c->efold_ev[k], hipEventDisableTiming));
+    }
     for (int k = 0; k < 2; k++) LURK_HIP_CHECK(hipStreamCreateWithFlags(&c->stage_stream[k], hipStreamNonBlocking));
     LURK_HIP_CHECK(hipEventCreateWithFlags(&c->patch_ev, hipEventDisableTiming));
     LURK_HIP_CHECK(hipEventCreateWithFlags(&c->w2_ready, hipEventDisableTiming));
@@ -750,9 +807,14 @@ int lurk_hip_fold_ctx_set_running(lurk_hip_fold_ctx* c, const void* z1, const vo
         DeviceGuard dg(c->device);
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_REQUIRE(!c->begun, "a step is open: finish it first");
+        if (c->fold_stream) LURK_HIP_CHECK(hipStreamSynchronize(c->fold_stream));  // the last step's folds of z and E write the buffers replaced here
         LURK_HIP_CHECK(hipMemcpyAsync(c->z[c->cur].p, z1, c->ncols * 32, hipMemcpyHostToDevice, c->stream));
         LURK_HIP_CHECK(hipMemcpyAsync(c->e[c->cur].p, e1, c->num_cons * 32, hipMemcpyHostToDevice, c->stream));
-        if (c->cached) ok(lurk_hip_r1cs_multiply_vec_dev(c->shape, c->z[c->cur].p, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p, c->stream));
+        if (c->cached) {  // the cache of the new running instance, whole; whatever fold of the old one was pending is void
+            ok(lurk_hip_r1cs_multiply_vec_dev(c->shape, c->z[c->cur].p, c->abc1[0].p, c->abc1[1].p, c->abc1[2].p, c->stream));
+            c->abc_pending = false;
+            memcpy(c->u_host, (const char*)z1 + c->num_vars * 32, 32);
+        }
         LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
         fold_instance_settle(c);  // the commitments of the last step first: only u and X are replaced here
         memcpy(c->ux.data(), (const char*)z1 + c->num_vars * 32, (1 + c->num_io) * 32);
@@ -909,6 +971,10 @@ int lurk_hip_fold_ctx_running_dev(lurk_hip_fold_ctx* c, void** d_z, void** d_e, 
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         if (d_z) *d_z = c->z[c->cur].p;
         if (d_e) *d_e = c->e[c->cur].p;
+        if (c->fold_stream) {  // the folds of z and E run on a side stream: the stream handed out is ordered behind the last of them
+            DeviceGuard dg(c->device);
+            LURK_HIP_CHECK(hipStreamWaitEvent(c->stream, c->zfold_ev, 0));
+        }
         if (stream) *stream = (void*)c->stream;
     });
 }
@@ -919,6 +985,7 @@ int lurk_hip_fold_ctx_read(lurk_hip_fold_ctx* c, void* z_host, void* e_host) {
         DeviceGuard dg(c->device);
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (c->fold_stream) LURK_HIP_CHECK(hipStreamSynchronize(c->fold_stream));
         if (z_host) LURK_HIP_CHECK(hipMemcpy(z_host, c->z[c->cur].p, c->ncols * 32, hipMemcpyDeviceToHost));
         if (e_host) LURK_HIP_CHECK(hipMemcpy(e_host, c->e[c->cur].p, c->num_cons * 32, hipMemcpyDeviceToHost));
     });

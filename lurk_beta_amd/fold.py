@@ -64,17 +64,21 @@ class R1CSShape:
         _lib.check(_lib.load().lurk_hip_r1cs_cross_term_dev(self._h, _lib.ptr(d_z1), _lib.ptr(d_z2), _lib.ptr(out), _lib.ptr(s)))
         return out
 
-    def cross_term_cached(self, d_z2, d_abc1, d_u1, stream=None):
-        """The same T from the running instance's cached products (A z1, B z1, C z1) and z2 alone; d_u1: the running u (one element on
-        the device).  Returns (T, [A z2, B z2, C z2]) - ``lurk_hip_r1cs_cross_term_cached_dev``."""
+    def cross_term_cached(self, d_z2, d_abc1, u1_mont, prev=None, r_prev_mont=None, stream=None):
+        """The same T from the running instance's cached products (A z1, B z1, C z1) and z2 alone; u1_mont: the running u (4 x u64, host).
+        prev = [A z2, B z2, C z2] of the previous step with its challenge r_prev_mont: folded into the cache IN PLACE by the same launch.
+        Returns (T, [A z2, B z2, C z2]) - ``lurk_hip_r1cs_cross_term_cached_dev``."""
         import torch
 
         assert d_z2.is_cuda and d_z2.shape[0] == self.num_cols and len(d_abc1) == 3
         t = torch.empty((self.num_cons, 4), dtype=torch.int64, device=d_z2.device)
         abc2 = [torch.empty_like(t) for _ in range(3)]
         s = stream if stream is not None else torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.load().lurk_hip_r1cs_cross_term_cached_dev(self._h, _lib.ptr(d_z2), *[_lib.ptr(x) for x in d_abc1], _lib.ptr(d_u1), _lib.ptr(t),
-                                                                  *[_lib.ptr(x) for x in abc2], _lib.ptr(s)))
+        u1 = np.ascontiguousarray(u1_mont, dtype=np.uint64).reshape(4)
+        rp = None if r_prev_mont is None else np.ascontiguousarray(r_prev_mont, dtype=np.uint64).reshape(4)
+        pv = [None, None, None] if prev is None else list(prev)
+        _lib.check(_lib.load().lurk_hip_r1cs_cross_term_cached_dev(self._h, _lib.ptr(d_z2), *[_lib.ptr(x) for x in d_abc1], _lib.ptr(u1), *[_lib.ptr(x) for x in pv],
+                                                                  _lib.ptr(rp), _lib.ptr(t), *[_lib.ptr(x) for x in abc2], _lib.ptr(s)))
         return t, abc2
 
     def close(self):

@@ -38,6 +38,11 @@ def point_mul(curve: int, point: np.ndarray, scalar: np.ndarray, is_mont: bool =
     return out
 
 
+class _W2Patch(ctypes.Structure):
+    """lurk_hip_w2_patch (module level: building a ctypes Structure class per call cost the step ~50 us of host time on its serial chain)"""
+    _fields_ = [("offset", ctypes.c_size_t), ("count", ctypes.c_size_t), ("values", ctypes.c_void_p)]
+
+
 class FoldingContext:
     """One curve of the cycle: R1CS shape + commitment key (both resident, borrowed) + the running relaxed pair."""
 
@@ -164,14 +169,10 @@ class FoldingContext:
     def begin_prefetched(self, x2_mont: np.ndarray, patches=()):
         """Open the step of the oldest staged instance.  patches: [(offset, host (k, 4) u64 array)], the ranges of W2 known only
         now.  Returns (comm_W2, comm_T)."""
-
-        class Patch(ctypes.Structure):
-            _fields_ = [("offset", ctypes.c_size_t), ("count", ctypes.c_size_t), ("values", ctypes.c_void_p)]
-
         keep = [np.ascontiguousarray(v, dtype=np.uint64) for _, v in patches]
-        arr = (Patch * max(1, len(keep)))()
+        arr = (_W2Patch * max(1, len(keep)))()
         for k, ((off, _), v) in enumerate(zip(patches, keep)):
-            arr[k] = Patch(int(off), v.size // 4, v.ctypes.data)
+            arr[k] = _W2Patch(int(off), v.size // 4, v.ctypes.data)
         x2 = np.ascontiguousarray(x2_mont, dtype=np.uint64)
         cw, ct = np.zeros(12, dtype=np.uint64), np.zeros(12, dtype=np.uint64)
         self._check_begin(_lib.load().lurk_hip_fold_step_begin_prefetched(self._h, ctypes.cast(arr, ctypes.c_void_p), len(keep), _lib.ptr(x2),

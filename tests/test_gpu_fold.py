@@ -193,7 +193,8 @@ def test_cached_products_cross_term_and_multi_fold_match_oracle(hip, f):
     u1 = C.limbs_to_ints(z1[nv:nv + 1])[0]
     u2 = C.limbs_to_ints(z2[nv:nv + 1])[0]
     t_want = C.cross_term(f, *want1, *want2, u1, u2)
-    d_t, abc2 = sh.cross_term_cached(d_z2, abc1, d_z1[nv:nv + 1])
+    u1_mont = C.to_mont(f, z1[nv:nv + 1])
+    d_t, abc2 = sh.cross_term_cached(d_z2, abc1, u1_mont)
     assert np.array_equal(C.from_mont(f, _host(d_t)), t_want)
     assert np.array_equal(_host(d_t), _host(sh.cross_term(d_z1, d_z2)))  # bit for bit the six-gather kernel's T
     for g, w in zip(abc2, want2):
@@ -213,12 +214,29 @@ def test_cached_products_cross_term_and_multi_fold_match_oracle(hip, f):
     torch.cuda.synchronize()
     for g, M in zip(inplace, (A, B, Cm)):
         assert np.array_equal(C.from_mont(f, _host(g)), C.spmv(f, *M, zf))  # A (z1 + r z2) = A z1 + r A z2
+    # the cache's own fold rides in the cross-term launch: given the previous step's products (here: z2's) and its challenge, the cached
+    # rows become A (z1 + r z2), B (..), C (..) IN PLACE and T is the cross term of (z1 + r z2, z3)
+    z3 = np.concatenate([C.synth_scalars(f, 31, 1, nv), C.ints_to_limbs([1]), C.synth_scalars(f, 32, 0, nio)])
+    d_z3 = _dev(C.to_mont(f, z3))
+    fused = [x.clone() for x in abc1]
+    uf = C.to_mont(f, zf[nv:nv + 1])  # the running u after the fold (the host folds scalars itself)
+    t3, abc3 = sh.cross_term_cached(d_z3, fused, uf, prev=abc2, r_prev_mont=r_mont)
+    torch.cuda.synchronize()
+    for g, M in zip(fused, (A, B, Cm)):
+        assert np.array_equal(C.from_mont(f, _host(g)), C.spmv(f, *M, zf))
+    want3 = [C.spmv(f, *M, z3) for M in (A, B, Cm)]
+    t3_want = C.cross_term(f, *[C.spmv(f, *M, zf) for M in (A, B, Cm)], *want3, C.limbs_to_ints(zf[nv:nv + 1])[0], 1)
+    assert np.array_equal(C.from_mont(f, _host(t3)), t3_want)
+    for g, w in zip(abc3, want3):
+        assert np.array_equal(C.from_mont(f, _host(g)), w)
+    from lurk_beta_amd import LurkHipError
+
+    with pytest.raises(LurkHipError, match="go together"):
+        sh.cross_term_cached(d_z3, fused, uf, prev=abc2)  # products without their challenge
     # edge: zero vectors in the list, a single vector, the empty call
     assert fold_vecs(f, [], r_mont) == []
     one = fold_vecs(f, [(d_e1, d_t)], r_mont)
     assert np.array_equal(C.from_mont(f, _host(one[0])), ef)
-    from lurk_beta_amd import LurkHipError
-
     with pytest.raises(LurkHipError):
         fold_vecs(f, [(d_e1, d_t)] * 9, r_mont)
     sh.close()
