@@ -351,7 +351,13 @@ def fold_step_workload(args, lib, world, rank):
         # algorithmic HBM bytes of the cross-term kernel: 8 B per CSR record + 4 B per row pointer, two 32-byte gathers
         # per record (z1, z2), 32 B of T per row; fold_vec: two reads + one write of 32 B per element
         ct_bytes = nnz * 8.0 + 3 * 4.0 * n_t + 2 * 32.0 * nnz + 32.0 * n_t
-        fv_bytes = 96.0 * ((n_w + 1 + n_io) + n_t) / 2
+        cached = os.environ.get("LURK_FOLD_CACHED_PRODUCTS", "1") != "0" and not devices
+        if cached:
+            # the cached-products kernel (round 6): ONE 32-byte gather per record (z2 alone); per row the three cached products read (96 B),
+            # T written (32 B), the step's three products written (96 B), and - the cache's own fold riding in the launch - the previous
+            # step's products read (96 B) and the cache written back (96 B)
+            ct_bytes = nnz * 8.0 + 3 * 4.0 * n_t + 32.0 * nnz + n_t * (96.0 + 32.0 + 96.0 + 96.0 + 96.0)
+        fv_bytes = 96.0 * ((n_w + 1 + n_io) + n_t) / (1 if cached else 2)  # cached flow: z and E fold in ONE launch (on a side stream)
         res = {
             "metric": "equivalent Lurk iterations/s (synthetic stand-in for one Nova folding step, Pallas)",
             "value": round(rc / (ms * 1e-3), 1), "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -379,7 +385,11 @@ def fold_step_workload(args, lib, world, rank):
                          "note": "96 B per point over the mean of the step's two commitments (W2 and T), launches timed inside the step (they share the device with "
                                  "the cross term and each other's sort); integer-VALU bound as in the msm workload: see its roofline_valu"},
             "fold_kernels": {
-                "r1cs_cross_term": {"ms": round(ct_ms, 4), "algorithmic_bytes": ct_bytes, "achieved_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms else None,
+                "r1cs_cross_term": {"kernel": "r1cs_cross_term_cached_kernel (z2's gathers + the cached A z1, B z1, C z1; the cache's fold in the same launch)" if cached
+                                    else "r1cs_cross_term_kernel (six gathers per row)",
+                                    "note": "launches timed INSIDE the step, beside the staged commitment's kernels and the witness producer; alone: bench_tools/fold_bench.py "
+                                            "(profiles/r06_fold_kernels_isolated.txt: 0.20 ms = 43 % of 8 TB/s for the cached kernel at rc = 100)",
+                                    "ms": round(ct_ms, 4), "algorithmic_bytes": ct_bytes, "achieved_GBps": round(ct_bytes / (ct_ms * 1e-3) / 1e9, 1) if ct_ms else None,
                                     "hbm_frac": round(ct_bytes / (ct_ms * 1e-3) / 8e12, 4) if ct_ms else None},
                 "fold_vec": {"ms_per_launch": round(fv_ms, 4), "algorithmic_bytes_per_launch": fv_bytes,
                              "achieved_GBps": round(fv_bytes / (fv_ms * 1e-3) / 1e9, 1) if fv_ms else None,
@@ -421,7 +431,9 @@ def fold_step_workload(args, lib, world, rank):
         cu_ms, _ = kernel_ms("r1cs_cross_term")
         lib.lurk_hip_profile_enable(0)
         shape_u.close()
-        res["fold_kernels"]["r1cs_cross_term_uniform_columns"] = {"ms": round(cu_ms, 4), "hbm_frac": round(ct_bytes / (cu_ms * 1e-3) / 8e12, 4) if cu_ms else None}
+        cu_bytes = nnz * 8.0 + 3 * 4.0 * n_t + 2 * 32.0 * nnz + 32.0 * n_t  # (this leg runs the six-gather kernel, alone on the device)
+        res["fold_kernels"]["r1cs_cross_term_uniform_columns"] = {"kernel": "r1cs_cross_term_kernel (six gathers per row), alone on the device", "ms": round(cu_ms, 4),
+                                                                   "hbm_frac": round(cu_bytes / (cu_ms * 1e-3) / 8e12, 4) if cu_ms else None}
         if not args.no_cpu_baseline:
             from oracle import coracle as C
 
