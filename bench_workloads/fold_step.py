@@ -500,6 +500,14 @@ def verify_fold_step(L, ctx, host_mats, F, q, n_w, n_t, n_io, d_bases, pp_digest
     ok["folded_comm_W"] = L.point_to_affine(curve, gcw) == C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_w], zf[:n_w]))
     ok["folded_comm_E"] = L.point_to_affine(curve, gce) == C.jac_to_affine(curve, C.msm_fast(curve, bases[:n_t], ef))
     if not all(ok.values()):
-        raise SystemExit(f"bench.py --verify: the fold step does not match the oracle: {ok}")
+        diag = {}
+        try:  # which side is off: the device vector, the host-folded instance, or the checker?  (the GPU's own commitment of the read-back vector)
+            import torch as _t
+
+            g = L.point_to_affine(curve, ctx.key.commit_device(_t.from_numpy(np.ascontiguousarray(z1m[:n_w]).view(np.int64)).cuda(), n_w, is_mont=True))
+            diag = {"gpu_commit_of_read_back_z1_equals_instance": pt(g) == pt(L.point_to_affine(curve, cw1)), "gpu_commit_of_read_back_z1_equals_oracle": pt(g) == cw1_o}
+        except Exception as e:  # noqa: BLE001
+            diag = {"diagnostic_failed": repr(e)}
+        raise SystemExit(f"bench.py --verify: the fold step does not match the oracle: {ok} {diag}")
     return {"ok": True, "checks": sorted(ok), "oracle_s": round(time.perf_counter() - t0, 1),
             "against": "oracle/oracle.c (spmv, cross term, axpy), oracle/msm_fast.c (6 commitments), oracle/pyref.py (transcript), one extra step after the timed loop"}

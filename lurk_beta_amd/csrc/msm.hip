@@ -557,7 +557,10 @@ struct MsmCtx : MsmCtxBase {
         if (n == 0) return;
         if (small) {
             DevBuf zeros(32);
+            // (hipMemset of device memory is a NULL-stream operation that may return before it has run, and the NULL stream orders nothing
+            // against this library's non-blocking streams: wait for it before a kernel on another stream reads the buffer)
             LURK_HIP_CHECK(hipMemset(zeros.p, 0, 32));
+            LURK_HIP_CHECK(hipStreamSynchronize(nullptr));
             for (int k = 0; k < slots; k++) {
                 Work& wk = work[k];
                 std::lock_guard<std::mutex> lk(wk.mu);
@@ -574,6 +577,7 @@ struct MsmCtx : MsmCtxBase {
         const size_t nz = n < 256 ? n : 256;
         DevBuf zeros(nz * 32);
         LURK_HIP_CHECK(hipMemset(zeros.p, 0, nz * 32));
+        LURK_HIP_CHECK(hipStreamSynchronize(nullptr));  // (see above)
         for (int k = 0; k < slots; k++) {
             Work& wk = work[k];
             std::lock_guard<std::mutex> lk(wk.mu);
@@ -595,11 +599,15 @@ struct MsmCtx : MsmCtxBase {
         c = c_;
     }
 
-    void ensure_workspace_small(Work& wk) {
+    void ensure_workspace_small(Work& wk, hipStream_t s) {
         if (wk.small_ready) return;
         wk.partials.ensure(msm_small_group_bytes());
         wk.small_counter.ensure(16);
-        LURK_HIP_CHECK(hipMemset(wk.small_counter.p, 0, 16));  // the small kernel's arrival counter: zero before its first launch, left zero by every launch
+        // the small kernel's arrival counter: zero before its first launch, left zero by every launch.  Zeroed ON THE STREAM of that
+        // first launch (round 6): a NULL-stream hipMemset may still be pending when a kernel on a non-blocking stream starts - nothing
+        // orders the two - and with a garbage ticket base no workgroup is ever "the last to arrive": the slot's pinned result keeps
+        // whatever it held.
+        LURK_HIP_CHECK(hipMemsetAsync(wk.small_counter.p, 0, 16, s));
         if (!wk.host_pts) LURK_HIP_CHECK(hipHostMalloc((void**)&wk.host_pts, (size_t)MSM_MAX_W * 20 * sizeof(Xyzz<P>)));
         wk.small_ready = true;
     }
@@ -643,7 +651,7 @@ struct MsmCtx : MsmCtxBase {
     void enqueue(Work& wk, const void* d_scalars, size_t n, int is_mont, hipStream_t s, hipStream_t s_acc = nullptr,
                  const std::function<void()>* before_accumulate = nullptr) {
         if (small) {  // one launch; <= 16 points land in the slot's pinned buffer
-            ensure_workspace_small(wk);
+            ensure_workspace_small(wk, s);
             msm_small_launch<P, SF>(d_scalars, n, is_mont, small_table.as<Affine<P>>(), c, wk.partials.p,
                                     wk.small_counter.template as<uint32_t>(), wk.host_pts, s);
             if (wk.planned) LURK_HIP_CHECK(hipEventRecord(wk.planned, s));

@@ -15,7 +15,7 @@ import ctypes, sys
 from lurk_beta_amd import _lib
 lib = _lib.load()
 for name, (res, args) in _lib.SIGNATURES.items():
-    if res is not ctypes.c_int or name in ("lurk_hip_device_count", "lurk_hip_msm_multi_num_shards"):  # these return a count
+    if res is not ctypes.c_int or name in ("lurk_hip_device_count", "lurk_hip_msm_multi_num_shards", "lurk_hip_abi_version"):  # these return a count / a revision
         continue
     vals = [None if (a in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(a, type) and issubclass(a, ctypes._Pointer))) else 0 for a in args]
     print("CALL", name, flush=True)
@@ -38,6 +38,8 @@ def test_null_arguments_never_crash(hip):
         "lurk_hip_device_count", "lurk_hip_set_device", "lurk_hip_profile_enable", "lurk_hip_profile_reset", "lurk_hip_msm_oneshot_key_cache",
         "lurk_hip_msm_multi_num_shards", "lurk_hip_shake256", "lurk_hip_witness_blocks_dev",
         # all-zero arguments are an empty request (n = 0) for these: a no-op by contract
-        "lurk_hip_ck_from_label_dev", "lurk_hip_store_hydrate", "lurk_hip_synth_scalars_dev", "lurk_hip_synth_bases_dev")]
+        "lurk_hip_ck_from_label_dev", "lurk_hip_ck_from_label_host", "lurk_hip_store_hydrate", "lurk_hip_synth_scalars_dev", "lurk_hip_synth_bases_dev",
+        # set(NULL) restores the defaults, trim(NULL) just trims: both by contract (include/lurk_hip.h)
+        "lurk_hip_ro_params_set", "lurk_hip_ck_params_set", "lurk_hip_scratch_trim")]
     silent = [n for n in must_fail if rets[n] == 0]
     assert not silent, f"accepted null arguments without an error: {silent}"

@@ -196,12 +196,13 @@ def test_submit_scheduling_classes_and_four_slots(hip, log_n):
         ck = CommitmentKey(c, d_bases, n=n, device=True, precompute=pre)
         ck.reserve(n, 4)
         want = [point_to_affine(c, ck.commit_device(sc, n, is_mont=True)) for sc in scal]
-        for modes in ((1, 2, 2, 0), (2, 1, 0, 1), (2, 2, 2, 2), (1, 1, 1, 1)):  # 1 = foreground, 2 = background
+        # 1 = foreground, 2 = background, 3 = follow (round 6: behind the latest foreground commitment's accumulation; with nothing to follow it just runs)
+        for modes in ((1, 2, 2, 0), (2, 1, 0, 1), (2, 2, 2, 2), (1, 1, 1, 1), (1, 3, 3, 0), (3, 1, 3, 1), (3, 3, 3, 3)):
             for slot in range(4):
                 ck.submit_device(slot, scal[slot], n, is_mont=True, stream=s, mode=modes[slot])
             assert [point_to_affine(c, ck.wait(slot)) for slot in range(4)] == want, modes
         with pytest.raises(LurkHipError):
-            ck.submit_device(0, scal[0], n, is_mont=True, stream=s, mode=3)  # unknown class
+            ck.submit_device(0, scal[0], n, is_mont=True, stream=s, mode=4)  # unknown class
         with pytest.raises(LurkHipError):
             ck.submit_device(6, scal[0], n, is_mont=True, stream=s)  # LURK_MSM_SLOTS = 6 slots
         ck.close()
