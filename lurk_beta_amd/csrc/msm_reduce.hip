@@ -26,6 +26,13 @@
 //     0.7-1.4 ms now - and the slot came back that much later.  2^22, three in flight: 953-961 -> 969-972 Mscalar-mul/s on one box
 //     (alternating runs), 2^20, two in flight: 790 -> 812; alone the reduction got 4 % faster too (four waves per SIMD in the early
 //     levels): profiles/r04_msm_pipeline_coresidency.txt.
+//   * round 6, adopted: the LATE levels as wave butterflies (msm_planes29_wave_kernel).  From the level where a whole level is fewer
+//     waves than the chip has SIMDs, a level's launch costs ~10 us for its one 4.5 us addition (launch, two dependent 160-byte
+//     loads, the store: rocprofv3 trace of a lone 2^20 commitment, profiles/r06_reduce_levels.txt: 13 launches of 7-14 us).  A
+//     component of the merged vector is a plain SUM over the merged segments (the new planes: a sum of the S values of the segments
+//     whose index has that bit set), so one wave takes 64 adjacent segments of ONE component and sums them with six
+//     exchange-and-add steps across its lanes: six levels per launch, nothing between them but 37 ds_bpermute.  It does ~3x the
+//     additions of the tree (lanes idle from the second step on) - which is why the first levels stay as they are.
 #include "common.hpp"
 #include "msm_core.cuh"
 #include "curve29.cuh"
@@ -93,14 +100,83 @@ __global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyz
     }
 }
 
+// LOG consecutive levels in one launch, from the input of level K (segments of 2^K buckets, K + 1 components each, nseg_in = B >> K of
+// them per key space): one wave per (key space, output component, 64 adjacent input segments); lane l holds segment l's record of the
+// component - for a new plane K + t, segment l's S if bit t of l is set, the identity if not - and LOG exchange-and-add steps leave the
+// sum of every 2^LOG adjacent segments in the group's first lane.  Output layout = the level kernel's (out[g][seg >> LOG][0 .. K + LOG]).
+template <class P, bool LAST>
+__global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_wave_kernel(const Plane29<P>* __restrict__ in, Plane29<P>* __restrict__ out,
+                                                                           Xyzz<P>* __restrict__ out_host, int K, int LOG, int G, uint32_t nseg_in) {
+    __builtin_amdgcn_s_setprio(3);
+    const size_t comps_in = (size_t)K + 1, comps_out = comps_in + LOG;
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * REDUCE_BLOCK + threadIdx.x) >> 6;
+    const size_t chunks = ((size_t)nseg_in + 63) / 64;
+    if (wave >= (size_t)G * comps_out * chunks) return;
+    const size_t chunk = wave % chunks, comp = (wave / chunks) % comps_out, g = wave / (chunks * comps_out);
+    const size_t seg = chunk * 64 + lane;
+    Xyzz29<P> r;
+    bool r_id = true;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.x.l[i] = r.y.l[i] = r.zz.l[i] = r.zzz.l[i] = 0;
+    if (seg < nseg_in) {
+        const Plane29<P>* src = in + (g * nseg_in + seg) * comps_in;
+        if (comp < comps_in) plane_load<P>(src + comp, r, r_id);
+        else if ((seg >> (comp - comps_in)) & 1) plane_load<P>(src, r, r_id);
+    }
+    for (int t = 0; t < LOG; t++) {
+        const int m = 1 << t;
+        Xyzz29<P> h;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            h.x.l[i] = (uint32_t)__shfl_xor((int)r.x.l[i], m);
+            h.y.l[i] = (uint32_t)__shfl_xor((int)r.y.l[i], m);
+            h.zz.l[i] = (uint32_t)__shfl_xor((int)r.zz.l[i], m);
+            h.zzz.l[i] = (uint32_t)__shfl_xor((int)r.zzz.l[i], m);
+        }
+        const bool h_id = __shfl_xor((int)r_id, m) != 0;
+        xyzz29_add<P>(r, r_id, h, h_id);  // (both lanes of a pair form the same sum; only the lower one's is used from here on)
+    }
+    if ((lane & ((1u << LOG) - 1u)) != 0 || seg >= nseg_in) return;
+    const size_t nseg_out = (size_t)nseg_in >> LOG;
+    const size_t id = (g * nseg_out + (seg >> LOG)) * comps_out + comp;
+    if (LAST) {
+        out_host[id] = xyzz29_to_xyzz<P>(r, r_id);
+    } else {
+        Plane29<P> o;
+        o.p = r;
+        o.id = r_id;
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        out[id] = o;
+    }
+}
+
 size_t msm_reduce_plane_bytes(size_t nb) { return nb * 160; }
+
+// LURK_MSM_REDUCE_WAVE=0: every level as its own launch (the round-3 form)
+static bool reduce_wave_levels() {
+    static const bool on = [] { const char* v = getenv("LURK_MSM_REDUCE_WAVE"); return !v || atoi(v) != 0; }();
+    return on;
+}
 
 // planes_a / planes_b: msm_reduce_plane_bytes(G * B) each; out_host: G * c XYZZ points of pinned host memory
 template <class P>
 void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s) {
     static_assert(sizeof(Plane29<P>) == 160, "plane record");
     Plane29<P>* bufs[2] = {(Plane29<P>*)planes_a, (Plane29<P>*)planes_b};
-    for (int k = 0; k < c - 1; k++) {
+    // the last <= 12 levels as two wave butterflies, starting where the first of them is at most two waves per SIMD
+    int K = c - 1;  // levels [0, K) one launch each
+    if (reduce_wave_levels() && c >= 3 && B == (1u << (c - 1))) {
+        K = c - 1 > 12 ? c - 1 - 12 : 0;
+        if (K < 1) K = 1;  // (level 0 converts the buckets)
+        const size_t cap = (size_t)num_cus() * 4 * 2;
+        auto waves = [&](int k) {
+            const int rem = c - 1 - k, log1 = rem > 6 ? rem - rem / 2 : rem;
+            return (size_t)G * ((((size_t)B >> k) + 63) / 64) * (size_t)(k + 1 + log1);
+        };
+        while (K < c - 1 && waves(K) > cap) K++;
+    }
+    for (int k = 0; k < K; k++) {
         const size_t threads = (size_t)G * ((size_t)B >> (k + 1)) * (k + 2);
         const dim3 grid(div_up(threads, REDUCE_BLOCK)), block(REDUCE_BLOCK);
         const Plane29<P>* in = bufs[(k + 1) & 1];
@@ -110,6 +186,23 @@ void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, i
         else if (k == 0) hipLaunchKernelGGL((msm_planes29_kernel<P, true, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
         else if (last) hipLaunchKernelGGL((msm_planes29_kernel<P, false, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
         else hipLaunchKernelGGL((msm_planes29_kernel<P, false, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+    }
+    for (int k = K; k < c - 1;) {
+        const int rem = c - 1 - k, log = rem > 6 ? rem - rem / 2 : rem;
+        const uint32_t nseg_in = B >> k;
+        const size_t nwaves = (size_t)G * (((size_t)nseg_in + 63) / 64) * (size_t)(k + 1 + log);
+        const dim3 grid(div_up(nwaves * 64, REDUCE_BLOCK)), block(REDUCE_BLOCK);
+        const Plane29<P>* in = bufs[(k + 1) & 1];  // what level k - 1 wrote
+        Plane29<P>* out = bufs[k & 1];
+        if (k + log == c - 1) hipLaunchKernelGGL((msm_planes29_wave_kernel<P, true>), grid, block, 0, s, in, out, out_host, k, log, G, nseg_in);
+        else hipLaunchKernelGGL((msm_planes29_wave_kernel<P, false>), grid, block, 0, s, in, out, out_host, k, log, G, nseg_in);
+        // the next launch reads bufs[k & 1]: make it what "level k + log - 1" would have written
+        if (((k + log - 1) & 1) != (k & 1)) {
+            Plane29<P>* t = bufs[0];
+            bufs[0] = bufs[1];
+            bufs[1] = t;
+        }
+        k += log;
     }
     LURK_HIP_CHECK(hipGetLastError());
 }

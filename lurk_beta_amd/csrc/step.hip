@@ -341,6 +341,13 @@ static bool fold_late_key(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches
     return true;
 }
 
+// LURK_STEP_TRACE: absolute host times (us) of the step's seams on stderr
+static void step_mark(const char* what) {
+    static const bool trace = getenv("LURK_STEP_TRACE") != nullptr;
+    if (trace)
+        fprintf(stderr, "[mark] %.1f %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(), what);
+}
+
 // T of the open step on the context's stream: from the cached products of the running instance (z2's gathers alone; the previous
 // step's fold of the cache rides in the same launch) or from (z1, z2)
 static void fold_cross_term(lurk_hip_fold_ctx* c, const void* z2) {
@@ -376,6 +383,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double tt[8] = {0};
     tt[0] = now();
+    step_mark("begin");
     const int b = c->staged[0];
     char* z2 = (char*)c->z2[b].p;
     size_t patched = 0;
@@ -464,6 +472,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     // its successor commit(T) is what the host waits for last.
     const int fg = LURK_MSM_SUBMIT_FOREGROUND;
     fold_cross_term(c, z2);                                                                     // T ...
+    step_mark("cross term launched");
     fold_submit_staged(c, b, fg);
     tt[1] = now();
     ok(lurk_hip_msm_ctx_submit_dev_mode(c->key, 1, c->t[c->tcur].p, c->num_cons, 1, c->stream, fg));  // ... commit(T): what the host waits for
@@ -504,6 +513,7 @@ static void fold_begin(lurk_hip_fold_ctx* c, const lurk_hip_w2_patch* patches, s
     ok(lurk_hip_msm_ctx_wait(c->key, 1, comm_t_jac96));
     rollback.armed = false;
     tt[5] = now();
+    step_mark("T collected");
     if (trace)
         fprintf(stderr, "[step] copies %.0f us, cross+T submit %.0f, next-W2 submit %.0f, W2 wait %.0f, T wait %.0f\n", tt[1] - tt[0], tt[2] - tt[1],
                 tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4]);
@@ -951,7 +961,9 @@ int lurk_hip_fold_step_challenge(lurk_hip_fold_ctx* c, void* r32_mont) {
     return guarded([&] {
         LURK_REQUIRE(c && r32_mont, "null argument");
         std::lock_guard<std::recursive_mutex> lk(c->mu);
+        step_mark("challenge");
         fold_challenge_finish(c, r32_mont);
+        step_mark("challenge done");
     });
 }
 
@@ -961,7 +973,9 @@ int lurk_hip_fold_step_finish(lurk_hip_fold_ctx* c, const void* r32_mont) {
         DeviceGuard dg(c->device);
         std::lock_guard<std::recursive_mutex> lk(c->mu);
         LURK_REQUIRE(c->begun, "no step is open");
+        step_mark("finish");
         fold_finish(c, r32_mont);
+        step_mark("finish done");
     });
 }
 

@@ -91,6 +91,7 @@ print("child ok")
     ({"LURK_FOLD_STAGED_MODE": "1"}, None),                       # ... in the foreground class
     ({"LURK_MSM_FOLLOW_WGS": "0"}, None),                         # a FOLLOW commitment's accumulation as the plain launch
     ({"LURK_MSM_FOLLOW_WGS": "1"}, None),
+    ({"LURK_MSM_REDUCE_WAVE": "0"}, None),                        # one launch per reduction level
     ({"LURK_MSM_FOLLOW_WGS": "3", "LURK_FOLD_CACHED_PRODUCTS": "0"}, None),
 ])
 def test_switch_settings_keep_the_results(hip, env, expect_stderr):
