@@ -23,6 +23,8 @@ rm -rf gpurun_out/prof_${TAG}_msm_n22
 Q="--no-cpu-baseline --pmc off --no-plain-leg --sub-records off"
 {
   for cfg in "20 1" "20 2" "22 1" "22 3" "22 4"; do set -- $cfg; python bench.py --log-n $1 --pipeline $2 --steps 20 --warmup 5 $Q; done
+  LURK_MSM_REDUCE_WAVE=0 python bench.py --log-n 20 --pipeline 1 --steps 20 --warmup 5 $Q   # one launch per reduction level (rounds 3-5)
+  LURK_MSM_REDUCE_WAVE=0 python bench.py --log-n 20 --pipeline 2 --steps 20 --warmup 5 $Q
   python bench.py --log-n 22 --dist witness --steps 20 --warmup 5 $Q
   python bench.py --log-n 22 --precompute 0 --pipeline 1 --steps 10 --warmup 3 $Q
   python bench.py --gpus 2 --backend gloo --scaling strong --log-n 22 --steps 10 --warmup 3 $Q --verify   # two ranks on this box's one GPU: the strong-scaling path, functional
@@ -38,6 +40,7 @@ Q="--no-cpu-baseline --pmc off --no-plain-leg --sub-records off"
   python bench.py --workload store_hydrate --steps 10 --warmup 2 --verify
   python bench.py --workload compress --steps 10 --warmup 3 --verify
   python bench.py --workload compress --steps 10 --warmup 3 --spartan-prover python --no-cpu-baseline
+  LURK_MSM_REDUCE_WAVE=0 python bench.py --workload compress --steps 10 --warmup 3 --no-cpu-baseline
   python bench.py --workload poseidon_tree --steps 5 --warmup 2 --no-cpu-baseline
   python bench.py --workload ntt --log-n 24 --steps 10 --warmup 3 --no-cpu-baseline
   python bench.py --workload ntt --log-n 20 --steps 10 --warmup 3 --no-cpu-baseline
@@ -68,6 +71,17 @@ rm -rf $E/pmc_tree
 { python bench_tools/fold_bench.py 100; python bench_tools/fold_bench.py 900; } > $E/profiles/${TAG}_fold_kernels_isolated.txt 2> $E/fold_bench.err
 LURK_PROF_TIMELINE=$E/step_scopes.txt python bench.py --workload fold_step --steps 12 --warmup 4 --no-cpu-baseline --secondary 0 > /dev/null 2> $E/step_tl.err
 { echo "# device-side scope timeline (LURK_PROF_TIMELINE, bench_tools/scope_timeline.py) of one step of bench.py --workload fold_step (rc = 100, default flow: --stage-ahead 3,"; echo "# GPU_MAX_HW_QUEUES=8, primary curve only); microseconds relative to the step's cross term: start, end, duration, stream, scope"; python bench_tools/scope_timeline.py $E/step_scopes.txt; } > $E/profiles/${TAG}_step_timeline_rc100.txt 2>&1
+# 3d. cold starts of the staged flow at rc = 900, every output against the oracle after two steps (the flow whose first late-range commitment
+# raced a NULL-stream memset until round 6)
+{ echo "# 12 processes of: bench.py --workload fold_step --rc 900 --secondary 0 --no-cpu-baseline --verify --steps 2 --warmup 0 (exit code, ms per step)"
+  for i in 1 2 3 4 5 6 7 8 9 10 11 12; do
+    python bench.py --workload fold_step --rc 900 --secondary 0 --no-cpu-baseline --verify --steps 2 --warmup 0 > $E/cold.json 2> $E/cold.err; rc=$?
+    python -c "
+import json,sys
+try:
+    d=json.loads([l for l in open('$E/cold.json') if l.startswith('{')][-1]); print('run $i rc $rc', d['ms_per_step'], 'verified', (d['config'].get('verified') or {}).get('ok'))
+except Exception as e: print('run $i rc $rc no line', e)"
+  done; } > $E/profiles/${TAG}_rc900_cold_starts.txt 2>&1
 ./bench_tools/microbench > $E/profiles/${TAG}_microbench_instr_rates.txt 2>&1
 ./bench_tools/mds_mfma > $E/profiles/${TAG}_mds_mfma_final.txt 2>&1
 tail -c 400 $E/bench_default.json; echo; tail -3 $E/bench_default.err; wc -l $E/profiles/${TAG}_sweep.jsonl

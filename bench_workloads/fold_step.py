@@ -419,6 +419,30 @@ def fold_step_workload(args, lib, world, rank):
             sec["ctx"].close()
             sec["ck"].close()
             sec["shape"].close()
+        # the step's own cross-term launch ALONE on the device (the in-step figure above shares the chip with the staged commitment's
+        # accumulation, its tail and the witness producer): the cached kernel with the cache's fold riding in it, as the step launches it
+        if cached:
+            lib.lurk_hip_profile_enable(1)
+            lib.lurk_hip_profile_reset()
+            d_z1a = torch.from_numpy(z1.view(np.int64)).cuda()
+            d_z2a = torch.cat([d_w2, d_z1a[n_w:]])
+            torch.cuda.synchronize()
+            abc1 = shape.multiply_vec(d_z1a, stream=stream)
+            u1a = z1[n_w:n_w + 1].reshape(4)
+            _, abc2a = shape.cross_term_cached(d_z2a, abc1, u1a, stream=stream)
+            ra = np.array([3, 5, 7, 11], dtype=np.uint64)
+            torch.cuda.synchronize()
+            lib.lurk_hip_profile_reset()
+            for _ in range(10):
+                shape.cross_term_cached(d_z2a, abc1, u1a, prev=abc2a, r_prev_mont=ra, stream=stream)
+            torch.cuda.synchronize()
+            ca_ms, _ = kernel_ms("r1cs_cross_term")
+            lib.lurk_hip_profile_enable(0)
+            del abc1, abc2a, d_z1a, d_z2a
+            res["fold_kernels"]["r1cs_cross_term"]["alone_on_the_device"] = {
+                "ms": round(ca_ms, 4), "algorithmic_bytes": ct_bytes, "achieved_GBps": round(ct_bytes / (ca_ms * 1e-3) / 1e9, 1) if ca_ms else None,
+                "hbm_frac": round(ct_bytes / (ca_ms * 1e-3) / 8e12, 4) if ca_ms else None,
+                "note": "mean of 10 launches with nothing else on the device, the cache's fold in the launch (HIP events on the launch stream)"}
         # the same cross term over a structure-free shape (uniformly random columns): the other end of the sparsity range
         lib.lurk_hip_profile_enable(1)
         lib.lurk_hip_profile_reset()

@@ -32,12 +32,34 @@
 //     component of the merged vector is a plain SUM over the merged segments (the new planes: a sum of the S values of the segments
 //     whose index has that bit set), so one wave takes 64 adjacent segments of ONE component and sums them with six
 //     exchange-and-add steps across its lanes: six levels per launch, nothing between them but 37 ds_bpermute.  It does ~3x the
-//     additions of the tree (lanes idle from the second step on) - which is why the first levels stay as they are.
+//     additions of the tree (lanes idle from the second step on) - which is why the first levels stay a tree.
+//   * round 6, adopted: the EARLY levels in pairs (msm_planes29_quad_kernel).  With their additions replaced by an xor the seven early
+//     launches take 191 us against 203: they are bound by their memory side (160-byte records, one per lane), not by the VALU - which is
+//     why the component-major order of round 4 gained nothing (re-measured: - 7..14 us, kept as the adding-threads-first order).  A pair
+//     of levels that never writes the level between them moves half the bytes: levels 0-6 of a 2^20 commitment 203 -> 155 us
+//     (63 + 49 + 28 for the pairs, 16 for level 6), the reduction 0.286 -> 0.245 ms, a 2^20 commitment 1.41 -> 1.37 ms synchronous,
+//     1.18 -> 1.15 with two in flight, the folding step 3.01 -> 2.93 ms (one box, alternating: profiles/r06_reduce_levels.txt).
 #include "common.hpp"
 #include "msm_core.cuh"
 #include "curve29.cuh"
 
+#ifndef LURK_REDUCE_COMPACT
+#define LURK_REDUCE_COMPACT 1
+#endif
+
 namespace lurk {
+
+#if defined(LURK_REDUCE_NOADD)  // experiment: the levels' memory side alone (results are wrong)
+template <class P>
+__device__ __forceinline__ void level_add(Xyzz29<P>& r, bool& r_id, const Xyzz29<P>& h, bool h_id) {
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r.x.l[i] ^= h.x.l[i]; r.y.l[i] ^= h.y.l[i]; r.zz.l[i] ^= h.zz.l[i]; r.zzz.l[i] ^= h.zzz.l[i]; }
+    r_id = r_id && h_id;
+}
+#else
+template <class P>
+__device__ __forceinline__ void level_add(Xyzz29<P>& r, bool& r_id, const Xyzz29<P>& h, bool h_id) { xyzz29_add<P>(r, r_id, h, h_id); }
+#endif
 
 constexpr int REDUCE_BLOCK = 256;
 
@@ -62,9 +84,26 @@ __global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyz
     __builtin_amdgcn_s_setprio(3);  // a latency-bound tail kernel: issue ahead of an accumulation sharing the SIMD
     const size_t nseg_out = (size_t)B >> (k + 1);
     const size_t comps_out = (size_t)k + 2, comps_in = (size_t)k + 1;
-    const size_t id = (size_t)blockIdx.x * REDUCE_BLOCK + threadIdx.x;
-    if (id >= (size_t)G * nseg_out * comps_out) return;
+    const size_t tid = (size_t)blockIdx.x * REDUCE_BLOCK + threadIdx.x;
+    if (tid >= (size_t)G * nseg_out * comps_out) return;
+#if LURK_REDUCE_COMPACT
+    // the adding threads first (k + 1 components per output segment), the copying ones (the new plane) in waves of their own behind them
+    size_t comp, seg, g;
+    const size_t adders = (size_t)G * nseg_out * comps_in;
+    if (tid < adders) {
+        comp = tid % comps_in;
+        seg = (tid / comps_in) % nseg_out;
+        g = tid / (comps_in * nseg_out);
+    } else {
+        comp = comps_in;
+        seg = (tid - adders) % nseg_out;
+        g = (tid - adders) / nseg_out;
+    }
+    const size_t id = (g * nseg_out + seg) * comps_out + comp;
+#else
+    const size_t id = tid;
     const size_t comp = id % comps_out, seg = (id / comps_out) % nseg_out, g = id / (comps_out * nseg_out);
+#endif
     Xyzz29<P> r, h;
     bool r_id, h_id;
     if (FIRST) {  // segments of one bucket, one component (S)
@@ -73,7 +112,7 @@ __global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyz
         if (comp == 0) {
             const Xyzz<P> lo = buckets[g * B + 2 * seg];
             xyzz29_from_xyzz<P>(lo, r, r_id);
-            xyzz29_add<P>(r, r_id, h, h_id);
+            level_add<P>(r, r_id, h, h_id);
         } else {
             r = h;
             r_id = h_id;
@@ -84,7 +123,7 @@ __global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyz
         if (comp <= (size_t)k) {
             plane_load<P>(lo + comp, r, r_id);
             plane_load<P>(hi + comp, h, h_id);
-            xyzz29_add<P>(r, r_id, h, h_id);
+            level_add<P>(r, r_id, h, h_id);
         } else {
             plane_load<P>(hi, r, r_id);  // the new plane k: the upper half's S
         }
@@ -98,6 +137,68 @@ __global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyz
         o.pad[0] = o.pad[1] = o.pad[2] = 0;
         out[id] = o;
     }
+}
+
+// Levels k and k + 1 in one launch (round 6): the early levels are bound by their memory side, not by their additions (with the additions
+// replaced by an xor the seven level launches of a 2^20 commitment take 191 us against 203: profiles/r06_reduce_levels.txt), so a pair of
+// levels that never writes the level between them halves the traffic of the pair.  Four adjacent segments of 2^k buckets (k + 1
+// components each) merge into one of 2^(k+2) (k + 3 components) with exactly the tree's additions: a component below k + 1 is the sum of
+// the four (three additions, one thread: in2 + in3, + in0, + in1), the new plane k is S1 + S3 (one addition, a thread of its own), the
+// new plane k + 1 is S2 + S3 - what the S thread holds after its first addition, stored from there.  The three-addition threads come
+// first, the one-addition threads in waves of their own behind them.  FIRST: the inputs are the buckets themselves (k = 0).
+template <class P, bool FIRST>
+__global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_quad_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
+                                                                           Plane29<P>* __restrict__ out, int k, int G, uint32_t B) {
+    __builtin_amdgcn_s_setprio(3);
+    const size_t nseg_out = (size_t)B >> (k + 2);
+    const size_t ci = (size_t)k + 1, co = ci + 2;
+    const size_t tid = (size_t)blockIdx.x * REDUCE_BLOCK + threadIdx.x;
+    const size_t heavy = (size_t)G * nseg_out * ci;
+    if (tid >= heavy + (size_t)G * nseg_out) return;
+    size_t comp, seg, g;
+    const bool light = tid >= heavy;
+    if (!light) {
+        comp = tid % ci;
+        seg = (tid / ci) % nseg_out;
+        g = tid / (ci * nseg_out);
+    } else {
+        comp = 0;  // (reads S)
+        seg = (tid - heavy) % nseg_out;
+        g = (tid - heavy) / nseg_out;
+    }
+    auto load = [&](int q, Xyzz29<P>& v, bool& id) {
+        if (FIRST) {
+            const Xyzz<P> b = buckets[g * B + 4 * seg + q];
+            xyzz29_from_xyzz<P>(b, v, id);
+        } else {
+            plane_load<P>(in + ((g * (nseg_out * 4) + 4 * seg + q) * ci + comp), v, id);
+        }
+    };
+    auto store = [&](size_t c_out, const Xyzz29<P>& v, bool id) {
+        Plane29<P> o;
+        o.p = v;
+        o.id = id;
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        out[(g * nseg_out + seg) * co + c_out] = o;
+    };
+    Xyzz29<P> r, h;
+    bool r_id, h_id;
+    if (light) {
+        load(1, r, r_id);
+        load(3, h, h_id);
+        level_add<P>(r, r_id, h, h_id);
+        store(ci, r, r_id);
+        return;
+    }
+    load(2, r, r_id);
+    load(3, h, h_id);
+    level_add<P>(r, r_id, h, h_id);
+    if (comp == 0) store(ci + 1, r, r_id);
+    load(0, h, h_id);
+    level_add<P>(r, r_id, h, h_id);
+    load(1, h, h_id);
+    level_add<P>(r, r_id, h, h_id);
+    store(comp, r, r_id);
 }
 
 // LOG consecutive levels in one launch, from the input of level K (segments of 2^K buckets, K + 1 components each, nseg_in = B >> K of
@@ -159,6 +260,12 @@ static bool reduce_wave_levels() {
     return on;
 }
 
+// LURK_MSM_REDUCE_QUAD=0: no level pairs
+static bool reduce_quad_levels() {
+    static const bool on = [] { const char* v = getenv("LURK_MSM_REDUCE_QUAD"); return !v || atoi(v) != 0; }();
+    return on;
+}
+
 // planes_a / planes_b: msm_reduce_plane_bytes(G * B) each; out_host: G * c XYZZ points of pinned host memory
 template <class P>
 void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, int c, int G, uint32_t B, Xyzz<P>* out_host, hipStream_t s) {
@@ -176,32 +283,42 @@ void msm_launch_reduce(const Xyzz<P>* buckets, void* planes_a, void* planes_b, i
         };
         while (K < c - 1 && waves(K) > cap) K++;
     }
-    for (int k = 0; k < K; k++) {
-        const size_t threads = (size_t)G * ((size_t)B >> (k + 1)) * (k + 2);
-        const dim3 grid(div_up(threads, REDUCE_BLOCK)), block(REDUCE_BLOCK);
-        const Plane29<P>* in = bufs[(k + 1) & 1];
-        Plane29<P>* out = bufs[k & 1];
-        const bool last = k == c - 2;
-        if (k == 0 && last) hipLaunchKernelGGL((msm_planes29_kernel<P, true, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
-        else if (k == 0) hipLaunchKernelGGL((msm_planes29_kernel<P, true, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
-        else if (last) hipLaunchKernelGGL((msm_planes29_kernel<P, false, true>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
-        else hipLaunchKernelGGL((msm_planes29_kernel<P, false, false>), grid, block, 0, s, buckets, in, out, out_host, k, G, B);
+    // levels [0, K): in pairs that skip the level between them (LURK_MSM_REDUCE_QUAD=0: one launch each), an odd one out as it was
+    const Plane29<P>* src = bufs[1];
+    Plane29<P>* dst = bufs[0];
+    auto swap = [&] {
+        Plane29<P>* t = dst;
+        dst = const_cast<Plane29<P>*>(src);
+        src = t;
+    };
+    int k = 0;
+    while (k < K) {
+        if (reduce_quad_levels() && k + 2 <= K && k + 2 <= c - 2) {
+            const size_t threads = (size_t)G * ((size_t)B >> (k + 2)) * (k + 2);
+            const dim3 grid(div_up(threads, REDUCE_BLOCK)), block(REDUCE_BLOCK);
+            if (k == 0) hipLaunchKernelGGL((msm_planes29_quad_kernel<P, true>), grid, block, 0, s, buckets, src, dst, k, G, B);
+            else hipLaunchKernelGGL((msm_planes29_quad_kernel<P, false>), grid, block, 0, s, buckets, src, dst, k, G, B);
+            k += 2;
+        } else {
+            const size_t threads = (size_t)G * ((size_t)B >> (k + 1)) * (k + 2);
+            const dim3 grid(div_up(threads, REDUCE_BLOCK)), block(REDUCE_BLOCK);
+            const bool last = k == c - 2;
+            if (k == 0 && last) hipLaunchKernelGGL((msm_planes29_kernel<P, true, true>), grid, block, 0, s, buckets, src, dst, out_host, k, G, B);
+            else if (k == 0) hipLaunchKernelGGL((msm_planes29_kernel<P, true, false>), grid, block, 0, s, buckets, src, dst, out_host, k, G, B);
+            else if (last) hipLaunchKernelGGL((msm_planes29_kernel<P, false, true>), grid, block, 0, s, buckets, src, dst, out_host, k, G, B);
+            else hipLaunchKernelGGL((msm_planes29_kernel<P, false, false>), grid, block, 0, s, buckets, src, dst, out_host, k, G, B);
+            k += 1;
+        }
+        swap();  // what was written is the next launch's input
     }
-    for (int k = K; k < c - 1;) {
+    while (k < c - 1) {
         const int rem = c - 1 - k, log = rem > 6 ? rem - rem / 2 : rem;
         const uint32_t nseg_in = B >> k;
         const size_t nwaves = (size_t)G * (((size_t)nseg_in + 63) / 64) * (size_t)(k + 1 + log);
         const dim3 grid(div_up(nwaves * 64, REDUCE_BLOCK)), block(REDUCE_BLOCK);
-        const Plane29<P>* in = bufs[(k + 1) & 1];  // what level k - 1 wrote
-        Plane29<P>* out = bufs[k & 1];
-        if (k + log == c - 1) hipLaunchKernelGGL((msm_planes29_wave_kernel<P, true>), grid, block, 0, s, in, out, out_host, k, log, G, nseg_in);
-        else hipLaunchKernelGGL((msm_planes29_wave_kernel<P, false>), grid, block, 0, s, in, out, out_host, k, log, G, nseg_in);
-        // the next launch reads bufs[k & 1]: make it what "level k + log - 1" would have written
-        if (((k + log - 1) & 1) != (k & 1)) {
-            Plane29<P>* t = bufs[0];
-            bufs[0] = bufs[1];
-            bufs[1] = t;
-        }
+        if (k + log == c - 1) hipLaunchKernelGGL((msm_planes29_wave_kernel<P, true>), grid, block, 0, s, src, dst, out_host, k, log, G, nseg_in);
+        else hipLaunchKernelGGL((msm_planes29_wave_kernel<P, false>), grid, block, 0, s, src, dst, out_host, k, log, G, nseg_in);
+        swap();
         k += log;
     }
     LURK_HIP_CHECK(hipGetLastError());

@@ -92,6 +92,8 @@ print("child ok")
     ({"LURK_MSM_FOLLOW_WGS": "0"}, None),                         # a FOLLOW commitment's accumulation as the plain launch
     ({"LURK_MSM_FOLLOW_WGS": "1"}, None),
     ({"LURK_MSM_REDUCE_WAVE": "0"}, None),                        # one launch per reduction level
+    ({"LURK_MSM_REDUCE_QUAD": "0"}, None),                        # no level pairs
+    ({"LURK_MSM_REDUCE_QUAD": "0", "LURK_MSM_REDUCE_WAVE": "0"}, None),
     ({"LURK_MSM_FOLLOW_WGS": "3", "LURK_FOLD_CACHED_PRODUCTS": "0"}, None),
 ])
 def test_switch_settings_keep_the_results(hip, env, expect_stderr):
