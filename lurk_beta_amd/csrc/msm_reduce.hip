@@ -43,6 +43,12 @@
 #include "msm_core.cuh"
 #include "curve29.cuh"
 
+// register budget of the reduction kernels: 128 VGPRs (four waves per SIMD; see "round 4, adopted" above) unless a build overrides it
+#ifdef LURK_REDUCE_VGPRS  // here: waves per SIMD the compiler is to leave room for (4 -> 128 VGPRs, 3 -> 168, 2 -> 256)
+#define LURK_REDUCE_BOUNDS __launch_bounds__(REDUCE_BLOCK, LURK_REDUCE_VGPRS)  /* (the second argument: workgroups per CU = waves per SIMD at 256 threads) */
+#else
+#define LURK_REDUCE_BOUNDS __launch_bounds__(REDUCE_BLOCK, 4)
+#endif
 #ifndef LURK_REDUCE_COMPACT
 #define LURK_REDUCE_COMPACT 1
 #endif
@@ -79,7 +85,7 @@ __device__ __forceinline__ void plane_load(const Plane29<P>* __restrict__ src, X
 // level k: in[g][seg][0..k] (segments of 2^k buckets; level 0 reads the buckets themselves) -> out[g][seg / 2][0..k+1]
 // LAST: the G x c plane sums leave as ordinary XYZZ points (out_host, pinned host memory) instead of plane records
 template <class P, bool FIRST, bool LAST>
-__global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
+__global__ LURK_REDUCE_BOUNDS void msm_planes29_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
                                                                       Plane29<P>* __restrict__ out, Xyzz<P>* __restrict__ out_host, int k, int G, uint32_t B) {
     __builtin_amdgcn_s_setprio(3);  // a latency-bound tail kernel: issue ahead of an accumulation sharing the SIMD
     const size_t nseg_out = (size_t)B >> (k + 1);
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_kernel(const Xyz
 // new plane k + 1 is S2 + S3 - what the S thread holds after its first addition, stored from there.  The three-addition threads come
 // first, the one-addition threads in waves of their own behind them.  FIRST: the inputs are the buckets themselves (k = 0).
 template <class P, bool FIRST>
-__global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_quad_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
+__global__ LURK_REDUCE_BOUNDS void msm_planes29_quad_kernel(const Xyzz<P>* __restrict__ buckets, const Plane29<P>* __restrict__ in,
                                                                            Plane29<P>* __restrict__ out, int k, int G, uint32_t B) {
     __builtin_amdgcn_s_setprio(3);
     const size_t nseg_out = (size_t)B >> (k + 2);
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_quad_kernel(cons
 // component - for a new plane K + t, segment l's S if bit t of l is set, the identity if not - and LOG exchange-and-add steps leave the
 // sum of every 2^LOG adjacent segments in the group's first lane.  Output layout = the level kernel's (out[g][seg >> LOG][0 .. K + LOG]).
 template <class P, bool LAST>
-__global__ __launch_bounds__(REDUCE_BLOCK, 4) void msm_planes29_wave_kernel(const Plane29<P>* __restrict__ in, Plane29<P>* __restrict__ out,
+__global__ LURK_REDUCE_BOUNDS void msm_planes29_wave_kernel(const Plane29<P>* __restrict__ in, Plane29<P>* __restrict__ out,
                                                                            Xyzz<P>* __restrict__ out_host, int K, int LOG, int G, uint32_t nseg_in) {
     __builtin_amdgcn_s_setprio(3);
     const size_t comps_in = (size_t)K + 1, comps_out = comps_in + LOG;
