@@ -4,12 +4,14 @@ import sys
 L = [x.split() for x in open(sys.argv[1]) if not x.startswith("#")]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 idx = [i for i, x in enumerate(L) if x[4].startswith("r1cs_cross")]
+# the bench's stand-alone legs (the cross term alone on the device, the uniform-column shape) launch cross terms on another stream at
+# the very end: a step's cross terms are the ones on the stream of the FIRST cross term of the file
+idx = [i for i in idx if L[i][3] == L[idx[0]][3]]
 streams0 = {}
 for x in L:
     streams0.setdefault(x[3], len(streams0))
-# the roofline leg's cross terms run on the default stream at the very end: skip streams that only ever carry cross terms
-t0 = float(L[idx[-back - 3]][0])
-t1 = float(L[idx[-back - 2]][0])
+t0 = float(L[idx[-back]][0])
+t1 = float(L[idx[-back + 1]][0])
 for x in sorted(L, key=lambda x: float(x[0])):
     t = float(x[0]) - t0
     if -900 < t < (t1 - t0) + 100:
