@@ -62,7 +62,11 @@ int lurk_hip_abi_version(void);
  * (device, stream) that grows by blocks of >= 256 MiB and is KEPT between proofs: about 2 GB per stream that has run a 2^20-row proof,
  * for the life of the process.  trim releases every arena no prover is using right now (nothing is live in it) back to the driver;
  * *released_bytes (may be NULL) = what went back.  The next proof on that stream re-allocates (a device-wide synchronisation the first
- * time a size is seen): call it when a process stops proving, not between proofs. */
+ * time a size is seen): call it when a process stops proving, not between proofs.
+ * Threads: a prover call (lurk_hip_spartan_prove*_dev, lurk_hip_ipa_prove_dev, lurk_hip_sumcheck_prove*_dev) holds its stream's arena
+ * for as long as the call runs - two calls on ONE stream from two threads run one after the other, calls on different streams run
+ * side by side.  No entry point of the library takes the arenas of two streams at once, so the arenas cannot deadlock among
+ * themselves; a caller that wraps prover calls in locks of its own must take them in one order. */
 int lurk_hip_scratch_trim(size_t* released_bytes);
 /* bind the calling thread to a device (one process per GPU; the multi-GPU layer calls this) */
 int lurk_hip_set_device(int device);
