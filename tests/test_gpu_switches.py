@@ -28,6 +28,14 @@ for rep in range(2):
         key.submit_device(k, dev[k], n, is_mont=True)      # DEFAULT class: the persistent accumulation when the switch says so
     for k in range(3):
         assert L.point_to_affine(0, key.wait(k)) == C.jac_to_affine(0, C.msm_fast(0, B, vecs[k])), (rep, k)
+# the bucket reduction's launch mix (level pairs, single levels, wave butterflies: LURK_MSM_REDUCE_QUAD / _WAVE) depends on the window
+# width and on the number of key spaces: a plain key (sixteen key spaces of 16-bit windows) and table keys of 18- and 20-bit windows
+Bs, vs = B[:4096], C.synth_scalars(1, 90, 0, 4096)
+want_s = C.jac_to_affine(0, C.msm_fast(0, Bs, vs))
+for kw in (dict(precompute=False), dict(precompute=True, window_bits=18), dict(precompute=True, window_bits=20)):
+    kk = L.CommitmentKey(0, Bs, **kw)
+    assert L.point_to_affine(0, kk.commit(vs)) == want_s, kw
+    kk.close()
 # a step through the context (LURK_STEP_TRACE prints its phases)
 A, Bm, Cm, z2 = C.synth_r1cs(1, 3000, 2500, 2, seed=9)
 mont = lambda M: (M[0], M[1], C.to_mont(1, M[2]))
