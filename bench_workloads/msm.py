@@ -167,7 +167,7 @@ def collect_counters(args):
 def pipeline_budget(valu_per_commit, ms_per_step):
     """The issue-cycle budget of EVERY kernel of one commitment: wave-level VALU instructions per commitment by
     stage (SQ_INSTS_VALU, this run's own PMC pass) x the stage's mean issue cost per instruction (the static mix of its ISA priced at the
-    rates of profiles/r04_microbench_instr_rates.txt by bench_tools/issue_model.py mix -> profiles/r05_issue_mix.json) on 1024 SIMDs
+    rates of profiles/r04_microbench_instr_rates.txt by bench_tools/issue_model.py mix -> profiles/rNN_issue_mix.json, the newest one is read) on 1024 SIMDs
     at 2.15 GHz.  Their sum is the floor of a commitment if everything beside the accumulation overlapped it perfectly."""
     if not valu_per_commit:
         return None
